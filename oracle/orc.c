@@ -1,0 +1,998 @@
+/*
+ * oracle/orc.c -- TEST INFRASTRUCTURE ONLY (see orc.h).
+ *
+ * Restates, function by function, the reference's hot path.  "ref:" comments give the
+ * reference file:line each block follows (paths relative to /root/reference).
+ */
+#include "orc.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+/* ------------------------------------------------------------------ types */
+
+typedef struct particle {
+    int32_t s;    /* domain state index                                     */
+    float* cnt;   /* Dirichlet counts of this particle (NULL for plain POMDP) */
+    double w;     /* importance weight (WeightedFilter only)                */
+} particle;
+
+typedef struct simstate { /* what the planner / filters hand to simulator.step */
+    int32_t s;
+    float* cnt; /* read-only in KeepCounts mode */
+} simstate;
+
+typedef struct tree {
+    int32_t* visits; /* ActionNode::_visit_count           [max_nodes]     */
+    int32_t* cn;     /* ChanceNode::_visit_count           [max_nodes * A] */
+    double* cq;      /* ChanceNode::_q                     [max_nodes * A] */
+    int32_t* child;  /* dense child table [max_nodes*A*O] or NULL when hashed */
+    uint64_t* hkey;  /* open-addressing hash: key = (node*A+a)*O+o+1 */
+    int32_t* hval;
+    uint64_t hmask;
+    int32_t n_nodes, max_nodes;
+    int32_t max_tree_depth, tree_depth;
+} tree;
+
+struct orc_ctx {
+    orc_config cfg;
+    orc_rng rng;
+    char err[256];
+    int32_t S, A, O;
+    int32_t tiger_K;   /* factored tiger: number of irrelevant features */
+    int32_t ncnt;      /* floats per particle count blob */
+    int32_t phi_len;   /* tabular: S*A*S */
+    float* prior;      /* tabular prior blob (phi then psi) */
+    double* log1p_tab; /* log1p(m), m < sims (POUCT.cpp:330-338 factorised) */
+    double gamma;
+    tree tr;
+    /* belief */
+    particle* P;
+    particle* Pnew;
+    float* pool;
+    float* pool_new;
+    double total_w; /* WeightedFilter::_total_weight */
+    double* wscratch;
+    double* wscan;
+    /* counters */
+    uint64_t sim_steps, belief_steps, env_steps;
+    uint64_t* step_counter; /* which counter sim_step bumps */
+    /* trace */
+    orc_trace_rec* trace;
+    int32_t n_trace, cap_trace;
+    /* per-selectAction outputs */
+    int32_t last_update_count;
+    double last_weight_total;
+};
+
+/* ------------------------------------------------------------------ utils */
+
+/* ref: src/utils/Statistic.cpp:5-46 */
+void orc_stat_add(orc_stat* s, double v)
+{
+    double delta, delta2;
+    s->count += 1;
+    delta = v - s->mean;
+    s->mean += delta / s->count;
+    delta2 = v - s->mean;
+    s->m2 += delta * delta2;
+}
+double orc_stat_var(const orc_stat* s) { return s->count < 2 ? 0 : s->m2 / (s->count - 1); }
+double orc_stat_stder(const orc_stat* s)
+{
+    return s->count < 2 ? 0 : sqrt(orc_stat_var(s) / s->count);
+}
+
+/* ref: src/utils/random.hpp:93-115  sampleFromMult<float const>: CDF accumulated in float,
+ * compared against a double threshold; falls through to n-1 */
+int orc_sample_from_mult_f(orc_rng* g, const float* mult, int n, double total)
+{
+    double p  = orc_u01(g) * total;
+    float sum = mult[0];
+    int i;
+    for (i = 1; i < n; ++i) {
+        if (p < sum) return i - 1;
+        sum += mult[i];
+    }
+    return n - 1;
+}
+
+/* ref: src/utils/random.cpp:244-255  sampleFromExpectedMult: total accumulated in double */
+int orc_sample_expected_mult(orc_rng* g, const float* dir, int n)
+{
+    double total = dir[0];
+    int i;
+    for (i = 1; i < n; ++i) total += dir[i];
+    return orc_sample_from_mult_f(g, dir, n, total);
+}
+
+/* ref: src/utils/random.cpp:257-279  expectedMult: sum and division in float */
+void orc_expected_mult(const float* dir, int n, float* out)
+{
+    float sum = dir[0];
+    int i;
+    for (i = 1; i < n; ++i) sum += dir[i];
+    if (sum <= 1e-300) {
+        for (i = 0; i < n; ++i) out[i] = 0;
+        return;
+    }
+    for (i = 0; i < n; ++i) out[i] = dir[i] / sum;
+}
+
+static uint64_t mix64(uint64_t x)
+{
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27; x *= 0x94d049bb133111ebull;
+    x ^= x >> 31;
+    return x;
+}
+
+static uint64_t particle_hash(uint64_t i, int32_t s, double w, const float* cnt, int ncnt)
+{
+    uint64_t h, wb;
+    int k;
+    memcpy(&wb, &w, 8);
+    h = mix64(i * 0x9E3779B97F4A7C15ull + (uint64_t)(uint32_t)s);
+    h = mix64(h ^ wb);
+    for (k = 0; k < ncnt; ++k) {
+        uint32_t b;
+        memcpy(&b, &cnt[k], 4);
+        h = mix64(h ^ ((uint64_t)b + ((uint64_t)k << 32)));
+    }
+    return h;
+}
+
+/* ------------------------------------------------------------------ domains */
+
+static int is_tiger(int d) { return d == ORC_DOM_TIGER_EPISODIC || d == ORC_DOM_TIGER_CONTINUOUS; }
+static int is_ftiger(int d)
+{
+    return d == ORC_DOM_FTIGER_EPISODIC || d == ORC_DOM_FTIGER_CONTINUOUS;
+}
+static int is_episodic(int d)
+{
+    return d == ORC_DOM_TIGER_EPISODIC || d == ORC_DOM_FTIGER_EPISODIC;
+}
+
+/* ref: Tiger::sampleStartState src/domains/tiger/Tiger.cpp:16-19 (LEFT=0 iff boolean()),
+ *      FactoredTiger::sampleStartState src/domains/tiger/FactoredTiger.cpp (uniform_int{0,S-1}) */
+static int32_t domain_start(orc_ctx* c)
+{
+    if (is_tiger(c->cfg.domain)) return orc_bool(&c->rng) ? 0 : 1;
+    if (is_ftiger(c->cfg.domain)) return orc_int(&c->rng, c->S);
+    return 0;
+}
+
+/* ref: Tiger::generateRandomAction Tiger.cpp:21-25 (uniform_int_distribution<int>{0,2}),
+ *      FactoredTiger::generateRandomAction (uniform_int_distribution<int>{0,A-1}) */
+static int32_t domain_random_action(orc_ctx* c, int32_t s)
+{
+    (void)s;
+    if (is_tiger(c->cfg.domain) || is_ftiger(c->cfg.domain)) return orc_int(&c->rng, 3);
+    return 0;
+}
+
+/* true dynamics.  ref: Tiger::step Tiger.cpp:40-82, FactoredTiger::step FactoredTiger.cpp:77-122 */
+static int domain_step(orc_ctx* c, int32_t* s, int32_t a, int32_t* o, double* r)
+{
+    int d = c->cfg.domain;
+    if (is_tiger(d)) {
+        int tiger_left = (*s == 0);
+        if (a == 2) { /* OBSERVE */
+            int correct = orc_u01(&c->rng) < .85;
+            *r          = -1;
+            *o          = ((correct ^ tiger_left) != 0) ? 1 : 0;
+        } else {
+            *r = (a == *s) ? 10 : -100;
+            *o = orc_bool(&c->rng) ? 1 : 0; /* _observations.get((int)boolean()) */
+            *s = orc_bool(&c->rng) ? 1 : 0; /* _states.get((int)boolean())       */
+        }
+        return is_episodic(d) && a != 2;
+    }
+    if (is_ftiger(d)) {
+        int loc = (*s < c->S / 2) ? 0 : 1; /* tigerLocation: LEFT iff idx < S/2 */
+        if (a == 2) {
+            int correct = orc_u01(&c->rng) < .85;
+            *r          = -1;
+            *o          = ((correct ^ (loc == 0)) != 0) ? 1 : 0;
+        } else {
+            *r = (a == loc) ? 10 : -100;
+            *o = orc_bool(&c->rng) ? 0 : 1; /* boolean() ? &_observations[0] : &_observations[1] */
+            *s = orc_int(&c->rng, c->S);    /* sampleStartState() */
+        }
+        return is_episodic(d) && a != 2;
+    }
+    return 1;
+}
+
+/* ref: Tiger::computeObservationProbability Tiger.cpp:27-38; FactoredTiger ditto */
+static double domain_obs_prob(orc_ctx* c, int32_t o, int32_t a, int32_t new_s)
+{
+    int d = c->cfg.domain;
+    if (is_tiger(d)) {
+        if (a != 2) return .5;
+        return (new_s == o) ? .85 : .15;
+    }
+    if (is_ftiger(d)) {
+        int loc = (new_s < c->S / 2) ? 0 : 1;
+        if (a != 2) return .5;
+        return (loc == o) ? .85 : .15;
+    }
+    return 0;
+}
+
+/* BADomainExtension::terminal / reward.
+ * ref: TigerBAExtension.cpp:21-44, FactoredTigerBAExtension.cpp (reward uses the PRE-state s) */
+static int ext_terminal(orc_ctx* c, int32_t s, int32_t a, int32_t ns)
+{
+    (void)s; (void)ns;
+    return is_episodic(c->cfg.domain) && a != 2;
+}
+static double ext_reward(orc_ctx* c, int32_t s, int32_t a, int32_t ns)
+{
+    int d = c->cfg.domain;
+    (void)ns;
+    if (a == 2) return -1;
+    if (is_tiger(d)) return (a == s) ? 10 : -100;
+    return (a == ((s < c->S / 2) ? 0 : 1)) ? 10 : -100;
+}
+
+/* ------------------------------------------------------------------ priors (tabular) */
+
+/* ref: TigerBAPrior src/domains/tiger/TigerPriors.cpp:14-43;
+ *      FactoredTigerFlatPrior src/domains/tiger/FactoredTigerPriors.cpp:18-88;
+ *      layout BAFlatModel: phi[s*A*S + a*S + s'], psi[a*S*O + s'*O + o] (utils/index.cpp:13-16) */
+static int build_tabular_prior(orc_ctx* c)
+{
+    int S = c->S, A = c->A, O = c->O, i, s, ns;
+    float noise = c->cfg.noise, total = c->cfg.counts_total;
+    float acc   = (.85f - noise) * total;
+    float inacc = (.15f + noise) * total;
+    float* phi;
+    float* psi;
+    c->phi_len = S * A * S;
+    c->ncnt    = S * A * S + A * S * O;
+    c->prior   = (float*)malloc(sizeof(float) * (size_t)c->ncnt);
+    phi        = c->prior;
+    psi        = c->prior + c->phi_len;
+    if (noise <= -.15 || noise > .3) {
+        snprintf(c->err, sizeof c->err, "noise has to be between -.15 and .3");
+        return -1;
+    }
+    for (i = 0; i < c->ncnt; ++i) c->prior[i] = 5000;
+    if (is_tiger(c->cfg.domain)) {
+        phi[1 * A * S + 2 * S + 0] = 0; /* count(right, listen, left)  = 0 */
+        phi[0 * A * S + 2 * S + 1] = 0; /* count(left,  listen, right) = 0 */
+        psi[2 * S * O + 1 * O + 1] = acc;   /* listen, right, hear right */
+        psi[2 * S * O + 1 * O + 0] = inacc; /* listen, right, hear left  */
+        psi[2 * S * O + 0 * O + 1] = inacc; /* listen, left,  hear right */
+        psi[2 * S * O + 0 * O + 0] = acc;   /* listen, left,  hear left  */
+        return 0;
+    }
+    if (is_ftiger(c->cfg.domain)) {
+        for (s = 0; s < S; ++s)
+            for (ns = 0; ns < S; ++ns)
+                if (s != ns) phi[s * A * S + 2 * S + ns] = 0;
+        for (s = 0; s < S; ++s) {
+            int left                       = s < S / 2;
+            psi[2 * S * O + s * O + (left ? 0 : 1)] = acc;
+            psi[2 * S * O + s * O + (left ? 1 : 0)] = inacc;
+        }
+        return 0;
+    }
+    snprintf(c->err, sizeof c->err, "domain %d has no tabular prior in the oracle", c->cfg.domain);
+    return -1;
+}
+
+/* ------------------------------------------------------------------ simulator.step */
+
+/* ref: BAPOMDP::step src/bayes-adaptive/models/table/BAPOMDP.cpp:111-143 with
+ *      BAFlatModel::sampleStateIndex/sampleObservationIndex/incrementCountsOf
+ *      src/bayes-adaptive/states/table/BAFlatModel.cpp:83-139 (expected-Dirichlet method) */
+static int ba_table_step(orc_ctx* c, simstate* st, int32_t a, int32_t* o, double* r, int update)
+{
+    int S = c->S, A = c->A, O = c->O;
+    float* phi = st->cnt;
+    float* psi = st->cnt + c->phi_len;
+    int32_t s  = st->s;
+    int32_t ns = orc_sample_expected_mult(&c->rng, &phi[s * A * S + a * S], S);
+    int t;
+    *o = orc_sample_expected_mult(&c->rng, &psi[a * S * O + ns * O], O);
+    t  = ext_terminal(c, s, a, ns);
+    *r = ext_reward(c, s, a, ns);
+    if (update) {
+        phi[s * A * S + a * S + ns] += 1;
+        psi[a * S * O + ns * O + *o] += 1;
+    }
+    st->s = ns;
+    return t;
+}
+
+static int sim_step(orc_ctx* c, simstate* st, int32_t a, int32_t* o, double* r, int update)
+{
+    (*c->step_counter)++;
+    switch (c->cfg.model) {
+        case ORC_MODEL_POMDP: return domain_step(c, &st->s, a, o, r);
+        case ORC_MODEL_BA_TABLE: return ba_table_step(c, st, a, o, r, update);
+        default: return 1;
+    }
+}
+
+/* POMDP::computeObservationProbability for the simulator in use.
+ * ref: BAPOMDP.cpp:93-99 -> BAFlatModel::computeObservationProbability BAFlatModel.cpp:106-124
+ *      (expectedMult()[o]: float sum, float division) */
+static double sim_obs_prob(orc_ctx* c, const simstate* st, int32_t a, int32_t o)
+{
+    if (c->cfg.model == ORC_MODEL_POMDP) return domain_obs_prob(c, o, a, st->s);
+    if (c->cfg.model == ORC_MODEL_BA_TABLE) {
+        float tmp[64];
+        const float* row = st->cnt + c->phi_len + a * c->S * c->O + st->s * c->O;
+        if (c->O == 1) return 1;
+        if (c->O <= 64) {
+            orc_expected_mult(row, c->O, tmp);
+            return tmp[o];
+        } else {
+            float sum = row[0];
+            int i;
+            for (i = 1; i < c->O; ++i) sum += row[i];
+            if (sum <= 1e-300) return 0;
+            return row[o] / sum;
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ tree */
+
+static int tree_alloc(orc_ctx* c)
+{
+    tree* t       = &c->tr;
+    size_t mn     = (size_t)c->cfg.sims + 2;
+    size_t A      = (size_t)c->A;
+    t->max_nodes  = (int32_t)mn;
+    t->visits     = (int32_t*)malloc(mn * sizeof(int32_t));
+    t->cn         = (int32_t*)malloc(mn * A * sizeof(int32_t));
+    t->cq         = (double*)malloc(mn * A * sizeof(double));
+    if ((size_t)c->A * c->O <= 64) {
+        t->child = (int32_t*)malloc(mn * A * c->O * sizeof(int32_t));
+        t->hkey  = NULL;
+        t->hval  = NULL;
+    } else {
+        uint64_t cap = 1;
+        while (cap < 4 * mn) cap <<= 1;
+        t->child = NULL;
+        t->hkey  = (uint64_t*)malloc(cap * sizeof(uint64_t));
+        t->hval  = (int32_t*)malloc(cap * sizeof(int32_t));
+        t->hmask = cap - 1;
+    }
+    return 0;
+}
+
+static void tree_reset(orc_ctx* c)
+{
+    tree* t   = &c->tr;
+    t->n_nodes = 0;
+    t->tree_depth = 0;
+    if (t->hkey) memset(t->hkey, 0, (t->hmask + 1) * sizeof(uint64_t));
+}
+
+/* ref: POUCT::createActionNode POUCT.cpp:305-315 + ActionNode ctor MCTSTreeNodes.cpp:52-57 */
+static int32_t tree_new_node(orc_ctx* c)
+{
+    tree* t   = &c->tr;
+    int32_t n = t->n_nodes++;
+    int a;
+    t->visits[n] = 0;
+    for (a = 0; a < c->A; ++a) {
+        t->cn[n * c->A + a] = 0;
+        t->cq[n * c->A + a] = 0;
+    }
+    if (t->child) {
+        int k, m = c->A * c->O;
+        for (k = 0; k < m; ++k) t->child[(size_t)n * m + k] = -1;
+    }
+    return n;
+}
+
+static int32_t tree_get_child(orc_ctx* c, int32_t node, int32_t a, int32_t o)
+{
+    tree* t = &c->tr;
+    if (t->child) return t->child[((size_t)node * c->A + a) * c->O + o];
+    {
+        uint64_t key = ((uint64_t)node * c->A + a) * c->O + o + 1;
+        uint64_t h   = mix64(key) & t->hmask;
+        while (t->hkey[h]) {
+            if (t->hkey[h] == key) return t->hval[h];
+            h = (h + 1) & t->hmask;
+        }
+        return -1;
+    }
+}
+
+static void tree_set_child(orc_ctx* c, int32_t node, int32_t a, int32_t o, int32_t ch)
+{
+    tree* t = &c->tr;
+    if (t->child) {
+        t->child[((size_t)node * c->A + a) * c->O + o] = ch;
+        return;
+    }
+    {
+        uint64_t key = ((uint64_t)node * c->A + a) * c->O + o + 1;
+        uint64_t h   = mix64(key) & t->hmask;
+        while (t->hkey[h]) h = (h + 1) & t->hmask;
+        t->hkey[h] = key;
+        t->hval[h] = ch;
+    }
+}
+
+/* ref: POUCT::UCB/initiateUCBTable POUCT.cpp:131-136,330-338: table[m][n] = u*sqrt(log1p(m)/n),
+ *      table[m][0] = DBL_MAX.  Evaluated on the fly (value-identical to the table entry). */
+static double ucb(const orc_ctx* c, int m, int n)
+{
+    if (n == 0) return DBL_MAX;
+    return c->cfg.exploration * sqrt(c->log1p_tab[m] / n);
+}
+
+/* ref: POUCT::selectChanceNodeUCB POUCT.cpp:138-181 (= RBAPOUCT.cpp:162-205).
+ * Always draws one slowRandomInt for the tie-break, even with a single candidate. */
+static int32_t select_chance_ucb(orc_ctx* c, int32_t node, int explore)
+{
+    int32_t best[ORC_MAX_ACTIONS];
+    int nbest     = 0, a;
+    double best_q = -DBL_MAX;
+    int m         = c->tr.visits[node];
+    for (a = 0; a < c->A; ++a) {
+        double q = c->tr.cq[node * c->A + a];
+        if (explore) q += ucb(c, m, c->tr.cn[node * c->A + a]);
+        if (q >= best_q) {
+            if (q > best_q) nbest = 0;
+            best_q        = q;
+            best[nbest++] = a;
+        }
+    }
+    return best[orc_slow_int(&c->rng, 0, nbest)];
+}
+
+/* ref: POUCT::rollout POUCT.cpp:273-303 (= RBAPOUCT.cpp:295-323) */
+static double rollout(orc_ctx* c, simstate* st, int depth_to_go)
+{
+    double ret = 0, disc = 1, r = 0;
+    int term = 0;
+    int32_t o;
+    while (depth_to_go > 0 && !term) {
+        int32_t a = domain_random_action(c, st->s);
+        term      = sim_step(c, st, a, &o, &r, 0);
+        ret += r * disc;
+        disc *= c->gamma;
+        depth_to_go--;
+    }
+    return ret;
+}
+
+static double traverse_action(orc_ctx* c, int32_t node, simstate* st, int depth_to_go);
+
+/* ref: POUCT::traverseChanceNode POUCT.cpp:210-257 (= RBAPOUCT.cpp:233-277) */
+static double traverse_chance(orc_ctx* c, int32_t node, int32_t a, simstate* st, int depth_to_go)
+{
+    int32_t o;
+    double r = 0, delayed = 0, ret;
+    int term = sim_step(c, st, a, &o, &r, 0);
+    if (!term) {
+        int32_t ch = tree_get_child(c, node, a, o);
+        if (ch >= 0) {
+            delayed = traverse_action(c, ch, st, depth_to_go - 1);
+        } else {
+            ch = tree_new_node(c);
+            tree_set_child(c, node, a, o, ch);
+            delayed = rollout(c, st, depth_to_go - 1);
+        }
+    }
+    ret = r + c->gamma * delayed;
+    /* ChanceNode::addVisit MCTSTreeNodes.cpp:8-12 */
+    c->tr.cn[node * c->A + a]++;
+    c->tr.cq[node * c->A + a] += (ret - c->tr.cq[node * c->A + a]) / c->tr.cn[node * c->A + a];
+    return ret;
+}
+
+/* ref: POUCT::traverseActionNode POUCT.cpp:183-208 (= RBAPOUCT.cpp:207-231) */
+static double traverse_action(orc_ctx* c, int32_t node, simstate* st, int depth_to_go)
+{
+    int32_t a;
+    double ret;
+    int d = c->tr.max_tree_depth - depth_to_go;
+    if (d > c->tr.tree_depth) c->tr.tree_depth = d;
+    if (depth_to_go == 0) return 0;
+    a   = select_chance_ucb(c, node, 1);
+    ret = traverse_chance(c, node, a, st, depth_to_go);
+    c->tr.visits[node]++; /* ActionNode::addVisit, after the recursion */
+    return ret;
+}
+
+/* ------------------------------------------------------------------ filters */
+
+/* Canonical summation order of the HIP engine (DESIGN.md "device-order sums"):
+ * groups of 4 consecutive elements summed sequentially per lane, a 64-lane Kogge-Stone
+ * inclusive scan across the lane sums of one 256-element chunk, chunks chained sequentially.
+ * Writes the inclusive prefix sums; returns the total. */
+static double dev_scan(const double* w, int n, double* incl)
+{
+    double carry = 0;
+    int base;
+    for (base = 0; base < n; base += 256) {
+        double lane[64], pre[64];
+        int l, k, d;
+        for (l = 0; l < 64; ++l) {
+            double s = 0;
+            for (k = 0; k < 4; ++k) {
+                int i = base + 4 * l + k;
+                s     = (k == 0) ? ((i < n) ? w[i] : 0.0) : s + ((i < n) ? w[i] : 0.0);
+            }
+            lane[l] = s;
+        }
+        for (d = 1; d < 64; d <<= 1) { /* Kogge-Stone inclusive */
+            for (l = 0; l < 64; ++l) pre[l] = (l >= d) ? lane[l] + lane[l - d] : lane[l];
+            memcpy(lane, pre, sizeof lane);
+        }
+        for (l = 0; l < 64; ++l) {
+            double excl = (l > 0) ? lane[l - 1] : 0.0;
+            double run  = carry + excl;
+            for (k = 0; k < 4; ++k) {
+                int i = base + 4 * l + k;
+                if (i < n) {
+                    run += w[i];
+                    if (incl) incl[i] = run;
+                }
+            }
+        }
+        carry = carry + lane[63];
+    }
+    return carry;
+}
+
+/* FlatFilter::sample.  ref: src/beliefs/particle_filters/FlatFilter.cpp:97-102 */
+static int32_t flat_sample(orc_ctx* c) { return orc_int(&c->rng, c->cfg.particles); }
+
+/* WeightedFilter::sample.  ref: src/beliefs/particle_filters/WeightedFilter.cpp:163-191
+ * (scan from the back, strict >, index 0 is the fall-through).
+ * DEV order: largest i >= 1 whose exclusive device-order prefix sum is < threshold, else 0. */
+static int32_t weighted_sample(orc_ctx* c)
+{
+    int n            = c->cfg.particles;
+    double threshold = orc_u01(&c->rng) * c->total_w;
+    if (c->cfg.arith == ORC_ARITH_REF) {
+        int32_t sample   = n - 1;
+        double remaining = c->total_w;
+        for (; sample > 0; --sample) {
+            remaining -= c->P[sample].w;
+            if (threshold > remaining) break;
+        }
+        return sample;
+    } else {
+        /* wscan[i] = inclusive prefix; exclusive prefix of i is wscan[i-1] */
+        int lo = 0, hi = n - 1; /* find largest i in [1,n-1] with wscan[i-1] < threshold */
+        while (lo < hi) {
+            int mid = (lo + hi + 1) >> 1;
+            if (c->wscan[mid - 1] < threshold) lo = mid; else hi = mid - 1;
+        }
+        return lo;
+    }
+}
+
+static void weighted_refresh_scan(orc_ctx* c)
+{
+    int i, n = c->cfg.particles;
+    if (c->cfg.arith != ORC_ARITH_DEV) return;
+    for (i = 0; i < n; ++i) c->wscratch[i] = c->P[i].w;
+    c->total_w = dev_scan(c->wscratch, n, c->wscan);
+}
+
+static int32_t belief_sample(orc_ctx* c)
+{
+    return c->cfg.belief == ORC_BELIEF_REJECTION ? flat_sample(c) : weighted_sample(c);
+}
+
+static void swap_pools(orc_ctx* c)
+{
+    particle* p = c->P;
+    float* q    = c->pool;
+    c->P        = c->Pnew;
+    c->Pnew     = p;
+    c->pool     = c->pool_new;
+    c->pool_new = q;
+}
+
+/* simulator.sampleStartState() into slot i.
+ * ref: BAPOMDP::sampleStartState BAPOMDP.cpp:101-104 -> prior->sample(domain start state) */
+static void sample_start_into(orc_ctx* c, particle* p)
+{
+    p->s = domain_start(c);
+    if (c->cfg.model == ORC_MODEL_BA_TABLE) memcpy(p->cnt, c->prior, sizeof(float) * c->ncnt);
+}
+
+/* Belief::initiate.  ref: RejectionSampling.cpp:15-20 / BARejectionSampling (FlatFilter(n, alloc));
+ *                         ImportanceSampler.cpp:45-55 / BAImportanceSampling (add(start, 1/n)) */
+static void belief_initiate(orc_ctx* c)
+{
+    int i, n = c->cfg.particles;
+    double w = 1.0 / (double)n;
+    c->total_w = 0;
+    for (i = 0; i < n; ++i) {
+        orc_rng_stream(&c->rng, ORC_PH_INIT, (uint32_t)i);
+        sample_start_into(c, &c->P[i]);
+        c->P[i].w = w;
+        c->total_w += w; /* WeightedFilter::add(T, w) WeightedFilter.cpp:60-66 */
+    }
+    if (c->cfg.belief == ORC_BELIEF_IMPORTANCE) weighted_refresh_scan(c);
+}
+
+/* beliefs::rejectSample.  ref: src/beliefs/particle_filters/RejectionSampling.hpp:26-72 */
+static void reject_sample(orc_ctx* c, int32_t a, int32_t o)
+{
+    int n = c->cfg.particles, acc = 0, count = 0;
+    c->step_counter = &c->belief_steps;
+    while (acc < n) {
+        int32_t src, so;
+        double r;
+        simstate st;
+        particle* dst = &c->Pnew[acc];
+        orc_rng_stream(&c->rng, ORC_PH_REJECT, (uint32_t)count);
+        src  = flat_sample(c);
+        st.s = c->P[src].s;
+        st.cnt = dst->cnt;
+        if (c->ncnt) memcpy(dst->cnt, c->P[src].cnt, sizeof(float) * c->ncnt); /* copyState */
+        sim_step(c, &st, a, &so, &r, 1); /* BA: mode is UpdateCounts outside the planner */
+        if (so == o) {
+            dst->s = st.s;
+            dst->w = 0;
+            acc++;
+        }
+        count++;
+    }
+    c->last_update_count = count;
+    swap_pools(c);
+}
+
+/* importance_sampling::update + resample.
+ * ref: src/beliefs/particle_filters/ImportanceSampler.hpp:31-62, 71-94;
+ *      WeightedFilter::normalize WeightedFilter.cpp:130-143 */
+static void importance_update(orc_ctx* c, int32_t a, int32_t o)
+{
+    int i, n = c->cfg.particles;
+    double total = 0, accw = 0, w1 = 1.0 / (double)n;
+    c->step_counter = &c->belief_steps;
+    for (i = 0; i < n; ++i) {
+        int32_t so;
+        double r;
+        simstate st;
+        orc_rng_stream(&c->rng, ORC_PH_IS_UPDATE, (uint32_t)i);
+        st.s   = c->P[i].s;
+        st.cnt = c->P[i].cnt;
+        sim_step(c, &st, a, &so, &r, 1);
+        c->P[i].s = st.s;
+        c->P[i].w *= sim_obs_prob(c, &st, a, o);
+        total += c->P[i].w;
+    }
+    if (c->cfg.arith == ORC_ARITH_DEV) {
+        for (i = 0; i < n; ++i) c->wscratch[i] = c->P[i].w;
+        total = dev_scan(c->wscratch, n, NULL);
+    }
+    c->last_weight_total = total;
+    for (i = 0; i < n; ++i) {
+        c->P[i].w /= total;
+        accw += c->P[i].w;
+    }
+    c->total_w = accw;
+    weighted_refresh_scan(c);
+    /* resample */
+    {
+        double new_total = 0;
+        for (i = 0; i < n; ++i) {
+            int32_t src;
+            orc_rng_stream(&c->rng, ORC_PH_RESAMPLE, (uint32_t)i);
+            src          = weighted_sample(c);
+            c->Pnew[i].s = c->P[src].s;
+            c->Pnew[i].w = w1;
+            if (c->ncnt) memcpy(c->Pnew[i].cnt, c->P[src].cnt, sizeof(float) * c->ncnt);
+            new_total += w1;
+        }
+        swap_pools(c);
+        c->total_w = new_total;
+        weighted_refresh_scan(c);
+    }
+    c->last_update_count = -1;
+}
+
+static void belief_update(orc_ctx* c, int32_t a, int32_t o)
+{
+    c->last_weight_total = 0;
+    if (c->cfg.belief == ORC_BELIEF_REJECTION) reject_sample(c, a, o);
+    else importance_update(c, a, o);
+}
+
+/* BABelief::resetDomainStateDistribution.
+ * ref: BARejectionSampling.cpp:49-60 (reset every particle in order);
+ *      BAImportanceSampling.cpp:90-111 (resample n copies, reset each, weight 1/n) */
+static void belief_reset_domain_state(orc_ctx* c)
+{
+    int i, n = c->cfg.particles;
+    if (c->cfg.belief == ORC_BELIEF_REJECTION) {
+        for (i = 0; i < n; ++i) {
+            orc_rng_stream(&c->rng, ORC_PH_RESET, (uint32_t)i);
+            c->P[i].s = domain_start(c);
+        }
+    } else {
+        double w1 = 1.0 / (double)n, new_total = 0;
+        for (i = 0; i < n; ++i) {
+            int32_t src;
+            orc_rng_stream(&c->rng, ORC_PH_RESET, (uint32_t)i);
+            src = weighted_sample(c);
+            if (c->ncnt) memcpy(c->Pnew[i].cnt, c->P[src].cnt, sizeof(float) * c->ncnt);
+            c->Pnew[i].s = domain_start(c);
+            c->Pnew[i].w = w1;
+            new_total += w1;
+        }
+        swap_pools(c);
+        c->total_w = new_total;
+        weighted_refresh_scan(c);
+    }
+}
+
+static uint64_t belief_hash(orc_ctx* c)
+{
+    uint64_t h = 0;
+    int i, n = c->cfg.particles;
+    int weighted = c->cfg.belief == ORC_BELIEF_IMPORTANCE;
+    for (i = 0; i < n; ++i)
+        h += particle_hash((uint64_t)i, c->P[i].s, weighted ? c->P[i].w : 0.0, c->P[i].cnt,
+                           c->ncnt);
+    return h;
+}
+
+/* ------------------------------------------------------------------ planner */
+
+/* ref: POUCT::selectAction POUCT.cpp:63-129; RBAPOUCT::selectAction RBAPOUCT.cpp:67-153
+ * (root particle borrowed by pointer, counts read-only: StepType::KeepCounts) */
+static int32_t select_action(orc_ctx* c, int hist_len, orc_trace_rec* rec)
+{
+    int i, n = c->cfg.sims, a;
+    int32_t root, best;
+    c->step_counter = &c->sim_steps;
+    tree_reset(c);
+    /* simulator.addLegalActions(belief.sample(), ...) : one belief draw, result unused here
+     * because every supported domain has state-independent legal actions */
+    orc_rng_stream(&c->rng, ORC_PH_SEARCH, (uint32_t)n);
+    (void)belief_sample(c);
+    root = tree_new_node(c);
+    {
+        int d = c->cfg.horizon - hist_len;
+        c->tr.max_tree_depth = d < c->cfg.max_depth ? d : c->cfg.max_depth;
+    }
+    for (i = 0; i < n; ++i) {
+        simstate st;
+        int32_t src;
+        orc_rng_stream(&c->rng, ORC_PH_SEARCH, (uint32_t)i);
+        src    = belief_sample(c);
+        st.s   = c->P[src].s;
+        st.cnt = c->P[src].cnt;
+        traverse_action(c, root, &st, c->tr.max_tree_depth);
+    }
+    orc_rng_stream(&c->rng, ORC_PH_SEARCH, (uint32_t)n + 1);
+    best = select_chance_ucb(c, root, 0);
+    if (rec) {
+        rec->n_nodes    = c->tr.n_nodes;
+        rec->tree_depth = c->tr.tree_depth;
+        for (a = 0; a < c->A && a < ORC_MAX_ACTIONS; ++a) {
+            rec->root_n[a] = c->tr.cn[root * c->A + a];
+            rec->root_q[a] = c->tr.cq[root * c->A + a];
+        }
+    }
+    return best;
+}
+
+/* ------------------------------------------------------------------ episode / experiments */
+
+static orc_trace_rec* trace_push(orc_ctx* c)
+{
+    if (!c->cfg.trace) return NULL;
+    if (c->n_trace == c->cap_trace) {
+        c->cap_trace = c->cap_trace ? 2 * c->cap_trace : 1024;
+        c->trace     = (orc_trace_rec*)realloc(c->trace, sizeof(orc_trace_rec) * c->cap_trace);
+    }
+    memset(&c->trace[c->n_trace], 0, sizeof(orc_trace_rec));
+    return &c->trace[c->n_trace++];
+}
+
+/* ref: episode::run src/experiments/Episode.cpp:16-64 */
+static double episode_run(orc_ctx* c, int run, int episode, int* length)
+{
+    double ret = 0, disc = 1, r = 0;
+    int term = 0, t;
+    int32_t s, o = 0;
+    uint32_t R = (uint32_t)(run + c->cfg.run_offset);
+    orc_rng_episode(&c->rng, R, (uint32_t)episode, 0);
+    orc_rng_stream(&c->rng, ORC_PH_START, 0);
+    s = domain_start(c);
+    for (t = 0; t < c->cfg.horizon && !term; ++t) {
+        orc_trace_rec* rec = trace_push(c);
+        int32_t a;
+        orc_rng_episode(&c->rng, R, (uint32_t)episode, (uint32_t)t);
+        a = select_action(c, t, rec);
+        orc_rng_stream(&c->rng, ORC_PH_ENV, 0);
+        term = domain_step(c, &s, a, &o, &r);
+        c->env_steps++;
+        c->last_update_count = -1;
+        c->last_weight_total = 0;
+        if (!term) belief_update(c, a, o);
+        if (rec) {
+            rec->run = run + c->cfg.run_offset; rec->episode = episode; rec->t = t;
+            rec->action = a; rec->state = s; rec->obs = o; rec->terminal = term;
+            rec->reward = r;
+            rec->update_count = term ? -1 : c->last_update_count;
+            rec->weight_total = c->last_weight_total;
+            rec->belief_hash  = belief_hash(c);
+        }
+        ret += r * disc;
+        disc *= c->cfg.discount;
+    }
+    *length = t;
+    return ret;
+}
+
+static double now_sec(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void fill_result(orc_ctx* c, orc_result* res, double t0)
+{
+    if (!res) return;
+    res->sim_steps    = c->sim_steps;
+    res->belief_steps = c->belief_steps;
+    res->env_steps    = c->env_steps;
+    res->seconds      = now_sec() - t0;
+    res->n_trace      = c->n_trace;
+}
+
+/* ref: experiment::planning::run src/experiments/PlanningExperiment.cpp:27-55 */
+int orc_run_planning(orc_ctx* c, orc_stat* stats, orc_result* res)
+{
+    int run, len;
+    double t0 = now_sec();
+    if (c->cfg.model != ORC_MODEL_POMDP) {
+        snprintf(c->err, sizeof c->err, "planning::run needs model = POMDP");
+        return -1;
+    }
+    memset(stats, 0, sizeof(*stats));
+    for (run = 0; run < c->cfg.runs; ++run) {
+        orc_rng_episode(&c->rng, (uint32_t)(run + c->cfg.run_offset), 0, 0);
+        belief_initiate(c);
+        orc_stat_add(stats, episode_run(c, run, 0, &len));
+    }
+    fill_result(c, res, t0);
+    return 0;
+}
+
+/* ref: experiment::bapomdp::run src/experiments/BAPOMDPExperiment.cpp:32-78 */
+int orc_run_bapomdp(orc_ctx* c, orc_stat* stats, orc_result* res)
+{
+    int run, ep, len;
+    double t0 = now_sec();
+    if (c->cfg.model == ORC_MODEL_POMDP) {
+        snprintf(c->err, sizeof c->err, "bapomdp::run needs a Bayes-adaptive model");
+        return -1;
+    }
+    memset(stats, 0, sizeof(*stats) * (size_t)c->cfg.episodes);
+    for (run = 0; run < c->cfg.runs; ++run) {
+        uint32_t R = (uint32_t)(run + c->cfg.run_offset);
+        orc_rng_episode(&c->rng, R, 0, 0);
+        belief_initiate(c);
+        for (ep = 0; ep < c->cfg.episodes; ++ep) {
+            orc_rng_episode(&c->rng, R, (uint32_t)ep, 0);
+            belief_reset_domain_state(c);
+            orc_stat_add(&stats[ep], episode_run(c, run, ep, &len));
+        }
+    }
+    fill_result(c, res, t0);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ lifecycle */
+
+orc_ctx* orc_create(const orc_config* cfg)
+{
+    orc_ctx* c = (orc_ctx*)calloc(1, sizeof(orc_ctx));
+    int i, n;
+    c->cfg = *cfg;
+    if (c->cfg.max_depth < 0) c->cfg.max_depth = c->cfg.horizon; /* ArgumentParser.cpp:37-40 */
+    if (cfg->rng_mode == ORC_RNG_MT) {
+        if (cfg->seed_str[0]) orc_rng_init_mt_str(&c->rng, cfg->seed_str, strlen(cfg->seed_str));
+        else orc_rng_init_mt_u32(&c->rng, (uint32_t)time(NULL)); /* rnd::initiate() */
+    } else {
+        orc_rng_init_philox(&c->rng, cfg->philox_seed);
+    }
+    c->gamma = cfg->discount;
+    switch (cfg->domain) {
+        case ORC_DOM_TIGER_EPISODIC:
+        case ORC_DOM_TIGER_CONTINUOUS: c->S = 2; c->A = 3; c->O = 2; break;
+        case ORC_DOM_FTIGER_EPISODIC:
+        case ORC_DOM_FTIGER_CONTINUOUS:
+            if (cfg->size < 1) {
+                snprintf(c->err, sizeof c->err, "cannot initiate FactoredTiger with %d irrelevant features", cfg->size);
+                return c;
+            }
+            c->tiger_K = cfg->size; c->S = 2 << cfg->size; c->A = 3; c->O = 2;
+            break;
+        default:
+            snprintf(c->err, sizeof c->err, "domain %d not supported by the oracle", cfg->domain);
+            return c;
+    }
+    if (cfg->sims < 1) { snprintf(c->err, sizeof c->err, "cannot initiate POUCT with %d simulations, must be greater than 0", cfg->sims); return c; }
+    if (c->cfg.max_depth < 0) { snprintf(c->err, sizeof c->err, "max depth must be >= 0"); return c; }
+    if (cfg->horizon <= 0) { snprintf(c->err, sizeof c->err, "cannot initiate POUCT with %d horizon, must be greater than 0", cfg->horizon); return c; }
+    if (cfg->particles < 1) { snprintf(c->err, sizeof c->err, "cannot initiate belief with n = %d", cfg->particles); return c; }
+    if (cfg->model == ORC_MODEL_BA_TABLE) {
+        if (build_tabular_prior(c)) return c;
+    } else if (cfg->model != ORC_MODEL_POMDP) {
+        snprintf(c->err, sizeof c->err, "model %d not supported by the oracle", cfg->model);
+        return c;
+    }
+    c->log1p_tab = (double*)malloc(sizeof(double) * (size_t)(cfg->sims + 1));
+    for (i = 0; i <= cfg->sims; ++i) c->log1p_tab[i] = log1p((double)i);
+    tree_alloc(c);
+    n        = cfg->particles;
+    c->P     = (particle*)calloc((size_t)n, sizeof(particle));
+    c->Pnew  = (particle*)calloc((size_t)n, sizeof(particle));
+    c->wscratch = (double*)malloc(sizeof(double) * (size_t)n);
+    c->wscan    = (double*)malloc(sizeof(double) * (size_t)n);
+    if (c->ncnt) {
+        c->pool     = (float*)malloc(sizeof(float) * (size_t)n * c->ncnt);
+        c->pool_new = (float*)malloc(sizeof(float) * (size_t)n * c->ncnt);
+        for (i = 0; i < n; ++i) {
+            c->P[i].cnt    = c->pool + (size_t)i * c->ncnt;
+            c->Pnew[i].cnt = c->pool_new + (size_t)i * c->ncnt;
+        }
+    }
+    c->step_counter = &c->sim_steps;
+    return c;
+}
+
+void orc_destroy(orc_ctx* c)
+{
+    if (!c) return;
+    free(c->prior); free(c->log1p_tab);
+    free(c->tr.visits); free(c->tr.cn); free(c->tr.cq); free(c->tr.child);
+    free(c->tr.hkey); free(c->tr.hval);
+    free(c->P); free(c->Pnew); free(c->pool); free(c->pool_new);
+    free(c->wscratch); free(c->wscan); free(c->trace);
+    free(c);
+}
+
+const char* orc_error(const orc_ctx* c) { return c->err[0] ? c->err : NULL; }
+const orc_trace_rec* orc_trace(const orc_ctx* c) { return c->trace; }
+orc_rng* orc_ctx_rng(orc_ctx* c) { return &c->rng; }
+
+int orc_domain_sizes(const orc_ctx* c, int32_t* S, int32_t* A, int32_t* O)
+{
+    *S = c->S; *A = c->A; *O = c->O;
+    return 0;
+}
+int orc_counts_len(const orc_ctx* c) { return c->ncnt; }
+int orc_prior_counts(orc_ctx* c, float* out)
+{
+    if (!c->prior) return -1;
+    memcpy(out, c->prior, sizeof(float) * (size_t)c->ncnt);
+    return 0;
+}
+
+int orc_env_step(orc_ctx* c, int32_t* s, int32_t a, int32_t* o, double* r)
+{
+    return domain_step(c, s, a, o, r);
+}
+int orc_env_start(orc_ctx* c) { return domain_start(c); }
+int orc_random_action(orc_ctx* c, int32_t s) { return domain_random_action(c, s); }

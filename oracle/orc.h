@@ -1,0 +1,135 @@
+/*
+ * oracle/orc.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C) of the BA-POMCP hot path of samkatt/fba-pomdp:
+ * domains, Bayes-adaptive count models, POUCT / RBAPOUCT tree search, rejection- and
+ * importance-sampling particle filters, and the episode / experiment loops that call them.
+ * Every function in orc.c cites the reference file:line it restates.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this library,
+ * and only as the checker / reported baseline.  The product path (fba_pomdp_amd/) must never
+ * link, import or call it.
+ *
+ * Pinning status: see oracle/README.md.
+ */
+#ifndef ORC_H
+#define ORC_H
+
+#include <stdint.h>
+
+#include "orc_rng.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* domains (reference src/domains) */
+enum {
+    ORC_DOM_TIGER_EPISODIC    = 0,
+    ORC_DOM_TIGER_CONTINUOUS  = 1,
+    ORC_DOM_FTIGER_EPISODIC   = 2,
+    ORC_DOM_FTIGER_CONTINUOUS = 3,
+    ORC_DOM_GRIDWORLD         = 4,
+    ORC_DOM_COLLISION_AVOID   = 5
+};
+/* simulator model */
+enum { ORC_MODEL_POMDP = 0, ORC_MODEL_BA_TABLE = 1, ORC_MODEL_BA_FACTORED = 2 };
+/* belief */
+enum { ORC_BELIEF_REJECTION = 0, ORC_BELIEF_IMPORTANCE = 1 };
+/* floating-point summation order of the importance-sampling filter:
+ * REF = the reference's sequential loops; DEV = the HIP engine's fixed reduction tree */
+enum { ORC_ARITH_REF = 0, ORC_ARITH_DEV = 1 };
+/* FBA structure prior (reference FBAConf::structure_prior) */
+enum { ORC_SP_NONE = 0, ORC_SP_UNIFORM = 1, ORC_SP_MATCH_UNIFORM = 2, ORC_SP_FULLY_CONNECTED = 3 };
+
+#define ORC_MAX_ACTIONS 16
+
+typedef struct orc_config {
+    int32_t domain;
+    int32_t size;   /* --size   */
+    int32_t width;  /* --width  */
+    int32_t height; /* --height */
+    int32_t model;
+    int32_t belief;
+    int32_t particles;     /* --particle-amount */
+    int32_t sims;          /* -s   */
+    int32_t max_depth;     /* --mcts-max-depth; < 0 => horizon (ArgumentParser.cpp:37-40) */
+    int32_t horizon;       /* -H   */
+    double exploration;    /* -u   */
+    double discount;       /* -d   */
+    int32_t runs;          /* --runs */
+    int32_t episodes;      /* --episodes (BA only) */
+    float noise;           /* --noise */
+    float counts_total;    /* -C */
+    int32_t structure_prior;
+    int32_t rng_mode;      /* ORC_RNG_MT | ORC_RNG_PHILOX */
+    int32_t arith;         /* ORC_ARITH_REF | ORC_ARITH_DEV */
+    uint64_t philox_seed;
+    char seed_str[64];     /* --seed (MT mode) */
+    int32_t run_offset;    /* first run index (Philox streams; episode sharding) */
+    int32_t trace;         /* 1 = record orc_trace_rec per real step */
+} orc_config;
+
+/* One record per real time-step; the HIP engine emits the same layout (fba_trace_rec). */
+typedef struct orc_trace_rec {
+    int32_t run, episode, t;
+    int32_t action, state, obs; /* env s' and o after the step */
+    int32_t terminal;
+    int32_t n_nodes, tree_depth; /* POUCT.cpp:95-100 */
+    int32_t update_count;        /* rejection attempts (RejectionSampling.hpp:68); -1 if no update */
+    int32_t root_n[ORC_MAX_ACTIONS];
+    double root_q[ORC_MAX_ACTIONS];
+    double reward;
+    double weight_total;   /* IS: total weight before normalisation; 0 otherwise */
+    uint64_t belief_hash;  /* position-sensitive hash of the particle set after the update */
+} orc_trace_rec;
+
+typedef struct orc_stat { /* utils::Statistic, src/utils/Statistic.cpp:5-46 */
+    double count, mean, m2;
+} orc_stat;
+
+typedef struct orc_result {
+    uint64_t sim_steps;    /* simulator.step calls made by the planner (tree + rollout) */
+    uint64_t belief_steps; /* simulator.step calls made by the belief update */
+    uint64_t env_steps;
+    double seconds;
+    int32_t n_trace;
+} orc_result;
+
+typedef struct orc_ctx orc_ctx;
+
+orc_ctx* orc_create(const orc_config* cfg);
+void orc_destroy(orc_ctx* c);
+const char* orc_error(const orc_ctx* c);
+
+/* experiment::planning::run (PlanningExperiment.cpp:27-55): stats[1] */
+int orc_run_planning(orc_ctx* c, orc_stat* stats, orc_result* res);
+/* experiment::bapomdp::run (BAPOMDPExperiment.cpp:32-78): stats[episodes] */
+int orc_run_bapomdp(orc_ctx* c, orc_stat* stats, orc_result* res);
+
+const orc_trace_rec* orc_trace(const orc_ctx* c);
+
+/* model introspection (prior tables), for fixtures and for feeding fba_set_model_* */
+int orc_domain_sizes(const orc_ctx* c, int32_t* S, int32_t* A, int32_t* O);
+int orc_counts_len(const orc_ctx* c);
+/* draws one prior particle's count blob with the ctx RNG positioned by the caller */
+int orc_prior_counts(orc_ctx* c, float* out);
+
+/* stand-alone pieces for unit tests */
+double orc_stat_var(const orc_stat* s);
+double orc_stat_stder(const orc_stat* s);
+void orc_stat_add(orc_stat* s, double v);
+int orc_sample_from_mult_f(orc_rng* g, const float* row, int n, double total);
+int orc_sample_expected_mult(orc_rng* g, const float* row, int n);
+void orc_expected_mult(const float* row, int n, float* out);
+orc_rng* orc_ctx_rng(orc_ctx* c);
+
+/* tiger true-environment step exposed for golden-vector tests; returns terminal */
+int orc_env_step(orc_ctx* c, int32_t* s, int32_t a, int32_t* o, double* r);
+int orc_env_start(orc_ctx* c);
+int orc_random_action(orc_ctx* c, int32_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
