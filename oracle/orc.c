@@ -656,13 +656,13 @@ static void reject_sample(orc_ctx* c, int32_t a, int32_t o)
     swap_pools(c);
 }
 
-/* importance_sampling::update + resample.
- * ref: src/beliefs/particle_filters/ImportanceSampler.hpp:31-62, 71-94;
+/* importance_sampling::update.
+ * ref: src/beliefs/particle_filters/ImportanceSampler.hpp:31-62;
  *      WeightedFilter::normalize WeightedFilter.cpp:130-143 */
-static void importance_update(orc_ctx* c, int32_t a, int32_t o)
+static double is_update(orc_ctx* c, int32_t a, int32_t o)
 {
     int i, n = c->cfg.particles;
-    double total = 0, accw = 0, w1 = 1.0 / (double)n;
+    double total = 0, accw = 0;
     c->step_counter = &c->belief_steps;
     for (i = 0; i < n; ++i) {
         int32_t so;
@@ -686,23 +686,29 @@ static void importance_update(orc_ctx* c, int32_t a, int32_t o)
         accw += c->P[i].w;
     }
     c->total_w = accw;
-    weighted_refresh_scan(c);
-    /* resample */
-    {
-        double new_total = 0;
-        for (i = 0; i < n; ++i) {
-            int32_t src;
-            orc_rng_stream(&c->rng, ORC_PH_RESAMPLE, (uint32_t)i);
-            src          = weighted_sample(c);
-            c->Pnew[i].s = c->P[src].s;
-            c->Pnew[i].w = w1;
-            if (c->ncnt) memcpy(c->Pnew[i].cnt, c->P[src].cnt, sizeof(float) * c->ncnt);
-            new_total += w1;
-        }
-        swap_pools(c);
-        c->total_w = new_total;
-        weighted_refresh_scan(c);
+    weighted_refresh_scan(c); /* DEV: total and prefix sums in device order */
+    return total;
+}
+
+/* importance_sampling::resample.
+ * ref: src/beliefs/particle_filters/ImportanceSampler.hpp:71-94 (n multinomial draws through
+ *      WeightedFilter::sample, deep copies, weight 1/n; WeightedFilter::add accumulates total) */
+static void is_resample(orc_ctx* c)
+{
+    int i, n = c->cfg.particles;
+    double w1 = 1.0 / (double)n, new_total = 0;
+    for (i = 0; i < n; ++i) {
+        int32_t src;
+        orc_rng_stream(&c->rng, ORC_PH_RESAMPLE, (uint32_t)i);
+        src          = weighted_sample(c);
+        c->Pnew[i].s = c->P[src].s;
+        c->Pnew[i].w = w1;
+        if (c->ncnt) memcpy(c->Pnew[i].cnt, c->P[src].cnt, sizeof(float) * c->ncnt);
+        new_total += w1;
     }
+    swap_pools(c);
+    c->total_w = new_total;
+    weighted_refresh_scan(c);
     c->last_update_count = -1;
 }
 
@@ -710,7 +716,10 @@ static void belief_update(orc_ctx* c, int32_t a, int32_t o)
 {
     c->last_weight_total = 0;
     if (c->cfg.belief == ORC_BELIEF_REJECTION) reject_sample(c, a, o);
-    else importance_update(c, a, o);
+    else {
+        is_update(c, a, o);
+        is_resample(c);
+    }
 }
 
 /* BABelief::resetDomainStateDistribution.
@@ -761,6 +770,11 @@ static int32_t select_action(orc_ctx* c, int hist_len, orc_trace_rec* rec)
     int i, n = c->cfg.sims, a;
     int32_t root, best;
     c->step_counter = &c->sim_steps;
+    if (c->cfg.planner == ORC_PLANNER_RANDOM) {
+        /* ref: RandomPlanner::selectAction src/planners/random/RandomPlanner.cpp:14-24 */
+        orc_rng_stream(&c->rng, ORC_PH_SEARCH, (uint32_t)n);
+        return domain_random_action(c, c->P[belief_sample(c)].s);
+    }
     tree_reset(c);
     /* simulator.addLegalActions(belief.sample(), ...) : one belief draw, result unused here
      * because every supported domain has state-independent legal actions */
@@ -996,3 +1010,52 @@ int orc_env_step(orc_ctx* c, int32_t* s, int32_t a, int32_t* o, double* r)
 }
 int orc_env_start(orc_ctx* c) { return domain_start(c); }
 int orc_random_action(orc_ctx* c, int32_t s) { return domain_random_action(c, s); }
+
+/* ---- filter-level entry points for golden-vector tests ---- */
+void orc_belief_initiate(orc_ctx* c) { belief_initiate(c); }
+void orc_belief_update(orc_ctx* c, int32_t a, int32_t o) { belief_update(c, a, o); }
+double orc_is_update(orc_ctx* c, int32_t a, int32_t o) { return is_update(c, a, o); }
+void orc_is_resample(orc_ctx* c) { is_resample(c); }
+void orc_belief_reset_domain_state(orc_ctx* c) { belief_reset_domain_state(c); }
+int orc_select_action(orc_ctx* c, int hist_len, orc_trace_rec* rec) { return select_action(c, hist_len, rec); }
+uint64_t orc_belief_hash(orc_ctx* c) { return belief_hash(c); }
+int orc_last_update_count(const orc_ctx* c) { return c->last_update_count; }
+void orc_belief_get(const orc_ctx* c, int32_t* s, double* w, float* cnt)
+{
+    int i;
+    for (i = 0; i < c->cfg.particles; ++i) {
+        if (s) s[i] = c->P[i].s;
+        if (w) w[i] = c->P[i].w;
+        if (cnt && c->ncnt) memcpy(cnt + (size_t)i * c->ncnt, c->P[i].cnt, sizeof(float) * c->ncnt);
+    }
+}
+void orc_belief_set(orc_ctx* c, const int32_t* s, const double* w, const float* cnt)
+{
+    int i;
+    double tot = 0;
+    for (i = 0; i < c->cfg.particles; ++i) {
+        if (s) c->P[i].s = s[i];
+        if (w) c->P[i].w = w[i];
+        tot += c->P[i].w;
+        if (cnt && c->ncnt) memcpy(c->P[i].cnt, cnt + (size_t)i * c->ncnt, sizeof(float) * c->ncnt);
+    }
+    c->total_w = tot;
+    weighted_refresh_scan(c);
+}
+/* simulator.step / computeObservationProbability on a caller-owned count blob */
+int orc_model_step(orc_ctx* c, float* cnt, int32_t* s, int32_t a, int32_t* o, double* r, int update)
+{
+    simstate st;
+    int t;
+    st.s = *s; st.cnt = cnt;
+    t = sim_step(c, &st, a, o, r, update);
+    *s = st.s;
+    return t;
+}
+double orc_model_obs_prob(orc_ctx* c, const float* cnt, int32_t new_s, int32_t a, int32_t o)
+{
+    simstate st;
+    st.s = new_s; st.cnt = (float*)cnt;
+    return sim_obs_prob(c, &st, a, o);
+}
+double orc_dev_scan(const double* w, int n, double* incl) { return dev_scan(w, n, incl); }

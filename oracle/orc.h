@@ -39,6 +39,8 @@ enum { ORC_BELIEF_REJECTION = 0, ORC_BELIEF_IMPORTANCE = 1 };
 /* floating-point summation order of the importance-sampling filter:
  * REF = the reference's sequential loops; DEV = the HIP engine's fixed reduction tree */
 enum { ORC_ARITH_REF = 0, ORC_ARITH_DEV = 1 };
+/* planner (reference -P) */
+enum { ORC_PLANNER_POUCT = 0, ORC_PLANNER_RANDOM = 1 };
 /* FBA structure prior (reference FBAConf::structure_prior) */
 enum { ORC_SP_NONE = 0, ORC_SP_UNIFORM = 1, ORC_SP_MATCH_UNIFORM = 2, ORC_SP_FULLY_CONNECTED = 3 };
 
@@ -68,6 +70,7 @@ typedef struct orc_config {
     char seed_str[64];     /* --seed (MT mode) */
     int32_t run_offset;    /* first run index (Philox streams; episode sharding) */
     int32_t trace;         /* 1 = record orc_trace_rec per real step */
+    int32_t planner;       /* ORC_PLANNER_* */
 } orc_config;
 
 /* One record per real time-step; the HIP engine emits the same layout (fba_trace_rec). */
@@ -128,6 +131,21 @@ orc_rng* orc_ctx_rng(orc_ctx* c);
 int orc_env_step(orc_ctx* c, int32_t* s, int32_t a, int32_t* o, double* r);
 int orc_env_start(orc_ctx* c);
 int orc_random_action(orc_ctx* c, int32_t s);
+
+/* filter / planner level entry points (golden-vector and step-level parity tests) */
+void orc_belief_initiate(orc_ctx* c);
+void orc_belief_update(orc_ctx* c, int32_t a, int32_t o);
+double orc_is_update(orc_ctx* c, int32_t a, int32_t o);
+void orc_is_resample(orc_ctx* c);
+void orc_belief_reset_domain_state(orc_ctx* c);
+int orc_select_action(orc_ctx* c, int hist_len, orc_trace_rec* rec);
+uint64_t orc_belief_hash(orc_ctx* c);
+int orc_last_update_count(const orc_ctx* c);
+void orc_belief_get(const orc_ctx* c, int32_t* s, double* w, float* cnt);
+void orc_belief_set(orc_ctx* c, const int32_t* s, const double* w, const float* cnt);
+int orc_model_step(orc_ctx* c, float* cnt, int32_t* s, int32_t a, int32_t* o, double* r, int update);
+double orc_model_obs_prob(orc_ctx* c, const float* cnt, int32_t new_s, int32_t a, int32_t o);
+double orc_dev_scan(const double* w, int n, double* incl);
 
 #ifdef __cplusplus
 }

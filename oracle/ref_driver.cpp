@@ -1,0 +1,390 @@
+/*
+ * oracle/ref_driver.cpp -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Drives the REAL reference (the subset of /root/reference/src that compiles with g++ alone:
+ * no Boost, no stand-ins) and prints golden vectors as JSON.  Built by `make -C oracle ref`
+ * into oracle/_ref/ref_driver, only where /root/reference exists; its output is committed as
+ * tests/golden/ref_vectors.json by oracle/gen_golden.py.  Nothing here is reference source:
+ * it only #includes the reference's headers where they lie and calls its functions.
+ *
+ * Not buildable here (they include <boost/program_options.hpp> through configurations/Conf.hpp):
+ * planners/mcts/POUCT.cpp, planners/bayes-adaptive/RBAPOUCT.cpp,
+ * bayes-adaptive/models/table/BAPOMDP.cpp, every *Priors.cpp and every factory.
+ */
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "easylogging++.h"
+
+#include "bayes-adaptive/models/Domain_Size.hpp"
+#include "bayes-adaptive/states/table/BAFlatModel.hpp"
+#include "beliefs/particle_filters/FlatFilter.hpp"
+#include "beliefs/particle_filters/ImportanceSampler.hpp"
+#include "beliefs/particle_filters/RejectionSampling.hpp"
+#include "beliefs/particle_filters/WeightedFilter.hpp"
+#include "domains/gridworld/GridWorld.hpp"
+#include "domains/tiger/FactoredTiger.hpp"
+#include "domains/tiger/Tiger.hpp"
+#include "environment/Action.hpp"
+#include "environment/Discount.hpp"
+#include "environment/Horizon.hpp"
+#include "environment/Observation.hpp"
+#include "environment/Reward.hpp"
+#include "environment/State.hpp"
+#include "experiments/Episode.hpp"
+#include "planners/random/RandomPlanner.hpp"
+#include "utils/Statistic.hpp"
+#include "utils/index.hpp"
+#include "utils/random.hpp"
+
+INITIALIZE_EASYLOGGINGPP
+
+static bool first_key = true;
+static void key(char const* k)
+{
+    printf("%s\n\"%s\": ", first_key ? "" : ",", k);
+    first_key = false;
+}
+static void seed(char const* s)
+{
+    std::string str(s);
+    rnd::seed(str);
+}
+template<typename T, typename F>
+static void arr(std::vector<T> const& v, F fmt)
+{
+    printf("[");
+    for (size_t i = 0; i < v.size(); ++i) {
+        if (i) printf(",");
+        fmt(v[i]);
+    }
+    printf("]");
+}
+static void pi(int x) { printf("%d", x); }
+static void pd(double x) { printf("%.17g", x); }
+
+static void rng_vectors(char const* s)
+{
+    std::vector<double> u;
+    std::vector<int> b, si, i3, i256, i4096, i100;
+    seed(s);
+    for (int i = 0; i < 64; ++i) u.push_back(rnd::uniform_rand01());
+    for (int i = 0; i < 64; ++i) b.push_back(rnd::boolean());
+    for (int i = 0; i < 64; ++i) si.push_back(rnd::slowRandomInt(0, 5));
+    auto d3 = rnd::integerDistribution(0, 3);
+    for (int i = 0; i < 64; ++i) i3.push_back(d3(rnd::rng()));
+    auto d256 = rnd::integerDistribution(0, 256);
+    for (int i = 0; i < 64; ++i) i256.push_back(d256(rnd::rng()));
+    auto d100 = rnd::integerDistribution(0, 100);
+    for (int i = 0; i < 64; ++i) i100.push_back(d100(rnd::rng()));
+    auto d4096 = rnd::integerDistribution(0, 4096);
+    for (int i = 0; i < 64; ++i) i4096.push_back(d4096(rnd::rng()));
+    printf("{\"seed\": \"%s\", \"u01\": ", s);
+    arr(u, pd);
+    printf(", \"bool\": ");
+    arr(b, pi);
+    printf(", \"slow_int_0_5\": ");
+    arr(si, pi);
+    printf(", \"int3\": ");
+    arr(i3, pi);
+    printf(", \"int256\": ");
+    arr(i256, pi);
+    printf(", \"int100\": ");
+    arr(i100, pi);
+    printf(", \"int4096\": ");
+    arr(i4096, pi);
+    printf("}");
+}
+
+/* random walk through a POMDP: start state, then (random action, step) n times;
+ * after a terminal step a new start state is drawn. */
+static void walk(POMDP const& d, char const* s, int n)
+{
+    std::vector<int> rec; /* a, s', o, r, term, flattened */
+    seed(s);
+    State const* st = d.sampleStartState();
+    int start       = st->index();
+    for (int i = 0; i < n; ++i) {
+        Observation const* o = nullptr;
+        Reward r(0);
+        auto a = d.generateRandomAction(st);
+        auto t = d.step(&st, a, &o, &r);
+        rec.push_back(a->index());
+        rec.push_back(st->index());
+        rec.push_back(o->index());
+        rec.push_back((int)r.toDouble());
+        rec.push_back(t.terminated() ? 1 : 0);
+        d.releaseAction(a);
+        d.releaseObservation(o);
+        if (t.terminated()) {
+            d.releaseState(st);
+            st = d.sampleStartState();
+            rec.push_back(st->index());
+        }
+    }
+    printf("{\"seed\": \"%s\", \"start\": %d, \"rec\": ", s, start);
+    arr(rec, pi);
+    printf("}");
+}
+
+/* P(o | a, s') table */
+static void obs_table(POMDP const& d, int S, int A, int O)
+{
+    std::vector<double> p;
+    for (int a = 0; a < A; ++a)
+        for (int s = 0; s < S; ++s)
+            for (int o = 0; o < O; ++o) {
+                IndexAction ia(a);
+                IndexState is(s);
+                IndexObservation io(o);
+                p.push_back(d.computeObservationProbability(&io, &ia, &is));
+            }
+    arr(p, pd);
+}
+
+static std::vector<int> indices(FlatFilter<State const*> const& f)
+{
+    std::vector<int> v;
+    for (auto p : f.particles()) v.push_back(p->index());
+    return v;
+}
+
+/* beliefs::rejectSample on the real Tiger simulator */
+static void reject_tiger(char const* s, int n)
+{
+    domains::Tiger d(domains::Tiger::CONTINUOUS);
+    seed(s);
+    FlatFilter<State const*> f((size_t)n, [&d] { return d.sampleStartState(); });
+    int const acts[] = {2, 2, 0, 2, 1, 2, 2, 2};
+    int const obs[]  = {0, 1, 1, 0, 0, 0, 0, 1};
+    printf("{\"seed\": \"%s\", \"n\": %d, \"init\": ", s, n);
+    arr(indices(f), pi);
+    printf(", \"a\": [2,2,0,2,1,2,2,2], \"o\": [0,1,1,0,0,0,0,1], \"after\": [");
+    for (int k = 0; k < 8; ++k) {
+        IndexAction a(acts[k]);
+        IndexObservation o(obs[k]);
+        beliefs::rejectSample<State const*>(&a, &o, d, (size_t)n, f);
+        if (k) printf(",");
+        arr(indices(f), pi);
+    }
+    /* one draw afterwards pins the number of engine words consumed */
+    printf("], \"next_u01\": %.17g}", rnd::uniform_rand01());
+}
+
+/* importance_sampling::update / resample on the real Tiger simulator */
+static void is_tiger(char const* s, int n)
+{
+    domains::Tiger d(domains::Tiger::CONTINUOUS);
+    seed(s);
+    WeightedFilter<State const*> f;
+    for (int i = 0; i < n; ++i) f.add(d.sampleStartState(), 1.0 / (double)n);
+    int const acts[] = {2, 2, 1, 2, 2, 0};
+    int const obs[]  = {1, 1, 0, 0, 1, 1};
+    printf("{\"seed\": \"%s\", \"n\": %d, \"a\": [2,2,1,2,2,0], \"o\": [1,1,0,0,1,1], \"steps\": [", s, n);
+    for (int k = 0; k < 6; ++k) {
+        IndexAction a(acts[k]);
+        IndexObservation o(obs[k]);
+        double tot = beliefs::importance_sampling::update(f, &a, &o, d);
+        std::vector<int> idx;
+        std::vector<double> w;
+        for (size_t i = 0; i < f.size(); ++i) {
+            idx.push_back(f.particle(i)->particle->index());
+            w.push_back(f.particle(i)->w);
+        }
+        if (k) printf(",");
+        printf("{\"total\": %.17g, \"idx\": ", tot);
+        arr(idx, pi);
+        printf(", \"w\": ");
+        arr(w, pd);
+        beliefs::importance_sampling::resample(f, d, (size_t)n);
+        idx.clear();
+        for (size_t i = 0; i < f.size(); ++i) idx.push_back(f.particle(i)->particle->index());
+        printf(", \"resampled\": ");
+        arr(idx, pi);
+        printf("}");
+    }
+    printf("], \"next_u01\": %.17g}", rnd::uniform_rand01());
+}
+
+/* BAFlatModel sampling / probability / increment with the expected-Dirichlet method */
+static void flat_model(char const* s)
+{
+    Domain_Size sz(2, 3, 2);
+    bayes_adaptive::table::BAFlatModel m(&sz);
+    /* tiger-prior-like counts, deliberately asymmetric */
+    for (int st = 0; st < 2; ++st)
+        for (int a = 0; a < 3; ++a)
+            for (int ns = 0; ns < 2; ++ns) {
+                IndexState x(st), y(ns);
+                IndexAction ia(a);
+                m.count(&x, &ia, &y) = (a == 2) ? ((st == ns) ? 5000.f : 0.f) : 5000.f + 7.f * (float)(st + 2 * ns + a);
+            }
+    for (int a = 0; a < 3; ++a)
+        for (int ns = 0; ns < 2; ++ns)
+            for (int o = 0; o < 2; ++o) {
+                IndexState y(ns);
+                IndexAction ia(a);
+                IndexObservation io(o);
+                m.count(&ia, &y, &io) = (a == 2) ? ((ns == o) ? 8500.f : 1500.f) : 5000.f + 3.f * (float)(o + a);
+            }
+    seed(s);
+    std::vector<int> rec;
+    std::vector<double> probs;
+    int st = 0;
+    for (int i = 0; i < 300; ++i) {
+        int a = i % 3;
+        IndexState x(st);
+        IndexAction ia(a);
+        int ns = m.sampleStateIndex(&x, &ia, rnd::sample::Dir::sampleFromExpectedMult);
+        IndexState y(ns);
+        int o = m.sampleObservationIndex(&ia, &y, rnd::sample::Dir::sampleFromExpectedMult);
+        IndexObservation io(o);
+        probs.push_back(m.computeObservationProbability(&io, &ia, &y, rnd::sample::Dir::expectedMult));
+        m.incrementCountsOf(&x, &ia, &io, &y);
+        rec.push_back(a);
+        rec.push_back(ns);
+        rec.push_back(o);
+        st = ns;
+    }
+    std::vector<double> phi, psi;
+    for (int s0 = 0; s0 < 2; ++s0)
+        for (int a = 0; a < 3; ++a)
+            for (int ns = 0; ns < 2; ++ns) {
+                IndexState x(s0), y(ns);
+                IndexAction ia(a);
+                phi.push_back(m.count(&x, &ia, &y));
+            }
+    for (int a = 0; a < 3; ++a)
+        for (int ns = 0; ns < 2; ++ns)
+            for (int o = 0; o < 2; ++o) {
+                IndexState y(ns);
+                IndexAction ia(a);
+                IndexObservation io(o);
+                psi.push_back(m.count(&ia, &y, &io));
+            }
+    printf("{\"seed\": \"%s\", \"rec\": ", s);
+    arr(rec, pi);
+    printf(", \"obs_prob\": ");
+    arr(probs, pd);
+    printf(", \"phi_after\": ");
+    arr(phi, pd);
+    printf(", \"psi_after\": ");
+    arr(psi, pd);
+    printf("}");
+}
+
+/* episode::run with the reference's RandomPlanner and RejectionSampling belief */
+static void random_planner_episodes(char const* s, int n, int episodes)
+{
+    domains::Tiger env(domains::Tiger::EPISODIC), sim(domains::Tiger::EPISODIC);
+    planners::RandomPlanner planner;
+    beliefs::RejectionSampling belief((size_t)n);
+    seed(s);
+    std::vector<double> rets;
+    std::vector<int> lens;
+    for (int e = 0; e < episodes; ++e) {
+        belief.initiate(sim);
+        auto r = episode::run(planner, belief, env, sim, Horizon(10), Discount(.95));
+        rets.push_back(r.ret.toDouble());
+        lens.push_back(r.length);
+        belief.free(sim);
+    }
+    printf("{\"seed\": \"%s\", \"particles\": %d, \"returns\": ", s, n);
+    arr(rets, pd);
+    printf(", \"lengths\": ");
+    arr(lens, pi);
+    printf(", \"next_u01\": %.17g}", rnd::uniform_rand01());
+}
+
+static void statistic()
+{
+    utils::Statistic st;
+    double const xs[] = {1.5, -2.25, 10, -100, 3.125, 0, 7, 7, -1e-3, 42};
+    for (double x : xs) st.add(x);
+    printf("{\"x\": [1.5,-2.25,10,-100,3.125,0,7,7,-0.001,42], \"mean\": %.17g, \"var\": %.17g, \"count\": %.17g, \"stder\": %.17g}",
+           st.mean(), st.var(), st.count(), st.stder());
+}
+
+static void expected_mult()
+{
+    float const rows[3][4] = {{5000, 0, 0, 0}, {8500, 1500, 3, 0.25f}, {1, 2, 3, 4}};
+    printf("[");
+    for (int r = 0; r < 3; ++r) {
+        auto v = rnd::sample::Dir::expectedMult(rows[r], 4);
+        std::vector<double> d(v.begin(), v.end());
+        if (r) printf(",");
+        arr(d, pd);
+    }
+    printf("]");
+}
+
+int main(int argc, char** argv)
+{
+    START_EASYLOGGINGPP(argc, argv);
+    el::Configurations conf;
+    conf.setToDefault();
+    conf.setGlobally(el::ConfigurationType::Enabled, "false");
+    el::Loggers::reconfigureAllLoggers(conf);
+    rnd::initiate();
+
+    printf("{");
+    key("rng");
+    printf("[");
+    rng_vectors("1");
+    printf(",");
+    rng_vectors("7");
+    printf(",");
+    rng_vectors("hello fba");
+    printf("]");
+
+    key("tiger_episodic");
+    { domains::Tiger d(domains::Tiger::EPISODIC); walk(d, "3", 300); }
+    key("tiger_continuous");
+    { domains::Tiger d(domains::Tiger::CONTINUOUS); walk(d, "4", 300); }
+    key("ftiger3_episodic");
+    { domains::FactoredTiger d(domains::FactoredTiger::EPISODIC, 3); walk(d, "5", 300); }
+    key("ftiger2_continuous");
+    { domains::FactoredTiger d(domains::FactoredTiger::CONTINUOUS, 2); walk(d, "6", 300); }
+    key("gridworld5");
+    { domains::GridWorld d(5); walk(d, "8", 400); }
+    key("gridworld7");
+    { domains::GridWorld d(7); walk(d, "9", 400); }
+    key("gridworld3");
+    { domains::GridWorld d(3); walk(d, "10", 200); }
+
+    key("tiger_obs_prob");
+    { domains::Tiger d(domains::Tiger::EPISODIC); obs_table(d, 2, 3, 2); }
+    key("ftiger2_obs_prob");
+    { domains::FactoredTiger d(domains::FactoredTiger::EPISODIC, 2); obs_table(d, 8, 3, 2); }
+
+    key("reject_tiger");
+    printf("[");
+    reject_tiger("11", 64);
+    printf(",");
+    reject_tiger("12", 200);
+    printf("]");
+
+    key("is_tiger");
+    printf("[");
+    is_tiger("13", 48);
+    printf(",");
+    is_tiger("14", 300);
+    printf("]");
+
+    key("flat_model");
+    flat_model("15");
+
+    key("random_planner_episodes");
+    random_planner_episodes("16", 32, 60);
+
+    key("statistic");
+    statistic();
+
+    key("expected_mult");
+    expected_mult();
+
+    printf("\n}\n");
+    return 0;
+}

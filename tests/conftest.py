@@ -1,0 +1,20 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box only)")
+    config.addinivalue_line("markers", "slow: long CPU test")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "ref_vectors.json")) as f:
+        return json.load(f)
