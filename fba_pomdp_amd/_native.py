@@ -1,0 +1,161 @@
+"""Build and load libfba_hip.so (the C-ABI of include/fba_hip.h) through ctypes.
+
+There is no fallback: if the shared library is missing or has no gfx950 device to run on, the
+calls raise.  torch is not involved here; it is only used by bench.py for torch.distributed.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB_PATH = os.path.join(HERE, "libfba_hip.so")
+SOURCES = [os.path.join(HERE, "csrc", f) for f in ("fba_kernels.hip", "fba_engine.hip")]
+HEADERS = [os.path.join(HERE, "csrc", f) for f in ("fba_device.h", "fba_state.h", "fba_kernels.h")] + [
+    os.path.join(ROOT, "include", "fba_hip.h")]
+
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    # the reference rounds a*b+c twice; contraction into FMA would break bit parity
+    "-ffp-contract=off", "-fno-fast-math",
+    "-Wall", "-Wno-unused-function",
+]
+
+MAX_ACTIONS = 16
+K_SEARCH, K_ENV, K_BELIEF_RS, K_BELIEF_IS, K_BELIEF_RESET, K_BELIEF_INIT, K_COUNT = range(7)
+KERNEL_NAMES = ["search_kernel", "env_kernel", "reject_kernel", "importance_kernel", "reset_kernel", "init_kernel"]
+
+DOM_TIGER_EPISODIC, DOM_TIGER_CONTINUOUS, DOM_FTIGER_EPISODIC, DOM_FTIGER_CONTINUOUS, DOM_GRIDWORLD, DOM_COLLISION_AVOID = range(6)
+MODEL_POMDP, MODEL_BA_TABLE, MODEL_BA_FACTORED = range(3)
+BELIEF_REJECTION, BELIEF_IMPORTANCE = range(2)
+PLANNER_POUCT, PLANNER_RANDOM = range(2)
+OK, EINVAL, EHIP, ENODEVICE, ESTATE = 0, -1, -2, -3, -4
+
+DOMAIN_NAMES = {  # reference -D strings (DomainConf.cpp)
+    "episodic-tiger": DOM_TIGER_EPISODIC, "continuous-tiger": DOM_TIGER_CONTINUOUS,
+    "episodic-factored-tiger": DOM_FTIGER_EPISODIC, "continuous-factored-tiger": DOM_FTIGER_CONTINUOUS,
+    "gridworld": DOM_GRIDWORLD,
+}
+BELIEF_NAMES = {"rejection_sampling": BELIEF_REJECTION, "importance_sampling": BELIEF_IMPORTANCE}
+PLANNER_NAMES = {"po-uct": PLANNER_POUCT, "random": PLANNER_RANDOM}
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("domain", C.c_int32), ("size", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+        ("model", C.c_int32), ("belief", C.c_int32), ("planner", C.c_int32),
+        ("particles", C.c_int32), ("sims", C.c_int32), ("max_depth", C.c_int32), ("horizon", C.c_int32),
+        ("exploration", C.c_double), ("discount", C.c_double),
+        ("runs", C.c_int32), ("episodes", C.c_int32),
+        ("noise", C.c_float), ("counts_total", C.c_float), ("structure_prior", C.c_int32),
+        ("seed", C.c_uint64), ("run_offset", C.c_int32), ("slots", C.c_int32),
+        ("device", C.c_int32), ("trace", C.c_int32),
+    ]
+
+
+TRACE_DTYPE = np.dtype([
+    ("run", "<i4"), ("episode", "<i4"), ("t", "<i4"),
+    ("action", "<i4"), ("state", "<i4"), ("obs", "<i4"), ("terminal", "<i4"),
+    ("n_nodes", "<i4"), ("tree_depth", "<i4"), ("update_count", "<i4"),
+    ("root_n", "<i4", (MAX_ACTIONS,)), ("root_q", "<f8", (MAX_ACTIONS,)),
+    ("reward", "<f8"), ("weight_total", "<f8"), ("belief_hash", "<u8"),
+], align=True)
+
+
+class Stat(C.Structure):
+    _fields_ = [("count", C.c_double), ("mean", C.c_double), ("m2", C.c_double)]
+
+    @property
+    def var(self):
+        return 0.0 if self.count < 2 else self.m2 / (self.count - 1)
+
+    @property
+    def stder(self):
+        return 0.0 if self.count < 2 else (self.var / self.count) ** 0.5
+
+
+class Counters(C.Structure):
+    _fields_ = [("sim_steps", C.c_uint64), ("belief_steps", C.c_uint64), ("env_steps", C.c_uint64)]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("ms", C.c_double), ("launches", C.c_uint64), ("units", C.c_uint64), ("bytes", C.c_uint64)]
+
+
+# every symbol include/fba_hip.h declares
+EXPORTS = [
+    "fba_abi_version", "fba_default_config", "fba_create", "fba_destroy", "fba_last_error",
+    "fba_domain_sizes", "fba_counts_len", "fba_slots", "fba_set_model_tabular", "fba_get_prior",
+    "fba_set_position", "fba_belief_init", "fba_belief_reset_domain_state", "fba_select_action",
+    "fba_belief_update", "fba_belief_get", "fba_belief_set", "fba_last_step_info",
+    "fba_run_planning", "fba_run_bapomdp", "fba_run_ticks", "fba_get_returns", "fba_get_counters",
+    "fba_get_kernel_times", "fba_reset_kernel_times", "fba_trace_count", "fba_get_trace",
+    "fba_selftest_ucb", "fba_stat_add", "fba_stat_var", "fba_stat_stder",
+]
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU) -> fba_pomdp_amd/libfba_hip.so"""
+    deps = SOURCES + HEADERS
+    if (not force and os.path.exists(LIB_PATH)
+            and all(os.path.getmtime(d) <= os.path.getmtime(LIB_PATH) for d in deps)):
+        return LIB_PATH
+    cmd = ["hipcc"] + HIPCC_FLAGS + ["-I" + os.path.join(ROOT, "include")] + SOURCES + ["-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP engine.  Raises if the library is absent -- there is no other implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc) first; "
+                           "fba_pomdp_amd has no non-HIP implementation")
+    L = C.CDLL(LIB_PATH)
+    P = C.POINTER
+    vp = C.c_void_p
+    L.fba_abi_version.restype = C.c_int
+    L.fba_default_config.argtypes = [P(Config)]
+    L.fba_create.argtypes = [P(Config), P(vp)]
+    L.fba_destroy.argtypes = [vp]
+    L.fba_last_error.restype = C.c_char_p
+    L.fba_last_error.argtypes = [vp]
+    L.fba_domain_sizes.argtypes = [vp, P(C.c_int32), P(C.c_int32), P(C.c_int32)]
+    L.fba_counts_len.argtypes = [vp]
+    L.fba_slots.argtypes = [vp]
+    L.fba_set_model_tabular.argtypes = [vp, vp, vp]
+    L.fba_get_prior.argtypes = [vp, vp]
+    L.fba_set_position.argtypes = [vp, vp, vp, vp]
+    L.fba_belief_init.argtypes = [vp]
+    L.fba_belief_reset_domain_state.argtypes = [vp]
+    L.fba_select_action.argtypes = [vp, vp, vp, vp]
+    L.fba_belief_update.argtypes = [vp, vp, vp, vp]
+    L.fba_belief_get.argtypes = [vp, C.c_int32, vp, vp, vp]
+    L.fba_belief_set.argtypes = [vp, C.c_int32, vp, vp, vp]
+    L.fba_last_step_info.argtypes = [vp, vp]
+    L.fba_run_planning.argtypes = [vp, P(Stat)]
+    L.fba_run_bapomdp.argtypes = [vp, P(Stat)]
+    L.fba_run_ticks.argtypes = [vp, C.c_int32]
+    L.fba_get_returns.argtypes = [vp, vp, vp]
+    L.fba_get_counters.argtypes = [vp, P(Counters)]
+    L.fba_get_kernel_times.argtypes = [vp, P(KernelTime)]
+    L.fba_reset_kernel_times.argtypes = [vp]
+    L.fba_trace_count.argtypes = [vp]
+    L.fba_get_trace.argtypes = [vp, vp, C.c_int32]
+    L.fba_selftest_ucb.argtypes = [vp, vp, vp, C.c_int32, C.c_double, vp]
+    L.fba_stat_add.argtypes = [P(Stat), C.c_double]
+    L.fba_stat_var.restype = C.c_double
+    L.fba_stat_var.argtypes = [P(Stat)]
+    L.fba_stat_stder.restype = C.c_double
+    L.fba_stat_stder.argtypes = [P(Stat)]
+    _lib = L
+    return L

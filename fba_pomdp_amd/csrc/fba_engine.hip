@@ -1,0 +1,807 @@
+// fba_engine.hip -- host side of libfba_hip.so: context, HBM allocation, prior tables,
+// kernel orchestration (one HIP stream per ctx), HIP-event timing, and the C-ABI of
+// include/fba_hip.h.  There is no CPU fallback anywhere in this file: without a gfx950 device
+// fba_create fails with FBA_ENODEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "fba_kernels.h"
+
+using namespace fba;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct EventPair {
+    hipEvent_t a, b;
+    int kind;
+};
+
+}  // namespace
+
+struct fba_ctx {
+    fba_config cfg{};
+    Problem P{};
+    DeviceState D{};
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<void*> allocs;
+    std::vector<float> prior;  // host copy, C floats
+    float* d_prior       = nullptr;
+    double* d_uni_scan   = nullptr;
+    double* d_log1p      = nullptr;
+    int32_t* d_n_active  = nullptr;
+    size_t returns_cap   = 0;
+    bool started         = false;  // fba_run_ticks has set the slots up
+    bool belief_ready    = false;
+    // timing
+    bool timing = true;
+    std::vector<EventPair> pending;
+    std::vector<EventPair> free_events;
+    double k_ms[FBA_K_COUNT]          = {0};
+    uint64_t k_launches[FBA_K_COUNT]  = {0};
+    uint64_t base_sim = 0, base_attempts = 0, base_particles = 0;
+    std::vector<fba_trace_rec> trace_host;
+};
+
+namespace {
+
+int fail(fba_ctx* c, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                             \
+    do {                                                                                            \
+        hipError_t _e = (call);                                                                     \
+        if (_e != hipSuccess)                                                                       \
+            return fail((c), FBA_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+template <typename T>
+int dev_alloc(fba_ctx* c, T** p, size_t n, bool zero = true)
+{
+    if (n == 0) n = 1;
+    void* q = nullptr;
+    HIPCHK(c, hipMalloc(&q, n * sizeof(T)));
+    c->allocs.push_back(q);
+    if (zero) HIPCHK(c, hipMemsetAsync(q, 0, n * sizeof(T), c->stream));
+    *p = static_cast<T*>(q);
+    return FBA_OK;
+}
+
+bool is_tiger(int d) { return d == FBA_DOM_TIGER_EPISODIC || d == FBA_DOM_TIGER_CONTINUOUS; }
+bool is_ftiger(int d) { return d == FBA_DOM_FTIGER_EPISODIC || d == FBA_DOM_FTIGER_CONTINUOUS; }
+
+// Tabular prior count tables, built on the host once per ctx (cold path).
+// TigerBAPrior (reference src/domains/tiger/TigerPriors.cpp:14-43): every count 5000 except
+// listen: T off-diagonal 0, O = (.85 - noise) * C / (.15 + noise) * C.
+// FactoredTigerFlatPrior (src/domains/tiger/FactoredTigerPriors.cpp:18-88): same over S = 2^(K+1)
+// states, tiger location = (s < S/2 ? LEFT : RIGHT).
+int build_tabular_prior(fba_ctx* c)
+{
+    const Problem& P = c->P;
+    const int S = P.S, A = P.A, O = P.O;
+    const float noise = c->cfg.noise, total = c->cfg.counts_total;
+    if (noise <= -.15 || noise > .3) return fail(c, FBA_EINVAL, "noise has to be between -.15 and .3");
+    const float acc = (.85f - noise) * total, inacc = (.15f + noise) * total;
+    c->prior.assign((size_t)P.C, 5000.f);
+    float* phi = c->prior.data();
+    float* psi = c->prior.data() + P.phi_len;
+    const int listen = 2;
+    if (is_tiger(P.domain)) {
+        phi[1 * A * S + listen * S + 0] = 0;
+        phi[0 * A * S + listen * S + 1] = 0;
+        psi[listen * S * O + 1 * O + 1] = acc;
+        psi[listen * S * O + 1 * O + 0] = inacc;
+        psi[listen * S * O + 0 * O + 1] = inacc;
+        psi[listen * S * O + 0 * O + 0] = acc;
+    } else if (is_ftiger(P.domain)) {
+        for (int s = 0; s < S; ++s)
+            for (int ns = 0; ns < S; ++ns)
+                if (s != ns) phi[s * A * S + listen * S + ns] = 0;
+        for (int s = 0; s < S; ++s) {
+            const bool left = s < S / 2;
+            psi[listen * S * O + s * O + (left ? 0 : 1)] = acc;
+            psi[listen * S * O + s * O + (left ? 1 : 0)] = inacc;
+        }
+    } else {
+        return fail(c, FBA_EINVAL, "domain %d has no built-in tabular prior; use fba_set_model_tabular", P.domain);
+    }
+    return FBA_OK;
+}
+
+int upload_prior(fba_ctx* c)
+{
+    std::vector<float> padded((size_t)c->P.Cs, 0.f);
+    std::copy(c->prior.begin(), c->prior.end(), padded.begin());
+    HIPCHK(c, hipMemcpyAsync(c->d_prior, padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FBA_OK;
+}
+
+// ---- timed launches ---------------------------------------------------------------------------
+int flush_events(fba_ctx* c)
+{
+    if (c->pending.empty()) return FBA_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (auto& p : c->pending) {
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, p.a, p.b));
+        c->k_ms[p.kind] += ms;
+        c->k_launches[p.kind] += 1;
+        c->free_events.push_back(p);
+    }
+    c->pending.clear();
+    return FBA_OK;
+}
+
+template <typename F>
+int timed(fba_ctx* c, int kind, F&& launch)
+{
+    if (!c->timing) {
+        launch();
+        return FBA_OK;
+    }
+    if (c->pending.size() >= 2048) {
+        int rc = flush_events(c);
+        if (rc) return rc;
+    }
+    EventPair p;
+    if (!c->free_events.empty()) {
+        p = c->free_events.back();
+        c->free_events.pop_back();
+    } else {
+        HIPCHK(c, hipEventCreate(&p.a));
+        HIPCHK(c, hipEventCreate(&p.b));
+    }
+    p.kind = kind;
+    HIPCHK(c, hipEventRecord(p.a, c->stream));
+    launch();
+    HIPCHK(c, hipEventRecord(p.b, c->stream));
+    c->pending.push_back(p);
+    return FBA_OK;
+}
+
+int k_update_kind(const fba_ctx* c) { return c->P.belief == FBA_BELIEF_REJECTION ? FBA_K_BELIEF_RS : FBA_K_BELIEF_IS; }
+
+// one real time-step of every active slot
+int tick(fba_ctx* c)
+{
+    int rc;
+    if ((rc = timed(c, FBA_K_SEARCH, [&] { launch_search(c->P, c->D, c->stream); }))) return rc;
+    if ((rc = timed(c, FBA_K_ENV, [&] { launch_env(c->P, c->D, c->d_n_active, c->stream); }))) return rc;
+    if ((rc = timed(c, k_update_kind(c), [&] { launch_belief_update(c->P, c->D, c->stream); }))) return rc;
+    if (c->D.trace_on) launch_flush(c->P, c->D, c->stream);
+    launch_advance(c->P, c->D, c->d_n_active, c->stream);
+    if ((rc = timed(c, FBA_K_BELIEF_INIT, [&] { launch_init(c->P, c->D, c->stream); }))) return rc;
+    if (c->P.model != FBA_MODEL_POMDP)
+        if ((rc = timed(c, FBA_K_BELIEF_RESET, [&] { launch_reset(c->P, c->D, c->stream); }))) return rc;
+    HIPCHK(c, hipGetLastError());
+    return FBA_OK;
+}
+
+int set_flags(fba_ctx* c, uint8_t* dev, const uint8_t* mask, uint8_t value)
+{
+    std::vector<uint8_t> h((size_t)c->P.E, value);
+    if (mask)
+        for (int e = 0; e < c->P.E; ++e) h[e] = mask[e] ? value : 0;
+    HIPCHK(c, hipMemcpyAsync(dev, h.data(), h.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FBA_OK;
+}
+
+int ensure_outputs(fba_ctx* c, int runs)
+{
+    const size_t need = (size_t)std::max(runs, 1) * c->P.episodes;
+    if (need > c->returns_cap) {
+        int rc;
+        if ((rc = dev_alloc(c, &c->D.returns, need))) return rc;
+        if ((rc = dev_alloc(c, &c->D.lengths, need))) return rc;
+        c->returns_cap = need;
+    } else {
+        HIPCHK(c, hipMemsetAsync(c->D.returns, 0, need * sizeof(double), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->D.lengths, 0, need * sizeof(int32_t), c->stream));
+    }
+    if (c->cfg.trace) {
+        const size_t cap = std::min<size_t>((size_t)std::max(runs, 1) * c->P.episodes * c->P.horizon, (size_t)1 << 22);
+        if ((size_t)c->D.trace_cap < cap) {
+            int rc;
+            if ((rc = dev_alloc(c, &c->D.trace, cap))) return rc;
+            c->D.trace_cap = (int32_t)cap;
+        }
+        HIPCHK(c, hipMemsetAsync(c->D.trace_count, 0, sizeof(int32_t), c->stream));
+    }
+    return FBA_OK;
+}
+
+int start_experiment(fba_ctx* c, int runs_total)
+{
+    int rc;
+    c->D.runs_total = runs_total;
+    c->D.run_offset = c->cfg.run_offset;
+    const int32_t n_active = runs_total < 0 ? c->P.E : std::min(c->P.E, runs_total);
+    HIPCHK(c, hipMemcpyAsync(c->d_n_active, &n_active, sizeof n_active, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->D.bufsel, 0, (size_t)c->P.E, c->stream));
+    launch_start(c->P, c->D, c->stream);
+    if ((rc = timed(c, FBA_K_BELIEF_INIT, [&] { launch_init(c->P, c->D, c->stream); }))) return rc;
+    if (c->P.model != FBA_MODEL_POMDP)
+        if ((rc = timed(c, FBA_K_BELIEF_RESET, [&] { launch_reset(c->P, c->D, c->stream); }))) return rc;
+    HIPCHK(c, hipGetLastError());
+    c->belief_ready = true;
+    return FBA_OK;
+}
+
+int run_experiment(fba_ctx* c, fba_stat* stats)
+{
+    int rc;
+    const int runs = c->cfg.runs, E = c->P.E, eps = c->P.episodes;
+    if ((rc = ensure_outputs(c, runs))) return rc;
+    if ((rc = start_experiment(c, runs))) return rc;
+    const long long max_ticks = (long long)((runs + E - 1) / E) * eps * c->P.horizon + 2;
+    for (long long k = 0; k < max_ticks; ++k) {
+        if ((rc = tick(c))) return rc;
+        int32_t n_active = 0;
+        HIPCHK(c, hipMemcpyAsync(&n_active, c->d_n_active, sizeof n_active, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (n_active <= 0) break;
+    }
+    std::vector<double> ret((size_t)runs * eps);
+    HIPCHK(c, hipMemcpy(ret.data(), c->D.returns, ret.size() * sizeof(double), hipMemcpyDeviceToHost));
+    std::memset(stats, 0, sizeof(fba_stat) * (size_t)eps);
+    for (int r = 0; r < runs; ++r)
+        for (int ep = 0; ep < eps; ++ep) fba_stat_add(&stats[ep], ret[(size_t)r * eps + ep]);
+    c->started = false;
+    return FBA_OK;
+}
+
+template <typename T>
+uint64_t sum_counter(fba_ctx* c, const T* dev, int n, int* rc)
+{
+    std::vector<unsigned long long> h((size_t)n);
+    hipError_t e = hipMemcpy(h.data(), dev, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+        *rc = fail(c, FBA_EHIP, "counter download failed: %s", hipGetErrorString(e));
+        return 0;
+    }
+    uint64_t s = 0;
+    for (auto v : h) s += v;
+    return s;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C-ABI
+// =============================================================================================
+extern "C" {
+
+int fba_abi_version(void) { return FBA_ABI_VERSION; }
+
+void fba_default_config(fba_config* cfg)
+{
+    std::memset(cfg, 0, sizeof *cfg);
+    cfg->domain       = FBA_DOM_TIGER_EPISODIC;
+    cfg->model        = FBA_MODEL_POMDP;
+    cfg->belief       = FBA_BELIEF_REJECTION;
+    cfg->planner      = FBA_PLANNER_POUCT;
+    cfg->particles    = 100;
+    cfg->sims         = 1000;
+    cfg->max_depth    = -1;
+    cfg->horizon      = 10;
+    cfg->exploration  = 100;
+    cfg->discount     = .95;
+    cfg->runs         = 1;
+    cfg->episodes     = 1;
+    cfg->noise        = 0;
+    cfg->counts_total = 10000;
+    cfg->slots        = 0;
+}
+
+const char* fba_last_error(const fba_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+void fba_destroy(fba_ctx* c)
+{
+    if (!c) return;
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto& p : c->free_events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (void* p : c->allocs) (void)hipFree(p);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int fba_create(const fba_config* cfg, fba_ctx** out)
+{
+    if (!cfg || !out) return fail(nullptr, FBA_EINVAL, "fba_create: null argument");
+    *out = nullptr;
+    // ---- validation: the reference's constructor / validate() errors
+    // (POUCT.cpp:34-50, RejectionSampling.cpp:7-13, FactoredTiger.cpp:13-17, TigerPriors.cpp:22-25)
+    if (cfg->sims < 1 && cfg->planner == FBA_PLANNER_POUCT)
+        return fail(nullptr, FBA_EINVAL, "cannot initiate POUCT with %d simulations, must be greater than 0", cfg->sims);
+    if (cfg->horizon <= 0) return fail(nullptr, FBA_EINVAL, "cannot initiate POUCT with %d horizon, must be greater than 0", cfg->horizon);
+    if (cfg->horizon > 255) return fail(nullptr, FBA_EINVAL, "horizon %d exceeds the 255 steps a stream address holds", cfg->horizon);
+    if (cfg->particles < 1) return fail(nullptr, FBA_EINVAL, "cannot initiate belief with n = %d", cfg->particles);
+    if (cfg->discount <= 0 || cfg->discount > 1) return fail(nullptr, FBA_EINVAL, "discount must be in (0, 1]");
+    if (cfg->runs < 1 || cfg->episodes < 1) return fail(nullptr, FBA_EINVAL, "runs and episodes must be >= 1");
+    if (cfg->episodes > 65535) return fail(nullptr, FBA_EINVAL, "episodes %d exceeds the 65535 a stream address holds", cfg->episodes);
+    if (cfg->model == FBA_MODEL_POMDP && cfg->episodes != 1) return fail(nullptr, FBA_EINVAL, "planning runs have exactly one episode per run");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, FBA_ENODEVICE, "no HIP device visible: libfba_hip has no CPU path");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, FBA_EINVAL, "device %d out of range (%d visible)", cfg->device, ndev);
+
+    fba_ctx* c = new fba_ctx();
+    c->cfg     = *cfg;
+    Problem& P = c->P;
+    P.domain = cfg->domain; P.model = cfg->model; P.belief = cfg->belief; P.planner = cfg->planner;
+    switch (cfg->domain) {
+        case FBA_DOM_TIGER_EPISODIC:
+        case FBA_DOM_TIGER_CONTINUOUS: P.S = 2; P.A = 3; P.O = 2; break;
+        case FBA_DOM_FTIGER_EPISODIC:
+        case FBA_DOM_FTIGER_CONTINUOUS:
+            if (cfg->size < 1 || cfg->size > 12) {
+                fail(nullptr, FBA_EINVAL, "cannot initiate FactoredTiger with %d irrelevant features", cfg->size);
+                delete c;
+                return FBA_EINVAL;
+            }
+            P.S = 2 << cfg->size; P.A = 3; P.O = 2;
+            break;
+        default:
+            fail(nullptr, FBA_EINVAL, "domain %d is not supported by this build", cfg->domain);
+            delete c;
+            return FBA_EINVAL;
+    }
+    P.N = cfg->particles;
+    P.sims = cfg->sims;
+    P.horizon = cfg->horizon;
+    P.max_depth = cfg->max_depth < 0 ? cfg->horizon : cfg->max_depth;  // ArgumentParser.cpp:37-40
+    P.episodes = cfg->episodes;
+    P.exploration = cfg->exploration;
+    P.gamma = cfg->discount;
+    P.seed_lo = (uint32_t)cfg->seed;
+    P.seed_hi = (uint32_t)(cfg->seed >> 32);
+    if (cfg->model == FBA_MODEL_BA_TABLE) {
+        P.phi_len = P.S * P.A * P.S;
+        P.C       = P.phi_len + P.A * P.S * P.O;
+    } else if (cfg->model == FBA_MODEL_POMDP) {
+        P.phi_len = 0;
+        P.C       = 0;
+    } else {
+        fail(nullptr, FBA_EINVAL, "model %d is not supported by this build", cfg->model);
+        delete c;
+        return FBA_EINVAL;
+    }
+    P.Cs = (P.C + 3) & ~3;
+    if (P.A > FBA_MAX_ACTIONS || P.A * P.O > 4096) {
+        fail(nullptr, FBA_EINVAL, "action/observation space too large for the dense child table");
+        delete c;
+        return FBA_EINVAL;
+    }
+    if (cfg->belief == FBA_BELIEF_IMPORTANCE && P.N > IS_MAX_CHUNKS * 256) {
+        fail(nullptr, FBA_EINVAL, "importance sampling supports at most %d particles per slot", IS_MAX_CHUNKS * 256);
+        delete c;
+        return FBA_EINVAL;
+    }
+
+#define CHK(x)            \
+    do {                  \
+        int _rc = (x);    \
+        if (_rc) {        \
+            g_create_error = c->err; \
+            fba_destroy(c); \
+            return _rc;   \
+        }                 \
+    } while (0)
+#define HIPC(call)                                                                                           \
+    do {                                                                                                     \
+        hipError_t _e = (call);                                                                              \
+        if (_e != hipSuccess) {                                                                              \
+            fail(nullptr, FBA_EHIP, "%s failed: %s", #call, hipGetErrorString(_e));                          \
+            fba_destroy(c);                                                                                  \
+            return FBA_EHIP;                                                                                 \
+        }                                                                                                    \
+    } while (0)
+
+    HIPC(hipSetDevice(cfg->device));
+    HIPC(hipStreamCreate(&c->stream));
+
+    // node record layout (fba_state.h)
+    DeviceState& D = c->D;
+    D.cq_off     = (1 + P.A + 1) & ~1;
+    D.child_off  = D.cq_off + 2 * P.A;
+    D.node_words = (D.child_off + P.A * P.O + 1) & ~1;
+    D.max_nodes  = P.sims + 2;
+
+    // slots
+    const size_t per_slot = (size_t)P.N * (2 * 4 + 2 * 8 + 8 + 4 + 2 * (size_t)P.Cs * 4) + (size_t)D.max_nodes * D.node_words * 4 + 1024;
+    int E = cfg->slots;
+    if (E <= 0) {
+        size_t free_b = 0, total_b = 0;
+        HIPC(hipMemGetInfo(&free_b, &total_b));
+        const size_t budget = free_b / 2;
+        E = (int)std::min<size_t>(std::max<size_t>(budget / per_slot, 1), 32768);
+        E = std::min(E, cfg->runs);
+    }
+    P.E = E;
+
+    CHK(dev_alloc(c, &D.run, E));
+    CHK(dev_alloc(c, &D.episode, E));
+    CHK(dev_alloc(c, &D.t, E));
+    CHK(dev_alloc(c, &D.active, E));
+    CHK(dev_alloc(c, &D.need_update, E));
+    CHK(dev_alloc(c, &D.need_reset, E));
+    CHK(dev_alloc(c, &D.need_init, E));
+    CHK(dev_alloc(c, &D.env_state, E));
+    CHK(dev_alloc(c, &D.ret, E));
+    CHK(dev_alloc(c, &D.disc, E));
+    CHK(dev_alloc(c, &D.action, E));
+    CHK(dev_alloc(c, &D.obs, E));
+    CHK(dev_alloc(c, &D.bufsel, E));
+    CHK(dev_alloc(c, &D.p_state, (size_t)2 * E * P.N));
+    const bool is = cfg->belief == FBA_BELIEF_IMPORTANCE;
+    CHK(dev_alloc(c, &D.p_weight, is ? (size_t)2 * E * P.N : 1));
+    CHK(dev_alloc(c, &D.p_cnt, (size_t)2 * E * P.N * P.Cs, false));
+    CHK(dev_alloc(c, &D.wscan, is ? (size_t)E * P.N : 1, false));
+    CHK(dev_alloc(c, &D.src_idx, 1));
+    CHK(dev_alloc(c, &D.nodes, (size_t)E * D.max_nodes * D.node_words, false));
+    CHK(dev_alloc(c, &D.sim_steps, E));
+    CHK(dev_alloc(c, &D.belief_steps, E));
+    CHK(dev_alloc(c, &D.env_steps, E));
+    CHK(dev_alloc(c, &D.upd_particles, E));
+    CHK(dev_alloc(c, &D.upd_attempts, E));
+    CHK(dev_alloc(c, &D.cur, E));
+    CHK(dev_alloc(c, &D.trace_count, 1));
+    CHK(dev_alloc(c, &c->d_n_active, 1));
+    CHK(dev_alloc(c, &c->d_prior, std::max(P.Cs, 4)));
+    CHK(dev_alloc(c, &c->d_uni_scan, (size_t)P.N + 1));
+    CHK(dev_alloc(c, &c->d_log1p, (size_t)P.sims + 2));
+    D.prior     = c->d_prior;
+    D.uni_scan  = c->d_uni_scan;
+    D.log1p_tab = c->d_log1p;
+    D.trace_on  = cfg->trace ? 1 : 0;
+    D.trace_cap = 0;
+    D.runs_total = cfg->runs;
+    D.run_offset = cfg->run_offset;
+
+    // log1p(m) table: UCB(m, n) = u * sqrt(log1p(m) / n)  (POUCT.cpp:330-338, factorised so the
+    // n x n table -- 134 MB at 4096 simulations, int overflow at 65536 -- never exists)
+    {
+        std::vector<double> t((size_t)P.sims + 2);
+        for (size_t m = 0; m < t.size(); ++m) t[m] = std::log1p((double)m);
+        HIPC(hipMemcpyAsync(c->d_log1p, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPC(hipStreamSynchronize(c->stream));
+    }
+    if (is) {
+        double* tmp = nullptr;
+        CHK(dev_alloc(c, &tmp, (size_t)P.N + 1));
+        launch_uniform_scan(P.N, tmp, c->d_uni_scan, c->d_uni_scan + P.N, c->stream);
+        HIPC(hipMemcpyAsync(&D.uni_total, c->d_uni_scan + P.N, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPC(hipStreamSynchronize(c->stream));
+    }
+    if (cfg->model == FBA_MODEL_BA_TABLE) {
+        CHK(build_tabular_prior(c));
+        CHK(upload_prior(c));
+    }
+    // default positions for the per-step interface: slot e is run run_offset + e
+    {
+        std::vector<int32_t> run((size_t)E);
+        for (int e = 0; e < E; ++e) run[e] = cfg->run_offset + e;
+        HIPC(hipMemcpyAsync(D.run, run.data(), run.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPC(hipMemsetAsync(D.active, 1, (size_t)E, c->stream));
+        HIPC(hipStreamSynchronize(c->stream));
+    }
+    CHK(ensure_outputs(c, cfg->runs));
+    HIPC(hipStreamSynchronize(c->stream));
+    *out = c;
+    return FBA_OK;
+#undef CHK
+#undef HIPC
+}
+
+int fba_domain_sizes(const fba_ctx* c, int32_t* S, int32_t* A, int32_t* O)
+{
+    if (!c) return FBA_EINVAL;
+    *S = c->P.S; *A = c->P.A; *O = c->P.O;
+    return FBA_OK;
+}
+int fba_counts_len(const fba_ctx* c) { return c ? c->P.C : FBA_EINVAL; }
+int fba_slots(const fba_ctx* c) { return c ? c->P.E : FBA_EINVAL; }
+
+int fba_set_model_tabular(fba_ctx* c, const float* phi, const float* psi)
+{
+    if (!c || !phi || !psi) return FBA_EINVAL;
+    if (c->P.model != FBA_MODEL_BA_TABLE) return fail(c, FBA_EINVAL, "fba_set_model_tabular needs model = BA_TABLE");
+    c->prior.assign((size_t)c->P.C, 0.f);
+    std::copy(phi, phi + c->P.phi_len, c->prior.begin());
+    std::copy(psi, psi + (c->P.C - c->P.phi_len), c->prior.begin() + c->P.phi_len);
+    return upload_prior(c);
+}
+
+int fba_get_prior(const fba_ctx* c, float* counts)
+{
+    if (!c || !counts) return FBA_EINVAL;
+    std::copy(c->prior.begin(), c->prior.end(), counts);
+    return FBA_OK;
+}
+
+int fba_set_position(fba_ctx* c, const int32_t* run, const int32_t* episode, const int32_t* t)
+{
+    if (!c) return FBA_EINVAL;
+    const size_t n = (size_t)c->P.E * 4;
+    if (run) HIPCHK(c, hipMemcpyAsync(c->D.run, run, n, hipMemcpyHostToDevice, c->stream));
+    if (episode) HIPCHK(c, hipMemcpyAsync(c->D.episode, episode, n, hipMemcpyHostToDevice, c->stream));
+    if (t) HIPCHK(c, hipMemcpyAsync(c->D.t, t, n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FBA_OK;
+}
+
+int fba_belief_init(fba_ctx* c)
+{
+    if (!c) return FBA_EINVAL;
+    int rc;
+    if ((rc = set_flags(c, c->D.need_init, nullptr, 1))) return rc;
+    if ((rc = timed(c, FBA_K_BELIEF_INIT, [&] { launch_init(c->P, c->D, c->stream); }))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->belief_ready = true;
+    return FBA_OK;
+}
+
+int fba_belief_reset_domain_state(fba_ctx* c)
+{
+    if (!c) return FBA_EINVAL;
+    if (c->P.model == FBA_MODEL_POMDP) return fail(c, FBA_EINVAL, "resetDomainStateDistribution exists for Bayes-adaptive beliefs only");
+    if (!c->belief_ready) return fail(c, FBA_ESTATE, "belief not initiated");
+    int rc;
+    if ((rc = set_flags(c, c->D.need_reset, nullptr, 1))) return rc;
+    if ((rc = timed(c, FBA_K_BELIEF_RESET, [&] { launch_reset(c->P, c->D, c->stream); }))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FBA_OK;
+}
+
+int fba_select_action(fba_ctx* c, const int32_t* hist_len, const uint8_t* active, int32_t* action)
+{
+    if (!c || !action) return FBA_EINVAL;
+    if (!c->belief_ready) return fail(c, FBA_ESTATE, "belief not initiated");
+    int rc;
+    if (hist_len) HIPCHK(c, hipMemcpyAsync(c->D.t, hist_len, (size_t)c->P.E * 4, hipMemcpyHostToDevice, c->stream));
+    if ((rc = set_flags(c, c->D.active, active, 1))) return rc;
+    if ((rc = timed(c, FBA_K_SEARCH, [&] { launch_search(c->P, c->D, c->stream); }))) return rc;
+    HIPCHK(c, hipMemcpyAsync(action, c->D.action, (size_t)c->P.E * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FBA_OK;
+}
+
+int fba_belief_update(fba_ctx* c, const int32_t* action, const int32_t* obs, const uint8_t* active)
+{
+    if (!c || !action || !obs) return FBA_EINVAL;
+    if (!c->belief_ready) return fail(c, FBA_ESTATE, "belief not initiated");
+    for (int e = 0; e < c->P.E; ++e) {
+        if (active && !active[e]) continue;
+        if (action[e] < 0 || action[e] >= c->P.A) return fail(c, FBA_EINVAL, "action %d out of range", action[e]);
+        if (obs[e] < 0 || obs[e] >= c->P.O) return fail(c, FBA_EINVAL, "observation %d out of range", obs[e]);
+    }
+    int rc;
+    HIPCHK(c, hipMemcpyAsync(c->D.action, action, (size_t)c->P.E * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->D.obs, obs, (size_t)c->P.E * 4, hipMemcpyHostToDevice, c->stream));
+    if ((rc = set_flags(c, c->D.need_update, active, 1))) return rc;
+    if ((rc = timed(c, k_update_kind(c), [&] { launch_belief_update(c->P, c->D, c->stream); }))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    return FBA_OK;
+}
+
+int fba_belief_get(fba_ctx* c, int32_t slot, int32_t* state, double* weight, float* counts)
+{
+    if (!c || slot < 0 || slot >= c->P.E) return FBA_EINVAL;
+    const Problem& P = c->P;
+    uint8_t sel = 0;
+    HIPCHK(c, hipMemcpy(&sel, c->D.bufsel + slot, 1, hipMemcpyDeviceToHost));
+    const size_t pb = ((size_t)sel * P.E + slot) * (size_t)P.N;
+    if (state) HIPCHK(c, hipMemcpy(state, c->D.p_state + pb, (size_t)P.N * 4, hipMemcpyDeviceToHost));
+    if (weight) {
+        if (P.belief != FBA_BELIEF_IMPORTANCE) return fail(c, FBA_EINVAL, "the rejection filter is unweighted");
+        HIPCHK(c, hipMemcpy(weight, c->D.p_weight + pb, (size_t)P.N * 8, hipMemcpyDeviceToHost));
+    }
+    if (counts && P.C) {
+        std::vector<float> tmp((size_t)P.N * P.Cs);
+        HIPCHK(c, hipMemcpy(tmp.data(), c->D.p_cnt + pb * P.Cs, tmp.size() * 4, hipMemcpyDeviceToHost));
+        for (int i = 0; i < P.N; ++i) std::copy(tmp.begin() + (size_t)i * P.Cs, tmp.begin() + (size_t)i * P.Cs + P.C, counts + (size_t)i * P.C);
+    }
+    return FBA_OK;
+}
+
+int fba_belief_set(fba_ctx* c, int32_t slot, const int32_t* state, const double* weight, const float* counts)
+{
+    if (!c || slot < 0 || slot >= c->P.E) return FBA_EINVAL;
+    const Problem& P = c->P;
+    uint8_t sel = 0;
+    HIPCHK(c, hipMemcpy(&sel, c->D.bufsel + slot, 1, hipMemcpyDeviceToHost));
+    const size_t pb = ((size_t)sel * P.E + slot) * (size_t)P.N;
+    if (state) {
+        for (int i = 0; i < P.N; ++i)
+            if (state[i] < 0 || state[i] >= P.S) return fail(c, FBA_EINVAL, "state %d out of range", state[i]);
+        HIPCHK(c, hipMemcpy(c->D.p_state + pb, state, (size_t)P.N * 4, hipMemcpyHostToDevice));
+    }
+    if (weight && P.belief == FBA_BELIEF_IMPORTANCE) HIPCHK(c, hipMemcpy(c->D.p_weight + pb, weight, (size_t)P.N * 8, hipMemcpyHostToDevice));
+    if (counts && P.C) {
+        std::vector<float> tmp((size_t)P.N * P.Cs, 0.f);
+        for (int i = 0; i < P.N; ++i) std::copy(counts + (size_t)i * P.C, counts + (size_t)(i + 1) * P.C, tmp.begin() + (size_t)i * P.Cs);
+        HIPCHK(c, hipMemcpy(c->D.p_cnt + pb * P.Cs, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
+    }
+    c->belief_ready = true;
+    return FBA_OK;
+}
+
+int fba_last_step_info(fba_ctx* c, fba_trace_rec* recs)
+{
+    if (!c || !recs) return FBA_EINVAL;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(recs, c->D.cur, (size_t)c->P.E * sizeof(fba_trace_rec), hipMemcpyDeviceToHost));
+    return FBA_OK;
+}
+
+int fba_run_planning(fba_ctx* c, fba_stat* stats)
+{
+    if (!c || !stats) return FBA_EINVAL;
+    if (c->P.model != FBA_MODEL_POMDP) return fail(c, FBA_EINVAL, "planning::run needs model = POMDP");
+    return run_experiment(c, stats);
+}
+
+int fba_run_bapomdp(fba_ctx* c, fba_stat* stats)
+{
+    if (!c || !stats) return FBA_EINVAL;
+    if (c->P.model == FBA_MODEL_POMDP) return fail(c, FBA_EINVAL, "bapomdp::run needs a Bayes-adaptive model");
+    return run_experiment(c, stats);
+}
+
+int fba_run_ticks(fba_ctx* c, int32_t ticks)
+{
+    if (!c || ticks < 0) return FBA_EINVAL;
+    int rc;
+    if (!c->started) {
+        if ((rc = start_experiment(c, -1))) return rc;
+        c->started = true;
+    }
+    for (int k = 0; k < ticks; ++k)
+        if ((rc = tick(c))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FBA_OK;
+}
+
+int fba_get_returns(const fba_ctx* cc, double* returns, int32_t* lengths)
+{
+    fba_ctx* c = const_cast<fba_ctx*>(cc);
+    if (!c) return FBA_EINVAL;
+    const size_t n = (size_t)c->cfg.runs * c->P.episodes;
+    if (returns) HIPCHK(c, hipMemcpy(returns, c->D.returns, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (lengths) HIPCHK(c, hipMemcpy(lengths, c->D.lengths, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return FBA_OK;
+}
+
+int fba_get_counters(fba_ctx* c, fba_counters* out)
+{
+    if (!c || !out) return FBA_EINVAL;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int rc = FBA_OK;
+    out->sim_steps    = sum_counter(c, c->D.sim_steps, c->P.E, &rc);
+    out->belief_steps = sum_counter(c, c->D.belief_steps, c->P.E, &rc);
+    out->env_steps    = sum_counter(c, c->D.env_steps, c->P.E, &rc);
+    return rc;
+}
+
+int fba_get_kernel_times(fba_ctx* c, fba_kernel_time* out)
+{
+    if (!c || !out) return FBA_EINVAL;
+    int rc = flush_events(c);
+    if (rc) return rc;
+    const Problem& P = c->P;
+    const uint64_t sim       = sum_counter(c, c->D.sim_steps, P.E, &rc) - c->base_sim;
+    const uint64_t attempts  = sum_counter(c, c->D.upd_attempts, P.E, &rc) - c->base_attempts;
+    const uint64_t particles = sum_counter(c, c->D.upd_particles, P.E, &rc) - c->base_particles;
+    if (rc) return rc;
+    // algorithmic bytes, SURVEY.md section 8(d): Pb = particle payload, Rt / Ro = bytes of the
+    // transition / observation rows one step consults
+    const uint64_t Pb = 4 + 4 * (uint64_t)P.C;
+    const uint64_t Rt = P.model == FBA_MODEL_POMDP ? 0 : 4 * (uint64_t)P.S;
+    const uint64_t Ro = P.model == FBA_MODEL_POMDP ? 0 : 4 * (uint64_t)P.O;
+    for (int k = 0; k < FBA_K_COUNT; ++k) {
+        out[k].ms = c->k_ms[k];
+        out[k].launches = c->k_launches[k];
+        out[k].units = 0;
+        out[k].bytes = 0;
+    }
+    out[FBA_K_SEARCH].units = sim;
+    if (P.belief == FBA_BELIEF_REJECTION) {
+        out[FBA_K_BELIEF_RS].units = particles;
+        out[FBA_K_BELIEF_RS].bytes = attempts * (Pb + Rt + Ro) + particles * Pb;
+    } else {
+        out[FBA_K_BELIEF_IS].units = particles;
+        out[FBA_K_BELIEF_IS].bytes = particles * (32 + Rt + Ro) + particles * (8 + 2 * Pb);
+    }
+    return FBA_OK;
+}
+
+int fba_reset_kernel_times(fba_ctx* c)
+{
+    if (!c) return FBA_EINVAL;
+    int rc = flush_events(c);
+    if (rc) return rc;
+    for (int k = 0; k < FBA_K_COUNT; ++k) { c->k_ms[k] = 0; c->k_launches[k] = 0; }
+    c->base_sim       = sum_counter(c, c->D.sim_steps, c->P.E, &rc);
+    c->base_attempts  = sum_counter(c, c->D.upd_attempts, c->P.E, &rc);
+    c->base_particles = sum_counter(c, c->D.upd_particles, c->P.E, &rc);
+    return rc;
+}
+
+int fba_trace_count(const fba_ctx* cc)
+{
+    fba_ctx* c = const_cast<fba_ctx*>(cc);
+    if (!c) return FBA_EINVAL;
+    int32_t n = 0;
+    if (hipMemcpy(&n, c->D.trace_count, sizeof n, hipMemcpyDeviceToHost) != hipSuccess) return FBA_EHIP;
+    return std::min(n, c->D.trace_cap);
+}
+
+int fba_get_trace(const fba_ctx* cc, fba_trace_rec* out, int32_t cap)
+{
+    fba_ctx* c = const_cast<fba_ctx*>(cc);
+    if (!c || !out) return FBA_EINVAL;
+    const int n = std::min(fba_trace_count(c), cap);
+    if (n <= 0) return n;
+    HIPCHK(c, hipMemcpy(out, c->D.trace, (size_t)n * sizeof(fba_trace_rec), hipMemcpyDeviceToHost));
+    // slots finish their ticks in arbitrary order: present the records as the reference would
+    // print them, by (run, episode, t)
+    std::sort(out, out + n, [](const fba_trace_rec& a, const fba_trace_rec& b) {
+        if (a.run != b.run) return a.run < b.run;
+        if (a.episode != b.episode) return a.episode < b.episode;
+        return a.t < b.t;
+    });
+    return n;
+}
+
+int fba_selftest_ucb(fba_ctx* c, const double* L, const int32_t* n, int32_t count, double u, double* out)
+{
+    if (!c || !L || !n || !out || count <= 0) return FBA_EINVAL;
+    double *dL = nullptr, *dout = nullptr;
+    int32_t* dn = nullptr;
+    HIPCHK(c, hipMalloc(&dL, (size_t)count * 8));
+    HIPCHK(c, hipMalloc(&dout, (size_t)count * 8));
+    HIPCHK(c, hipMalloc(&dn, (size_t)count * 4));
+    HIPCHK(c, hipMemcpy(dL, L, (size_t)count * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dn, n, (size_t)count * 4, hipMemcpyHostToDevice));
+    launch_selftest_ucb(dL, dn, count, u, dout, c->stream);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, dout, (size_t)count * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(dL); (void)hipFree(dout); (void)hipFree(dn);
+    return FBA_OK;
+}
+
+// utils::Statistic (reference src/utils/Statistic.cpp:5-46)
+void fba_stat_add(fba_stat* s, double v)
+{
+    s->count += 1;
+    const double delta = v - s->mean;
+    s->mean += delta / s->count;
+    const double delta2 = v - s->mean;
+    s->m2 += delta * delta2;
+}
+double fba_stat_var(const fba_stat* s) { return s->count < 2 ? 0 : s->m2 / (s->count - 1); }
+double fba_stat_stder(const fba_stat* s) { return s->count < 2 ? 0 : std::sqrt(fba_stat_var(s) / s->count); }
+
+}  // extern "C"

@@ -1,0 +1,26 @@
+// fba_kernels.h -- launch interface between the host engine and the HIP kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "fba_state.h"
+
+namespace fba {
+
+constexpr int SEARCH_BLOCK  = 64;    // one wave per workgroup, one tree per lane
+constexpr int REJECT_BLOCK  = 256;   // attempts per chunk of the rejection filter
+constexpr int IS_BLOCK      = 1024;  // one workgroup per slot in the importance filter
+constexpr int IS_MAX_CHUNKS = 256;   // 256-element scan chunks per slot => N <= 65536
+
+void launch_search(const Problem& P, const DeviceState& D, hipStream_t st);
+void launch_start(const Problem& P, const DeviceState& D, hipStream_t st);
+void launch_env(const Problem& P, const DeviceState& D, int32_t* n_active, hipStream_t st);
+void launch_advance(const Problem& P, const DeviceState& D, int32_t* n_active, hipStream_t st);
+void launch_belief_update(const Problem& P, const DeviceState& D, hipStream_t st);
+void launch_init(const Problem& P, const DeviceState& D, hipStream_t st);
+void launch_reset(const Problem& P, const DeviceState& D, hipStream_t st);
+void launch_flush(const Problem& P, const DeviceState& D, hipStream_t st);
+void launch_selftest_ucb(const double* L, const int32_t* n, int count, double u, double* out, hipStream_t st);
+void launch_uniform_scan(int n, double* w_tmp, double* out, double* total, hipStream_t st);
+
+}  // namespace fba

@@ -1,0 +1,728 @@
+// fba_kernels.hip -- the HIP kernels of the BA-POMCP engine (gfx950 / CDNA4, wave64).
+//
+//   search_kernel        POUCT / RBAPOUCT tree search            (P1-P8)
+//   env_kernel           true-environment step + episode loop    (E1-E3, D1/D2)
+//   reject_kernel        rejection-sampling belief update        (B4)
+//   importance_kernel    importance update + scan + resample     (B5, B6, B3)
+//   reset_kernel         resetDomainStateDistribution            (B7)
+//   init_kernel          Belief::initiate                        (B7)
+//   flush_kernel         belief checksum + trace record
+//
+// None of this work is a dense contraction, so nothing here touches MFMA.  The belief kernels are
+// HBM-streaming (one workgroup per slot, wave ballot / prefix-sum compaction, whole-record
+// gathers); the search kernel is latency bound and gets its throughput from running one
+// independent tree per lane, all lanes executing the common "simulate one step" body together.
+#include "fba_kernels.h"
+
+#include <float.h>
+
+namespace fba {
+
+// ---------------------------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ Rng slot_rng(const Problem& P, const DeviceState& D, int e)
+{
+    Rng g;
+    g.seed(P.seed_lo, P.seed_hi);
+    g.position((uint32_t)D.run[e], (uint32_t)D.episode[e], (uint32_t)D.t[e]);
+    g.draw = 0; g.c1 = 0; g.keep_lo = 0; g.keep_hi = 0;
+    return g;
+}
+
+__device__ __forceinline__ size_t pbase(const Problem& P, int e, int buf) { return ((size_t)buf * P.E + e) * (size_t)P.N; }
+
+// WeightedFilter::sample (WeightedFilter.cpp:163-191) in device order: the largest i >= 1 whose
+// exclusive prefix sum is below the threshold, else 0.  `incl` holds inclusive prefix sums.
+__device__ __forceinline__ int weighted_pick(const double* __restrict__ incl, int n, double threshold)
+{
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (incl[mid - 1] < threshold) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// Belief::sample() of a freshly initiated / resampled filter (all weights 1/N)
+__device__ __forceinline__ int belief_sample_uniform(const Problem& P, const DeviceState& D, Rng& g)
+{
+    if (P.belief == FBA_BELIEF_REJECTION) return g.uniform_int(P.N);          // FlatFilter.cpp:97-102
+    return weighted_pick(D.uni_scan, P.N, g.u01() * D.uni_total);
+}
+
+__device__ __forceinline__ void node_init(const DeviceState& D, int32_t* rec, int A, int O)
+{
+    rec[0] = 0;
+    for (int a = 0; a < A; ++a) rec[1 + a] = 0;
+    double* q = reinterpret_cast<double*>(rec + D.cq_off);
+    for (int a = 0; a < A; ++a) q[a] = 0.0;
+    for (int k = 0; k < A * O; ++k) rec[D.child_off + k] = -1;
+}
+
+// POUCT::selectChanceNodeUCB (POUCT.cpp:138-181 = RBAPOUCT.cpp:162-205).
+// UCB(m, n) = u * sqrt(log1p(m) / n), DBL_MAX for n = 0 (POUCT.cpp:330-338); ties are collected in
+// action order and one slowRandomInt is ALWAYS drawn, also for a single candidate.
+__device__ __forceinline__ int ucb_select(const Problem& P, const DeviceState& D, Rng& g, const int32_t* rec, bool explore)
+{
+    const int m      = rec[0];
+    const double L   = explore ? D.log1p_tab[m] : 0.0;
+    const double* cq = reinterpret_cast<const double*>(rec + D.cq_off);
+    double best_q    = -DBL_MAX;
+    uint32_t mask    = 0;
+    for (int a = 0; a < P.A; ++a) {
+        double q = cq[a];
+        if (explore) {
+            const int n = rec[1 + a];
+            q += (n == 0) ? DBL_MAX : P.exploration * sqrt(L / (double)n);
+        }
+        if (q >= best_q) {
+            if (q > best_q) mask = 0;
+            best_q = q;
+            mask |= 1u << a;
+        }
+    }
+    int k = g.slow_int(0, __popc(mask));
+    while (k-- > 0) mask &= mask - 1;  // drop the k lowest candidates
+    return __ffs(mask) - 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// search_kernel: one lane = one slot = one tree; `sims` simulations, sequential semantics.
+// POUCT::selectAction POUCT.cpp:63-129, RBAPOUCT::selectAction RBAPOUCT.cpp:67-153 (the root
+// particle's counts are read in place and never written: StepType::KeepCounts).
+// The recursion traverseActionNode / traverseChanceNode / rollout (POUCT.cpp:183-303) is unrolled
+// into a state machine whose every iteration performs exactly one simulator.step, so the 64
+// trees of a wave execute the expensive part (Philox + Dirichlet-row sampling) in lock-step;
+// the path needed for the bottom-up back-up lives in LDS, laid out [depth][lane].
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceState D)
+{
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int e    = blockIdx.x * SEARCH_BLOCK + lane;
+    if (e >= P.E || !D.active[e]) return;
+
+    const int depth_cap = P.max_depth > 0 ? P.max_depth : 1;
+    double* path_r      = lds + lane;                                                   // [depth][block]
+    int32_t* path_na    = reinterpret_cast<int32_t*>(lds + (size_t)depth_cap * SEARCH_BLOCK) + lane;
+
+    Rng g               = slot_rng(P, D, e);
+    const int hist_len  = D.t[e];
+    const int max_tree_depth = min(P.horizon - hist_len, P.max_depth);
+    const int W         = D.node_words;
+    int32_t* tree       = D.nodes + (size_t)e * D.max_nodes * W;
+    const size_t pb     = pbase(P, e, D.bufsel[e]);
+    const int32_t* pst  = D.p_state + pb;
+    const float* pcn    = D.p_cnt + pb * (size_t)P.Cs;
+
+    if (P.planner == FBA_PLANNER_RANDOM) {  // RandomPlanner::selectAction RandomPlanner.cpp:14-24
+        g.stream(FBA_PHASE_SEARCH, (uint32_t)P.sims);
+        const int src = belief_sample_uniform(P, D, g);
+        D.action[e]   = domain_random_action(P, g, pst[src]);
+        return;
+    }
+
+    // addLegalActions(belief.sample(), ...): the probe draw lives in its own stream (unit = sims)
+    // and its result is not needed -- legal actions do not depend on the state in these domains.
+    node_init(D, tree, P.A, P.O);
+    int n_nodes = 1, tree_depth = 0;
+    unsigned long long steps = 0;
+
+    int sim = 0, mode = 0;  // 0 = start a simulation, 1 = in the tree, 2 = rollout
+    int s = 0, node = 0, dtg = 0, plen = 0, rdepth = 0;
+    const float* cnt = pcn;
+    double rret = 0, rdisc = 1;
+    while (true) {
+        if (mode == 0) {
+            if (sim >= P.sims) break;
+            g.stream(FBA_PHASE_SEARCH, (uint32_t)sim);
+            const int src = belief_sample_uniform(P, D, g);
+            s    = pst[src];
+            cnt  = pcn + (size_t)src * P.Cs;
+            node = 0; dtg = max_tree_depth; plen = 0; mode = 1;
+        }
+        bool finish = false, do_step = true;
+        double delayed = 0;
+        int a = 0;
+        if (mode == 1) {  // traverseActionNode
+            tree_depth = max(tree_depth, max_tree_depth - dtg);
+            if (dtg == 0) { finish = true; do_step = false; }
+            else a = ucb_select(P, D, g, tree + (size_t)node * W, true);
+        } else {          // rollout: uniformly random action
+            a = domain_random_action(P, g, s);
+        }
+        if (do_step) {
+            int o, i0, i1;
+            double r;
+            const bool term = sim_step(P, g, cnt, s, a, o, r, i0, i1);
+            ++steps;
+            if (mode == 1) {  // traverseChanceNode
+                path_r[(size_t)plen * SEARCH_BLOCK]  = r;
+                path_na[(size_t)plen * SEARCH_BLOCK] = (node << 4) | a;
+                ++plen;
+                if (term) finish = true;
+                else {
+                    int32_t* ch = tree + (size_t)node * W + D.child_off + a * P.O + o;
+                    const int c = *ch;
+                    if (c >= 0) { node = c; --dtg; }
+                    else {  // expand: new leaf, then rollout(depth_to_go - 1)
+                        const int nn = n_nodes++;
+                        node_init(D, tree + (size_t)nn * W, P.A, P.O);
+                        *ch = nn;
+                        mode = 2; rdepth = dtg - 1; rret = 0; rdisc = 1;
+                        if (rdepth == 0) finish = true;
+                    }
+                }
+            } else {
+                rret += r * rdisc;
+                rdisc *= P.gamma;
+                --rdepth;
+                if (rdepth == 0 || term) { delayed = rret; finish = true; }
+            }
+        }
+        if (finish) {
+            // back-up, leaf to root: ret = r + gamma * delayed; ChanceNode::addVisit(ret)
+            // (MCTSTreeNodes.cpp:8-12); ActionNode::addVisit() (:59-62)
+            double del = delayed;
+            for (int k = plen - 1; k >= 0; --k) {
+                const int na     = path_na[(size_t)k * SEARCH_BLOCK];
+                const double ret = path_r[(size_t)k * SEARCH_BLOCK] + P.gamma * del;
+                int32_t* rec     = tree + (size_t)(na >> 4) * W;
+                const int act    = na & 15;
+                const int n      = ++rec[1 + act];
+                double* q        = reinterpret_cast<double*>(rec + D.cq_off) + act;
+                *q += (ret - *q) / (double)n;
+                ++rec[0];
+                del = ret;
+            }
+            ++sim;
+            mode = 0;
+        }
+    }
+    g.stream(FBA_PHASE_SEARCH, (uint32_t)P.sims + 1u);
+    const int best = ucb_select(P, D, g, tree, false);
+    D.action[e]    = best;
+    D.sim_steps[e] += steps;
+    fba_trace_rec& rec = D.cur[e];
+    rec.n_nodes    = n_nodes;
+    rec.tree_depth = tree_depth;
+    const double* cq = reinterpret_cast<const double*>(tree + D.cq_off);
+    for (int a = 0; a < FBA_MAX_ACTIONS; ++a) {
+        rec.root_n[a] = a < P.A ? tree[1 + a] : 0;
+        rec.root_q[a] = a < P.A ? cq[a] : 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Episode bookkeeping shared by start_kernel and env_kernel
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void begin_episode(const Problem& P, const DeviceState& D, int e)
+{
+    D.t[e] = 0;
+    Rng g  = slot_rng(P, D, e);
+    g.stream(FBA_PHASE_START, 0);
+    D.env_state[e] = domain_start(P, g);  // Episode.cpp:32
+    D.ret[e]  = 0;
+    D.disc[e] = 1;
+}
+
+// Sets every slot at the beginning of its first run.
+__global__ void start_kernel(Problem P, DeviceState D)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= P.E) return;
+    const int run  = D.run_offset + e;
+    const bool on  = D.runs_total < 0 || e < D.runs_total;
+    D.run[e]       = run;
+    D.episode[e]   = 0;
+    D.active[e]    = on;
+    D.need_update[e] = 0;
+    D.need_init[e]   = on;
+    D.need_reset[e]  = on && P.model != FBA_MODEL_POMDP;
+    D.cur[e].update_count = -1;
+    if (on) begin_episode(P, D, e);
+}
+
+// env_kernel: the body of episode::run's loop after selectAction (Episode.cpp:42-55) and the
+// run / episode loops of the two experiments (PlanningExperiment.cpp:39-52,
+// BAPOMDPExperiment.cpp:44-75).  One lane per slot.
+__global__ void env_kernel(Problem P, DeviceState D, int32_t* n_active)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= P.E || !D.active[e]) return;
+    Rng g = slot_rng(P, D, e);
+    g.stream(FBA_PHASE_ENV, 0);
+    const int a = D.action[e];
+    int s = D.env_state[e], o = 0;
+    double r = 0;
+    const bool term = domain_step(P, g, s, a, o, r);
+    D.env_state[e]  = s;
+    D.obs[e]        = o;
+    D.env_steps[e] += 1;
+    const double ret  = D.ret[e] + r * D.disc[e];  // Return::add (Return.cpp:6-9)
+    D.ret[e]          = ret;
+    D.disc[e]        *= P.gamma;
+    const int t       = D.t[e];
+    // belief.updateEstimation unless the step was terminal (Episode.cpp:47-50)
+    D.need_update[e] = !term;
+    if (D.trace_on) {
+        fba_trace_rec& rec = D.cur[e];
+        rec.run = D.run[e]; rec.episode = D.episode[e]; rec.t = t;
+        rec.action = a; rec.state = s; rec.obs = o; rec.terminal = term;
+        rec.reward = r; rec.update_count = -1; rec.weight_total = 0;
+        rec.belief_hash = 1;  // "flush pending" marker, overwritten by flush_kernel
+    }
+    if (!term && t + 1 < P.horizon) {
+        D.t[e] = t + 1;
+        return;
+    }
+    // episode over: record the return, then the next episode / run of this slot
+    const int run = D.run[e], ep = D.episode[e];
+    const long long slot_run = (long long)run - D.run_offset;
+    if (D.runs_total >= 0) {
+        D.returns[(size_t)slot_run * P.episodes + ep] = ret;
+        D.lengths[(size_t)slot_run * P.episodes + ep] = t + 1;
+    }
+    // the belief update of this last step still reads (run, episode, t): defer the position
+    // change to advance_kernel, which runs after the belief update of this tick
+    D.need_reset[e] = 2;  // 2 = "episode ended", resolved by advance_kernel
+    (void)n_active;
+}
+
+// advance_kernel: moves slots whose episode ended to their next episode or run (after this
+// tick's belief update has consumed the old stream position).
+__global__ void advance_kernel(Problem P, DeviceState D, int32_t* n_active)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= P.E || !D.active[e] || D.need_reset[e] != 2) return;
+    D.need_reset[e] = 0;
+    int run = D.run[e], ep = D.episode[e] + 1;
+    if (ep < P.episodes) {
+        D.episode[e]    = ep;
+        D.need_reset[e] = P.model != FBA_MODEL_POMDP;
+    } else {
+        run += P.E;  // slot e executes runs e, e + E, e + 2E, ...
+        if (D.runs_total >= 0 && run - D.run_offset >= D.runs_total) {
+            D.active[e] = 0;
+            atomicSub(n_active, 1);
+            return;
+        }
+        D.run[e]        = run;
+        D.episode[e]    = 0;
+        D.need_init[e]  = 1;
+        D.need_reset[e] = P.model != FBA_MODEL_POMDP;
+    }
+    begin_episode(P, D, e);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Whole-record gather: the m particles listed in s_src[] (LDS) are copied from `src` records to
+// consecutive `dst` records, applying the UpdateCounts "+1" at blob indices inc0/inc1 (-1 = none).
+// A record is C4 float4; a power-of-two group of lanes owns one record so consecutive lanes move
+// consecutive 16-byte pieces: every wave instruction reads and writes whole contiguous records.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void gather_records(float* __restrict__ dst, const float* __restrict__ src, const int32_t* s_src,
+                                               const int32_t* s_inc0, const int32_t* s_inc1, int m, int C4, int group,
+                                               int nthreads)
+{
+    const int gid = threadIdx.x / group, part0 = threadIdx.x % group, ngroups = nthreads / group;
+    for (int j = gid; j < m; j += ngroups) {
+        const float4* sp = reinterpret_cast<const float4*>(src) + (size_t)s_src[j] * C4;
+        float4* dp       = reinterpret_cast<float4*>(dst) + (size_t)j * C4;
+        const int i0 = s_inc0 ? s_inc0[j] : -1, i1 = s_inc1 ? s_inc1[j] : -1;
+        for (int part = part0; part < C4; part += group) {
+            float4 v = sp[part];
+            const int lo = part * 4;
+            if ((unsigned)(i0 - lo) < 4u) (&v.x)[i0 - lo] += 1.0f;
+            if ((unsigned)(i1 - lo) < 4u) (&v.x)[i1 - lo] += 1.0f;
+            dp[part] = v;
+        }
+    }
+}
+
+__device__ __forceinline__ int record_group(int C4)
+{
+    int g = 1;
+    while (g < C4 && g < 64) g <<= 1;
+    return g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// reject_kernel: beliefs::rejectSample (RejectionSampling.hpp:26-72), one workgroup per slot.
+// Attempt k is an independent Philox stream, so a chunk of 256 attempts runs in parallel; the
+// accepted ones are compacted in attempt order with a wave ballot + prefix sum, which keeps the
+// reference's result: the new filter is the first N accepted attempts, in order, and the
+// reported loop count is the index of the N-th accepted attempt + 1.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(REJECT_BLOCK) reject_kernel(Problem P, DeviceState D)
+{
+    __shared__ int32_t s_src[REJECT_BLOCK], s_ns[REJECT_BLOCK], s_inc0[REJECT_BLOCK], s_inc1[REJECT_BLOCK];
+    __shared__ int32_t s_wave[REJECT_BLOCK / 64];
+    __shared__ int32_t s_count;
+    const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (!D.need_update[e]) return;
+    const int a = D.action[e], o = D.obs[e], N = P.N;
+    const int cur = D.bufsel[e];
+    const size_t sb = pbase(P, e, cur), db = pbase(P, e, cur ^ 1);
+    const int32_t* sst = D.p_state + sb;
+    const float* scn   = D.p_cnt + sb * (size_t)P.Cs;
+    int32_t* dst_st    = D.p_state + db;
+    float* dcn         = D.p_cnt + db * (size_t)P.Cs;
+    const int C4 = P.Cs / 4, group = record_group(C4);
+    Rng g = slot_rng(P, D, e);
+
+    int acc = 0, base = 0;
+    while (acc < N) {
+        const int k = base + tid;
+        g.stream(FBA_PHASE_REJECT, (uint32_t)k);
+        const int src = g.uniform_int(N);                       // FlatFilter::sample
+        int s = sst[src], so, i0, i1;
+        double r;
+        sim_step(P, g, scn + (size_t)src * P.Cs, s, a, so, r, i0, i1);  // UpdateCounts: +1 lands in the copy
+        const bool ok = (so == o);
+        const unsigned long long ballot = __ballot(ok);
+        const int prefix = __popcll(ballot & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wave] = __popcll(ballot);
+        __syncthreads();
+        int woff = 0, chunk = 0;
+        for (int w = 0; w < REJECT_BLOCK / 64; ++w) {
+            if (w < wave) woff += s_wave[w];
+            chunk += s_wave[w];
+        }
+        const int j = woff + prefix;  // position among this chunk's accepted attempts
+        if (ok && acc + j < N) {
+            s_src[j] = src; s_ns[j] = s; s_inc0[j] = i0; s_inc1[j] = i1;
+            if (acc + j == N - 1) s_count = k + 1;
+        }
+        __syncthreads();
+        const int m = min(chunk, N - acc);
+        if (C4 > 0) gather_records(dcn + (size_t)acc * P.Cs, scn, s_src, s_inc0, s_inc1, m, C4, group, REJECT_BLOCK);
+        for (int q = tid; q < m; q += REJECT_BLOCK) dst_st[acc + q] = s_ns[q];
+        acc += m;
+        base += REJECT_BLOCK;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        D.bufsel[e]      = cur ^ 1;
+        D.need_update[e] = 0;
+        D.belief_steps[e] += (unsigned long long)s_count;
+        D.upd_attempts[e] += (unsigned long long)s_count;
+        D.upd_particles[e] += (unsigned long long)N;
+        D.cur[e].update_count = s_count;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device-order prefix sums (DESIGN.md "device-order sums"; oracle/orc.c dev_scan is the CPU twin):
+// each lane sums 4 consecutive elements sequentially, a 64-lane Kogge-Stone scan combines the
+// lane sums of one 256-element chunk, chunks are chained sequentially.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_inclusive_scan(double v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double t = __shfl_up(v, d, 64);
+        if (lane >= d) v = v + t;
+    }
+    return v;
+}
+
+// in: n doubles; out_incl may be null.  s_carry: LDS, at least n/256 + 2 doubles.  Returns the
+// total to every thread.  All threads of the block must call.
+__device__ double block_device_scan(const double* __restrict__ in, int n, double* __restrict__ out_incl, double* s_carry)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int nchunks = (n + 255) >> 8;
+    for (int c = wave; c < nchunks; c += nwaves) {
+        const int i0 = c * 256 + lane * 4;
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double x = (i0 + k < n) ? in[i0 + k] : 0.0;
+            s = (k == 0) ? x : s + x;
+        }
+        const double incl = wave_inclusive_scan(s, lane);
+        if (lane == 63) s_carry[c + 1] = incl;  // chunk total
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double carry = 0;
+        s_carry[0]   = 0;
+        for (int c = 0; c < nchunks; ++c) {
+            const double t = s_carry[c + 1];
+            carry          = carry + t;
+            s_carry[c + 1] = carry;  // carry into chunk c + 1 (the last one is the total)
+        }
+    }
+    __syncthreads();
+    const double total = s_carry[nchunks];
+    if (out_incl) {
+        for (int c = wave; c < nchunks; c += nwaves) {
+            const int i0 = c * 256 + lane * 4;
+            double x[4], s = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                x[k] = (i0 + k < n) ? in[i0 + k] : 0.0;
+                s    = (k == 0) ? x[k] : s + x[k];
+            }
+            const double incl = wave_inclusive_scan(s, lane);
+            double excl       = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = 0.0;
+            double run = s_carry[c] + excl;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (i0 + k < n) {
+                    run += x[k];
+                    out_incl[i0 + k] = run;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    return total;
+}
+
+// uniform_scan_kernel: prefix sums of N weights 1/N, computed once per ctx.
+__global__ void __launch_bounds__(IS_BLOCK) uniform_scan_kernel(int n, double* w_tmp, double* out, double* total)
+{
+    __shared__ double s_carry[IS_MAX_CHUNKS + 2];
+    const double w = 1.0 / (double)n;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) w_tmp[i] = w;
+    __syncthreads();
+    const double t = block_device_scan(w_tmp, n, out, s_carry);
+    if (threadIdx.x == 0) *total = t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// importance_kernel: importance_sampling::update + resample (ImportanceSampler.hpp:31-94,
+// WeightedFilter::normalize WeightedFilter.cpp:130-143, ::sample :163-191), one workgroup per slot.
+//   1. every particle steps in place (UpdateCounts) and multiplies its weight by P(o | a, s')
+//   2. total weight, normalisation, prefix sums of the normalised weights     (device order)
+//   3. N multinomial draws by binary search on the prefix sums
+//   4. whole-record gather into the other buffer, weights reset to 1/N
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceState D)
+{
+    __shared__ double s_carry[IS_MAX_CHUNKS + 2];
+    __shared__ int32_t s_src[IS_BLOCK];
+    const int e = blockIdx.x, tid = threadIdx.x;
+    if (!D.need_update[e]) return;
+    const int a = D.action[e], o = D.obs[e], N = P.N;
+    const int cur = D.bufsel[e];
+    const size_t sb = pbase(P, e, cur), db = pbase(P, e, cur ^ 1);
+    int32_t* sst = D.p_state + sb;
+    double* sw   = D.p_weight + sb;
+    float* scn   = D.p_cnt + sb * (size_t)P.Cs;
+    int32_t* dst_st = D.p_state + db;
+    double* dw      = D.p_weight + db;
+    float* dcn      = D.p_cnt + db * (size_t)P.Cs;
+    double* wscan   = D.wscan + (size_t)e * N;
+    const int C4 = P.Cs / 4, group = record_group(C4);
+    Rng g = slot_rng(P, D, e);
+
+    for (int i = tid; i < N; i += IS_BLOCK) {
+        g.stream(FBA_PHASE_IS_UPDATE, (uint32_t)i);
+        float* cnt = scn + (size_t)i * P.Cs;
+        int s = sst[i], so, i0, i1;
+        double r;
+        sim_step(P, g, cnt, s, a, so, r, i0, i1);
+        if (i0 >= 0) { cnt[i0] += 1.0f; cnt[i1] += 1.0f; }  // incrementCountsOf (BAFlatModel.cpp:126-139)
+        sst[i] = s;
+        sw[i] *= sim_obs_prob(P, cnt, s, a, o);  // probability from the updated counts
+    }
+    __syncthreads();
+    const double total = block_device_scan(sw, N, nullptr, s_carry);
+    for (int i = tid; i < N; i += IS_BLOCK) sw[i] /= total;
+    __syncthreads();
+    const double total_w = block_device_scan(sw, N, wscan, s_carry);
+    const double w1 = 1.0 / (double)N;
+    for (int j0 = 0; j0 < N; j0 += IS_BLOCK) {
+        const int j = j0 + tid;
+        if (j < N) {
+            g.stream(FBA_PHASE_RESAMPLE, (uint32_t)j);
+            const int src = weighted_pick(wscan, N, g.u01() * total_w);
+            s_src[tid]    = src;
+            dst_st[j]     = sst[src];
+            dw[j]         = w1;
+        }
+        __syncthreads();
+        const int m = min(IS_BLOCK, N - j0);
+        if (C4 > 0) gather_records(dcn + (size_t)j0 * P.Cs, scn, s_src, nullptr, nullptr, m, C4, group, IS_BLOCK);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        D.bufsel[e]      = cur ^ 1;
+        D.need_update[e] = 0;
+        D.belief_steps[e] += (unsigned long long)N;
+        D.upd_attempts[e] += (unsigned long long)N;
+        D.upd_particles[e] += (unsigned long long)N;
+        D.cur[e].update_count = -1;
+        D.cur[e].weight_total = total;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// init_kernel: Belief::initiate -- N x simulator.sampleStartState()
+// (RejectionSampling.cpp:15-20, ImportanceSampler.cpp:45-55; BAPOMDP::sampleStartState
+// BAPOMDP.cpp:101-104 = prior->sample(domain start state)).  One workgroup per slot.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) init_kernel(Problem P, DeviceState D)
+{
+    const int e = blockIdx.x, tid = threadIdx.x;
+    if (!D.need_init[e]) return;
+    const size_t pb = pbase(P, e, D.bufsel[e]);
+    Rng g = slot_rng(P, D, e);
+    g.position((uint32_t)D.run[e], 0, 0);
+    const double w1 = 1.0 / (double)P.N;
+    for (int i = tid; i < P.N; i += 256) {
+        g.stream(FBA_PHASE_INIT, (uint32_t)i);
+        D.p_state[pb + i] = domain_start(P, g);
+        if (P.belief == FBA_BELIEF_IMPORTANCE) D.p_weight[pb + i] = w1;
+    }
+    const int C4 = P.Cs / 4;
+    if (C4 > 0) {
+        const float4* pr = reinterpret_cast<const float4*>(D.prior);
+        float4* dp       = reinterpret_cast<float4*>(D.p_cnt + pb * (size_t)P.Cs);
+        const size_t tot = (size_t)P.N * C4;
+        for (size_t f = tid; f < tot; f += 256) dp[f] = pr[f % C4];
+    }
+    __syncthreads();
+    if (tid == 0) D.need_init[e] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// reset_kernel: BABelief::resetDomainStateDistribution.
+// Rejection filter (BARejectionSampling.cpp:49-60): every particle keeps its counts and gets a
+// fresh domain start state.  Importance filter (BAImportanceSampling.cpp:90-111): N particles are
+// re-drawn from the (uniformly weighted) filter, copied, and given a fresh start state.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) reset_kernel(Problem P, DeviceState D)
+{
+    __shared__ int32_t s_src[256];
+    const int e = blockIdx.x, tid = threadIdx.x;
+    if (D.need_reset[e] != 1) return;
+    const int cur = D.bufsel[e];
+    const size_t sb = pbase(P, e, cur), db = pbase(P, e, cur ^ 1);
+    Rng g = slot_rng(P, D, e);
+    g.position((uint32_t)D.run[e], (uint32_t)D.episode[e], 0);
+    if (P.belief == FBA_BELIEF_REJECTION) {
+        for (int i = tid; i < P.N; i += 256) {
+            g.stream(FBA_PHASE_RESET, (uint32_t)i);
+            D.p_state[sb + i] = domain_start(P, g);
+        }
+        __syncthreads();
+        if (tid == 0) D.need_reset[e] = 0;
+        return;
+    }
+    const int C4 = P.Cs / 4, group = record_group(C4);
+    const double w1 = 1.0 / (double)P.N;
+    for (int j0 = 0; j0 < P.N; j0 += 256) {
+        const int j = j0 + tid;
+        if (j < P.N) {
+            g.stream(FBA_PHASE_RESET, (uint32_t)j);
+            s_src[tid]        = weighted_pick(D.uni_scan, P.N, g.u01() * D.uni_total);
+            D.p_state[db + j] = domain_start(P, g);
+            D.p_weight[db + j] = w1;
+        }
+        __syncthreads();
+        const int m = min(256, P.N - j0);
+        if (C4 > 0)
+            gather_records(D.p_cnt + (db + j0) * (size_t)P.Cs, D.p_cnt + sb * (size_t)P.Cs, s_src, nullptr, nullptr, m, C4, group, 256);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        D.bufsel[e]     = cur ^ 1;
+        D.need_reset[e] = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// flush_kernel: belief checksum (sum over particles of a position-keyed hash, so the order of
+// the additions does not matter) and hand-over of the tick's trace record.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) flush_kernel(Problem P, DeviceState D)
+{
+    __shared__ unsigned long long s_sum;
+    const int e = blockIdx.x, tid = threadIdx.x;
+    if (!D.trace_on || D.cur[e].belief_hash != 1) return;
+    if (tid == 0) s_sum = 0;
+    __syncthreads();
+    const size_t pb = pbase(P, e, D.bufsel[e]);
+    unsigned long long local = 0;
+    for (int i = tid; i < P.N; i += 256) {
+        uint64_t h = mix64((uint64_t)i * 0x9E3779B97F4A7C15ull + (uint64_t)(uint32_t)D.p_state[pb + i]);
+        const double w = (P.belief == FBA_BELIEF_IMPORTANCE) ? D.p_weight[pb + i] : 0.0;
+        h = mix64(h ^ (uint64_t)__double_as_longlong(w));
+        const float* cnt = D.p_cnt + (pb + i) * (size_t)P.Cs;
+        for (int k = 0; k < P.C; ++k) h = mix64(h ^ ((uint64_t)__float_as_uint(cnt[k]) + ((uint64_t)k << 32)));
+        local += h;
+    }
+    atomicAdd(&s_sum, local);
+    __syncthreads();
+    if (tid == 0) {
+        D.cur[e].belief_hash = s_sum;
+        const int idx = atomicAdd(D.trace_count, 1);
+        if (idx < D.trace_cap) D.trace[idx] = D.cur[e];
+    }
+}
+
+// diagnostic: the UCB bonus expression exactly as ucb_select evaluates it
+__global__ void selftest_ucb_kernel(const double* L, const int32_t* n, int count, double u, double* out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = u * sqrt(L[i] / (double)n[i]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+void launch_search(const Problem& P, const DeviceState& D, hipStream_t st)
+{
+    const int depth_cap = P.max_depth > 0 ? P.max_depth : 1;
+    const size_t lds = (size_t)depth_cap * SEARCH_BLOCK * (sizeof(double) + sizeof(int32_t));
+    hipLaunchKernelGGL(search_kernel, dim3(ceil_div(P.E, SEARCH_BLOCK)), dim3(SEARCH_BLOCK), lds, st, P, D);
+}
+void launch_start(const Problem& P, const DeviceState& D, hipStream_t st)
+{
+    hipLaunchKernelGGL(start_kernel, dim3(ceil_div(P.E, 256)), dim3(256), 0, st, P, D);
+}
+void launch_env(const Problem& P, const DeviceState& D, int32_t* n_active, hipStream_t st)
+{
+    hipLaunchKernelGGL(env_kernel, dim3(ceil_div(P.E, 256)), dim3(256), 0, st, P, D, n_active);
+}
+void launch_advance(const Problem& P, const DeviceState& D, int32_t* n_active, hipStream_t st)
+{
+    hipLaunchKernelGGL(advance_kernel, dim3(ceil_div(P.E, 256)), dim3(256), 0, st, P, D, n_active);
+}
+void launch_belief_update(const Problem& P, const DeviceState& D, hipStream_t st)
+{
+    if (P.belief == FBA_BELIEF_REJECTION)
+        hipLaunchKernelGGL(reject_kernel, dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D);
+    else
+        hipLaunchKernelGGL(importance_kernel, dim3(P.E), dim3(IS_BLOCK), 0, st, P, D);
+}
+void launch_init(const Problem& P, const DeviceState& D, hipStream_t st)
+{
+    hipLaunchKernelGGL(init_kernel, dim3(P.E), dim3(256), 0, st, P, D);
+}
+void launch_reset(const Problem& P, const DeviceState& D, hipStream_t st)
+{
+    hipLaunchKernelGGL(reset_kernel, dim3(P.E), dim3(256), 0, st, P, D);
+}
+void launch_flush(const Problem& P, const DeviceState& D, hipStream_t st)
+{
+    hipLaunchKernelGGL(flush_kernel, dim3(P.E), dim3(256), 0, st, P, D);
+}
+void launch_selftest_ucb(const double* L, const int32_t* n, int count, double u, double* out, hipStream_t st)
+{
+    hipLaunchKernelGGL(selftest_ucb_kernel, dim3(ceil_div(count, 256)), dim3(256), 0, st, L, n, count, u, out);
+}
+void launch_uniform_scan(int n, double* w_tmp, double* out, double* total, hipStream_t st)
+{
+    hipLaunchKernelGGL(uniform_scan_kernel, dim3(1), dim3(IS_BLOCK), 0, st, n, w_tmp, out, total);
+}
+
+}  // namespace fba

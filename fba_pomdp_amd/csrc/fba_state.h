@@ -1,0 +1,74 @@
+// fba_state.h -- layout of everything the engine keeps resident in HBM.
+//
+// Particle set of slot e, buffer b (two buffers; resampling gathers from one into the other,
+// bufsel[e] says which one is live):
+//     state  : int32  [2][E][N]
+//     weight : double [2][E][N]                 (importance sampling only)
+//     counts : float  [2][E][N][Cs]             one contiguous record of Cs floats per particle
+//                                               (Cs = C rounded up to 4 so records are 16-B aligned)
+// Records are kept whole (AoS) because the resample/rejection gather moves whole particles:
+// a record is one contiguous burst on both the read and the write side, and the per-slot source
+// set (N * Cs * 4 B, 393 KB for tiger at N = 4096) stays L2-resident while its slot's workgroup
+// gathers from it.  The per-particle scalars (state, weight) are SoA so the streaming passes
+// (importance update, scan) read them fully coalesced.
+//
+// Search tree of slot e: `max_nodes` fixed-size node records, slot-major, so one tree step
+// touches one or two cache lines:
+//     word 0            : ActionNode visit count
+//     words 1..A        : ChanceNode visit counts
+//     words cq_off..    : ChanceNode Q values (double[A], 8-B aligned)
+//     words child_off.. : child node index per (action, observation), -1 = absent
+#pragma once
+
+#include <stdint.h>
+
+#include "fba_device.h"
+
+namespace fba {
+
+struct DeviceState {
+    // --- per-slot experiment position ---
+    int32_t* run;       // [E] global run index
+    int32_t* episode;   // [E]
+    int32_t* t;         // [E] real time-step inside the episode (= History::length())
+    uint8_t* active;    // [E] slot still has work
+    uint8_t* need_update;  // [E] belief update pending (last env step was not terminal)
+    uint8_t* need_reset;   // [E] resetDomainStateDistribution pending (new episode)
+    uint8_t* need_init;    // [E] Belief::initiate pending (new run)
+    int32_t* env_state; // [E] true environment state
+    double* ret;        // [E] discounted return so far
+    double* disc;       // [E] accumulated discount
+    int32_t* action;    // [E] last selected action
+    int32_t* obs;       // [E] last real observation
+    // --- belief ---
+    uint8_t* bufsel;    // [E]
+    int32_t* p_state;   // [2][E][N]
+    double* p_weight;   // [2][E][N]
+    float* p_cnt;       // [2][E][N][Cs]
+    double* wscan;      // [E][N] scratch: inclusive device-order prefix sums of normalised weights
+    int32_t* src_idx;   // [E][N] scratch: resample ancestors
+    const float* prior; // [Cs]
+    const double* uni_scan; // [N] prefix sums of N uniform weights 1/N (device order)
+    double uni_total;
+    // --- tree ---
+    int32_t* nodes;     // [E][max_nodes][node_words]
+    int32_t max_nodes, node_words, cq_off, child_off;
+    const double* log1p_tab; // [sims + 1]
+    // --- outputs ---
+    double* returns;    // [runs][episodes]
+    int32_t* lengths;   // [runs][episodes]
+    int32_t runs_total; // run indices >= run_offset + runs_total are not executed (<0: unbounded)
+    int32_t run_offset;
+    unsigned long long* sim_steps;    // [E]
+    unsigned long long* belief_steps; // [E]
+    unsigned long long* env_steps;    // [E]
+    unsigned long long* upd_particles; // [E] particles written by belief updates
+    unsigned long long* upd_attempts;  // [E] rejection attempts / importance particles stepped
+    fba_trace_rec* cur;  // [E] record being assembled for the current tick
+    fba_trace_rec* trace; // [trace_cap]
+    int32_t* trace_count;
+    int32_t trace_cap;
+    int32_t trace_on;
+};
+
+}  // namespace fba

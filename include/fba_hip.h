@@ -1,0 +1,218 @@
+/*
+ * include/fba_hip.h -- C-ABI of libfba_hip.so, the MI355X-native BA-POMCP engine.
+ *
+ * This is the drop-in boundary for the reference's hot path.  samkatt/fba-pomdp has no FFI of
+ * its own: its boundary is a set of C++ abstract classes + string-keyed factories
+ * (SURVEY.md section 8b).  Each entry point below names the reference interface it replaces;
+ * INTEGRATION.md shows the C++ adapter classes (fba_pomdp_amd/csrc/host/adapters.hpp) a
+ * maintainer registers in those factories.
+ *
+ * Conventions: every function returns 0 on success or a negative FBA_E* code;
+ * fba_last_error() gives the message (the adapters re-throw it as std::string, which the
+ * reference's main()s already catch: src/planning.cpp:46-54).  The caller owns every host
+ * buffer; the ctx owns all device memory.  One ctx <-> one host thread <-> one HIP stream.
+ *
+ * A ctx holds `slots` independent (planner, belief) pairs that advance in lock-step on the
+ * device; slots = 1 is exactly one reference Planner + Belief.  All per-slot array arguments
+ * have length `slots`.
+ */
+#ifndef FBA_HIP_H
+#define FBA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FBA_ABI_VERSION 1
+#define FBA_MAX_ACTIONS 16
+
+/* domains: reference src/domains, selected by -D (DomainConf.hpp) */
+enum {
+    FBA_DOM_TIGER_EPISODIC    = 0, /* episodic-tiger             src/domains/tiger/Tiger.cpp          */
+    FBA_DOM_TIGER_CONTINUOUS  = 1, /* continuous-tiger                                                */
+    FBA_DOM_FTIGER_EPISODIC   = 2, /* episodic-factored-tiger    src/domains/tiger/FactoredTiger.cpp  */
+    FBA_DOM_FTIGER_CONTINUOUS = 3, /* continuous-factored-tiger                                       */
+    FBA_DOM_GRIDWORLD         = 4, /* gridworld                  src/domains/gridworld/GridWorld.cpp  */
+    FBA_DOM_COLLISION_AVOID   = 5
+};
+/* simulator: plain POMDP (planning), tabular BA-POMDP (bapomdp), factored (fbapomdp) */
+enum { FBA_MODEL_POMDP = 0, FBA_MODEL_BA_TABLE = 1, FBA_MODEL_BA_FACTORED = 2 };
+/* -B rejection_sampling | importance_sampling (BeliefConf.hpp, Belief.cpp:13-24) */
+enum { FBA_BELIEF_REJECTION = 0, FBA_BELIEF_IMPORTANCE = 1 };
+/* -P po-uct | random (Planner.cpp:12-19) */
+enum { FBA_PLANNER_POUCT = 0, FBA_PLANNER_RANDOM = 1 };
+/* --structure-prior (FBAConf.hpp) */
+enum { FBA_SP_NONE = 0, FBA_SP_UNIFORM = 1, FBA_SP_MATCH_UNIFORM = 2, FBA_SP_FULLY_CONNECTED = 3 };
+
+/* Philox stream phases: a draw is addressed by (seed, run, episode, t, phase, unit, draw#) */
+enum {
+    FBA_PHASE_INIT      = 0,
+    FBA_PHASE_RESET     = 1,
+    FBA_PHASE_START     = 2,
+    FBA_PHASE_SEARCH    = 3,
+    FBA_PHASE_ENV       = 4,
+    FBA_PHASE_REJECT    = 5,
+    FBA_PHASE_IS_UPDATE = 6,
+    FBA_PHASE_RESAMPLE  = 7
+};
+
+enum {
+    FBA_OK        = 0,
+    FBA_EINVAL    = -1, /* bad argument / unsupported configuration (reference: throw "...") */
+    FBA_EHIP      = -2, /* HIP runtime error                                                  */
+    FBA_ENODEVICE = -3, /* no gfx950 device visible: the engine never falls back to the CPU   */
+    FBA_ESTATE    = -4  /* call order violated (e.g. select_action before belief_init)        */
+};
+
+/* Flag names and defaults follow the reference CLI (Conf.hpp:14-45, PlannerConf.hpp:16-18,
+ * BeliefConf.hpp:16-21, BAConf.hpp:17-22, FBAConf.hpp).  fba_default_config() fills them. */
+typedef struct fba_config {
+    int32_t domain;          /* -D                                  */
+    int32_t size;            /* --size                              */
+    int32_t width;           /* --width                             */
+    int32_t height;          /* --height                            */
+    int32_t model;           /* which executable: planning / bapomdp / fbapomdp */
+    int32_t belief;          /* -B                                  */
+    int32_t planner;         /* -P                                  */
+    int32_t particles;       /* --particle-amount        (100)      */
+    int32_t sims;            /* -s / --num-sims          (1000)     */
+    int32_t max_depth;       /* --mcts-max-depth   (-1 => horizon)  */
+    int32_t horizon;         /* -H                       (10)       */
+    double exploration;      /* -u                       (100)      */
+    double discount;         /* -d                       (0.95)     */
+    int32_t runs;            /* --runs                   (1)        */
+    int32_t episodes;        /* --episodes               (1)        */
+    float noise;             /* --noise                  (0)        */
+    float counts_total;      /* -C                       (10000)    */
+    int32_t structure_prior; /* --structure-prior                   */
+    uint64_t seed;           /* --seed (Philox key)                 */
+    int32_t run_offset;      /* global index of this ctx's first run (episode sharding)      */
+    int32_t slots;           /* concurrent runs on the device; 0 => min(runs, auto)          */
+    int32_t device;          /* HIP device ordinal                                           */
+    int32_t trace;           /* 1 => record one fba_trace_rec per real time-step             */
+} fba_config;
+
+/* One record per real time-step: the information the reference prints at -v 2 / -v 3
+ * (Episode.cpp:44-45, POUCT.cpp:93-101, RejectionSampling.hpp:68) plus a belief checksum. */
+typedef struct fba_trace_rec {
+    int32_t run, episode, t;
+    int32_t action, state, obs;
+    int32_t terminal;
+    int32_t n_nodes, tree_depth;
+    int32_t update_count;
+    int32_t root_n[FBA_MAX_ACTIONS];
+    double root_q[FBA_MAX_ACTIONS];
+    double reward;
+    double weight_total;
+    uint64_t belief_hash;
+} fba_trace_rec;
+
+/* utils::Statistic (src/utils/Statistic.cpp:5-46) */
+typedef struct fba_stat {
+    double count, mean, m2;
+} fba_stat;
+
+typedef struct fba_counters {
+    uint64_t sim_steps;    /* simulator.step calls made by the planner (tree + rollout) */
+    uint64_t belief_steps; /* simulator.step calls made by the belief update            */
+    uint64_t env_steps;    /* true-environment steps                                     */
+} fba_counters;
+
+/* kernels the engine times with HIP events on its own stream (bench.py roofline) */
+enum {
+    FBA_K_SEARCH       = 0,
+    FBA_K_ENV          = 1,
+    FBA_K_BELIEF_RS    = 2, /* rejection update: sample, step, compact, gather */
+    FBA_K_BELIEF_IS    = 3, /* importance update + scan + resample gather      */
+    FBA_K_BELIEF_RESET = 4,
+    FBA_K_BELIEF_INIT  = 5,
+    FBA_K_COUNT        = 6
+};
+typedef struct fba_kernel_time {
+    double ms;          /* sum of HIP-event durations */
+    uint64_t launches;
+    uint64_t units;     /* particles written (belief kernels) / simulated steps (search) */
+    uint64_t bytes;     /* algorithmic bytes, SURVEY.md section 8(d) formulas            */
+} fba_kernel_time;
+
+typedef struct fba_ctx fba_ctx;
+
+int fba_abi_version(void);
+void fba_default_config(fba_config* cfg);
+
+/* Construction.  Replaces the factory calls of experiment::planning::run /
+ * experiment::bapomdp::run (PlanningExperiment.cpp:31-36, BAPOMDPExperiment.cpp:36-42):
+ * makePlanner / makeBAPlanner, makeBelief / makeBABelief, makePOMDP / makeTBAPOMDP / makeFBAPOMDP. */
+int fba_create(const fba_config* cfg, fba_ctx** out);
+void fba_destroy(fba_ctx* ctx);
+const char* fba_last_error(const fba_ctx* ctx); /* ctx may be NULL: last create error */
+
+int fba_domain_sizes(const fba_ctx* ctx, int32_t* S, int32_t* A, int32_t* O);
+int fba_counts_len(const fba_ctx* ctx); /* floats per particle count blob (0 for plain POMDP) */
+int fba_slots(const fba_ctx* ctx);      /* slots actually resident (cfg.slots, or the library's choice) */
+
+/* Prior count tables.  fba_create builds the domain's own prior (TigerPriors.cpp:14-43,
+ * FactoredTigerPriors.cpp:18-88); this call overrides it with tables built by the caller
+ * (BAFlatModel layout: phi[s*A*S + a*S + s'], psi[a*S*O + s'*O + o]). */
+int fba_set_model_tabular(fba_ctx* ctx, const float* phi, const float* psi);
+int fba_get_prior(const fba_ctx* ctx, float* counts);
+
+/* ---- per-step interface: one call per reference virtual call -------------------------- */
+
+/* Where each slot is in its experiment; addresses the Philox streams of the calls below. */
+int fba_set_position(fba_ctx* ctx, const int32_t* run, const int32_t* episode, const int32_t* t);
+
+/* Belief::initiate(POMDP const&)                       src/beliefs/Belief.hpp:25          */
+int fba_belief_init(fba_ctx* ctx);
+/* BABelief::resetDomainStateDistribution(BAPOMDP const&) src/beliefs/bayes-adaptive/BABelief.hpp:34 */
+int fba_belief_reset_domain_state(fba_ctx* ctx);
+/* Planner::selectAction(POMDP const&, Belief const&, History const&)  src/planners/Planner.hpp:23-24
+ * hist_len[slot] = History::length(); action[slot] <- chosen action index.
+ * active may be NULL (all slots) */
+int fba_select_action(fba_ctx* ctx, const int32_t* hist_len, const uint8_t* active, int32_t* action);
+/* Belief::updateEstimation(Action const*, Observation const*, POMDP const&)  Belief.hpp:40 */
+int fba_belief_update(fba_ctx* ctx, const int32_t* action, const int32_t* obs, const uint8_t* active);
+/* Belief::sample() for a host-side planner, and bulk download for tests:
+ * state[particles], weight[particles] (may be NULL), counts[particles * counts_len] (may be NULL) */
+int fba_belief_get(fba_ctx* ctx, int32_t slot, int32_t* state, double* weight, float* counts);
+int fba_belief_set(fba_ctx* ctx, int32_t slot, const int32_t* state, const double* weight, const float* counts);
+/* per-slot record of the last select_action / belief_update (root statistics, rejection count,
+ * belief checksum) */
+int fba_last_step_info(fba_ctx* ctx, fba_trace_rec* recs /* [slots] */);
+
+/* ---- whole-experiment interface ------------------------------------------------------- */
+
+/* experiment::planning::run(conf)            src/experiments/PlanningExperiment.cpp:27-55
+ * stats[1]; all `runs` runs execute concurrently, `slots` at a time. */
+int fba_run_planning(fba_ctx* ctx, fba_stat* stats);
+/* experiment::bapomdp::run(bapomdp, conf)    src/experiments/BAPOMDPExperiment.cpp:32-78
+ * stats[episodes]: statistic e accumulates the return of episode e over runs, in run order. */
+int fba_run_bapomdp(fba_ctx* ctx, fba_stat* stats);
+/* throughput driver used by bench.py: advance every slot by `ticks` real time-steps
+ * (search + env step + belief update), restarting episodes/runs as they finish. */
+int fba_run_ticks(fba_ctx* ctx, int32_t ticks);
+
+/* per-(run, episode) discounted returns of the last fba_run_*: returns[runs * episodes] */
+int fba_get_returns(const fba_ctx* ctx, double* returns, int32_t* lengths);
+int fba_get_counters(fba_ctx* ctx, fba_counters* out);
+int fba_get_kernel_times(fba_ctx* ctx, fba_kernel_time* out /* [FBA_K_COUNT] */);
+int fba_reset_kernel_times(fba_ctx* ctx);
+int fba_trace_count(const fba_ctx* ctx);
+int fba_get_trace(const fba_ctx* ctx, fba_trace_rec* out, int32_t cap);
+
+/* diagnostic: out[i] = u * sqrt(L[i] / n[i]) evaluated on the device, to check that the
+ * engine's fp64 divide and square root round like the host's (they must, for UCB parity) */
+int fba_selftest_ucb(fba_ctx* ctx, const double* L, const int32_t* n, int32_t count, double u, double* out);
+
+/* utils::Statistic::add / var / stder, exported so hosts merge returns exactly as the
+ * reference does */
+void fba_stat_add(fba_stat* s, double v);
+double fba_stat_var(const fba_stat* s);
+double fba_stat_stder(const fba_stat* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

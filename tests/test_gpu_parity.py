@@ -1,0 +1,179 @@
+"""Parity of the HIP engine (through the C-ABI) with the CPU oracle on identical Philox streams.
+Integer outputs (actions, states, observations, node counts, rejection counts) and the belief
+checksum must be bit-exact; fp64 outputs (root Q values, total weights, returns) must be
+bit-identical too, because both sides perform the same IEEE operations in the same order."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import fba_pomdp_amd as fba
+from fba_pomdp_amd import _native as N
+from oracle import pyorc as orc
+
+pytestmark = pytest.mark.gpu
+
+DOM = {"episodic-tiger": orc.DOM_TIGER_EPISODIC, "continuous-tiger": orc.DOM_TIGER_CONTINUOUS,
+       "episodic-factored-tiger": orc.DOM_FTIGER_EPISODIC, "continuous-factored-tiger": orc.DOM_FTIGER_CONTINUOUS}
+
+
+def _pair(domain, model, belief, seed, slots=None, size=0, **kw):
+    runs = kw.get("runs", 1)
+    eng = fba.Engine(domain, model=model, belief=belief, seed=seed, slots=slots or runs, trace=1, size=size, **kw)
+    o = orc.Oracle(domain=DOM[domain], model=model, belief=N.BELIEF_NAMES[belief], rng_mode=orc.RNG_PHILOX,
+                   arith=orc.ARITH_DEV, philox_seed=seed, trace=1, size=size, **kw)
+    return eng, o
+
+
+def _assert_same_experiment(eng, o, ba):
+    stats = eng.run_bapomdp() if ba else [eng.run_planning()]
+    if ba:
+        ostats, res = o.run_bapomdp()
+    else:
+        st, res = o.run_planning()
+        ostats = [st]
+    tr, otr = eng.trace(), o.trace(res.n_trace)
+    assert len(tr) == len(otr)
+    for name in tr.dtype.names:
+        bad = np.nonzero(~np.all((tr[name] == otr[name]).reshape(len(tr), -1), axis=1))[0]
+        assert bad.size == 0, f"{name}: first mismatch at record {bad[0]}: {tr[bad[0]]} vs {otr[bad[0]]}"
+    for a, b in zip(stats, ostats):
+        assert (a.count, a.mean, a.m2) == (b.count, b.mean, b.m2)
+    c = eng.counters()
+    assert (c.sim_steps, c.belief_steps, c.env_steps) == (res.sim_steps, res.belief_steps, res.env_steps)
+
+
+def test_device_fp64_divide_and_sqrt_round_like_the_host():
+    eng = fba.Engine("episodic-tiger", particles=4, sims=4, slots=1)
+    rng = np.random.default_rng(0)
+    m = rng.integers(0, 70000, 200000)
+    n = rng.integers(1, 70000, 200000).astype(np.int32)
+    L = np.log1p(m.astype(np.float64))
+    out = np.zeros_like(L)
+    eng._chk(eng.L.fba_selftest_ucb(eng.h, L.ctypes.data, n.ctypes.data, len(L), 100.0, out.ctypes.data))
+    assert np.array_equal(out, 100.0 * np.sqrt(L / n))
+
+
+@pytest.mark.parametrize("seed", [1, 77])
+def test_planning_tiger_rejection(seed):
+    eng, o = _pair("episodic-tiger", N.MODEL_POMDP, "rejection_sampling", seed, particles=64, sims=200, runs=24)
+    _assert_same_experiment(eng, o, ba=False)
+
+
+def test_planning_c1_shape():
+    # BASELINE configs[0]: 1024 sims, 256 particles (fewer runs than the 10^4 of the statistical test)
+    eng, o = _pair("episodic-tiger", N.MODEL_POMDP, "rejection_sampling", 5, particles=256, sims=1024, runs=16)
+    _assert_same_experiment(eng, o, ba=False)
+
+
+def test_planning_continuous_tiger_importance():
+    eng, o = _pair("continuous-tiger", N.MODEL_POMDP, "importance_sampling", 3, particles=300, sims=150, runs=12, horizon=8)
+    _assert_same_experiment(eng, o, ba=False)
+
+
+def test_planning_slots_fewer_than_runs_reuses_slots():
+    eng, o = _pair("episodic-tiger", N.MODEL_POMDP, "rejection_sampling", 9, slots=5, particles=32, sims=64, runs=23)
+    _assert_same_experiment(eng, o, ba=False)
+
+
+def test_planning_factored_tiger_true_dynamics():
+    eng, o = _pair("episodic-factored-tiger", N.MODEL_POMDP, "rejection_sampling", 11, size=3, particles=128, sims=100, runs=10)
+    _assert_same_experiment(eng, o, ba=False)
+
+
+@pytest.mark.parametrize("belief", ["rejection_sampling", "importance_sampling"])
+def test_bapomdp_tiger(belief):
+    eng, o = _pair("episodic-tiger", N.MODEL_BA_TABLE, belief, 21, particles=200, sims=256, runs=10, episodes=4)
+    _assert_same_experiment(eng, o, ba=True)
+
+
+def test_bapomdp_tiger_noisy_prior_and_short_horizon():
+    eng, o = _pair("continuous-tiger", N.MODEL_BA_TABLE, "rejection_sampling", 22, particles=100, sims=128, runs=6,
+                   episodes=3, horizon=5, noise=0.1, counts_total=100.0)
+    _assert_same_experiment(eng, o, ba=True)
+
+
+def test_bapomdp_factored_tiger_flat_prior():
+    eng, o = _pair("episodic-factored-tiger", N.MODEL_BA_TABLE, "importance_sampling", 23, size=2, particles=96,
+                   sims=128, runs=6, episodes=3)
+    _assert_same_experiment(eng, o, ba=True)
+
+
+def test_bapomdp_slots_fewer_than_runs():
+    eng, o = _pair("episodic-tiger", N.MODEL_BA_TABLE, "rejection_sampling", 24, slots=3, particles=64, sims=64,
+                   runs=8, episodes=2)
+    _assert_same_experiment(eng, o, ba=True)
+
+
+def test_random_planner():
+    eng, o = _pair("episodic-tiger", N.MODEL_POMDP, "rejection_sampling", 31, particles=32, sims=10, runs=40,
+                   planner=N.PLANNER_RANDOM)
+    _assert_same_experiment(eng, o, ba=False)
+
+
+def test_prior_tables_equal_oracle():
+    for dom, size in [("episodic-tiger", 0), ("episodic-factored-tiger", 2)]:
+        eng = fba.Engine(dom, model=N.MODEL_BA_TABLE, size=size, particles=4, sims=4, slots=1, noise=0.05)
+        o = orc.Oracle(domain=DOM[dom], model=orc.MODEL_BA_TABLE, size=size, noise=0.05)
+        assert np.array_equal(eng.prior(), o.prior_counts())
+
+
+def test_per_step_interface_matches_oracle_calls():
+    """Planner::selectAction / Belief::updateEstimation one call at a time (slots = 1)."""
+    kw = dict(particles=128, sims=300)
+    eng = fba.Engine("episodic-tiger", model=N.MODEL_BA_TABLE, seed=41, slots=1, **kw)
+    o = orc.Oracle(domain=orc.DOM_TIGER_EPISODIC, model=orc.MODEL_BA_TABLE, rng_mode=orc.RNG_PHILOX,
+                   arith=orc.ARITH_DEV, philox_seed=41, **kw)
+    L = orc.lib()
+    L.orc_rng_episode(o.rng, 0, 0, 0)
+    o.belief_initiate()
+    eng.belief_init()
+    o.belief_reset_domain_state()
+    eng.belief_reset_domain_state()
+    s, _, cnt = eng.belief_get(0)
+    os_, _, ocnt = o.belief_get()
+    assert np.array_equal(s, os_) and np.array_equal(cnt, ocnt)
+    for t, ob in enumerate([0, 0, 1, 0]):
+        L.orc_rng_episode(o.rng, 0, 0, t)
+        eng.set_position(run=0, episode=0, t=t)
+        a_ref, rec = o.select_action(t)
+        a = eng.select_action(hist_len=t)[0]
+        info = eng.last_step_info()[0]
+        assert a == a_ref
+        assert np.array_equal(info["root_n"], rec["root_n"]) and np.array_equal(info["root_q"], rec["root_q"])
+        assert info["n_nodes"] == rec["n_nodes"] and info["tree_depth"] == rec["tree_depth"]
+        o.belief_update(2, ob)           # listen, hear `ob`
+        eng.belief_update(2, ob)
+        s, _, cnt = eng.belief_get(0)
+        os_, _, ocnt = o.belief_get()
+        assert np.array_equal(s, os_) and np.array_equal(cnt, ocnt)
+        assert eng.last_step_info()[0]["update_count"] == L.orc_last_update_count(o.h)
+
+
+def test_belief_update_rejects_out_of_range_arguments():
+    eng = fba.Engine("episodic-tiger", particles=8, sims=4, slots=2)
+    eng.belief_init()
+    with pytest.raises(ValueError, match="action"):
+        eng.belief_update([0, 3], [0, 0])
+    with pytest.raises(ValueError, match="observation"):
+        eng.belief_update([0, 1], [0, 2])
+    eng2 = fba.Engine("episodic-tiger", particles=8, sims=4, slots=1)
+    with pytest.raises(fba.FbaError, match="not initiated"):
+        eng2.select_action()
+
+
+def test_device_order_sums_equal_reference_order_on_ancestors():
+    """The importance filter sums weights in a fixed parallel order.  The reference
+    sums sequentially; the two may differ in the last bit of a total, which can only change an
+    ancestor index when a threshold falls within one ulp of a prefix sum.  On these seeded runs
+    the ancestors (hence every later state) must be identical."""
+    kw = dict(domain=orc.DOM_TIGER_CONTINUOUS, model=orc.MODEL_BA_TABLE, belief=orc.BELIEF_IMPORTANCE,
+              rng_mode=orc.RNG_PHILOX, philox_seed=55, particles=500, sims=64, runs=4, episodes=3, horizon=6, trace=1)
+    a = orc.Oracle(arith=orc.ARITH_DEV, **kw)
+    b = orc.Oracle(arith=orc.ARITH_REF, **kw)
+    _, ra = a.run_bapomdp()
+    _, rb = b.run_bapomdp()
+    ta, tb = a.trace(ra.n_trace), b.trace(rb.n_trace)
+    for name in ("action", "state", "obs", "n_nodes", "root_n"):
+        assert np.array_equal(ta[name], tb[name])
+    assert np.allclose(ta["weight_total"], tb["weight_total"], rtol=1e-14, atol=0)
