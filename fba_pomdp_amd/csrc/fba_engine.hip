@@ -447,6 +447,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     CHK(dev_alloc(c, &D.need_update, E));
     CHK(dev_alloc(c, &D.need_reset, E));
     CHK(dev_alloc(c, &D.need_init, E));
+    CHK(dev_alloc(c, &D.adv, E));
     CHK(dev_alloc(c, &D.env_state, E));
     CHK(dev_alloc(c, &D.ret, E));
     CHK(dev_alloc(c, &D.disc, E));

@@ -238,6 +238,7 @@ __global__ void start_kernel(Problem P, DeviceState D)
     D.episode[e]   = 0;
     D.active[e]    = on;
     D.need_update[e] = 0;
+    D.adv[e]         = 0;
     D.need_init[e]   = on;
     D.need_reset[e]  = on && P.model != FBA_MODEL_POMDP;
     D.cur[e].update_count = -1;
@@ -273,8 +274,10 @@ __global__ void env_kernel(Problem P, DeviceState D, int32_t* n_active)
         rec.reward = r; rec.update_count = -1; rec.weight_total = 0;
         rec.belief_hash = 1;  // "flush pending" marker, overwritten by flush_kernel
     }
+    // the belief update of this tick still addresses its streams with (run, episode, t): the
+    // position only moves in advance_kernel, after that update
     if (!term && t + 1 < P.horizon) {
-        D.t[e] = t + 1;
+        D.adv[e] = 1;
         return;
     }
     // episode over: record the return, then the next episode / run of this slot
@@ -284,9 +287,7 @@ __global__ void env_kernel(Problem P, DeviceState D, int32_t* n_active)
         D.returns[(size_t)slot_run * P.episodes + ep] = ret;
         D.lengths[(size_t)slot_run * P.episodes + ep] = t + 1;
     }
-    // the belief update of this last step still reads (run, episode, t): defer the position
-    // change to advance_kernel, which runs after the belief update of this tick
-    D.need_reset[e] = 2;  // 2 = "episode ended", resolved by advance_kernel
+    D.adv[e] = 2;
     (void)n_active;
 }
 
@@ -295,8 +296,11 @@ __global__ void env_kernel(Problem P, DeviceState D, int32_t* n_active)
 __global__ void advance_kernel(Problem P, DeviceState D, int32_t* n_active)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= P.E || !D.active[e] || D.need_reset[e] != 2) return;
-    D.need_reset[e] = 0;
+    if (e >= P.E || !D.active[e]) return;
+    const int adv = D.adv[e];
+    D.adv[e]      = 0;
+    if (adv == 1) { D.t[e] += 1; return; }
+    if (adv != 2) return;
     int run = D.run[e], ep = D.episode[e] + 1;
     if (ep < P.episodes) {
         D.episode[e]    = ep;

@@ -35,6 +35,7 @@ struct DeviceState {
     uint8_t* need_update;  // [E] belief update pending (last env step was not terminal)
     uint8_t* need_reset;   // [E] resetDomainStateDistribution pending (new episode)
     uint8_t* need_init;    // [E] Belief::initiate pending (new run)
+    uint8_t* adv;          // [E] set by env_kernel: 1 = next time-step, 2 = episode ended
     int32_t* env_state; // [E] true environment state
     double* ret;        // [E] discounted return so far
     double* disc;       // [E] accumulated discount
