@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""bench.py -- simulated env steps / sec (belief + rollout) of the BA-POMCP hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one real time-step of every resident slot: RBAPOUCT search (`sims` simulations),
+true-environment step, and the particle-filter belief update.  Workload (N = 1 and per GPU for
+N > 1) is BASELINE.json configs[1]: episodic-tiger BA-POMCP, 4096 sims/step, 4096 particles,
+tabular BA-POMDP, expected-Dirichlet sampling, rejection-sampling belief (the reference default).
+Runs are independent, so N GPUs run N disjoint sets of runs (weak scaling); the only collective is
+one all-reduce of {episodes, sum of returns, sum of squares} + the step counters at the end.
+
+`value` counts simulator.step calls of the planner (tree + rollout) plus those of the belief
+update, exactly as BASELINE.md defines the metric; inputs (priors, particles, trees) are resident
+in HBM before the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(args):
+    """The oracle (CPU restatement, mt19937 mode = the reference's own arithmetic and draw order)
+    timed on one host core on a bounded sample of the same workload."""
+    from oracle import pyorc as orc
+    o = orc.Oracle(domain=orc.DOM_TIGER_EPISODIC, model=orc.MODEL_BA_TABLE, belief=orc.BELIEF_REJECTION,
+                   sims=args.sims, particles=args.particles, horizon=args.horizon,
+                   runs=args.cpu_runs, episodes=args.cpu_episodes, seed_str="bench")
+    t0 = time.perf_counter()
+    _, res = o.run_bapomdp()
+    dt = time.perf_counter() - t0
+    steps = res.sim_steps + res.belief_steps
+    return {
+        "value": steps / dt, "unit": "simulated env steps/s", "cores": 1, "kind": "port",
+        "sample": f"{args.cpu_runs} runs x {args.cpu_episodes} episodes of the same config "
+                  f"({res.env_steps} real steps, {steps} simulated steps, {dt:.1f} s, gcc -O2, 1 thread)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--slots", type=int, default=16384, help="concurrent runs per GPU")
+    ap.add_argument("--sims", type=int, default=4096)
+    ap.add_argument("--particles", type=int, default=4096)
+    ap.add_argument("--horizon", type=int, default=10)
+    ap.add_argument("--belief", default="rejection_sampling", choices=["rejection_sampling", "importance_sampling"])
+    ap.add_argument("--cpu-runs", type=int, default=8)
+    ap.add_argument("--cpu-episodes", type=int, default=500)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: fba_pomdp_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    collective = None
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # nccl = RCCL on ROCm
+        collective = "rccl"
+
+    import fba_pomdp_amd as fba
+    eng = fba.Engine("episodic-tiger", model=fba.MODEL_BA_TABLE, belief=args.belief,
+                     sims=args.sims, particles=args.particles, horizon=args.horizon,
+                     episodes=64, runs=1 << 30, slots=args.slots, run_offset=rank * args.slots,
+                     seed=20261003, device=local_rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    eng.run_ticks(args.warmup)          # sets the slots up (init + reset) and warms the caches
+    c0 = eng.counters()
+    eng.reset_kernel_times()
+    barrier()
+    t0 = time.perf_counter()
+    eng.run_ticks(args.steps)           # synchronises its HIP stream before returning
+    barrier()
+    dt = time.perf_counter() - t0
+    c1 = eng.counters()
+    kt = eng.kernel_times()
+    steps = (c1.sim_steps - c0.sim_steps) + (c1.belief_steps - c0.belief_steps)
+    rets = eng.return_sums()
+
+    tot = torch.tensor([float(steps), float(c1.sim_steps - c0.sim_steps), rets[0], rets[1], rets[2]],
+                       dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    tot = tot.cpu().tolist()
+    dt_max = float(tmax.cpu()[0])
+
+    if rank == 0:
+        kname = "reject_kernel" if args.belief == "rejection_sampling" else "importance_kernel"
+        k = kt[kname]
+        achieved = (k.bytes / 1e9) / (k.ms / 1e3) if k.ms > 0 else 0.0
+        search = kt["search_kernel"]
+        n_ep = tot[2]
+        out = {
+            "metric": "simulated env steps/sec (belief+rollout)",
+            "value": tot[0] / dt_max,
+            "unit": "steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt_max / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",  # Q values, returns, weights; counts are f32, indices i32
+            "data": "synthetic",
+            "config": {
+                "workload": "episodic-tiger BA-POMCP (tabular BA-POMDP, expected Dirichlet), "
+                            f"{args.sims} sims/step, {args.particles} particles, {args.belief}, H={args.horizon}",
+                "slots_per_gpu": eng.slots, "parallelism": f"episode-sharded x{world}",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "launches": int(k.launches), "avg_ms": k.ms / max(int(k.launches), 1),
+                "algorithmic_bytes_per_launch": k.bytes / max(int(k.launches), 1),
+            },
+            "search_kernel": {"avg_ms": search.ms / max(int(search.launches), 1),
+                              "steps_per_s": search.units / (search.ms / 1e3) if search.ms > 0 else 0.0},
+            "returns": {"episodes": n_ep, "mean": tot[3] / n_ep if n_ep else None,
+                        "var": (tot[4] - tot[3] ** 2 / n_ep) / (n_ep - 1) if n_ep > 1 else None,
+                        "collective": collective},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

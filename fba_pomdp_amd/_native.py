@@ -90,7 +90,7 @@ EXPORTS = [
     "fba_domain_sizes", "fba_counts_len", "fba_slots", "fba_set_model_tabular", "fba_get_prior",
     "fba_set_position", "fba_belief_init", "fba_belief_reset_domain_state", "fba_select_action",
     "fba_belief_update", "fba_belief_get", "fba_belief_set", "fba_last_step_info",
-    "fba_run_planning", "fba_run_bapomdp", "fba_run_ticks", "fba_get_returns", "fba_get_counters",
+    "fba_run_planning", "fba_run_bapomdp", "fba_run_ticks", "fba_get_returns", "fba_get_counters", "fba_get_return_sums",
     "fba_get_kernel_times", "fba_reset_kernel_times", "fba_trace_count", "fba_get_trace",
     "fba_selftest_ucb", "fba_stat_add", "fba_stat_var", "fba_stat_stder",
 ]
@@ -147,6 +147,7 @@ def load():
     L.fba_run_ticks.argtypes = [vp, C.c_int32]
     L.fba_get_returns.argtypes = [vp, vp, vp]
     L.fba_get_counters.argtypes = [vp, P(Counters)]
+    L.fba_get_return_sums.argtypes = [vp, vp]
     L.fba_get_kernel_times.argtypes = [vp, P(KernelTime)]
     L.fba_reset_kernel_times.argtypes = [vp]
     L.fba_trace_count.argtypes = [vp]

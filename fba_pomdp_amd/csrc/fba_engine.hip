@@ -465,6 +465,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     CHK(dev_alloc(c, &D.belief_steps, E));
     CHK(dev_alloc(c, &D.env_steps, E));
     CHK(dev_alloc(c, &D.upd_particles, E));
+    CHK(dev_alloc(c, &D.ep_sums, (size_t)3 * E));
     CHK(dev_alloc(c, &D.upd_attempts, E));
     CHK(dev_alloc(c, &D.cur, E));
     CHK(dev_alloc(c, &D.trace_count, 1));
@@ -507,7 +508,6 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         HIPC(hipMemsetAsync(D.active, 1, (size_t)E, c->stream));
         HIPC(hipStreamSynchronize(c->stream));
     }
-    CHK(ensure_outputs(c, cfg->runs));
     HIPC(hipStreamSynchronize(c->stream));
     *out = c;
     return FBA_OK;
@@ -690,8 +690,21 @@ int fba_get_returns(const fba_ctx* cc, double* returns, int32_t* lengths)
     fba_ctx* c = const_cast<fba_ctx*>(cc);
     if (!c) return FBA_EINVAL;
     const size_t n = (size_t)c->cfg.runs * c->P.episodes;
+    if (n > c->returns_cap) return fail(c, FBA_ESTATE, "no experiment has been run on this ctx");
     if (returns) HIPCHK(c, hipMemcpy(returns, c->D.returns, n * sizeof(double), hipMemcpyDeviceToHost));
     if (lengths) HIPCHK(c, hipMemcpy(lengths, c->D.lengths, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return FBA_OK;
+}
+
+int fba_get_return_sums(fba_ctx* c, double* out)
+{
+    if (!c || !out) return FBA_EINVAL;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<double> h((size_t)3 * c->P.E);
+    HIPCHK(c, hipMemcpy(h.data(), c->D.ep_sums, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+    out[0] = out[1] = out[2] = 0;
+    for (int e = 0; e < c->P.E; ++e)
+        for (int k = 0; k < 3; ++k) out[k] += h[(size_t)3 * e + k];
     return FBA_OK;
 }
 

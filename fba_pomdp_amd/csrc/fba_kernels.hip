@@ -287,6 +287,9 @@ __global__ void env_kernel(Problem P, DeviceState D, int32_t* n_active)
         D.returns[(size_t)slot_run * P.episodes + ep] = ret;
         D.lengths[(size_t)slot_run * P.episodes + ep] = t + 1;
     }
+    D.ep_sums[3 * e + 0] += 1;
+    D.ep_sums[3 * e + 1] += ret;
+    D.ep_sums[3 * e + 2] += ret * ret;
     D.adv[e] = 2;
     (void)n_active;
 }

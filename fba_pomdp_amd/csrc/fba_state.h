@@ -63,6 +63,7 @@ struct DeviceState {
     unsigned long long* sim_steps;    // [E]
     unsigned long long* belief_steps; // [E]
     unsigned long long* env_steps;    // [E]
+    double* ep_sums;    // [E][3] finished episodes of this slot: count, sum of returns, sum of squares
     unsigned long long* upd_particles; // [E] particles written by belief updates
     unsigned long long* upd_attempts;  // [E] rejection attempts / importance particles stepped
     fba_trace_rec* cur;  // [E] record being assembled for the current tick

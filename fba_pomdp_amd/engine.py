@@ -93,6 +93,11 @@ class Engine:
         self._chk(self.L.fba_get_counters(self.h, C.byref(c)))
         return c
 
+    def return_sums(self):
+        out = np.zeros(3, np.float64)
+        self._chk(self.L.fba_get_return_sums(self.h, out.ctypes.data))
+        return out
+
     def kernel_times(self):
         kt = (N.KernelTime * N.K_COUNT)()
         self._chk(self.L.fba_get_kernel_times(self.h, kt))

@@ -197,6 +197,9 @@ int fba_run_ticks(fba_ctx* ctx, int32_t ticks);
 /* per-(run, episode) discounted returns of the last fba_run_*: returns[runs * episodes] */
 int fba_get_returns(const fba_ctx* ctx, double* returns, int32_t* lengths);
 int fba_get_counters(fba_ctx* ctx, fba_counters* out);
+/* {episodes finished, sum of returns, sum of squared returns} over all slots since fba_create:
+ * what a multi-GPU job all-reduces (the pooled merge of analysis/preprocess/merge_result_files.py:60-78) */
+int fba_get_return_sums(fba_ctx* ctx, double* out /* [3] */);
 int fba_get_kernel_times(fba_ctx* ctx, fba_kernel_time* out /* [FBA_K_COUNT] */);
 int fba_reset_kernel_times(fba_ctx* ctx);
 int fba_trace_count(const fba_ctx* ctx);

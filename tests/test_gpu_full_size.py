@@ -1,0 +1,103 @@
+"""Full-size checks of the HIP engine through size-independent properties, and the statistical tier
+of the parity contract (mean episodic return vs the reference binary's recorded run)."""
+import numpy as np
+import pytest
+
+import fba_pomdp_amd as fba
+from fba_pomdp_amd import _native as N
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c1_mean_return_within_one_sigma_of_the_reference(golden):
+    """BASELINE.json configs[0] / north_star: mean episodic return within 1 sigma over >= 1e4 episodes.
+    Reference (the reference binary, --seed 1): -2.64891 +- 0.303895 (stderr of 1e4 runs).
+    The engine uses Philox streams, so this is a statistical comparison: 40 000 runs, tolerance = the
+    reference's own standard error."""
+    ref_mean, ref_se = float(golden["baseline_md_c1"]["mean"]), float(golden["baseline_md_c1"]["stder"])
+    eng = fba.Engine("episodic-tiger", sims=1024, particles=256, runs=40000, slots=20000, seed=7)
+    st = eng.run_planning()
+    assert st.count == 40000
+    assert abs(st.mean - ref_mean) <= ref_se, (st.mean, st.stder, ref_mean, ref_se)
+    assert abs(st.var - float(golden["baseline_md_c1"]["var"])) / st.var < 0.1
+
+
+def test_results_do_not_depend_on_the_number_of_slots():
+    """Runs are addressed by their global run index, not by the slot that executes them."""
+    kw = dict(model=N.MODEL_BA_TABLE, sims=512, particles=512, runs=96, episodes=3, seed=3)
+    a = fba.Engine("episodic-tiger", slots=96, **kw)
+    b = fba.Engine("episodic-tiger", slots=17, **kw)
+    sa, sb = a.run_bapomdp(), b.run_bapomdp()
+    ra, la = a.returns()
+    rb, lb = b.returns()
+    assert np.array_equal(ra, rb) and np.array_equal(la, lb)
+    assert [(s.count, s.mean, s.m2) for s in sa] == [(s.count, s.mean, s.m2) for s in sb]
+    ca, cb = a.counters(), b.counters()
+    assert (ca.sim_steps, ca.belief_steps, ca.env_steps) == (cb.sim_steps, cb.belief_steps, cb.env_steps)
+
+
+def test_sharded_runs_equal_unsharded_runs():
+    """Episode sharding: two ctxs with run_offset 0 / 40 reproduce one ctx of 80 runs."""
+    kw = dict(model=N.MODEL_BA_TABLE, sims=256, particles=256, episodes=2, seed=5)
+    whole = fba.Engine("episodic-tiger", runs=80, slots=80, **kw)
+    whole.run_bapomdp()
+    parts = []
+    for off in (0, 40):
+        e = fba.Engine("episodic-tiger", runs=40, slots=40, run_offset=off, **kw)
+        e.run_bapomdp()
+        parts.append(e.returns()[0])
+    assert np.array_equal(whole.returns()[0], np.concatenate(parts))
+
+
+@pytest.mark.parametrize("belief", ["rejection_sampling", "importance_sampling"])
+def test_c2_size_count_invariants(belief):
+    """BASELINE configs[1] sizes (4096 sims, 4096 particles), per-step interface, 8 slots.
+    Invariants of the BA belief update that hold at any size:
+      * every particle of a slot has received exactly one T count and one O count per update
+        (BAPOMDP.cpp:134-137), so sum(counts - prior) == 2 * updates for every particle;
+      * counts never decrease; the O count incremented is the one of the real (action, observation);
+      * root visit counts add up to the number of simulations; the tree never outgrows sims + 1 nodes;
+      * rejection sampling needs at least N attempts; importance weights are uniform after resampling."""
+    E, Np, sims = 8, 4096, 4096
+    eng = fba.Engine("episodic-tiger", model=N.MODEL_BA_TABLE, belief=belief, sims=sims, particles=Np, slots=E, seed=11)
+    eng.belief_init()
+    eng.belief_reset_domain_state()
+    prior = eng.prior()
+    S, A, O = 2, 3, 2
+    for t, ob in enumerate([0, 1, 0]):
+        eng.set_position(t=t)
+        acts = eng.select_action(hist_len=t)
+        info = eng.last_step_info()
+        assert np.all((acts >= 0) & (acts < A))
+        assert np.all(info["root_n"][:, :A].sum(axis=1) == sims)
+        assert np.all(info["n_nodes"] <= sims + 1) and np.all(info["n_nodes"] >= 2)
+        eng.belief_update(2, ob)   # listen, hear `ob`
+        info = eng.last_step_info()
+        for e in range(E):
+            s, w, cnt = eng.belief_get(e)
+            assert np.all((s >= 0) & (s < S))
+            d = cnt - prior
+            assert np.all(d >= 0)
+            assert np.all(d.sum(axis=1) == 2 * (t + 1))
+            psi_listen = d[:, S * A * S + 2 * S * O:].reshape(Np, S, O)
+            assert np.all(psi_listen.sum(axis=(1, 2)) == t + 1)         # every O increment was a listen row
+            if belief == "rejection_sampling":
+                assert info["update_count"][e] >= Np
+            else:
+                assert np.all(w == 1.0 / Np)
+                assert 0 < info["weight_total"][e] <= 1.0
+
+
+def test_throughput_driver_counts_steps_and_finishes_episodes():
+    eng = fba.Engine("episodic-tiger", model=N.MODEL_BA_TABLE, sims=256, particles=256, slots=512,
+                     runs=1 << 30, episodes=16, seed=13)
+    eng.run_ticks(12)
+    c = eng.counters()
+    assert c.env_steps == 512 * 12
+    assert c.sim_steps >= 512 * 12 * 256           # at least one step per simulation
+    n, s1, s2 = eng.return_sums()
+    assert n > 512                                  # every slot finished at least one episode (H = 10)
+    assert -100 * 1.0 <= s1 / n <= 10.0
+    kt = eng.kernel_times()
+    assert kt["search_kernel"].launches == 12 and kt["reject_kernel"].launches == 12
+    assert kt["reject_kernel"].bytes > 0 and kt["search_kernel"].units == c.sim_steps
