@@ -10,16 +10,26 @@ pytestmark = pytest.mark.gpu
 
 
 def test_c1_mean_return_within_one_sigma_of_the_reference(golden):
-    """BASELINE.json configs[0] / north_star: mean episodic return within 1 sigma over >= 1e4 episodes.
-    Reference (the reference binary, --seed 1): -2.64891 +- 0.303895 (stderr of 1e4 runs).
-    The engine uses Philox streams, so this is a statistical comparison: 40 000 runs, tolerance = the
-    reference's own standard error."""
+    """BASELINE.json configs[0] / north_star: mean episodic return within 1 sigma over 1e4 episodes.
+    The engine draws from Philox streams, so this tier is statistical.  Two references:
+      * the reference binary's own run recorded in BASELINE.md section 2 (--seed 1, 1e4 runs):
+        -2.64891 +- 0.303895;
+      * the oracle in mt19937 mode (bit-identical to that binary on --seed 1) over 16 seeds x 1e4
+        runs (tests/golden/oracle_c1_mean.json, oracle/gen_c1_mean.py): -2.4974 +- 0.0756.
+    sigma = the standard error of a 1e4-episode mean (0.30).  The engine runs 1.6e5 episodes so that
+    its own sampling error (0.075) is small against that tolerance."""
+    import json
+    import os
     ref_mean, ref_se = float(golden["baseline_md_c1"]["mean"]), float(golden["baseline_md_c1"]["stder"])
-    eng = fba.Engine("episodic-tiger", sims=1024, particles=256, runs=40000, slots=20000, seed=7)
+    with open(os.path.join(os.path.dirname(__file__), "golden", "oracle_c1_mean.json")) as f:
+        orc_ref = json.load(f)
+    eng = fba.Engine("episodic-tiger", sims=1024, particles=256, runs=160000, slots=20000, seed=7)
     st = eng.run_planning()
-    assert st.count == 40000
+    assert st.count == 160000
     assert abs(st.mean - ref_mean) <= ref_se, (st.mean, st.stder, ref_mean, ref_se)
-    assert abs(st.var - float(golden["baseline_md_c1"]["var"])) / st.var < 0.1
+    assert abs(st.mean - orc_ref["mean"]) <= orc_ref["stder_at_1e4"], (st.mean, orc_ref["mean"])
+    assert abs(st.mean - orc_ref["mean"]) <= 3 * (st.stder ** 2 + orc_ref["stder"] ** 2) ** 0.5
+    assert abs(st.var - orc_ref["var"]) / orc_ref["var"] < 0.05
 
 
 def test_results_do_not_depend_on_the_number_of_slots():
