@@ -48,9 +48,9 @@ def cpu_baseline(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--slots", type=int, default=16384, help="concurrent runs per GPU")
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--slots", type=int, default=131072, help="concurrent runs per GPU (1.3 MB of HBM each at the default workload)")
     ap.add_argument("--sims", type=int, default=4096)
     ap.add_argument("--particles", type=int, default=4096)
     ap.add_argument("--horizon", type=int, default=10)

@@ -70,36 +70,53 @@ struct Rng {
 };
 
 // ---------------------------------------------------------------------------------------------
+// Views of a particle's count blob: straight from HBM, or staged in LDS as [word][lane]
+// (stride = workgroup size, so lane l only ever touches bank l mod 32: conflict-free).
+// ---------------------------------------------------------------------------------------------
+struct GlobalView {
+    const float* p;
+    __device__ __forceinline__ float at(int k) const { return p[k]; }
+};
+template <int STRIDE>
+struct LdsView {
+    const float* p;
+    __device__ __forceinline__ float at(int k) const { return p[k * STRIDE]; }
+};
+
+// ---------------------------------------------------------------------------------------------
 // Sampling primitives (reference src/utils/random.hpp:93-115, random.cpp:244-279)
 // ---------------------------------------------------------------------------------------------
 
 // sampleFromMult<float const>: CDF accumulated in float, compared with a double threshold.
-__device__ __forceinline__ int sample_from_mult_f(Rng& g, const float* __restrict__ row, int n, double total)
+template <class View>
+__device__ __forceinline__ int sample_from_mult_f(Rng& g, const View& row, int off, int n, double total)
 {
     const double p = g.u01() * total;
-    float sum      = row[0];
+    float sum      = row.at(off);
     for (int i = 1; i < n; ++i) {
         if (p < (double)sum) return i - 1;
-        sum += row[i];
+        sum += row.at(off + i);
     }
     return n - 1;
 }
 
 // sampleFromExpectedMult: total accumulated in double
-__device__ __forceinline__ int sample_expected_mult(Rng& g, const float* __restrict__ row, int n)
+template <class View>
+__device__ __forceinline__ int sample_expected_mult(Rng& g, const View& row, int off, int n)
 {
-    double total = (double)row[0];
-    for (int i = 1; i < n; ++i) total += (double)row[i];
-    return sample_from_mult_f(g, row, n, total);
+    double total = (double)row.at(off);
+    for (int i = 1; i < n; ++i) total += (double)row.at(off + i);
+    return sample_from_mult_f(g, row, off, n, total);
 }
 
 // expectedMult(row)[o]: float sum, float division (all-zero if the sum underflows)
-__device__ __forceinline__ double expected_mult_at(const float* __restrict__ row, int n, int o)
+template <class View>
+__device__ __forceinline__ double expected_mult_at(const View& row, int off, int n, int o)
 {
-    float sum = row[0];
-    for (int i = 1; i < n; ++i) sum += row[i];
+    float sum = row.at(off);
+    for (int i = 1; i < n; ++i) sum += row.at(off + i);
     if ((double)sum <= 1e-300) return 0.0;
-    return (double)(row[o] / sum);
+    return (double)(row.at(off + o) / sum);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -110,7 +127,7 @@ struct Problem {
     int32_t S, A, O;
     int32_t N;          // particles per slot
     int32_t C;          // floats per particle count blob
-    int32_t Cs;         // storage stride in floats (C rounded up to a multiple of 4)
+    int32_t Cs;         // record stride in floats: counts, then the state word at index C, then padding
     int32_t phi_len;    // tabular: S*A*S
     int32_t sims, max_depth, horizon, episodes;
     int32_t E;          // slots
@@ -188,8 +205,9 @@ __device__ __forceinline__ double ext_reward(const Problem& P, int s, int a, int
 // caller decides where the +1 lands (in place for importance sampling, in the copy for
 // rejection sampling).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool sim_step(const Problem& P, Rng& g, const float* __restrict__ cnt, int& s, int a, int& o,
-                                         double& r, int& inc0, int& inc1)
+template <class View>
+__device__ __forceinline__ bool sim_step(const Problem& P, Rng& g, const View& cnt, int& s, int a, int& o, double& r, int& inc0,
+                                         int& inc1)
 {
     if (P.model == FBA_MODEL_POMDP) {
         inc0 = inc1 = -1;
@@ -197,9 +215,9 @@ __device__ __forceinline__ bool sim_step(const Problem& P, Rng& g, const float* 
     }
     const int S = P.S, A = P.A, O = P.O;
     const int t_off = s * A * S + a * S;
-    const int ns    = sample_expected_mult(g, cnt + t_off, S);
+    const int ns    = sample_expected_mult(g, cnt, t_off, S);
     const int o_off = P.phi_len + a * S * O + ns * O;
-    o               = sample_expected_mult(g, cnt + o_off, O);
+    o               = sample_expected_mult(g, cnt, o_off, O);
     const bool t    = ext_terminal(P, s, a, ns);
     r               = ext_reward(P, s, a, ns);
     inc0            = t_off + ns;
@@ -210,11 +228,12 @@ __device__ __forceinline__ bool sim_step(const Problem& P, Rng& g, const float* 
 
 // POMDP::computeObservationProbability of the simulator in use
 // (BAPOMDP.cpp:93-99 -> BAFlatModel::computeObservationProbability BAFlatModel.cpp:106-124)
-__device__ __forceinline__ double sim_obs_prob(const Problem& P, const float* __restrict__ cnt, int new_s, int a, int o)
+template <class View>
+__device__ __forceinline__ double sim_obs_prob(const Problem& P, const View& cnt, int new_s, int a, int o)
 {
     if (P.model == FBA_MODEL_POMDP) return domain_obs_prob(P, o, a, new_s);
     if (P.O == 1) return 1.0;
-    return expected_mult_at(cnt + P.phi_len + a * P.S * P.O + new_s * P.O, P.O, o);
+    return expected_mult_at(cnt, P.phi_len + a * P.S * P.O + new_s * P.O, P.O, o);
 }
 
 // position-sensitive particle checksum (same function as oracle/orc.c particle_hash)

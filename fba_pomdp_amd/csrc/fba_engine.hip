@@ -387,7 +387,14 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         delete c;
         return FBA_EINVAL;
     }
-    P.Cs = (P.C + 3) & ~3;
+    // record stride (fba_state.h): counts + state word, padded to a power of two up to 64 words
+    // (so small particles are whole cache lines), to a multiple of 4 words beyond that
+    {
+        int need = P.C + 1, cs = 4;
+        if (need <= 64) { while (cs < need) cs <<= 1; }
+        else cs = (need + 3) & ~3;
+        P.Cs = cs;
+    }
     if (P.A > FBA_MAX_ACTIONS || P.A * P.O > 4096) {
         fail(nullptr, FBA_EINVAL, "action/observation space too large for the dense child table");
         delete c;
@@ -429,7 +436,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     D.max_nodes  = P.sims + 2;
 
     // slots
-    const size_t per_slot = (size_t)P.N * (2 * 4 + 2 * 8 + 8 + 4 + 2 * (size_t)P.Cs * 4) + (size_t)D.max_nodes * D.node_words * 4 + 1024;
+    const size_t per_slot = (size_t)P.N * (2 * 8 + 8 + 2 * (size_t)P.Cs * 4) + (size_t)D.max_nodes * D.node_words * 4 + 1024;
     int E = cfg->slots;
     if (E <= 0) {
         size_t free_b = 0, total_b = 0;
@@ -454,10 +461,9 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     CHK(dev_alloc(c, &D.action, E));
     CHK(dev_alloc(c, &D.obs, E));
     CHK(dev_alloc(c, &D.bufsel, E));
-    CHK(dev_alloc(c, &D.p_state, (size_t)2 * E * P.N));
     const bool is = cfg->belief == FBA_BELIEF_IMPORTANCE;
     CHK(dev_alloc(c, &D.p_weight, is ? (size_t)2 * E * P.N : 1));
-    CHK(dev_alloc(c, &D.p_cnt, (size_t)2 * E * P.N * P.Cs, false));
+    CHK(dev_alloc(c, &D.p_rec, (size_t)2 * E * P.N * P.Cs, false));
     CHK(dev_alloc(c, &D.wscan, is ? (size_t)E * P.N : 1, false));
     CHK(dev_alloc(c, &D.src_idx, 1));
     CHK(dev_alloc(c, &D.nodes, (size_t)E * D.max_nodes * D.node_words, false));
@@ -470,7 +476,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     CHK(dev_alloc(c, &D.cur, E));
     CHK(dev_alloc(c, &D.trace_count, 1));
     CHK(dev_alloc(c, &c->d_n_active, 1));
-    CHK(dev_alloc(c, &c->d_prior, std::max(P.Cs, 4)));
+    CHK(dev_alloc(c, &c->d_prior, P.Cs));
     CHK(dev_alloc(c, &c->d_uni_scan, (size_t)P.N + 1));
     CHK(dev_alloc(c, &c->d_log1p, (size_t)P.sims + 2));
     D.prior     = c->d_prior;
@@ -496,10 +502,8 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         HIPC(hipMemcpyAsync(&D.uni_total, c->d_uni_scan + P.N, sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPC(hipStreamSynchronize(c->stream));
     }
-    if (cfg->model == FBA_MODEL_BA_TABLE) {
-        CHK(build_tabular_prior(c));
-        CHK(upload_prior(c));
-    }
+    if (cfg->model == FBA_MODEL_BA_TABLE) CHK(build_tabular_prior(c));
+    CHK(upload_prior(c));
     // default positions for the per-step interface: slot e is run run_offset + e
     {
         std::vector<int32_t> run((size_t)E);
@@ -614,15 +618,18 @@ int fba_belief_get(fba_ctx* c, int32_t slot, int32_t* state, double* weight, flo
     uint8_t sel = 0;
     HIPCHK(c, hipMemcpy(&sel, c->D.bufsel + slot, 1, hipMemcpyDeviceToHost));
     const size_t pb = ((size_t)sel * P.E + slot) * (size_t)P.N;
-    if (state) HIPCHK(c, hipMemcpy(state, c->D.p_state + pb, (size_t)P.N * 4, hipMemcpyDeviceToHost));
     if (weight) {
         if (P.belief != FBA_BELIEF_IMPORTANCE) return fail(c, FBA_EINVAL, "the rejection filter is unweighted");
         HIPCHK(c, hipMemcpy(weight, c->D.p_weight + pb, (size_t)P.N * 8, hipMemcpyDeviceToHost));
     }
-    if (counts && P.C) {
+    if (state || (counts && P.C)) {
         std::vector<float> tmp((size_t)P.N * P.Cs);
-        HIPCHK(c, hipMemcpy(tmp.data(), c->D.p_cnt + pb * P.Cs, tmp.size() * 4, hipMemcpyDeviceToHost));
-        for (int i = 0; i < P.N; ++i) std::copy(tmp.begin() + (size_t)i * P.Cs, tmp.begin() + (size_t)i * P.Cs + P.C, counts + (size_t)i * P.C);
+        HIPCHK(c, hipMemcpy(tmp.data(), c->D.p_rec + pb * P.Cs, tmp.size() * 4, hipMemcpyDeviceToHost));
+        for (int i = 0; i < P.N; ++i) {
+            const float* rec = tmp.data() + (size_t)i * P.Cs;
+            if (state) std::memcpy(&state[i], &rec[P.C], 4);
+            if (counts && P.C) std::copy(rec, rec + P.C, counts + (size_t)i * P.C);
+        }
     }
     return FBA_OK;
 }
@@ -634,16 +641,19 @@ int fba_belief_set(fba_ctx* c, int32_t slot, const int32_t* state, const double*
     uint8_t sel = 0;
     HIPCHK(c, hipMemcpy(&sel, c->D.bufsel + slot, 1, hipMemcpyDeviceToHost));
     const size_t pb = ((size_t)sel * P.E + slot) * (size_t)P.N;
-    if (state) {
+    if (state)
         for (int i = 0; i < P.N; ++i)
             if (state[i] < 0 || state[i] >= P.S) return fail(c, FBA_EINVAL, "state %d out of range", state[i]);
-        HIPCHK(c, hipMemcpy(c->D.p_state + pb, state, (size_t)P.N * 4, hipMemcpyHostToDevice));
-    }
     if (weight && P.belief == FBA_BELIEF_IMPORTANCE) HIPCHK(c, hipMemcpy(c->D.p_weight + pb, weight, (size_t)P.N * 8, hipMemcpyHostToDevice));
-    if (counts && P.C) {
-        std::vector<float> tmp((size_t)P.N * P.Cs, 0.f);
-        for (int i = 0; i < P.N; ++i) std::copy(counts + (size_t)i * P.C, counts + (size_t)(i + 1) * P.C, tmp.begin() + (size_t)i * P.Cs);
-        HIPCHK(c, hipMemcpy(c->D.p_cnt + pb * P.Cs, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
+    if (state || (counts && P.C)) {
+        std::vector<float> tmp((size_t)P.N * P.Cs);
+        HIPCHK(c, hipMemcpy(tmp.data(), c->D.p_rec + pb * P.Cs, tmp.size() * 4, hipMemcpyDeviceToHost));
+        for (int i = 0; i < P.N; ++i) {
+            float* rec = tmp.data() + (size_t)i * P.Cs;
+            if (state) std::memcpy(&rec[P.C], &state[i], 4);
+            if (counts && P.C) std::copy(counts + (size_t)i * P.C, counts + (size_t)(i + 1) * P.C, rec);
+        }
+        HIPCHK(c, hipMemcpy(c->D.p_rec + pb * P.Cs, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
     }
     c->belief_ready = true;
     return FBA_OK;

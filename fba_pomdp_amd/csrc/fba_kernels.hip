@@ -32,6 +32,10 @@ __device__ __forceinline__ Rng slot_rng(const Problem& P, const DeviceState& D, 
 
 __device__ __forceinline__ size_t pbase(const Problem& P, int e, int buf) { return ((size_t)buf * P.E + e) * (size_t)P.N; }
 
+// particle record accessors (layout: fba_state.h)
+__device__ __forceinline__ int rec_state(const float* rec, int C) { return __float_as_int(rec[C]); }
+__device__ __forceinline__ void rec_set_state(float* rec, int C, int s) { rec[C] = __int_as_float(s); }
+
 // WeightedFilter::sample (WeightedFilter.cpp:163-191) in device order: the largest i >= 1 whose
 // exclusive prefix sum is below the threshold, else 0.  `incl` holds inclusive prefix sums.
 __device__ __forceinline__ int weighted_pick(const double* __restrict__ incl, int n, double threshold)
@@ -90,12 +94,15 @@ __device__ __forceinline__ int ucb_select(const Problem& P, const DeviceState& D
 // ---------------------------------------------------------------------------------------------
 // search_kernel: one lane = one slot = one tree; `sims` simulations, sequential semantics.
 // POUCT::selectAction POUCT.cpp:63-129, RBAPOUCT::selectAction RBAPOUCT.cpp:67-153 (the root
-// particle's counts are read in place and never written: StepType::KeepCounts).
+// particle's counts are read and never written: StepType::KeepCounts).
 // The recursion traverseActionNode / traverseChanceNode / rollout (POUCT.cpp:183-303) is unrolled
 // into a state machine whose every iteration performs exactly one simulator.step, so the 64
-// trees of a wave execute the expensive part (Philox + Dirichlet-row sampling) in lock-step;
-// the path needed for the bottom-up back-up lives in LDS, laid out [depth][lane].
+// trees of a wave execute the expensive part (Philox + Dirichlet-row sampling) in lock-step.
+// LDS per lane: the path needed for the bottom-up back-up, [depth][lane], and -- when a particle
+// record fits 32 words (STAGE) -- the root particle's whole count blob, [word][lane], fetched with
+// one burst of 16-byte loads per simulation so that no step waits on HBM for its Dirichlet rows.
 // ---------------------------------------------------------------------------------------------
+template <bool STAGE>
 __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceState D)
 {
     extern __shared__ double lds[];
@@ -106,20 +113,19 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
     const int depth_cap = P.max_depth > 0 ? P.max_depth : 1;
     double* path_r      = lds + lane;                                                   // [depth][block]
     int32_t* path_na    = reinterpret_cast<int32_t*>(lds + (size_t)depth_cap * SEARCH_BLOCK) + lane;
+    float* stage        = reinterpret_cast<float*>(path_na - lane + (size_t)depth_cap * SEARCH_BLOCK) + lane;  // [Cs][block]
 
     Rng g               = slot_rng(P, D, e);
     const int hist_len  = D.t[e];
     const int max_tree_depth = min(P.horizon - hist_len, P.max_depth);
     const int W         = D.node_words;
     int32_t* tree       = D.nodes + (size_t)e * D.max_nodes * W;
-    const size_t pb     = pbase(P, e, D.bufsel[e]);
-    const int32_t* pst  = D.p_state + pb;
-    const float* pcn    = D.p_cnt + pb * (size_t)P.Cs;
+    const float* prec   = D.p_rec + pbase(P, e, D.bufsel[e]) * (size_t)P.Cs;
 
     if (P.planner == FBA_PLANNER_RANDOM) {  // RandomPlanner::selectAction RandomPlanner.cpp:14-24
         g.stream(FBA_PHASE_SEARCH, (uint32_t)P.sims);
         const int src = belief_sample_uniform(P, D, g);
-        D.action[e]   = domain_random_action(P, g, pst[src]);
+        D.action[e]   = domain_random_action(P, g, rec_state(prec + (size_t)src * P.Cs, P.C));
         return;
     }
 
@@ -131,15 +137,28 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
 
     int sim = 0, mode = 0;  // 0 = start a simulation, 1 = in the tree, 2 = rollout
     int s = 0, node = 0, dtg = 0, plen = 0, rdepth = 0;
-    const float* cnt = pcn;
+    const float* cnt = prec;
     double rret = 0, rdisc = 1;
     while (true) {
         if (mode == 0) {
             if (sim >= P.sims) break;
             g.stream(FBA_PHASE_SEARCH, (uint32_t)sim);
             const int src = belief_sample_uniform(P, D, g);
-            s    = pst[src];
-            cnt  = pcn + (size_t)src * P.Cs;
+            cnt = prec + (size_t)src * P.Cs;
+            if (STAGE) {
+                const float4* rp = reinterpret_cast<const float4*>(cnt);
+                const int n4 = P.Cs >> 2;
+                for (int k = 0; k < n4; ++k) {
+                    const float4 v = rp[k];
+                    stage[(4 * k + 0) * SEARCH_BLOCK] = v.x;
+                    stage[(4 * k + 1) * SEARCH_BLOCK] = v.y;
+                    stage[(4 * k + 2) * SEARCH_BLOCK] = v.z;
+                    stage[(4 * k + 3) * SEARCH_BLOCK] = v.w;
+                }
+                s = __float_as_int(stage[P.C * SEARCH_BLOCK]);
+            } else {
+                s = rec_state(cnt, P.C);
+            }
             node = 0; dtg = max_tree_depth; plen = 0; mode = 1;
         }
         bool finish = false, do_step = true;
@@ -155,7 +174,9 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
         if (do_step) {
             int o, i0, i1;
             double r;
-            const bool term = sim_step(P, g, cnt, s, a, o, r, i0, i1);
+            bool term;
+            if (STAGE) term = sim_step(P, g, LdsView<SEARCH_BLOCK>{stage}, s, a, o, r, i0, i1);
+            else term = sim_step(P, g, GlobalView{cnt}, s, a, o, r, i0, i1);
             ++steps;
             if (mode == 1) {  // traverseChanceNode
                 path_r[(size_t)plen * SEARCH_BLOCK]  = r;
@@ -325,13 +346,14 @@ __global__ void advance_kernel(Problem P, DeviceState D, int32_t* n_active)
 
 // ---------------------------------------------------------------------------------------------
 // Whole-record gather: the m particles listed in s_src[] (LDS) are copied from `src` records to
-// consecutive `dst` records, applying the UpdateCounts "+1" at blob indices inc0/inc1 (-1 = none).
+// consecutive `dst` records, applying the UpdateCounts "+1" at blob indices inc0/inc1 (-1 = none)
+// and, if s_state is given, overwriting the state word (index C) with the particle's new state.
 // A record is C4 float4; a power-of-two group of lanes owns one record so consecutive lanes move
 // consecutive 16-byte pieces: every wave instruction reads and writes whole contiguous records.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void gather_records(float* __restrict__ dst, const float* __restrict__ src, const int32_t* s_src,
-                                               const int32_t* s_inc0, const int32_t* s_inc1, int m, int C4, int group,
-                                               int nthreads)
+                                               const int32_t* s_inc0, const int32_t* s_inc1, const int32_t* s_state, int m,
+                                               int C4, int C, int group, int nthreads)
 {
     const int gid = threadIdx.x / group, part0 = threadIdx.x % group, ngroups = nthreads / group;
     for (int j = gid; j < m; j += ngroups) {
@@ -343,6 +365,7 @@ __device__ __forceinline__ void gather_records(float* __restrict__ dst, const fl
             const int lo = part * 4;
             if ((unsigned)(i0 - lo) < 4u) (&v.x)[i0 - lo] += 1.0f;
             if ((unsigned)(i1 - lo) < 4u) (&v.x)[i1 - lo] += 1.0f;
+            if (s_state && (unsigned)(C - lo) < 4u) (&v.x)[C - lo] = __int_as_float(s_state[j]);  // new domain state
             dp[part] = v;
         }
     }
@@ -372,10 +395,8 @@ __global__ void __launch_bounds__(REJECT_BLOCK) reject_kernel(Problem P, DeviceS
     const int a = D.action[e], o = D.obs[e], N = P.N;
     const int cur = D.bufsel[e];
     const size_t sb = pbase(P, e, cur), db = pbase(P, e, cur ^ 1);
-    const int32_t* sst = D.p_state + sb;
-    const float* scn   = D.p_cnt + sb * (size_t)P.Cs;
-    int32_t* dst_st    = D.p_state + db;
-    float* dcn         = D.p_cnt + db * (size_t)P.Cs;
+    const float* scn   = D.p_rec + sb * (size_t)P.Cs;
+    float* dcn         = D.p_rec + db * (size_t)P.Cs;
     const int C4 = P.Cs / 4, group = record_group(C4);
     Rng g = slot_rng(P, D, e);
 
@@ -384,9 +405,10 @@ __global__ void __launch_bounds__(REJECT_BLOCK) reject_kernel(Problem P, DeviceS
         const int k = base + tid;
         g.stream(FBA_PHASE_REJECT, (uint32_t)k);
         const int src = g.uniform_int(N);                       // FlatFilter::sample
-        int s = sst[src], so, i0, i1;
+        const float* rec = scn + (size_t)src * P.Cs;
+        int s = rec_state(rec, P.C), so, i0, i1;
         double r;
-        sim_step(P, g, scn + (size_t)src * P.Cs, s, a, so, r, i0, i1);  // UpdateCounts: +1 lands in the copy
+        sim_step(P, g, GlobalView{rec}, s, a, so, r, i0, i1);  // UpdateCounts: +1 lands in the copy
         const bool ok = (so == o);
         const unsigned long long ballot = __ballot(ok);
         const int prefix = __popcll(ballot & ((1ull << lane) - 1ull));
@@ -404,8 +426,7 @@ __global__ void __launch_bounds__(REJECT_BLOCK) reject_kernel(Problem P, DeviceS
         }
         __syncthreads();
         const int m = min(chunk, N - acc);
-        if (C4 > 0) gather_records(dcn + (size_t)acc * P.Cs, scn, s_src, s_inc0, s_inc1, m, C4, group, REJECT_BLOCK);
-        for (int q = tid; q < m; q += REJECT_BLOCK) dst_st[acc + q] = s_ns[q];
+        gather_records(dcn + (size_t)acc * P.Cs, scn, s_src, s_inc0, s_inc1, s_ns, m, C4, P.C, group, REJECT_BLOCK);
         acc += m;
         base += REJECT_BLOCK;
         __syncthreads();
@@ -518,12 +539,10 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
     const int a = D.action[e], o = D.obs[e], N = P.N;
     const int cur = D.bufsel[e];
     const size_t sb = pbase(P, e, cur), db = pbase(P, e, cur ^ 1);
-    int32_t* sst = D.p_state + sb;
     double* sw   = D.p_weight + sb;
-    float* scn   = D.p_cnt + sb * (size_t)P.Cs;
-    int32_t* dst_st = D.p_state + db;
+    float* scn   = D.p_rec + sb * (size_t)P.Cs;
     double* dw      = D.p_weight + db;
-    float* dcn      = D.p_cnt + db * (size_t)P.Cs;
+    float* dcn      = D.p_rec + db * (size_t)P.Cs;
     double* wscan   = D.wscan + (size_t)e * N;
     const int C4 = P.Cs / 4, group = record_group(C4);
     Rng g = slot_rng(P, D, e);
@@ -531,12 +550,12 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
     for (int i = tid; i < N; i += IS_BLOCK) {
         g.stream(FBA_PHASE_IS_UPDATE, (uint32_t)i);
         float* cnt = scn + (size_t)i * P.Cs;
-        int s = sst[i], so, i0, i1;
+        int s = rec_state(cnt, P.C), so, i0, i1;
         double r;
-        sim_step(P, g, cnt, s, a, so, r, i0, i1);
+        sim_step(P, g, GlobalView{cnt}, s, a, so, r, i0, i1);
         if (i0 >= 0) { cnt[i0] += 1.0f; cnt[i1] += 1.0f; }  // incrementCountsOf (BAFlatModel.cpp:126-139)
-        sst[i] = s;
-        sw[i] *= sim_obs_prob(P, cnt, s, a, o);  // probability from the updated counts
+        rec_set_state(cnt, P.C, s);
+        sw[i] *= sim_obs_prob(P, GlobalView{cnt}, s, a, o);  // probability from the updated counts
     }
     __syncthreads();
     const double total = block_device_scan(sw, N, nullptr, s_carry);
@@ -550,12 +569,11 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
             g.stream(FBA_PHASE_RESAMPLE, (uint32_t)j);
             const int src = weighted_pick(wscan, N, g.u01() * total_w);
             s_src[tid]    = src;
-            dst_st[j]     = sst[src];
             dw[j]         = w1;
         }
         __syncthreads();
         const int m = min(IS_BLOCK, N - j0);
-        if (C4 > 0) gather_records(dcn + (size_t)j0 * P.Cs, scn, s_src, nullptr, nullptr, m, C4, group, IS_BLOCK);
+        gather_records(dcn + (size_t)j0 * P.Cs, scn, s_src, nullptr, nullptr, nullptr, m, C4, P.C, group, IS_BLOCK);
         __syncthreads();
     }
     if (tid == 0) {
@@ -579,20 +597,22 @@ __global__ void __launch_bounds__(256) init_kernel(Problem P, DeviceState D)
     const int e = blockIdx.x, tid = threadIdx.x;
     if (!D.need_init[e]) return;
     const size_t pb = pbase(P, e, D.bufsel[e]);
+    float* recs     = D.p_rec + pb * (size_t)P.Cs;
     Rng g = slot_rng(P, D, e);
     g.position((uint32_t)D.run[e], 0, 0);
+    // every particle starts from the prior record ...
+    const int C4 = P.Cs / 4;
+    const float4* pr = reinterpret_cast<const float4*>(D.prior);
+    float4* dp       = reinterpret_cast<float4*>(recs);
+    const size_t tot = (size_t)P.N * C4;
+    for (size_t f = tid; f < tot; f += 256) dp[f] = pr[f % C4];
+    __syncthreads();
+    // ... and its own domain start state
     const double w1 = 1.0 / (double)P.N;
     for (int i = tid; i < P.N; i += 256) {
         g.stream(FBA_PHASE_INIT, (uint32_t)i);
-        D.p_state[pb + i] = domain_start(P, g);
+        rec_set_state(recs + (size_t)i * P.Cs, P.C, domain_start(P, g));
         if (P.belief == FBA_BELIEF_IMPORTANCE) D.p_weight[pb + i] = w1;
-    }
-    const int C4 = P.Cs / 4;
-    if (C4 > 0) {
-        const float4* pr = reinterpret_cast<const float4*>(D.prior);
-        float4* dp       = reinterpret_cast<float4*>(D.p_cnt + pb * (size_t)P.Cs);
-        const size_t tot = (size_t)P.N * C4;
-        for (size_t f = tid; f < tot; f += 256) dp[f] = pr[f % C4];
     }
     __syncthreads();
     if (tid == 0) D.need_init[e] = 0;
@@ -606,7 +626,7 @@ __global__ void __launch_bounds__(256) init_kernel(Problem P, DeviceState D)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) reset_kernel(Problem P, DeviceState D)
 {
-    __shared__ int32_t s_src[256];
+    __shared__ int32_t s_src[256], s_ns[256];
     const int e = blockIdx.x, tid = threadIdx.x;
     if (D.need_reset[e] != 1) return;
     const int cur = D.bufsel[e];
@@ -614,9 +634,10 @@ __global__ void __launch_bounds__(256) reset_kernel(Problem P, DeviceState D)
     Rng g = slot_rng(P, D, e);
     g.position((uint32_t)D.run[e], (uint32_t)D.episode[e], 0);
     if (P.belief == FBA_BELIEF_REJECTION) {
+        float* recs = D.p_rec + sb * (size_t)P.Cs;
         for (int i = tid; i < P.N; i += 256) {
             g.stream(FBA_PHASE_RESET, (uint32_t)i);
-            D.p_state[sb + i] = domain_start(P, g);
+            rec_set_state(recs + (size_t)i * P.Cs, P.C, domain_start(P, g));
         }
         __syncthreads();
         if (tid == 0) D.need_reset[e] = 0;
@@ -628,14 +649,14 @@ __global__ void __launch_bounds__(256) reset_kernel(Problem P, DeviceState D)
         const int j = j0 + tid;
         if (j < P.N) {
             g.stream(FBA_PHASE_RESET, (uint32_t)j);
-            s_src[tid]        = weighted_pick(D.uni_scan, P.N, g.u01() * D.uni_total);
-            D.p_state[db + j] = domain_start(P, g);
+            s_src[tid] = weighted_pick(D.uni_scan, P.N, g.u01() * D.uni_total);
+            s_ns[tid]  = domain_start(P, g);
             D.p_weight[db + j] = w1;
         }
         __syncthreads();
         const int m = min(256, P.N - j0);
-        if (C4 > 0)
-            gather_records(D.p_cnt + (db + j0) * (size_t)P.Cs, D.p_cnt + sb * (size_t)P.Cs, s_src, nullptr, nullptr, m, C4, group, 256);
+        gather_records(D.p_rec + (db + j0) * (size_t)P.Cs, D.p_rec + sb * (size_t)P.Cs, s_src, nullptr, nullptr, s_ns, m, C4, P.C,
+                       group, 256);
         __syncthreads();
     }
     if (tid == 0) {
@@ -658,10 +679,10 @@ __global__ void __launch_bounds__(256) flush_kernel(Problem P, DeviceState D)
     const size_t pb = pbase(P, e, D.bufsel[e]);
     unsigned long long local = 0;
     for (int i = tid; i < P.N; i += 256) {
-        uint64_t h = mix64((uint64_t)i * 0x9E3779B97F4A7C15ull + (uint64_t)(uint32_t)D.p_state[pb + i]);
+        const float* cnt = D.p_rec + (pb + i) * (size_t)P.Cs;
+        uint64_t h = mix64((uint64_t)i * 0x9E3779B97F4A7C15ull + (uint64_t)(uint32_t)rec_state(cnt, P.C));
         const double w = (P.belief == FBA_BELIEF_IMPORTANCE) ? D.p_weight[pb + i] : 0.0;
         h = mix64(h ^ (uint64_t)__double_as_longlong(w));
-        const float* cnt = D.p_cnt + (pb + i) * (size_t)P.Cs;
         for (int k = 0; k < P.C; ++k) h = mix64(h ^ ((uint64_t)__float_as_uint(cnt[k]) + ((uint64_t)k << 32)));
         local += h;
     }
@@ -689,8 +710,13 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 void launch_search(const Problem& P, const DeviceState& D, hipStream_t st)
 {
     const int depth_cap = P.max_depth > 0 ? P.max_depth : 1;
-    const size_t lds = (size_t)depth_cap * SEARCH_BLOCK * (sizeof(double) + sizeof(int32_t));
-    hipLaunchKernelGGL(search_kernel, dim3(ceil_div(P.E, SEARCH_BLOCK)), dim3(SEARCH_BLOCK), lds, st, P, D);
+    const bool stage = P.model != FBA_MODEL_POMDP && P.Cs <= SEARCH_STAGE_WORDS;
+    const size_t lds = (size_t)depth_cap * SEARCH_BLOCK * (sizeof(double) + sizeof(int32_t)) +
+                       (stage ? (size_t)P.Cs * SEARCH_BLOCK * sizeof(float) : 0);
+    if (stage)
+        hipLaunchKernelGGL(search_kernel<true>, dim3(ceil_div(P.E, SEARCH_BLOCK)), dim3(SEARCH_BLOCK), lds, st, P, D);
+    else
+        hipLaunchKernelGGL(search_kernel<false>, dim3(ceil_div(P.E, SEARCH_BLOCK)), dim3(SEARCH_BLOCK), lds, st, P, D);
 }
 void launch_start(const Problem& P, const DeviceState& D, hipStream_t st)
 {

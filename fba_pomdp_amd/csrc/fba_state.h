@@ -2,15 +2,19 @@
 //
 // Particle set of slot e, buffer b (two buffers; resampling gathers from one into the other,
 // bufsel[e] says which one is live):
-//     state  : int32  [2][E][N]
-//     weight : double [2][E][N]                 (importance sampling only)
-//     counts : float  [2][E][N][Cs]             one contiguous record of Cs floats per particle
-//                                               (Cs = C rounded up to 4 so records are 16-B aligned)
-// Records are kept whole (AoS) because the resample/rejection gather moves whole particles:
-// a record is one contiguous burst on both the read and the write side, and the per-slot source
-// set (N * Cs * 4 B, 393 KB for tiger at N = 4096) stays L2-resident while its slot's workgroup
-// gathers from it.  The per-particle scalars (state, weight) are SoA so the streaming passes
-// (importance update, scan) read them fully coalesced.
+//     record : float  [2][E][N][Cs]   one particle = one contiguous record:
+//                                       words [0, C)  Dirichlet counts (BAFlatModel order: phi, psi)
+//                                       word  C       domain state index (int32 bits)
+//                                       words (C, Cs) padding
+//                                     Cs = next power of two >= C + 1 (min 4) while that is <= 64
+//                                     words, else C + 1 rounded up to 4: a tiger particle (C = 24) is
+//                                     exactly one 128-byte line, so a simulation's root sample, a
+//                                     rejection attempt and a resample copy each touch ONE line.
+//     weight : double [2][E][N]       (importance sampling only) SoA: the scans stream it coalesced
+// Records are kept whole (AoS) because every consumer wants the whole particle: the search reads
+// state + the rows it samples from, rejection/resampling move whole particles; and the per-slot
+// source set (N * Cs * 4 B = 512 KB for tiger at N = 4096) stays L2-resident while its slot's
+// workgroup gathers from it.
 //
 // Search tree of slot e: `max_nodes` fixed-size node records, slot-major, so one tree step
 // touches one or two cache lines:
@@ -43,12 +47,11 @@ struct DeviceState {
     int32_t* obs;       // [E] last real observation
     // --- belief ---
     uint8_t* bufsel;    // [E]
-    int32_t* p_state;   // [2][E][N]
     double* p_weight;   // [2][E][N]
-    float* p_cnt;       // [2][E][N][Cs]
+    float* p_rec;       // [2][E][N][Cs] particle records (counts | state | pad)
     double* wscan;      // [E][N] scratch: inclusive device-order prefix sums of normalised weights
     int32_t* src_idx;   // [E][N] scratch: resample ancestors
-    const float* prior; // [Cs]
+    const float* prior; // [Cs] prior record (state word unset)
     const double* uni_scan; // [N] prefix sums of N uniform weights 1/N (device order)
     double uni_total;
     // --- tree ---
