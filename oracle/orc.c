@@ -38,8 +38,27 @@ typedef struct tree {
     int32_t max_tree_depth, tree_depth;
 } tree;
 
+/* Factored Bayes-adaptive model (BABNModel + DBNNode), stored in a fixed "max layout":
+ * node (a, f) owns a region of the count blob big enough for its largest allowed parent set;
+ * a particle's actual parents are a bit mask over the node's `maxp` list (fixed for the ctx, or
+ * per particle in mask word `var` stored after the counts); rows are indexed compactly by the
+ * actual parents, exactly as DBNNode::cptIndex (DBNNode.cpp:171-205) does. */
+#define ORC_MAXF 8
+typedef struct fnode {
+    int32_t off, out, nmax, var;
+    int32_t maxp[ORC_MAXF];
+    uint32_t fixed_mask;
+} fnode;
+typedef struct fdesc {
+    int32_t FS, FO, nvar, ncounts;
+    int32_t Ssz[ORC_MAXF], Osz[ORC_MAXF], Sstep[ORC_MAXF], Ostep[ORC_MAXF];
+    fnode* T; /* [A * FS] */
+    fnode* O; /* [A * FO] */
+} fdesc;
+
 struct orc_ctx {
     orc_config cfg;
+    fdesc fd;
     orc_rng rng;
     char err[256];
     int32_t S, A, O;
@@ -312,12 +331,203 @@ static int ba_table_step(orc_ctx* c, simstate* st, int32_t a, int32_t* o, double
     return t;
 }
 
+/* ------------------------------------------------------------------ factored BA model */
+
+static uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+/* indexing::projectUsingStepSize (src/utils/index.cpp:98-118) */
+static void features_of(int v, const int32_t* step, int n, int* out)
+{
+    int i;
+    if (n == 1) { out[0] = v; return; }
+    for (i = 0; i < n; ++i) { out[i] = v / step[i]; v = v % step[i]; }
+}
+/* indexing::project (src/utils/index.cpp:51-83): last dimension fastest */
+static int project(const int* val, const int32_t* size, int n)
+{
+    int i, r = 0;
+    for (i = 0; i < n; ++i) r = r * size[i] + val[i];
+    return r;
+}
+static uint32_t node_mask(const orc_ctx* c, const fnode* nd, const float* cnt)
+{
+    return nd->var >= 0 ? f2u(cnt[c->fd.ncounts + nd->var]) : nd->fixed_mask;
+}
+/* DBNNode::cptIndex(graph input, 0) (DBNNode.cpp:171-205): mixed radix over the node's parents */
+static int node_row(const orc_ctx* c, const fnode* nd, uint32_t mask, const int* fv)
+{
+    int j, idx = 0;
+    for (j = 0; j < nd->nmax; ++j)
+        if ((mask >> j) & 1u) idx = idx * c->fd.Ssz[nd->maxp[j]] + fv[nd->maxp[j]];
+    return nd->off + idx * nd->out;
+}
+
+/* BAPOMDP::step with BABNModel::sampleStateIndex / sampleObservationIndex / incrementCountsOf
+ * ref: BABNModel.cpp:292-325, 354-382.  Quirk kept: the observation CPTs are
+ * incremented at the row of the PREVIOUS state's parent values (parent_values = features(s)). */
+static int ba_fact_step(orc_ctx* c, simstate* st, int32_t a, int32_t* o, double* r, int update)
+{
+    const fdesc* d = &c->fd;
+    int fv[ORC_MAXF], nf[ORC_MAXF], of[ORC_MAXF], f, t;
+    int32_t s = st->s, ns;
+    features_of(s, d->Sstep, d->FS, fv);
+    for (f = 0; f < d->FS; ++f) {
+        const fnode* nd = &d->T[a * d->FS + f];
+        nf[f] = orc_sample_expected_mult(&c->rng, st->cnt + node_row(c, nd, node_mask(c, nd, st->cnt), fv), nd->out);
+    }
+    ns = project(nf, d->Ssz, d->FS);
+    for (f = 0; f < d->FO; ++f) {
+        const fnode* nd = &d->O[a * d->FO + f];
+        of[f] = orc_sample_expected_mult(&c->rng, st->cnt + node_row(c, nd, node_mask(c, nd, st->cnt), nf), nd->out);
+    }
+    *o = project(of, d->Osz, d->FO);
+    t  = ext_terminal(c, s, a, ns);
+    *r = ext_reward(c, s, a, ns);
+    if (update) {
+        for (f = 0; f < d->FS; ++f) {
+            const fnode* nd = &d->T[a * d->FS + f];
+            st->cnt[node_row(c, nd, node_mask(c, nd, st->cnt), fv) + nf[f]] += 1;
+        }
+        for (f = 0; f < d->FO; ++f) {
+            const fnode* nd = &d->O[a * d->FO + f];
+            st->cnt[node_row(c, nd, node_mask(c, nd, st->cnt), fv) + of[f]] += 1;
+        }
+    }
+    st->s = ns;
+    return t;
+}
+
+/* BABNModel::computeObservationProbability (BABNModel.cpp:328-352): product over observation
+ * features of expectedMult(row(new_s))[o_f], accumulated in double */
+static double ba_fact_obs_prob(orc_ctx* c, const simstate* st, int32_t a, int32_t o)
+{
+    const fdesc* d = &c->fd;
+    int fv[ORC_MAXF], of[ORC_MAXF], f, i;
+    double prob = 1;
+    features_of(st->s, d->Sstep, d->FS, fv);
+    features_of(o, d->Ostep, d->FO, of);
+    for (f = 0; f < d->FO; ++f) {
+        const fnode* nd  = &d->O[a * d->FO + f];
+        const float* row = st->cnt + node_row(c, nd, node_mask(c, nd, st->cnt), fv);
+        float sum        = row[0];
+        for (i = 1; i < nd->out; ++i) sum += row[i];
+        prob *= (sum <= 1e-300) ? 0.0f : row[of[f]] / sum;
+    }
+    return prob;
+}
+
+static void fdesc_steps(const int32_t* size, int n, int32_t* step)
+{
+    int i;
+    step[n - 1] = 1;
+    for (i = n - 2; i >= 0; --i) step[i] = step[i + 1] * size[i + 1];
+}
+
+/* FactoredTigerFactoredPrior::setObservationModel (FactoredTigerPriors.cpp:221-263) into the
+ * listen observation node's region, for the parent set `mask` (bit j = state feature j) */
+static void ftiger_set_observation_model(orc_ctx* c, float* cnt, uint32_t mask)
+{
+    const fnode* nd = &c->fd.O[2 * c->fd.FO + 0];
+    float acc = (.85f - c->cfg.noise) * c->cfg.counts_total;
+    float inacc = (.15f + c->cfg.noise) * c->cfg.counts_total;
+    float unif = .5f * c->cfg.counts_total;
+    int np = __builtin_popcount(mask), rows = 1 << np, r;
+    float* row = cnt + nd->off;
+    memset(row, 0, sizeof(float) * (size_t)(2 << nd->nmax));
+    for (r = 0; r < rows; ++r) {
+        if (np > 0 && (mask & 1u)) { /* parents[0] == 0: informed by the tiger location */
+            int loc    = r >> (np - 1); /* first parent is the most significant digit */
+            row[2 * r + 0] = (loc == 0) ? acc : inacc;
+            row[2 * r + 1] = (loc == 1) ? acc : inacc;
+        } else {
+            row[2 * r + 0] = unif;
+            row[2 * r + 1] = unif;
+        }
+    }
+    cnt[c->fd.ncounts + 0] = u2f(mask);
+}
+
+/* FactoredTigerFactoredPrior ctor (FactoredTigerPriors.cpp:95-195): everything but the listen
+ * observation node, which is per particle */
+static int build_factored_prior(orc_ctx* c)
+{
+    fdesc* d = &c->fd;
+    int A = c->A, a, f, off = 0;
+    if (!is_ftiger(c->cfg.domain)) {
+        snprintf(c->err, sizeof c->err, "domain %d has no factored prior in the oracle", c->cfg.domain);
+        return -1;
+    }
+    if (c->cfg.noise <= -.15 || c->cfg.noise > .3) {
+        snprintf(c->err, sizeof c->err, "noise must be between -.15 and .3");
+        return -1;
+    }
+    d->FS = c->tiger_K + 1;
+    d->FO = 1;
+    if (d->FS > ORC_MAXF) { snprintf(c->err, sizeof c->err, "too many state features"); return -1; }
+    for (f = 0; f < d->FS; ++f) d->Ssz[f] = 2;
+    d->Osz[0] = 2;
+    fdesc_steps(d->Ssz, d->FS, d->Sstep);
+    fdesc_steps(d->Osz, d->FO, d->Ostep);
+    d->T = (fnode*)calloc((size_t)A * d->FS, sizeof(fnode));
+    d->O = (fnode*)calloc((size_t)A * d->FO, sizeof(fnode));
+    for (a = 0; a < A; ++a)
+        for (f = 0; f < d->FS; ++f) {
+            fnode* nd = &d->T[a * d->FS + f];
+            nd->off = off; nd->out = 2; nd->var = -1;
+            if (a == 2) { nd->nmax = 1; nd->maxp[0] = f; nd->fixed_mask = 1; off += 4; }
+            else { nd->nmax = 0; nd->fixed_mask = 0; off += 2; }
+        }
+    for (a = 0; a < A; ++a) {
+        fnode* nd = &d->O[a * d->FO];
+        nd->off = off; nd->out = 2; nd->var = -1;
+        if (a == 2) {
+            nd->nmax = d->FS; nd->var = 0;
+            for (f = 0; f < d->FS; ++f) nd->maxp[f] = f;
+            off += 2 << d->FS;
+        } else { nd->nmax = 0; off += 2; }
+    }
+    d->ncounts = off;
+    d->nvar    = 1;
+    c->ncnt    = off + d->nvar;
+    c->prior   = (float*)calloc((size_t)c->ncnt, sizeof(float));
+    for (a = 0; a < A; ++a)
+        for (f = 0; f < d->FS; ++f) {
+            const fnode* nd = &d->T[a * d->FS + f];
+            if (a == 2) { c->prior[nd->off + 0] = 5000; c->prior[nd->off + 3] = 5000; } /* listen keeps feature values */
+            else { c->prior[nd->off] = 5000; c->prior[nd->off + 1] = 5000; }
+        }
+    for (a = 0; a < 2; ++a) { c->prior[d->O[a].off] = 5000; c->prior[d->O[a].off + 1] = 5000; }
+    /* default listen model = correct structure {0}; overwritten per particle when a structure prior is set */
+    ftiger_set_observation_model(c, c->prior, 1u);
+    return 0;
+}
+
+/* FBAPOMDPPrior::sample -> FactoredTigerFactoredPrior::sampleFBAPOMDPState / sampleFullyConnectedState
+ * (FBAPOMDPPrior.cpp:27-37, FactoredTigerPriors.cpp:197-219, 265-291): draws the listen node's
+ * parent set (one boolean per state feature, feature 0 forced under match-uniform) */
+static void factored_prior_sample(orc_ctx* c, float* cnt)
+{
+    memcpy(cnt, c->prior, sizeof(float) * (size_t)c->ncnt);
+    if (c->cfg.structure_prior == ORC_SP_FULLY_CONNECTED) {
+        ftiger_set_observation_model(c, cnt, (1u << c->fd.FS) - 1u);
+    } else if (c->cfg.structure_prior == ORC_SP_UNIFORM || c->cfg.structure_prior == ORC_SP_MATCH_UNIFORM) {
+        uint32_t mask = 0;
+        int f;
+        for (f = 0; f < c->fd.FS; ++f)
+            if (orc_bool(&c->rng)) mask |= 1u << f;
+        if (c->cfg.structure_prior == ORC_SP_MATCH_UNIFORM) mask |= 1u;
+        ftiger_set_observation_model(c, cnt, mask);
+    }
+}
+
 static int sim_step(orc_ctx* c, simstate* st, int32_t a, int32_t* o, double* r, int update)
 {
     (*c->step_counter)++;
     switch (c->cfg.model) {
         case ORC_MODEL_POMDP: return domain_step(c, &st->s, a, o, r);
         case ORC_MODEL_BA_TABLE: return ba_table_step(c, st, a, o, r, update);
+        case ORC_MODEL_BA_FACTORED: return ba_fact_step(c, st, a, o, r, update);
         default: return 1;
     }
 }
@@ -328,6 +538,7 @@ static int sim_step(orc_ctx* c, simstate* st, int32_t a, int32_t* o, double* r, 
 static double sim_obs_prob(orc_ctx* c, const simstate* st, int32_t a, int32_t o)
 {
     if (c->cfg.model == ORC_MODEL_POMDP) return domain_obs_prob(c, o, a, st->s);
+    if (c->cfg.model == ORC_MODEL_BA_FACTORED) return ba_fact_obs_prob(c, st, a, o);
     if (c->cfg.model == ORC_MODEL_BA_TABLE) {
         float tmp[64];
         const float* row = st->cnt + c->phi_len + a * c->S * c->O + st->s * c->O;
@@ -611,6 +822,7 @@ static void sample_start_into(orc_ctx* c, particle* p)
 {
     p->s = domain_start(c);
     if (c->cfg.model == ORC_MODEL_BA_TABLE) memcpy(p->cnt, c->prior, sizeof(float) * c->ncnt);
+    if (c->cfg.model == ORC_MODEL_BA_FACTORED) factored_prior_sample(c, p->cnt);
 }
 
 /* Belief::initiate.  ref: RejectionSampling.cpp:15-20 / BARejectionSampling (FlatFilter(n, alloc));
@@ -952,6 +1164,8 @@ orc_ctx* orc_create(const orc_config* cfg)
     if (cfg->particles < 1) { snprintf(c->err, sizeof c->err, "cannot initiate belief with n = %d", cfg->particles); return c; }
     if (cfg->model == ORC_MODEL_BA_TABLE) {
         if (build_tabular_prior(c)) return c;
+    } else if (cfg->model == ORC_MODEL_BA_FACTORED) {
+        if (build_factored_prior(c)) return c;
     } else if (cfg->model != ORC_MODEL_POMDP) {
         snprintf(c->err, sizeof c->err, "model %d not supported by the oracle", cfg->model);
         return c;
@@ -979,7 +1193,7 @@ orc_ctx* orc_create(const orc_config* cfg)
 void orc_destroy(orc_ctx* c)
 {
     if (!c) return;
-    free(c->prior); free(c->log1p_tab);
+    free(c->prior); free(c->log1p_tab); free(c->fd.T); free(c->fd.O);
     free(c->tr.visits); free(c->tr.cn); free(c->tr.cq); free(c->tr.child);
     free(c->tr.hkey); free(c->tr.hval);
     free(c->P); free(c->Pnew); free(c->pool); free(c->pool_new);
@@ -1000,7 +1214,8 @@ int orc_counts_len(const orc_ctx* c) { return c->ncnt; }
 int orc_prior_counts(orc_ctx* c, float* out)
 {
     if (!c->prior) return -1;
-    memcpy(out, c->prior, sizeof(float) * (size_t)c->ncnt);
+    if (c->cfg.model == ORC_MODEL_BA_FACTORED) factored_prior_sample(c, out);
+    else memcpy(out, c->prior, sizeof(float) * (size_t)c->ncnt);
     return 0;
 }
 
@@ -1059,3 +1274,11 @@ double orc_model_obs_prob(orc_ctx* c, const float* cnt, int32_t new_s, int32_t a
     return sim_obs_prob(c, &st, a, o);
 }
 double orc_dev_scan(const double* w, int n, double* incl) { return dev_scan(w, n, incl); }
+
+/* test hook: write the factored-tiger listen observation model for parent set `mask` into a blob */
+int orc_ftiger_set_structure(orc_ctx* c, float* cnt, uint32_t mask)
+{
+    if (c->cfg.model != ORC_MODEL_BA_FACTORED || !is_ftiger(c->cfg.domain)) return -1;
+    ftiger_set_observation_model(c, cnt, mask);
+    return 0;
+}

@@ -146,6 +146,7 @@ void orc_belief_set(orc_ctx* c, const int32_t* s, const double* w, const float* 
 int orc_model_step(orc_ctx* c, float* cnt, int32_t* s, int32_t a, int32_t* o, double* r, int update);
 double orc_model_obs_prob(orc_ctx* c, const float* cnt, int32_t new_s, int32_t a, int32_t o);
 double orc_dev_scan(const double* w, int n, double* incl);
+int orc_ftiger_set_structure(orc_ctx* c, float* cnt, uint32_t mask);
 
 #ifdef __cplusplus
 }

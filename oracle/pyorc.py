@@ -121,6 +121,7 @@ def lib():
         L.orc_model_step.argtypes = [C.c_void_p, C.c_void_p, P(C.c_int32), C.c_int32, P(C.c_int32), P(C.c_double), C.c_int]
         L.orc_model_obs_prob.restype = C.c_double
         L.orc_model_obs_prob.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+        L.orc_ftiger_set_structure.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.orc_dev_scan.restype = C.c_double
         L.orc_dev_scan.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         # rng
@@ -284,6 +285,9 @@ class Oracle:
         cs, o, r = C.c_int32(s), C.c_int32(), C.c_double()
         t = self.L.orc_model_step(self.h, cnt.ctypes.data, C.byref(cs), a, C.byref(o), C.byref(r), int(update))
         return cs.value, o.value, r.value, t
+
+    def ftiger_set_structure(self, cnt, mask):
+        assert self.L.orc_ftiger_set_structure(self.h, cnt.ctypes.data, mask) == 0
 
     def model_obs_prob(self, cnt, new_s, a, o):
         return self.L.orc_model_obs_prob(self.h, cnt.ctypes.data, new_s, a, o)

@@ -19,6 +19,8 @@
 #include "easylogging++.h"
 
 #include "bayes-adaptive/models/Domain_Size.hpp"
+#include "bayes-adaptive/models/factored/Domain_Feature_Size.hpp"
+#include "bayes-adaptive/states/factored/BABNModel.hpp"
 #include "bayes-adaptive/states/table/BAFlatModel.hpp"
 #include "beliefs/particle_filters/FlatFilter.hpp"
 #include "beliefs/particle_filters/ImportanceSampler.hpp"
@@ -275,6 +277,95 @@ static void flat_model(char const* s)
     printf("}");
 }
 
+
+/* BABNModel / DBNNode: sampleStateIndex, sampleObservationIndex, incrementCountsOf,
+ * computeObservationProbability on a factored-tiger shaped model (K = 2: three binary state
+ * features, one binary observation feature) whose listen observation node has `parents`.
+ * The counts are filled through the reference's own DBNNode::count API. */
+static void babn_model(char const* s, std::vector<int> parents)
+{
+    using bayes_adaptive::factored::BABNModel;
+    Domain_Size sz(8, 3, 2);
+    Domain_Feature_Size fsz({2, 2, 2}, {2});
+    BABNModel::Indexing_Steps steps(indexing::stepSize(fsz._S), indexing::stepSize(fsz._O));
+    BABNModel m(&sz, &fsz, &steps);
+    IndexAction listen(2);
+    for (int f = 0; f < 3; ++f) {
+        m.resetTransitionNode(&listen, f, std::vector<int>({f}));
+        for (int v = 0; v < 2; ++v) m.transitionNode(&listen, f).count(std::vector<int>({v}), v) = 5000;
+    }
+    for (int a = 0; a < 2; ++a) {
+        IndexAction act(a);
+        for (int f = 0; f < 3; ++f)
+            for (int v = 0; v < 2; ++v) m.transitionNode(&act, f).count({}, v) = 5000 + 11.f * (float)(a + f + 2 * v);
+        m.observationNode(&act, 0).count({}, 0) = 5000;
+        m.observationNode(&act, 0).count({}, 1) = 4000;
+    }
+    m.resetObservationNode(&listen, 0, parents);
+    {
+        std::vector<int> pv(parents.size(), 0), pr(parents.size(), 2);
+        if (parents.empty()) {
+            m.observationNode(&listen, 0).setDirichletDistribution(pv, std::vector<float>({5000.f, 5000.f}));
+        } else {
+            do {
+                bool informed = parents[0] == 0;
+                m.observationNode(&listen, 0).count(pv, 0) = informed ? (pv[0] == 0 ? 8500.f : 1500.f) : 5000.f;
+                m.observationNode(&listen, 0).count(pv, 1) = informed ? (pv[0] == 1 ? 8500.f : 1500.f) : 5000.f;
+            } while (!indexing::increment(pv, pr));
+        }
+    }
+    seed(s);
+    std::vector<int> rec;
+    std::vector<double> probs;
+    int st = 5;
+    for (int i = 0; i < 240; ++i) {
+        int a = (i % 4 == 3) ? (i / 4) % 2 : 2; /* mostly listen, sometimes open */
+        IndexState x(st);
+        IndexAction ia(a);
+        int ns = m.sampleStateIndex(&x, &ia, rnd::sample::Dir::sampleFromExpectedMult);
+        IndexState y(ns);
+        int o = m.sampleObservationIndex(&ia, &y, rnd::sample::Dir::sampleFromExpectedMult);
+        IndexObservation io(o);
+        m.incrementCountsOf(&x, &ia, &io, &y);
+        IndexObservation other(1 - o);
+        probs.push_back(m.computeObservationProbability(&io, &ia, &y, rnd::sample::Dir::expectedMult));
+        probs.push_back(m.computeObservationProbability(&other, &ia, &y, rnd::sample::Dir::expectedMult));
+        rec.push_back(a);
+        rec.push_back(ns);
+        rec.push_back(o);
+        st = ns;
+    }
+    /* dump the listen observation CPT rows in parent-value order */
+    std::vector<double> cpt;
+    {
+        std::vector<int> pv(parents.size(), 0), pr(parents.size(), 2);
+        if (parents.empty()) {
+            cpt.push_back(m.observationNode(&listen, 0).count(pv, 0));
+            cpt.push_back(m.observationNode(&listen, 0).count(pv, 1));
+        } else {
+            do {
+                cpt.push_back(m.observationNode(&listen, 0).count(pv, 0));
+                cpt.push_back(m.observationNode(&listen, 0).count(pv, 1));
+            } while (!indexing::increment(pv, pr));
+        }
+    }
+    std::vector<double> tl;
+    for (int f = 0; f < 3; ++f)
+        for (int v = 0; v < 2; ++v)
+            for (int w = 0; w < 2; ++w) tl.push_back(m.transitionNode(&listen, f).count(std::vector<int>({v}), w));
+    printf("{\"seed\": \"%s\", \"parents\": ", s);
+    arr(parents, pi);
+    printf(", \"rec\": ");
+    arr(rec, pi);
+    printf(", \"obs_prob\": ");
+    arr(probs, pd);
+    printf(", \"listen_O_after\": ");
+    arr(cpt, pd);
+    printf(", \"listen_T_after\": ");
+    arr(tl, pd);
+    printf("}");
+}
+
 /* episode::run with the reference's RandomPlanner and RejectionSampling belief */
 static void random_planner_episodes(char const* s, int n, int episodes)
 {
@@ -375,6 +466,19 @@ int main(int argc, char** argv)
 
     key("flat_model");
     flat_model("15");
+
+    key("babn_model");
+    printf("[");
+    babn_model("17", {0});
+    printf(",");
+    babn_model("18", {0, 2});
+    printf(",");
+    babn_model("19", {1});
+    printf(",");
+    babn_model("20", {});
+    printf(",");
+    babn_model("21", {0, 1, 2});
+    printf("]");
 
     key("random_planner_episodes");
     random_planner_episodes("16", 32, 60);
