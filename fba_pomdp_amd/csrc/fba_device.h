@@ -122,7 +122,36 @@ __device__ __forceinline__ double expected_mult_at(const View& row, int off, int
 // ---------------------------------------------------------------------------------------------
 // Problem description shared by all kernels (filled on the host)
 // ---------------------------------------------------------------------------------------------
+// Factored Bayes-adaptive model (BABNModel + DBNNode, reference
+// src/bayes-adaptive/states/factored/) in a fixed "max layout": node (a, f) owns a region of the
+// count blob large enough for its biggest allowed parent set; a particle's actual parents are a
+// bit mask over the node's `maxp` list -- fixed for the ctx, or per particle in mask word `var`
+// stored right after the counts -- and rows are indexed compactly by the actual parents, exactly
+// as DBNNode::cptIndex (DBNNode.cpp:171-205).
+constexpr int MAXF     = 8;   // state / observation features
+constexpr int MAXNODES = 96;  // A * (FS + FO)
+constexpr int MAXINC   = 8;   // count increments of one UpdateCounts step (FS + FO)
+struct FNode {
+    int32_t off, out, nmax, var;
+    uint32_t fixed_mask;
+    uint8_t maxp[MAXF];
+};
+struct FDesc {
+    int32_t FS, FO, nvar, ncounts;
+    int32_t Ssz[MAXF], Osz[MAXF], Sstep[MAXF], Ostep[MAXF];
+    FNode nodes[MAXNODES];  // T(a, f) at a*FS + f, O(a, f) at A*FS + a*FO + f
+};
+
+// the "+1"s of one UpdateCounts step, as indices into the particle's count blob
+struct Inc {
+    int n;
+    int idx[MAXINC];
+};
+
 struct Problem {
+    const FDesc* fd;  // device pointer; null unless model = BA_FACTORED
+    float noise, counts_total;
+    int32_t structure_prior;
     int32_t domain, model, belief, planner;
     int32_t S, A, O;
     int32_t N;          // particles per slot
@@ -205,14 +234,105 @@ __device__ __forceinline__ double ext_reward(const Problem& P, int s, int a, int
 // caller decides where the +1 lands (in place for importance sampling, in the copy for
 // rejection sampling).
 // ---------------------------------------------------------------------------------------------
+// ---- factored model ---------------------------------------------------------------------------
+// feature values travel packed, 8 bits each, so no runtime-indexed register arrays are needed
+__device__ __forceinline__ uint64_t pack_features(int v, const int32_t* step, int n)
+{
+    if (n == 1) return (uint64_t)v;
+    uint64_t p = 0;
+#pragma unroll
+    for (int i = 0; i < MAXF; ++i)
+        if (i < n) { p |= (uint64_t)(v / step[i]) << (8 * i); v = v % step[i]; }  // indexing::projectUsingStepSize
+    return p;
+}
+__device__ __forceinline__ int feat(uint64_t p, int i) { return (int)((p >> (8 * i)) & 0xffu); }
+
 template <class View>
-__device__ __forceinline__ bool sim_step(const Problem& P, Rng& g, const View& cnt, int& s, int a, int& o, double& r, int& inc0,
-                                         int& inc1)
+__device__ __forceinline__ uint32_t node_mask(const FDesc* fd, const FNode& nd, const View& cnt)
+{
+    return nd.var >= 0 ? __float_as_uint(cnt.at(fd->ncounts + nd.var)) : nd.fixed_mask;
+}
+// DBNNode::cptIndex(graph input, 0): mixed radix over the node's actual parents
+__device__ __forceinline__ int node_row(const FDesc* fd, const FNode& nd, uint32_t mask, uint64_t fv)
+{
+    int idx = 0;
+#pragma unroll
+    for (int j = 0; j < MAXF; ++j)
+        if (j < nd.nmax && ((mask >> j) & 1u)) idx = idx * fd->Ssz[nd.maxp[j]] + feat(fv, nd.maxp[j]);
+    return nd.off + idx * nd.out;
+}
+
+// BAPOMDP::step over BABNModel (BABNModel.cpp:292-325) + the indices incrementCountsOf would
+// touch (:354-382).  Quirk kept: observation CPTs are incremented at the row of
+// the PREVIOUS state's parent values.
+template <class View>
+__device__ __forceinline__ bool fact_step(const Problem& P, Rng& g, const View& cnt, int& s, int a, int& o, double& r, Inc& inc)
+{
+    const FDesc* fd   = P.fd;
+    const int FS = fd->FS, FO = fd->FO;
+    const uint64_t fv = pack_features(s, fd->Sstep, FS);
+    uint64_t nf = 0;
+    int ns = 0;
+    inc.n = FS + FO;
+#pragma unroll
+    for (int f = 0; f < MAXF; ++f)
+        if (f < FS) {
+            const FNode& nd = fd->nodes[a * FS + f];
+            const int row   = node_row(fd, nd, node_mask(fd, nd, cnt), fv);
+            const int v     = sample_expected_mult(g, cnt, row, nd.out);
+            inc.idx[f]      = row + v;
+            nf |= (uint64_t)v << (8 * f);
+            ns = ns * fd->Ssz[f] + v;  // indexing::project
+        }
+    int ob = 0;
+#pragma unroll
+    for (int f = 0; f < MAXF; ++f)
+        if (f < FO) {
+            const FNode& nd     = fd->nodes[P.A * FS + a * FO + f];
+            const uint32_t mask = node_mask(fd, nd, cnt);
+            const int v         = sample_expected_mult(g, cnt, node_row(fd, nd, mask, nf), nd.out);
+            ob = ob * fd->Osz[f] + v;
+            // MAXINC = FS + FO slots: observation feature f uses slot FS + f
+#pragma unroll
+            for (int k = 0; k < MAXINC; ++k)
+                if (k == FS + f) inc.idx[k] = node_row(fd, nd, mask, fv) + v;
+        }
+    o            = ob;
+    const bool t = ext_terminal(P, s, a, ns);
+    r            = ext_reward(P, s, a, ns);
+    s            = ns;
+    return t;
+}
+
+// BABNModel::computeObservationProbability (BABNModel.cpp:328-352)
+template <class View>
+__device__ __forceinline__ double fact_obs_prob(const Problem& P, const View& cnt, int new_s, int a, int o)
+{
+    const FDesc* fd   = P.fd;
+    const uint64_t fv = pack_features(new_s, fd->Sstep, fd->FS);
+    const uint64_t of = pack_features(o, fd->Ostep, fd->FO);
+    double prob = 1;
+#pragma unroll
+    for (int f = 0; f < MAXF; ++f)
+        if (f < fd->FO) {
+            const FNode& nd = fd->nodes[P.A * fd->FS + a * fd->FO + f];
+            const int row   = node_row(fd, nd, node_mask(fd, nd, cnt), fv);
+            float sum       = cnt.at(row);
+            for (int i = 1; i < nd.out; ++i) sum += cnt.at(row + i);
+            prob *= ((double)sum <= 1e-300) ? 0.0f : cnt.at(row + feat(of, f)) / sum;
+        }
+    return prob;
+}
+
+// ---- simulator.step for the three simulators --------------------------------------------------
+template <class View>
+__device__ __forceinline__ bool sim_step(const Problem& P, Rng& g, const View& cnt, int& s, int a, int& o, double& r, Inc& inc)
 {
     if (P.model == FBA_MODEL_POMDP) {
-        inc0 = inc1 = -1;
+        inc.n = 0;
         return domain_step(P, g, s, a, o, r);
     }
+    if (P.model == FBA_MODEL_BA_FACTORED) return fact_step(P, g, cnt, s, a, o, r, inc);
     const int S = P.S, A = P.A, O = P.O;
     const int t_off = s * A * S + a * S;
     const int ns    = sample_expected_mult(g, cnt, t_off, S);
@@ -220,8 +340,9 @@ __device__ __forceinline__ bool sim_step(const Problem& P, Rng& g, const View& c
     o               = sample_expected_mult(g, cnt, o_off, O);
     const bool t    = ext_terminal(P, s, a, ns);
     r               = ext_reward(P, s, a, ns);
-    inc0            = t_off + ns;
-    inc1            = o_off + o;
+    inc.n           = 2;
+    inc.idx[0]      = t_off + ns;
+    inc.idx[1]      = o_off + o;
     s               = ns;
     return t;
 }
@@ -232,8 +353,53 @@ template <class View>
 __device__ __forceinline__ double sim_obs_prob(const Problem& P, const View& cnt, int new_s, int a, int o)
 {
     if (P.model == FBA_MODEL_POMDP) return domain_obs_prob(P, o, a, new_s);
+    if (P.model == FBA_MODEL_BA_FACTORED) return fact_obs_prob(P, cnt, new_s, a, o);
     if (P.O == 1) return 1.0;
     return expected_mult_at(cnt, P.phi_len + a * P.S * P.O + new_s * P.O, P.O, o);
+}
+
+// FactoredTigerFactoredPrior::setObservationModel (FactoredTigerPriors.cpp:221-263): the listen
+// observation node of one particle for parent set `mask` (bit j = state feature j)
+__device__ __forceinline__ void ftiger_set_observation_model(const Problem& P, float* rec, uint32_t mask)
+{
+    const FDesc* fd = P.fd;
+    const FNode& nd = fd->nodes[P.A * fd->FS + 2 * fd->FO];
+    const float acc = (.85f - P.noise) * P.counts_total, inacc = (.15f + P.noise) * P.counts_total;
+    const float unif = .5f * P.counts_total;
+    const int np = __popc(mask), rows = 1 << np, max_rows = 1 << nd.nmax;
+    float* row = rec + nd.off;
+    for (int r = 0; r < max_rows; ++r) {
+        float l = 0.f, rr = 0.f;
+        if (r < rows) {
+            if (np > 0 && (mask & 1u)) {  // parents[0] == 0: informed by the tiger location
+                const int loc = r >> (np - 1);
+                l  = (loc == 0) ? acc : inacc;
+                rr = (loc == 1) ? acc : inacc;
+            } else {
+                l = rr = unif;
+            }
+        }
+        row[2 * r + 0] = l;
+        row[2 * r + 1] = rr;
+    }
+    rec[fd->ncounts + 0] = __uint_as_float(mask);
+}
+
+// FBAPOMDPPrior::sample -> sampleFBAPOMDPState / sampleFullyConnectedState
+// (FBAPOMDPPrior.cpp:27-37, FactoredTigerPriors.cpp:197-219, 265-291).  `rec` already holds the
+// base prior record; the structure draws follow the domain start-state draw in the same stream.
+__device__ __forceinline__ void factored_prior_sample(const Problem& P, Rng& g, float* rec)
+{
+    const int FS = P.fd->FS;
+    if (P.structure_prior == FBA_SP_FULLY_CONNECTED) {
+        ftiger_set_observation_model(P, rec, (1u << FS) - 1u);
+    } else if (P.structure_prior == FBA_SP_UNIFORM || P.structure_prior == FBA_SP_MATCH_UNIFORM) {
+        uint32_t mask = 0;
+        for (int f = 0; f < FS; ++f)
+            if (g.boolean()) mask |= 1u << f;
+        if (P.structure_prior == FBA_SP_MATCH_UNIFORM) mask |= 1u;
+        ftiger_set_observation_model(P, rec, mask);
+    }
 }
 
 // position-sensitive particle checksum (same function as oracle/orc.c particle_hash)

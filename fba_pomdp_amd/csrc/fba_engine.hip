@@ -36,6 +36,8 @@ struct fba_ctx {
     std::vector<void*> allocs;
     std::vector<float> prior;  // host copy, C floats
     float* d_prior       = nullptr;
+    FDesc fdesc{};          // host copy of the factored model description
+    FDesc* d_fdesc       = nullptr;
     double* d_uni_scan   = nullptr;
     double* d_log1p      = nullptr;
     int32_t* d_n_active  = nullptr;
@@ -121,6 +123,75 @@ int build_tabular_prior(fba_ctx* c)
         }
     } else {
         return fail(c, FBA_EINVAL, "domain %d has no built-in tabular prior; use fba_set_model_tabular", P.domain);
+    }
+    return FBA_OK;
+}
+
+void fdesc_steps(const int32_t* size, int n, int32_t* step)
+{
+    step[n - 1] = 1;
+    for (int i = n - 2; i >= 0; --i) step[i] = step[i + 1] * size[i + 1];
+}
+
+// Factored model description + base prior record for episodic/continuous factored tiger.
+// FactoredTigerFactoredPrior ctor (reference src/domains/tiger/FactoredTigerPriors.cpp:95-195):
+//   T listen (a = 2): feature f depends on feature f only, count 5000 on "keeps its value";
+//   T open: no parents, {5000, 5000};  O open: no parents, {5000, 5000};
+//   O listen: parents are per particle (structure prior), filled on the device by
+//   ftiger_set_observation_model; the base record carries the correct structure {tiger location}.
+int build_factored_prior(fba_ctx* c)
+{
+    Problem& P = c->P;
+    if (!is_ftiger(P.domain)) return fail(c, FBA_EINVAL, "domain %d has no built-in factored prior", P.domain);
+    const float noise = c->cfg.noise, total = c->cfg.counts_total;
+    if (noise <= -.15 || noise > .3) return fail(c, FBA_EINVAL, "noise must be between -.15 and .3");
+    FDesc& d = c->fdesc;
+    std::memset(&d, 0, sizeof d);
+    d.FS = c->cfg.size + 1;
+    d.FO = 1;
+    if (d.FS > MAXF) return fail(c, FBA_EINVAL, "factored tiger supports at most %d irrelevant features", MAXF - 1);
+    if (P.A * (d.FS + d.FO) > MAXNODES) return fail(c, FBA_EINVAL, "too many DBN nodes");
+    for (int f = 0; f < d.FS; ++f) d.Ssz[f] = 2;
+    d.Osz[0] = 2;
+    fdesc_steps(d.Ssz, d.FS, d.Sstep);
+    fdesc_steps(d.Osz, d.FO, d.Ostep);
+    int off = 0;
+    for (int a = 0; a < P.A; ++a)
+        for (int f = 0; f < d.FS; ++f) {
+            FNode& nd = d.nodes[a * d.FS + f];
+            nd.off = off; nd.out = 2; nd.var = -1;
+            if (a == 2) { nd.nmax = 1; nd.maxp[0] = (uint8_t)f; nd.fixed_mask = 1; off += 4; }
+            else { nd.nmax = 0; nd.fixed_mask = 0; off += 2; }
+        }
+    for (int a = 0; a < P.A; ++a) {
+        FNode& nd = d.nodes[P.A * d.FS + a * d.FO];
+        nd.off = off; nd.out = 2; nd.var = -1;
+        if (a == 2) {
+            nd.nmax = d.FS; nd.var = 0;
+            for (int f = 0; f < d.FS; ++f) nd.maxp[f] = (uint8_t)f;
+            off += 2 << d.FS;
+        } else { nd.nmax = 0; off += 2; }
+    }
+    d.ncounts = off;
+    d.nvar    = 1;
+    c->prior.assign((size_t)off + d.nvar, 0.f);
+    for (int a = 0; a < P.A; ++a)
+        for (int f = 0; f < d.FS; ++f) {
+            const FNode& nd = d.nodes[a * d.FS + f];
+            if (a == 2) { c->prior[nd.off + 0] = 5000; c->prior[nd.off + 3] = 5000; }
+            else { c->prior[nd.off] = 5000; c->prior[nd.off + 1] = 5000; }
+        }
+    for (int a = 0; a < 2; ++a) {
+        const FNode& nd = d.nodes[P.A * d.FS + a * d.FO];
+        c->prior[nd.off] = 5000; c->prior[nd.off + 1] = 5000;
+    }
+    {   // correct structure {0}: rows (LEFT, RIGHT) = (acc, inacc), (inacc, acc)
+        const FNode& nd = d.nodes[P.A * d.FS + 2 * d.FO];
+        const float acc = (.85f - noise) * total, inacc = (.15f + noise) * total;
+        c->prior[nd.off + 0] = acc; c->prior[nd.off + 1] = inacc;
+        c->prior[nd.off + 2] = inacc; c->prior[nd.off + 3] = acc;
+        const uint32_t mask = 1u;
+        std::memcpy(&c->prior[off + 0], &mask, 4);
     }
     return FBA_OK;
 }
@@ -376,12 +447,25 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     P.gamma = cfg->discount;
     P.seed_lo = (uint32_t)cfg->seed;
     P.seed_hi = (uint32_t)(cfg->seed >> 32);
+    P.noise = cfg->noise;
+    P.counts_total = cfg->counts_total;
+    P.structure_prior = cfg->structure_prior;
+    P.fd = nullptr;
     if (cfg->model == FBA_MODEL_BA_TABLE) {
         P.phi_len = P.S * P.A * P.S;
         P.C       = P.phi_len + P.A * P.S * P.O;
     } else if (cfg->model == FBA_MODEL_POMDP) {
         P.phi_len = 0;
         P.C       = 0;
+    } else if (cfg->model == FBA_MODEL_BA_FACTORED) {
+        P.phi_len = 0;
+        int rc = build_factored_prior(c);
+        if (rc) {
+            g_create_error = c->err;
+            delete c;
+            return rc;
+        }
+        P.C = c->fdesc.ncounts + c->fdesc.nvar;
     } else {
         fail(nullptr, FBA_EINVAL, "model %d is not supported by this build", cfg->model);
         delete c;
@@ -503,6 +587,11 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         HIPC(hipStreamSynchronize(c->stream));
     }
     if (cfg->model == FBA_MODEL_BA_TABLE) CHK(build_tabular_prior(c));
+    if (cfg->model == FBA_MODEL_BA_FACTORED) {
+        CHK(dev_alloc(c, &c->d_fdesc, 1));
+        HIPC(hipMemcpyAsync(c->d_fdesc, &c->fdesc, sizeof(FDesc), hipMemcpyHostToDevice, c->stream));
+        P.fd = c->d_fdesc;
+    }
     CHK(upload_prior(c));
     // default positions for the per-step interface: slot e is run run_offset + e
     {
@@ -742,8 +831,12 @@ int fba_get_kernel_times(fba_ctx* c, fba_kernel_time* out)
     // algorithmic bytes, SURVEY.md section 8(d): Pb = particle payload, Rt / Ro = bytes of the
     // transition / observation rows one step consults
     const uint64_t Pb = 4 + 4 * (uint64_t)P.C;
-    const uint64_t Rt = P.model == FBA_MODEL_POMDP ? 0 : 4 * (uint64_t)P.S;
-    const uint64_t Ro = P.model == FBA_MODEL_POMDP ? 0 : 4 * (uint64_t)P.O;
+    uint64_t Rt = 0, Ro = 0;
+    if (P.model == FBA_MODEL_BA_TABLE) { Rt = 4 * (uint64_t)P.S; Ro = 4 * (uint64_t)P.O; }
+    if (P.model == FBA_MODEL_BA_FACTORED) {
+        for (int f = 0; f < c->fdesc.FS; ++f) Rt += 4 * (uint64_t)c->fdesc.Ssz[f];
+        for (int f = 0; f < c->fdesc.FO; ++f) Ro += 4 * (uint64_t)c->fdesc.Osz[f];
+    }
     for (int k = 0; k < FBA_K_COUNT; ++k) {
         out[k].ms = c->k_ms[k];
         out[k].launches = c->k_launches[k];

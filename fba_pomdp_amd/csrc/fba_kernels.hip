@@ -172,11 +172,12 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
             a = domain_random_action(P, g, s);
         }
         if (do_step) {
-            int o, i0, i1;
+            int o;
             double r;
             bool term;
-            if (STAGE) term = sim_step(P, g, LdsView<SEARCH_BLOCK>{stage}, s, a, o, r, i0, i1);
-            else term = sim_step(P, g, GlobalView{cnt}, s, a, o, r, i0, i1);
+            Inc inc;
+            if (STAGE) term = sim_step(P, g, LdsView<SEARCH_BLOCK>{stage}, s, a, o, r, inc);
+            else term = sim_step(P, g, GlobalView{cnt}, s, a, o, r, inc);
             ++steps;
             if (mode == 1) {  // traverseChanceNode
                 path_r[(size_t)plen * SEARCH_BLOCK]  = r;
@@ -346,25 +347,26 @@ __global__ void advance_kernel(Problem P, DeviceState D, int32_t* n_active)
 
 // ---------------------------------------------------------------------------------------------
 // Whole-record gather: the m particles listed in s_src[] (LDS) are copied from `src` records to
-// consecutive `dst` records, applying the UpdateCounts "+1" at blob indices inc0/inc1 (-1 = none)
+// consecutive `dst` records, applying the UpdateCounts "+1"s at the blob indices listed in s_inc[k][j], k < ninc,
 // and, if s_state is given, overwriting the state word (index C) with the particle's new state.
 // A record is C4 float4; a power-of-two group of lanes owns one record so consecutive lanes move
 // consecutive 16-byte pieces: every wave instruction reads and writes whole contiguous records.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void gather_records(float* __restrict__ dst, const float* __restrict__ src, const int32_t* s_src,
-                                               const int32_t* s_inc0, const int32_t* s_inc1, const int32_t* s_state, int m,
+                                               const int32_t* s_inc, int ninc, int inc_stride, const int32_t* s_state, int m,
                                                int C4, int C, int group, int nthreads)
 {
     const int gid = threadIdx.x / group, part0 = threadIdx.x % group, ngroups = nthreads / group;
     for (int j = gid; j < m; j += ngroups) {
         const float4* sp = reinterpret_cast<const float4*>(src) + (size_t)s_src[j] * C4;
         float4* dp       = reinterpret_cast<float4*>(dst) + (size_t)j * C4;
-        const int i0 = s_inc0 ? s_inc0[j] : -1, i1 = s_inc1 ? s_inc1[j] : -1;
         for (int part = part0; part < C4; part += group) {
             float4 v = sp[part];
             const int lo = part * 4;
-            if ((unsigned)(i0 - lo) < 4u) (&v.x)[i0 - lo] += 1.0f;
-            if ((unsigned)(i1 - lo) < 4u) (&v.x)[i1 - lo] += 1.0f;
+            for (int k = 0; k < ninc; ++k) {
+                const int d = s_inc[k * inc_stride + j] - lo;
+                if ((unsigned)d < 4u) (&v.x)[d] += 1.0f;
+            }
             if (s_state && (unsigned)(C - lo) < 4u) (&v.x)[C - lo] = __int_as_float(s_state[j]);  // new domain state
             dp[part] = v;
         }
@@ -387,7 +389,7 @@ __device__ __forceinline__ int record_group(int C4)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(REJECT_BLOCK) reject_kernel(Problem P, DeviceState D)
 {
-    __shared__ int32_t s_src[REJECT_BLOCK], s_ns[REJECT_BLOCK], s_inc0[REJECT_BLOCK], s_inc1[REJECT_BLOCK];
+    __shared__ int32_t s_src[REJECT_BLOCK], s_ns[REJECT_BLOCK], s_inc[MAXINC * REJECT_BLOCK];
     __shared__ int32_t s_wave[REJECT_BLOCK / 64];
     __shared__ int32_t s_count;
     const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -398,6 +400,7 @@ __global__ void __launch_bounds__(REJECT_BLOCK) reject_kernel(Problem P, DeviceS
     const float* scn   = D.p_rec + sb * (size_t)P.Cs;
     float* dcn         = D.p_rec + db * (size_t)P.Cs;
     const int C4 = P.Cs / 4, group = record_group(C4);
+    const int ninc = P.model == FBA_MODEL_POMDP ? 0 : (P.model == FBA_MODEL_BA_TABLE ? 2 : P.fd->FS + P.fd->FO);
     Rng g = slot_rng(P, D, e);
 
     int acc = 0, base = 0;
@@ -406,9 +409,10 @@ __global__ void __launch_bounds__(REJECT_BLOCK) reject_kernel(Problem P, DeviceS
         g.stream(FBA_PHASE_REJECT, (uint32_t)k);
         const int src = g.uniform_int(N);                       // FlatFilter::sample
         const float* rec = scn + (size_t)src * P.Cs;
-        int s = rec_state(rec, P.C), so, i0, i1;
+        int s = rec_state(rec, P.C), so;
         double r;
-        sim_step(P, g, GlobalView{rec}, s, a, so, r, i0, i1);  // UpdateCounts: +1 lands in the copy
+        Inc inc;
+        sim_step(P, g, GlobalView{rec}, s, a, so, r, inc);  // UpdateCounts: the +1s land in the copy
         const bool ok = (so == o);
         const unsigned long long ballot = __ballot(ok);
         const int prefix = __popcll(ballot & ((1ull << lane) - 1ull));
@@ -421,12 +425,15 @@ __global__ void __launch_bounds__(REJECT_BLOCK) reject_kernel(Problem P, DeviceS
         }
         const int j = woff + prefix;  // position among this chunk's accepted attempts
         if (ok && acc + j < N) {
-            s_src[j] = src; s_ns[j] = s; s_inc0[j] = i0; s_inc1[j] = i1;
+            s_src[j] = src; s_ns[j] = s;
+#pragma unroll
+            for (int q = 0; q < MAXINC; ++q)
+                if (q < inc.n) s_inc[q * REJECT_BLOCK + j] = inc.idx[q];
             if (acc + j == N - 1) s_count = k + 1;
         }
         __syncthreads();
         const int m = min(chunk, N - acc);
-        gather_records(dcn + (size_t)acc * P.Cs, scn, s_src, s_inc0, s_inc1, s_ns, m, C4, P.C, group, REJECT_BLOCK);
+        gather_records(dcn + (size_t)acc * P.Cs, scn, s_src, s_inc, ninc, REJECT_BLOCK, s_ns, m, C4, P.C, group, REJECT_BLOCK);
         acc += m;
         base += REJECT_BLOCK;
         __syncthreads();
@@ -550,10 +557,13 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
     for (int i = tid; i < N; i += IS_BLOCK) {
         g.stream(FBA_PHASE_IS_UPDATE, (uint32_t)i);
         float* cnt = scn + (size_t)i * P.Cs;
-        int s = rec_state(cnt, P.C), so, i0, i1;
+        int s = rec_state(cnt, P.C), so;
         double r;
-        sim_step(P, g, GlobalView{cnt}, s, a, so, r, i0, i1);
-        if (i0 >= 0) { cnt[i0] += 1.0f; cnt[i1] += 1.0f; }  // incrementCountsOf (BAFlatModel.cpp:126-139)
+        Inc inc;
+        sim_step(P, g, GlobalView{cnt}, s, a, so, r, inc);
+#pragma unroll
+        for (int q = 0; q < MAXINC; ++q)
+            if (q < inc.n) cnt[inc.idx[q]] += 1.0f;  // incrementCountsOf (BAFlatModel.cpp:126-139, BABNModel.cpp:354-382)
         rec_set_state(cnt, P.C, s);
         sw[i] *= sim_obs_prob(P, GlobalView{cnt}, s, a, o);  // probability from the updated counts
     }
@@ -573,7 +583,7 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
         }
         __syncthreads();
         const int m = min(IS_BLOCK, N - j0);
-        gather_records(dcn + (size_t)j0 * P.Cs, scn, s_src, nullptr, nullptr, nullptr, m, C4, P.C, group, IS_BLOCK);
+        gather_records(dcn + (size_t)j0 * P.Cs, scn, s_src, nullptr, 0, 0, nullptr, m, C4, P.C, group, IS_BLOCK);
         __syncthreads();
     }
     if (tid == 0) {
@@ -612,6 +622,7 @@ __global__ void __launch_bounds__(256) init_kernel(Problem P, DeviceState D)
     for (int i = tid; i < P.N; i += 256) {
         g.stream(FBA_PHASE_INIT, (uint32_t)i);
         rec_set_state(recs + (size_t)i * P.Cs, P.C, domain_start(P, g));
+        if (P.model == FBA_MODEL_BA_FACTORED) factored_prior_sample(P, g, recs + (size_t)i * P.Cs);
         if (P.belief == FBA_BELIEF_IMPORTANCE) D.p_weight[pb + i] = w1;
     }
     __syncthreads();
@@ -655,7 +666,7 @@ __global__ void __launch_bounds__(256) reset_kernel(Problem P, DeviceState D)
         }
         __syncthreads();
         const int m = min(256, P.N - j0);
-        gather_records(D.p_rec + (db + j0) * (size_t)P.Cs, D.p_rec + sb * (size_t)P.Cs, s_src, nullptr, nullptr, s_ns, m, C4, P.C,
+        gather_records(D.p_rec + (db + j0) * (size_t)P.Cs, D.p_rec + sb * (size_t)P.Cs, s_src, nullptr, 0, 0, s_ns, m, C4, P.C,
                        group, 256);
         __syncthreads();
     }

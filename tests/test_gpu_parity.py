@@ -99,6 +99,37 @@ def test_bapomdp_factored_tiger_flat_prior():
     _assert_same_experiment(eng, o, ba=True)
 
 
+@pytest.mark.parametrize("sp,belief,size", [
+    (0, "rejection_sampling", 3),      # "" = correct structure
+    (2, "rejection_sampling", 3),      # match-uniform (BASELINE configs[2])
+    (2, "importance_sampling", 2),
+    (1, "importance_sampling", 3),     # uniform
+    (3, "rejection_sampling", 2),      # fully-connected
+])
+def test_fbapomdp_factored_tiger(sp, belief, size):
+    """fbapomdp -D episodic-factored-tiger: BABNModel / DBNNode sampling, per-particle structure
+    drawn from the structure prior, observation-CPT increment quirk (SURVEY App. A #6)."""
+    eng, o = _pair("episodic-factored-tiger", N.MODEL_BA_FACTORED, belief, 61 + sp, size=size, particles=150,
+                   sims=200, runs=8, episodes=4, structure_prior=sp)
+    _assert_same_experiment(eng, o, ba=True)
+
+
+def test_fbapomdp_prior_particles_equal_oracle():
+    kw = dict(size=3, particles=64, sims=16, structure_prior=2)
+    eng = fba.Engine("episodic-factored-tiger", model=N.MODEL_BA_FACTORED, seed=71, slots=1, **kw)
+    o = orc.Oracle(domain=orc.DOM_FTIGER_EPISODIC, model=orc.MODEL_BA_FACTORED, rng_mode=orc.RNG_PHILOX,
+                   arith=orc.ARITH_DEV, philox_seed=71, **kw)
+    orc.lib().orc_rng_episode(o.rng, 0, 0, 0)
+    o.belief_initiate()
+    eng.belief_init()
+    s, _, cnt = eng.belief_get(0)
+    os_, _, ocnt = o.belief_get()
+    assert np.array_equal(s, os_)
+    assert np.array_equal(cnt.view(np.uint32), ocnt.view(np.uint32))   # counts and structure masks
+    masks = cnt.view(np.uint32)[:, -1]
+    assert np.all(masks & 1 == 1) and len(set(masks.tolist())) > 1       # match-uniform: feature 0 forced, rest random
+
+
 def test_bapomdp_slots_fewer_than_runs():
     eng, o = _pair("episodic-tiger", N.MODEL_BA_TABLE, "rejection_sampling", 24, slots=3, particles=64, sims=64,
                    runs=8, episodes=2)
