@@ -63,6 +63,10 @@ struct orc_ctx {
     char err[256];
     int32_t S, A, O;
     int32_t tiger_K;   /* factored tiger: number of irrelevant features */
+    /* gridworld (src/domains/gridworld/GridWorld.cpp) */
+    int32_t gw_N, gw_G, gw_nslow;
+    int32_t gw_goal[16][2], gw_slow[8][2];
+    float gw_disp[32]; /* _obs_displacement_probs */
     int32_t ncnt;      /* floats per particle count blob */
     int32_t phi_len;   /* tabular: S*A*S */
     float* prior;      /* tabular prior blob (phi then psi) */
@@ -176,6 +180,73 @@ static int is_episodic(int d)
 {
     return d == ORC_DOM_TIGER_EPISODIC || d == ORC_DOM_FTIGER_EPISODIC;
 }
+static int is_grid(int d) { return d == ORC_DOM_GRIDWORLD; }
+
+/* ---- gridworld.  ref: src/domains/gridworld/GridWorld.cpp
+ * state index = x*N*G + y*G + g (positionsToIndex :329-340); actions UP, RIGHT, DOWN, LEFT */
+static void gw_setup(orc_ctx* c, int N)
+{
+    int edge = N - 1, start, i, G = 0, ns = 0;
+    double prob;
+    c->gw_N = N;
+    /* goalLocations :124-152 */
+    start = (N < 5) ? N - 2 : (N < 7) ? N - 3 : N - 4;
+    for (i = start; i < N - 1; ++i) {
+        c->gw_goal[G][0] = i; c->gw_goal[G][1] = edge; G++;
+        c->gw_goal[G][0] = edge; c->gw_goal[G][1] = i; G++;
+    }
+    c->gw_goal[G][0] = edge; c->gw_goal[G][1] = edge; G++;
+    if (N > 3) { c->gw_goal[G][0] = edge - 1; c->gw_goal[G][1] = edge - 1; G++; }
+    if (N > 6) {
+        c->gw_goal[G][0] = edge - 2; c->gw_goal[G][1] = edge - 1; G++;
+        c->gw_goal[G][0] = edge - 1; c->gw_goal[G][1] = edge - 2; G++;
+    }
+    c->gw_G = G;
+    /* generateSlowLocations :78-103 */
+    if (N > 5) { c->gw_slow[ns][0] = 1; c->gw_slow[ns][1] = 1; ns++; }
+    if (N == 3) { c->gw_slow[ns][0] = 1; c->gw_slow[ns][1] = 1; ns++; }
+    else if (N < 7) {
+        c->gw_slow[ns][0] = edge - 1; c->gw_slow[ns][1] = edge - 2; ns++;
+        c->gw_slow[ns][0] = edge - 2; c->gw_slow[ns][1] = edge - 1; ns++;
+    } else {
+        c->gw_slow[ns][0] = edge - 1; c->gw_slow[ns][1] = edge - 3; ns++;
+        c->gw_slow[ns][0] = edge - 3; c->gw_slow[ns][1] = edge - 1; ns++;
+        c->gw_slow[ns][0] = edge - 2; c->gw_slow[ns][1] = edge - 2; ns++;
+    }
+    c->gw_nslow = ns;
+    /* _obs_displacement_probs, ctor :60-70: {.8, .1, .05, ..., last repeated}, N entries */
+    c->gw_disp[0] = (float)(1 - .2);
+    prob = .2;
+    for (i = 1; i < N - 1; ++i) { prob *= .5; c->gw_disp[i] = (float)prob; }
+    c->gw_disp[N - 1] = (float)prob;
+}
+static int gw_slow_at(const orc_ctx* c, int x, int y)
+{
+    int i;
+    for (i = 0; i < c->gw_nslow; ++i)
+        if (c->gw_slow[i][0] == x && c->gw_slow[i][1] == y) return 1;
+    return 0;
+}
+/* applyMove :342-364 */
+static void gw_move(const orc_ctx* c, int a, int* x, int* y)
+{
+    int N = c->gw_N;
+    switch (a) {
+        case 0: if (*y != N - 1) (*y)++; break;
+        case 2: if (*y != 0) (*y)--; break;
+        case 1: if (*x != N - 1) (*x)++; break;
+        case 3: if (*x != 0) (*x)--; break;
+    }
+}
+/* obsDisplProb :164-185 (float result, double intermediate products) */
+static float gw_obs_displ_prob(const orc_ctx* c, int loc, int observed)
+{
+    int disp = abs(loc - observed), i;
+    float res = (disp == 0) ? (float)(1 - .2) : (float)(c->gw_disp[disp] * .5);
+    if (observed == c->gw_N - 1 || observed == 0)
+        for (i = disp + 1; i < c->gw_N; ++i) res = (float)(res + c->gw_disp[i] * .5);
+    return res;
+}
 
 /* ref: Tiger::sampleStartState src/domains/tiger/Tiger.cpp:16-19 (LEFT=0 iff boolean()),
  *      FactoredTiger::sampleStartState src/domains/tiger/FactoredTiger.cpp (uniform_int{0,S-1}) */
@@ -183,6 +254,12 @@ static int32_t domain_start(orc_ctx* c)
 {
     if (is_tiger(c->cfg.domain)) return orc_bool(&c->rng) ? 0 : 1;
     if (is_ftiger(c->cfg.domain)) return orc_int(&c->rng, c->S);
+    if (is_grid(c->cfg.domain)) { /* GridWorld::sampleStartState :260-266: start_locations = {{0,0}} */
+        int agent = orc_slow_int(&c->rng, 0, 1);
+        int goal  = orc_slow_int(&c->rng, 0, c->gw_G);
+        (void)agent;
+        return 0 * c->gw_N * c->gw_G + 0 * c->gw_G + goal;
+    }
     return 0;
 }
 
@@ -192,6 +269,7 @@ static int32_t domain_random_action(orc_ctx* c, int32_t s)
 {
     (void)s;
     if (is_tiger(c->cfg.domain) || is_ftiger(c->cfg.domain)) return orc_int(&c->rng, 3);
+    if (is_grid(c->cfg.domain)) return orc_slow_int(&c->rng, 0, 4); /* GridWorld::generateRandomAction :220-226 */
     return 0;
 }
 
@@ -225,6 +303,24 @@ static int domain_step(orc_ctx* c, int32_t* s, int32_t a, int32_t* o, double* r)
         }
         return is_episodic(d) && a != 2;
     }
+    if (is_grid(d)) { /* GridWorld::step :272-304, generateObservation :366-394 */
+        int N = c->gw_N, G = c->gw_G;
+        int x = *s / (N * G), y = (*s / G) % N, g = *s % G;
+        int slow = gw_slow_at(c, x, y);
+        int ok   = orc_u01(&c->rng) < (slow ? .15 : .95);
+        int nx = x, ny = y, ng = g, found, dx, dy, ox, oy;
+        if (ok) gw_move(c, a, &nx, &ny);
+        found = (c->gw_goal[g][0] == x && c->gw_goal[g][1] == y);
+        if (found) ng = orc_slow_int(&c->rng, 0, G);
+        *s = nx * N * G + ny * G + ng;
+        *r = found ? 1 : 0;
+        dx = orc_sample_from_mult_f(&c->rng, c->gw_disp, N, 1);
+        dy = orc_sample_from_mult_f(&c->rng, c->gw_disp, N, 1);
+        ox = orc_bool(&c->rng) ? (nx - dx > 0 ? nx - dx : 0) : (nx + dx < N - 1 ? nx + dx : N - 1);
+        oy = orc_bool(&c->rng) ? (ny - dy > 0 ? ny - dy : 0) : (ny + dy < N - 1 ? ny + dy : N - 1);
+        *o = ox * N * G + oy * G + ng;
+        return found;
+    }
     return 1;
 }
 
@@ -241,20 +337,34 @@ static double domain_obs_prob(orc_ctx* c, int32_t o, int32_t a, int32_t new_s)
         if (a != 2) return .5;
         return (loc == o) ? .85 : .15;
     }
+    if (is_grid(d)) { /* GridWorld::computeObservationProbability :236-250: float * float, goal ignored */
+        int N = c->gw_N, G = c->gw_G;
+        int x = new_s / (N * G), y = (new_s / G) % N, ox = o / (N * G), oy = (o / G) % N;
+        float p = gw_obs_displ_prob(c, x, ox) * gw_obs_displ_prob(c, y, oy);
+        (void)a;
+        return p;
+    }
     return 0;
 }
 
 /* BADomainExtension::terminal / reward.
  * ref: TigerBAExtension.cpp:21-44, FactoredTigerBAExtension.cpp (reward uses the PRE-state s) */
+static int gw_on_goal(const orc_ctx* c, int32_t s)
+{
+    int N = c->gw_N, G = c->gw_G, g = s % G;
+    return c->gw_goal[g][0] == s / (N * G) && c->gw_goal[g][1] == (s / G) % N;
+}
 static int ext_terminal(orc_ctx* c, int32_t s, int32_t a, int32_t ns)
 {
-    (void)s; (void)ns;
+    (void)ns;
+    if (is_grid(c->cfg.domain)) return gw_on_goal(c, s); /* GridWorldBAExtension.cpp:74-83: the PRE-state */
     return is_episodic(c->cfg.domain) && a != 2;
 }
 static double ext_reward(orc_ctx* c, int32_t s, int32_t a, int32_t ns)
 {
     int d = c->cfg.domain;
     (void)ns;
+    if (is_grid(d)) return gw_on_goal(c, s) ? 1 : 0; /* GridWorldBAExtension.cpp:85-99 */
     if (a == 2) return -1;
     if (is_tiger(d)) return (a == s) ? 10 : -100;
     return (a == ((s < c->S / 2) ? 0 : 1)) ? 10 : -100;
@@ -450,14 +560,10 @@ static void ftiger_set_observation_model(orc_ctx* c, float* cnt, uint32_t mask)
 
 /* FactoredTigerFactoredPrior ctor (FactoredTigerPriors.cpp:95-195): everything but the listen
  * observation node, which is per particle */
-static int build_factored_prior(orc_ctx* c)
+static int build_ftiger_factored_prior(orc_ctx* c)
 {
     fdesc* d = &c->fd;
     int A = c->A, a, f, off = 0;
-    if (!is_ftiger(c->cfg.domain)) {
-        snprintf(c->err, sizeof c->err, "domain %d has no factored prior in the oracle", c->cfg.domain);
-        return -1;
-    }
     if (c->cfg.noise <= -.15 || c->cfg.noise > .3) {
         snprintf(c->err, sizeof c->err, "noise must be between -.15 and .3");
         return -1;
@@ -503,12 +609,127 @@ static int build_factored_prior(orc_ctx* c)
     return 0;
 }
 
+/* GridWorldFactBAPrior::setNoisyTransitionNode (GridWorldBAPriors.cpp:255-295) when `with_goal`,
+ * else the x / y part of preComputePrior (:316-413): the agent-x (feature 0) or agent-y (feature 1)
+ * transition node of action a, written into its region of `cnt` */
+static void gw_fill_xy_node(orc_ctx* c, float* cnt, int a, int feature, int with_goal)
+{
+    const fnode* nd = &c->fd.T[a * c->fd.FS + feature];
+    int N = c->gw_N, G = c->gw_G, x, y, g;
+    float total = c->cfg.counts_total;
+    memset(cnt + nd->off, 0, sizeof(float) * (size_t)N * N * G * N);
+    for (x = 0; x < N; ++x)
+        for (y = 0; y < N; ++y) {
+            int nx = x, ny = y, loc, new_loc;
+            float trans_prob = gw_slow_at(c, x, y) ? (float)(.15 + c->cfg.noise) : (float).95;
+            gw_move(c, a, &nx, &ny);
+            loc     = feature == 0 ? x : y;
+            new_loc = feature == 0 ? nx : ny;
+            if (with_goal) {
+                for (g = 0; g < G; ++g) {
+                    float* row = cnt + nd->off + ((x * N + y) * G + g) * N;
+                    row[loc] += (1 - trans_prob) * total;
+                    row[new_loc] += (trans_prob)*total;
+                }
+            } else {
+                float* row = cnt + nd->off + (x * N + y) * N;
+                row[loc] += (1 - trans_prob) * total;
+                row[new_loc] += (trans_prob)*total;
+            }
+        }
+}
+
+/* GridWorldFactBAPrior ctor + preComputePrior (GridWorldBAPriors.cpp:158-198, 316-413): the
+ * correct-structure prior.  Features {x, y, goal}; T parents x:{x,y} y:{x,y} goal:{x,y,goal};
+ * O parents x_obs:{x} y_obs:{y} goal_obs:{goal}.  Under match-uniform each particle may add the
+ * goal as a parent of the x / y nodes per action (8 per-particle mask words). */
+static int build_gridworld_factored_prior(orc_ctx* c)
+{
+    fdesc* d = &c->fd;
+    int A = c->A, N = c->gw_N, G = c->gw_G, a, f, off = 0, v, x, y, g, ng, nvar = 0;
+    float static_total = 100000;
+    if (c->cfg.noise < 0 || c->cfg.noise > (1 - .15)) {
+        snprintf(c->err, sizeof c->err, "Gridworld expects noise in between 0 and %f (received %f)", 1 - .15, c->cfg.noise);
+        return -1;
+    }
+    if (c->cfg.structure_prior != ORC_SP_NONE && c->cfg.structure_prior != ORC_SP_MATCH_UNIFORM) {
+        snprintf(c->err, sizeof c->err, "Please enter a valid structure noise option for the GridWorld problem ('match-uniform' or 'match-counts')");
+        return -1;
+    }
+    d->FS = 3; d->FO = 3;
+    d->Ssz[0] = d->Ssz[1] = d->Osz[0] = d->Osz[1] = N;
+    d->Ssz[2] = d->Osz[2] = G;
+    fdesc_steps(d->Ssz, 3, d->Sstep);
+    fdesc_steps(d->Osz, 3, d->Ostep);
+    d->T = (fnode*)calloc((size_t)A * 3, sizeof(fnode));
+    d->O = (fnode*)calloc((size_t)A * 3, sizeof(fnode));
+    for (a = 0; a < A; ++a)
+        for (f = 0; f < 3; ++f) {
+            fnode* nd = &d->T[a * 3 + f];
+            nd->off = off; nd->nmax = 3; nd->maxp[0] = 0; nd->maxp[1] = 1; nd->maxp[2] = 2;
+            if (f < 2) { nd->out = N; nd->var = nvar++; nd->fixed_mask = 3; off += N * N * G * N; }
+            else { nd->out = G; nd->var = -1; nd->fixed_mask = 7; off += N * N * G * G; }
+        }
+    for (a = 0; a < A; ++a)
+        for (f = 0; f < 3; ++f) {
+            fnode* nd = &d->O[a * 3 + f];
+            nd->off = off; nd->nmax = 1; nd->maxp[0] = f; nd->var = -1; nd->fixed_mask = 1;
+            nd->out = d->Osz[f];
+            off += d->Ssz[f] * d->Osz[f];
+        }
+    d->ncounts = off;
+    d->nvar    = nvar;
+    c->ncnt    = off + nvar;
+    c->prior   = (float*)calloc((size_t)c->ncnt, sizeof(float));
+    for (a = 0; a < A; ++a) {
+        /* O (known): x / y observation = displacement model, goal observed exactly */
+        for (f = 0; f < 2; ++f)
+            for (v = 0; v < N; ++v)
+                for (x = 0; x < N; ++x) c->prior[d->O[a * 3 + f].off + v * N + x] = gw_obs_displ_prob(c, v, x) * static_total;
+        for (v = 0; v < G; ++v) c->prior[d->O[a * 3 + 2].off + v * G + v] = static_total;
+        /* T */
+        gw_fill_xy_node(c, c->prior, a, 0, 0);
+        gw_fill_xy_node(c, c->prior, a, 1, 0);
+        for (x = 0; x < N; ++x)
+            for (y = 0; y < N; ++y)
+                for (g = 0; g < G; ++g) {
+                    float* row = c->prior + d->T[a * 3 + 2].off + ((x * N + y) * G + g) * G;
+                    if (c->gw_goal[g][0] != x || c->gw_goal[g][1] != y) row[g] = static_total;
+                    else for (ng = 0; ng < G; ++ng) row[ng] = static_total;
+                }
+        c->prior[d->ncounts + d->T[a * 3 + 0].var] = u2f(3u);
+        c->prior[d->ncounts + d->T[a * 3 + 1].var] = u2f(3u);
+    }
+    return 0;
+}
+
+static int build_factored_prior(orc_ctx* c)
+{
+    if (is_ftiger(c->cfg.domain)) return build_ftiger_factored_prior(c);
+    if (is_grid(c->cfg.domain)) return build_gridworld_factored_prior(c);
+    snprintf(c->err, sizeof c->err, "domain %d has no factored prior in the oracle", c->cfg.domain);
+    return -1;
+}
+
 /* FBAPOMDPPrior::sample -> FactoredTigerFactoredPrior::sampleFBAPOMDPState / sampleFullyConnectedState
  * (FBAPOMDPPrior.cpp:27-37, FactoredTigerPriors.cpp:197-219, 265-291): draws the listen node's
  * parent set (one boolean per state feature, feature 0 forced under match-uniform) */
 static void factored_prior_sample(orc_ctx* c, float* cnt)
 {
     memcpy(cnt, c->prior, sizeof(float) * (size_t)c->ncnt);
+    if (is_grid(c->cfg.domain)) {
+        /* GridWorldFactBAPrior::sampleFBAPOMDPState (GridWorldBAPriors.cpp:415-441): per action,
+         * one boolean for the x node and one for the y node: add the goal feature as a parent */
+        int a, f;
+        if (c->cfg.structure_prior != ORC_SP_MATCH_UNIFORM) return;
+        for (a = 0; a < c->A; ++a)
+            for (f = 0; f < 2; ++f)
+                if (orc_bool(&c->rng)) {
+                    gw_fill_xy_node(c, cnt, a, f, 1);
+                    cnt[c->fd.ncounts + c->fd.T[a * 3 + f].var] = u2f(7u);
+                }
+        return;
+    }
     if (c->cfg.structure_prior == ORC_SP_FULLY_CONNECTED) {
         ftiger_set_observation_model(c, cnt, (1u << c->fd.FS) - 1u);
     } else if (c->cfg.structure_prior == ORC_SP_UNIFORM || c->cfg.structure_prior == ORC_SP_MATCH_UNIFORM) {
@@ -1153,6 +1374,14 @@ orc_ctx* orc_create(const orc_config* cfg)
                 return c;
             }
             c->tiger_K = cfg->size; c->S = 2 << cfg->size; c->A = 3; c->O = 2;
+            break;
+        case ORC_DOM_GRIDWORLD:
+            if (cfg->size < 3 || cfg->size > 15) {
+                snprintf(c->err, sizeof c->err, "please enter a size larger than 3 to be able to run gridworld (you entered %d)", cfg->size);
+                return c;
+            }
+            gw_setup(c, cfg->size);
+            c->S = c->O = cfg->size * cfg->size * c->gw_G; c->A = 4;
             break;
         default:
             snprintf(c->err, sizeof c->err, "domain %d not supported by the oracle", cfg->domain);

@@ -146,6 +146,23 @@ static void obs_table(POMDP const& d, int S, int A, int O)
     arr(p, pd);
 }
 
+/* GridWorld needs its own state / observation objects (it static_casts them) */
+static void gridworld_obs_table(int size)
+{
+    domains::GridWorld d(size);
+    auto goals = domains::GridWorld::goalLocations(size);
+    std::vector<double> p;
+    IndexAction a(0);
+    for (unsigned x = 0; x < (unsigned)size; ++x)
+        for (unsigned y = 0; y < (unsigned)size; ++y)
+            for (auto const& g : goals)
+                for (unsigned ox = 0; ox < (unsigned)size; ++ox)
+                    for (unsigned oy = 0; oy < (unsigned)size; ++oy)
+                        for (auto const& og : goals)
+                            p.push_back(d.computeObservationProbability(d.getObservation({ox, oy}, og), &a, d.getState({x, y}, g)));
+    arr(p, pd);
+}
+
 static std::vector<int> indices(FlatFilter<State const*> const& f)
 {
     std::vector<int> v;
@@ -206,6 +223,45 @@ static void is_tiger(char const* s, int n)
         printf(", \"resampled\": ");
         arr(idx, pi);
         printf("}");
+    }
+    printf("], \"next_u01\": %.17g}", rnd::uniform_rand01());
+}
+
+
+/* importance_sampling::update / resample with the real GridWorld as simulator and as environment:
+ * pins GridWorld::step + computeObservationProbability inside the filter */
+static void is_gridworld(char const* s, int size, int n, int steps)
+{
+    domains::GridWorld d(size);
+    seed(s);
+    WeightedFilter<State const*> f;
+    for (int i = 0; i < n; ++i) f.add(d.sampleStartState(), 1.0 / (double)n);
+    State const* st = d.sampleStartState();
+    printf("{\"seed\": \"%s\", \"size\": %d, \"n\": %d, \"start\": %d, \"steps\": [", s, size, n, st->index());
+    for (int k = 0; k < steps; ++k) {
+        Observation const* o = nullptr;
+        Reward r(0);
+        auto a = d.generateRandomAction(st);
+        d.step(&st, a, &o, &r);
+        double tot = beliefs::importance_sampling::update(f, a, o, d);
+        std::vector<int> idx;
+        std::vector<double> w;
+        for (size_t i = 0; i < f.size(); ++i) {
+            idx.push_back(f.particle(i)->particle->index());
+            w.push_back(f.particle(i)->w);
+        }
+        if (k) printf(",");
+        printf("{\"a\": %d, \"s\": %d, \"o\": %d, \"total\": %.17g, \"idx\": ", a->index(), st->index(), o->index(), tot);
+        arr(idx, pi);
+        printf(", \"w\": ");
+        arr(w, pd);
+        beliefs::importance_sampling::resample(f, d, (size_t)n);
+        idx.clear();
+        for (size_t i = 0; i < f.size(); ++i) idx.push_back(f.particle(i)->particle->index());
+        printf(", \"resampled\": ");
+        arr(idx, pi);
+        printf("}");
+        d.releaseAction(a);
     }
     printf("], \"next_u01\": %.17g}", rnd::uniform_rand01());
 }
@@ -449,6 +505,17 @@ int main(int argc, char** argv)
     { domains::Tiger d(domains::Tiger::EPISODIC); obs_table(d, 2, 3, 2); }
     key("ftiger2_obs_prob");
     { domains::FactoredTiger d(domains::FactoredTiger::EPISODIC, 2); obs_table(d, 8, 3, 2); }
+
+    key("gridworld3_obs_prob");
+    gridworld_obs_table(3);
+    key("gridworld4_obs_prob");
+    gridworld_obs_table(4);
+    key("is_gridworld");
+    printf("[");
+    is_gridworld("22", 5, 40, 8);
+    printf(",");
+    is_gridworld("23", 3, 64, 6);
+    printf("]");
 
     key("reject_tiger");
     printf("[");
