@@ -142,6 +142,14 @@ struct FDesc {
     FNode nodes[MAXNODES];  // T(a, f) at a*FS + f, O(a, f) at A*FS + a*FO + f
 };
 
+// GridWorld geometry (reference src/domains/gridworld/GridWorld.cpp: goalLocations :124-152,
+// generateSlowLocations :78-103, _obs_displacement_probs ctor :60-70), built on the host
+struct GridDesc {
+    int32_t N, G, nslow;
+    int32_t goal[16][2], slow[8][2];
+    float disp[32];
+};
+
 // the "+1"s of one UpdateCounts step, as indices into the particle's count blob
 struct Inc {
     int n;
@@ -150,6 +158,7 @@ struct Inc {
 
 struct Problem {
     const FDesc* fd;  // device pointer; null unless model = BA_FACTORED
+    const GridDesc* gw;  // device pointer; null unless domain = gridworld
     float noise, counts_total;
     int32_t structure_prior;
     int32_t domain, model, belief, planner;
@@ -167,22 +176,80 @@ struct Problem {
 __device__ __forceinline__ bool dom_is_tiger(int d) { return d == FBA_DOM_TIGER_EPISODIC || d == FBA_DOM_TIGER_CONTINUOUS; }
 __device__ __forceinline__ bool dom_is_ftiger(int d) { return d == FBA_DOM_FTIGER_EPISODIC || d == FBA_DOM_FTIGER_CONTINUOUS; }
 __device__ __forceinline__ bool dom_is_episodic(int d) { return d == FBA_DOM_TIGER_EPISODIC || d == FBA_DOM_FTIGER_EPISODIC; }
+__device__ __forceinline__ bool dom_is_grid(int d) { return d == FBA_DOM_GRIDWORLD; }
+
+// ---- gridworld helpers: state index = x*N*G + y*G + g (GridWorld.cpp:329-340) ----
+__device__ __forceinline__ bool gw_slow_at(const GridDesc* gw, int x, int y)
+{
+    bool slow = false;
+    for (int i = 0; i < gw->nslow; ++i) slow |= (gw->slow[i][0] == x && gw->slow[i][1] == y);
+    return slow;
+}
+__device__ __forceinline__ void gw_move(const GridDesc* gw, int a, int& x, int& y)  // applyMove :342-364
+{
+    const int N = gw->N;
+    if (a == 0) { if (y != N - 1) ++y; }
+    else if (a == 2) { if (y != 0) --y; }
+    else if (a == 1) { if (x != N - 1) ++x; }
+    else { if (x != 0) --x; }
+}
+__device__ __forceinline__ bool gw_on_goal(const GridDesc* gw, int s)
+{
+    const int N = gw->N, G = gw->G, g = s % G;
+    return gw->goal[g][0] == s / (N * G) && gw->goal[g][1] == (s / G) % N;
+}
+// obsDisplProb :164-185 (float result, double intermediate products)
+__device__ __forceinline__ float gw_obs_displ_prob(const GridDesc* gw, int loc, int observed)
+{
+    const int disp = abs(loc - observed);
+    float res = (disp == 0) ? (float)(1 - .2) : (float)((double)gw->disp[disp] * .5);
+    if (observed == gw->N - 1 || observed == 0)
+        for (int i = disp + 1; i < gw->N; ++i) res = (float)((double)res + (double)gw->disp[i] * .5);
+    return res;
+}
 
 // Tiger::sampleStartState (Tiger.cpp:16-19), FactoredTiger::sampleStartState
 __device__ __forceinline__ int domain_start(const Problem& P, Rng& g)
 {
     if (dom_is_tiger(P.domain)) return g.boolean() ? 0 : 1;
+    if (dom_is_grid(P.domain)) {  // GridWorld::sampleStartState :260-266 (start_locations = {{0,0}})
+        (void)g.slow_int(0, 1);
+        return g.slow_int(0, P.gw->G);
+    }
     return g.uniform_int(P.S);
 }
 
 // Tiger::generateRandomAction (Tiger.cpp:21-25), FactoredTiger::generateRandomAction
-__device__ __forceinline__ int domain_random_action(const Problem& P, Rng& g, int /*s*/) { return g.uniform_int(P.A); }
+__device__ __forceinline__ int domain_random_action(const Problem& P, Rng& g, int /*s*/)
+{
+    if (dom_is_grid(P.domain)) return g.slow_int(0, 4);  // GridWorld::generateRandomAction :220-226
+    return g.uniform_int(P.A);
+}
 
 // True dynamics: Tiger::step (Tiger.cpp:40-82), FactoredTiger::step (FactoredTiger.cpp:77-122).
 // Note the draw order when opening a door: observation coin first, then the next state.
 __device__ __forceinline__ bool domain_step(const Problem& P, Rng& g, int& s, int a, int& o, double& r)
 {
     const int d = P.domain;
+    if (dom_is_grid(d)) {  // GridWorld::step :272-304, generateObservation :366-394
+        const GridDesc* gw = P.gw;
+        const int N = gw->N, G = gw->G;
+        const int x = s / (N * G), y = (s / G) % N, gl = s % G;
+        const bool ok = g.u01() < (gw_slow_at(gw, x, y) ? .15 : .95);
+        int nx = x, ny = y, ng = gl;
+        if (ok) gw_move(gw, a, nx, ny);
+        const bool found = gw->goal[gl][0] == x && gw->goal[gl][1] == y;
+        if (found) ng = g.slow_int(0, G);
+        s = nx * N * G + ny * G + ng;
+        r = found ? 1 : 0;
+        const GlobalView dv{gw->disp};
+        const int dx = sample_from_mult_f(g, dv, 0, N, 1.0);
+        const int dy = sample_from_mult_f(g, dv, 0, N, 1.0);
+        const int ox = g.boolean() ? max(nx - dx, 0) : min(nx + dx, N - 1);
+        const int oy = g.boolean() ? max(ny - dy, 0) : min(ny + dy, N - 1);
+        o = ox * N * G + oy * G + ng;
+        return found;
+    }
     if (dom_is_tiger(d)) {
         if (a == 2) {
             const bool correct = g.u01() < .85;
@@ -211,6 +278,11 @@ __device__ __forceinline__ bool domain_step(const Problem& P, Rng& g, int& s, in
 // Tiger / FactoredTiger::computeObservationProbability (Tiger.cpp:27-38)
 __device__ __forceinline__ double domain_obs_prob(const Problem& P, int o, int a, int new_s)
 {
+    if (dom_is_grid(P.domain)) {  // GridWorld::computeObservationProbability :236-250 (goal part ignored)
+        const GridDesc* gw = P.gw;
+        const int N = gw->N, G = gw->G;
+        return (double)(gw_obs_displ_prob(gw, new_s / (N * G), o / (N * G)) * gw_obs_displ_prob(gw, (new_s / G) % N, (o / G) % N));
+    }
     if (a != 2) return .5;
     const int loc = dom_is_tiger(P.domain) ? new_s : ((new_s < P.S / 2) ? 0 : 1);
     return (loc == o) ? .85 : .15;
@@ -218,9 +290,14 @@ __device__ __forceinline__ double domain_obs_prob(const Problem& P, int o, int a
 
 // BADomainExtension::terminal / reward (TigerBAExtension.cpp:21-44, FactoredTigerBAExtension.cpp):
 // the reward is looked up with the PRE-state s.
-__device__ __forceinline__ bool ext_terminal(const Problem& P, int /*s*/, int a, int /*ns*/) { return dom_is_episodic(P.domain) && a != 2; }
+__device__ __forceinline__ bool ext_terminal(const Problem& P, int s, int a, int /*ns*/)
+{
+    if (dom_is_grid(P.domain)) return gw_on_goal(P.gw, s);  // GridWorldBAExtension.cpp:74-83
+    return dom_is_episodic(P.domain) && a != 2;
+}
 __device__ __forceinline__ double ext_reward(const Problem& P, int s, int a, int /*ns*/)
 {
+    if (dom_is_grid(P.domain)) return gw_on_goal(P.gw, s) ? 1 : 0;  // GridWorldBAExtension.cpp:85-99
     if (a == 2) return -1;
     const int loc = dom_is_tiger(P.domain) ? s : ((s < P.S / 2) ? 0 : 1);
     return (a == loc) ? 10 : -100;
@@ -388,8 +465,39 @@ __device__ __forceinline__ void ftiger_set_observation_model(const Problem& P, f
 // FBAPOMDPPrior::sample -> sampleFBAPOMDPState / sampleFullyConnectedState
 // (FBAPOMDPPrior.cpp:27-37, FactoredTigerPriors.cpp:197-219, 265-291).  `rec` already holds the
 // base prior record; the structure draws follow the domain start-state draw in the same stream.
+// GridWorldFactBAPrior::setNoisyTransitionNode (GridWorldBAPriors.cpp:255-295): the x (feature 0)
+// or y (feature 1) transition node of action a with the goal as third parent
+__device__ __forceinline__ void gw_fill_xy_node_with_goal(const Problem& P, float* rec, int a, int feature)
+{
+    const GridDesc* gw = P.gw;
+    const FNode& nd    = P.fd->nodes[a * 3 + feature];
+    const int N = gw->N, G = gw->G;
+    float* base = rec + nd.off;
+    for (int k = 0; k < N * N * G * N; ++k) base[k] = 0.f;
+    for (int x = 0; x < N; ++x)
+        for (int y = 0; y < N; ++y) {
+            int nx = x, ny = y;
+            const float trans_prob = gw_slow_at(gw, x, y) ? (float)(.15 + (double)P.noise) : (float).95;
+            gw_move(gw, a, nx, ny);
+            const int loc = feature == 0 ? x : y, new_loc = feature == 0 ? nx : ny;
+            for (int gl = 0; gl < G; ++gl) {
+                float* row = base + ((x * N + y) * G + gl) * N;
+                row[loc] += (1 - trans_prob) * P.counts_total;
+                row[new_loc] += (trans_prob)*P.counts_total;
+            }
+        }
+    rec[P.fd->ncounts + nd.var] = __uint_as_float(7u);
+}
+
 __device__ __forceinline__ void factored_prior_sample(const Problem& P, Rng& g, float* rec)
 {
+    if (dom_is_grid(P.domain)) {  // GridWorldFactBAPrior::sampleFBAPOMDPState :415-441
+        if (P.structure_prior != FBA_SP_MATCH_UNIFORM) return;
+        for (int a = 0; a < P.A; ++a)
+            for (int f = 0; f < 2; ++f)
+                if (g.boolean()) gw_fill_xy_node_with_goal(P, rec, a, f);
+        return;
+    }
     const int FS = P.fd->FS;
     if (P.structure_prior == FBA_SP_FULLY_CONNECTED) {
         ftiger_set_observation_model(P, rec, (1u << FS) - 1u);

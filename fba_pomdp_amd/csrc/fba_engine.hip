@@ -38,6 +38,8 @@ struct fba_ctx {
     float* d_prior       = nullptr;
     FDesc fdesc{};          // host copy of the factored model description
     FDesc* d_fdesc       = nullptr;
+    GridDesc gdesc{};
+    GridDesc* d_gdesc    = nullptr;
     double* d_uni_scan   = nullptr;
     double* d_log1p      = nullptr;
     int32_t* d_n_active  = nullptr;
@@ -89,6 +91,68 @@ int dev_alloc(fba_ctx* c, T** p, size_t n, bool zero = true)
 bool is_tiger(int d) { return d == FBA_DOM_TIGER_EPISODIC || d == FBA_DOM_TIGER_CONTINUOUS; }
 bool is_ftiger(int d) { return d == FBA_DOM_FTIGER_EPISODIC || d == FBA_DOM_FTIGER_CONTINUOUS; }
 
+// GridWorld geometry (reference src/domains/gridworld/GridWorld.cpp)
+void build_gridworld(GridDesc& g, int N)
+{
+    std::memset(&g, 0, sizeof g);
+    const int edge = N - 1;
+    g.N = N;
+    int G = 0;
+    // goalLocations :124-152
+    const int start = (N < 5) ? N - 2 : (N < 7) ? N - 3 : N - 4;
+    for (int i = start; i < N - 1; ++i) {
+        g.goal[G][0] = i; g.goal[G][1] = edge; ++G;
+        g.goal[G][0] = edge; g.goal[G][1] = i; ++G;
+    }
+    g.goal[G][0] = edge; g.goal[G][1] = edge; ++G;
+    if (N > 3) { g.goal[G][0] = edge - 1; g.goal[G][1] = edge - 1; ++G; }
+    if (N > 6) {
+        g.goal[G][0] = edge - 2; g.goal[G][1] = edge - 1; ++G;
+        g.goal[G][0] = edge - 1; g.goal[G][1] = edge - 2; ++G;
+    }
+    g.G = G;
+    // generateSlowLocations :78-103
+    int ns = 0;
+    if (N > 5) { g.slow[ns][0] = 1; g.slow[ns][1] = 1; ++ns; }
+    if (N == 3) { g.slow[ns][0] = 1; g.slow[ns][1] = 1; ++ns; }
+    else if (N < 7) {
+        g.slow[ns][0] = edge - 1; g.slow[ns][1] = edge - 2; ++ns;
+        g.slow[ns][0] = edge - 2; g.slow[ns][1] = edge - 1; ++ns;
+    } else {
+        g.slow[ns][0] = edge - 1; g.slow[ns][1] = edge - 3; ++ns;
+        g.slow[ns][0] = edge - 3; g.slow[ns][1] = edge - 1; ++ns;
+        g.slow[ns][0] = edge - 2; g.slow[ns][1] = edge - 2; ++ns;
+    }
+    g.nslow = ns;
+    // _obs_displacement_probs (ctor :60-70): {.8, .1, .05, ..., last one repeated}
+    g.disp[0] = (float)(1 - .2);
+    double prob = .2;
+    for (int i = 1; i < N - 1; ++i) { prob *= .5; g.disp[i] = (float)prob; }
+    g.disp[N - 1] = (float)prob;
+}
+bool gw_slow_at_h(const GridDesc& g, int x, int y)
+{
+    for (int i = 0; i < g.nslow; ++i)
+        if (g.slow[i][0] == x && g.slow[i][1] == y) return true;
+    return false;
+}
+void gw_move_h(const GridDesc& g, int a, int& x, int& y)
+{
+    const int N = g.N;
+    if (a == 0) { if (y != N - 1) ++y; }
+    else if (a == 2) { if (y != 0) --y; }
+    else if (a == 1) { if (x != N - 1) ++x; }
+    else { if (x != 0) --x; }
+}
+float gw_obs_displ_prob_h(const GridDesc& g, int loc, int observed)
+{
+    const int disp = std::abs(loc - observed);
+    float res = (disp == 0) ? (float)(1 - .2) : (float)((double)g.disp[disp] * .5);
+    if (observed == g.N - 1 || observed == 0)
+        for (int i = disp + 1; i < g.N; ++i) res = (float)((double)res + (double)g.disp[i] * .5);
+    return res;
+}
+
 // Tabular prior count tables, built on the host once per ctx (cold path).
 // TigerBAPrior (reference src/domains/tiger/TigerPriors.cpp:14-43): every count 5000 except
 // listen: T off-diagonal 0, O = (.85 - noise) * C / (.15 + noise) * C.
@@ -139,7 +203,84 @@ void fdesc_steps(const int32_t* size, int n, int32_t* step)
 //   T open: no parents, {5000, 5000};  O open: no parents, {5000, 5000};
 //   O listen: parents are per particle (structure prior), filled on the device by
 //   ftiger_set_observation_model; the base record carries the correct structure {tiger location}.
+// GridWorldFactBAPrior ctor + preComputePrior (reference
+// src/domains/gridworld/GridWorldBAPriors.cpp:158-198, 316-413): correct-structure prior.
+// Features {x, y, goal}; T parents x:{x,y}, y:{x,y}, goal:{x,y,goal}; O parents x_obs:{x},
+// y_obs:{y}, goal_obs:{goal}.  The x / y transition nodes own room for the goal as a third parent
+// (structure prior match-uniform, filled per particle on the device).
+int build_gridworld_factored_prior(fba_ctx* c)
+{
+    Problem& P = c->P;
+    const GridDesc& g = c->gdesc;
+    const int N = g.N, G = g.G, A = P.A;
+    const float noise = c->cfg.noise, total = c->cfg.counts_total, static_total = 100000;
+    if (noise < 0 || noise > (1 - .15)) return fail(c, FBA_EINVAL, "Gridworld expects noise in between 0 and %f (received %f)", 1 - .15, noise);
+    if (c->cfg.structure_prior != FBA_SP_NONE && c->cfg.structure_prior != FBA_SP_MATCH_UNIFORM)
+        return fail(c, FBA_EINVAL, "Please enter a valid structure noise option for the GridWorld problem ('match-uniform' or 'match-counts')");
+    FDesc& d = c->fdesc;
+    std::memset(&d, 0, sizeof d);
+    d.FS = d.FO = 3;
+    d.Ssz[0] = d.Ssz[1] = d.Osz[0] = d.Osz[1] = N;
+    d.Ssz[2] = d.Osz[2] = G;
+    fdesc_steps(d.Ssz, 3, d.Sstep);
+    fdesc_steps(d.Osz, 3, d.Ostep);
+    int off = 0, nvar = 0;
+    for (int a = 0; a < A; ++a)
+        for (int f = 0; f < 3; ++f) {
+            FNode& nd = d.nodes[a * 3 + f];
+            nd.off = off; nd.nmax = 3; nd.maxp[0] = 0; nd.maxp[1] = 1; nd.maxp[2] = 2;
+            if (f < 2) { nd.out = N; nd.var = nvar++; nd.fixed_mask = 3; off += N * N * G * N; }
+            else { nd.out = G; nd.var = -1; nd.fixed_mask = 7; off += N * N * G * G; }
+        }
+    for (int a = 0; a < A; ++a)
+        for (int f = 0; f < 3; ++f) {
+            FNode& nd = d.nodes[A * 3 + a * 3 + f];
+            nd.off = off; nd.nmax = 1; nd.maxp[0] = (uint8_t)f; nd.var = -1; nd.fixed_mask = 1;
+            nd.out = d.Osz[f];
+            off += d.Ssz[f] * d.Osz[f];
+        }
+    d.ncounts = off;
+    d.nvar    = nvar;
+    c->prior.assign((size_t)off + nvar, 0.f);
+    float* pr = c->prior.data();
+    for (int a = 0; a < A; ++a) {
+        for (int f = 0; f < 2; ++f)
+            for (int v = 0; v < N; ++v)
+                for (int x = 0; x < N; ++x) pr[d.nodes[A * 3 + a * 3 + f].off + v * N + x] = gw_obs_displ_prob_h(g, v, x) * static_total;
+        for (int v = 0; v < G; ++v) pr[d.nodes[A * 3 + a * 3 + 2].off + v * G + v] = static_total;
+        for (int x = 0; x < N; ++x)
+            for (int y = 0; y < N; ++y) {
+                int nx = x, ny = y;
+                const float trans_prob = gw_slow_at_h(g, x, y) ? (float)(.15 + (double)noise) : (float).95;
+                gw_move_h(g, a, nx, ny);
+                float* rx = pr + d.nodes[a * 3 + 0].off + (x * N + y) * N;
+                float* ry = pr + d.nodes[a * 3 + 1].off + (x * N + y) * N;
+                rx[x] += (1 - trans_prob) * total;
+                ry[y] += (1 - trans_prob) * total;
+                rx[nx] += (trans_prob)*total;
+                ry[ny] += (trans_prob)*total;
+                for (int gl = 0; gl < G; ++gl) {
+                    float* row = pr + d.nodes[a * 3 + 2].off + ((x * N + y) * G + gl) * G;
+                    if (g.goal[gl][0] != x || g.goal[gl][1] != y) row[gl] = static_total;
+                    else for (int ng = 0; ng < G; ++ng) row[ng] = static_total;
+                }
+            }
+        const uint32_t m3 = 3u;
+        std::memcpy(&pr[off + d.nodes[a * 3 + 0].var], &m3, 4);
+        std::memcpy(&pr[off + d.nodes[a * 3 + 1].var], &m3, 4);
+    }
+    return FBA_OK;
+}
+
+int build_ftiger_factored_prior(fba_ctx* c);
+
 int build_factored_prior(fba_ctx* c)
+{
+    if (c->P.domain == FBA_DOM_GRIDWORLD) return build_gridworld_factored_prior(c);
+    return build_ftiger_factored_prior(c);
+}
+
+int build_ftiger_factored_prior(fba_ctx* c)
 {
     Problem& P = c->P;
     if (!is_ftiger(P.domain)) return fail(c, FBA_EINVAL, "domain %d has no built-in factored prior", P.domain);
@@ -433,6 +574,15 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
             }
             P.S = 2 << cfg->size; P.A = 3; P.O = 2;
             break;
+        case FBA_DOM_GRIDWORLD:
+            if (cfg->size < 3 || cfg->size > 15) {
+                fail(nullptr, FBA_EINVAL, "please enter a size larger than 3 to be able to run gridworld (you entered %d)", cfg->size);
+                delete c;
+                return FBA_EINVAL;
+            }
+            build_gridworld(c->gdesc, cfg->size);
+            P.S = P.O = cfg->size * cfg->size * c->gdesc.G; P.A = 4;
+            break;
         default:
             fail(nullptr, FBA_EINVAL, "domain %d is not supported by this build", cfg->domain);
             delete c;
@@ -451,6 +601,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     P.counts_total = cfg->counts_total;
     P.structure_prior = cfg->structure_prior;
     P.fd = nullptr;
+    P.gw = nullptr;
     if (cfg->model == FBA_MODEL_BA_TABLE) {
         P.phi_len = P.S * P.A * P.S;
         P.C       = P.phi_len + P.A * P.S * P.O;
@@ -479,8 +630,13 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         else cs = (need + 3) & ~3;
         P.Cs = cs;
     }
-    if (P.A > FBA_MAX_ACTIONS || P.A * P.O > 4096) {
-        fail(nullptr, FBA_EINVAL, "action/observation space too large for the dense child table");
+    if (P.A > FBA_MAX_ACTIONS) {
+        fail(nullptr, FBA_EINVAL, "more than %d actions", FBA_MAX_ACTIONS);
+        delete c;
+        return FBA_EINVAL;
+    }
+    if (cfg->model == FBA_MODEL_BA_TABLE && cfg->domain == FBA_DOM_GRIDWORLD) {
+        fail(nullptr, FBA_EINVAL, "the tabular gridworld prior (S*A*S counts per particle) is not built; use the factored model");
         delete c;
         return FBA_EINVAL;
     }
@@ -514,13 +670,20 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
 
     // node record layout (fba_state.h)
     DeviceState& D = c->D;
+    const bool hashed = P.A * P.O > 64;
     D.cq_off     = (1 + P.A + 1) & ~1;
     D.child_off  = D.cq_off + 2 * P.A;
-    D.node_words = (D.child_off + P.A * P.O + 1) & ~1;
+    D.node_words = hashed ? D.child_off : ((D.child_off + P.A * P.O + 1) & ~1);
     D.max_nodes  = P.sims + 2;
+    uint32_t hcap = 0;
+    if (hashed) {
+        hcap = 64;
+        while (hcap < 2u * (uint32_t)D.max_nodes) hcap <<= 1;
+        D.hmask = hcap - 1;
+    }
 
     // slots
-    const size_t per_slot = (size_t)P.N * (2 * 8 + 8 + 2 * (size_t)P.Cs * 4) + (size_t)D.max_nodes * D.node_words * 4 + 1024;
+    const size_t per_slot = (size_t)P.N * (2 * 8 + 8 + 2 * (size_t)P.Cs * 4) + (size_t)D.max_nodes * D.node_words * 4 + (size_t)hcap * 16 + 1024;
     int E = cfg->slots;
     if (E <= 0) {
         size_t free_b = 0, total_b = 0;
@@ -551,6 +714,10 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     CHK(dev_alloc(c, &D.wscan, is ? (size_t)E * P.N : 1, false));
     CHK(dev_alloc(c, &D.src_idx, 1));
     CHK(dev_alloc(c, &D.nodes, (size_t)E * D.max_nodes * D.node_words, false));
+    if (hashed) {
+        CHK(dev_alloc(c, &D.hash, (size_t)E * hcap));
+        CHK(dev_alloc(c, &D.epoch, E));
+    }
     CHK(dev_alloc(c, &D.sim_steps, E));
     CHK(dev_alloc(c, &D.belief_steps, E));
     CHK(dev_alloc(c, &D.env_steps, E));
@@ -587,6 +754,11 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         HIPC(hipStreamSynchronize(c->stream));
     }
     if (cfg->model == FBA_MODEL_BA_TABLE) CHK(build_tabular_prior(c));
+    if (cfg->domain == FBA_DOM_GRIDWORLD) {
+        CHK(dev_alloc(c, &c->d_gdesc, 1));
+        HIPC(hipMemcpyAsync(c->d_gdesc, &c->gdesc, sizeof(GridDesc), hipMemcpyHostToDevice, c->stream));
+        P.gw = c->d_gdesc;
+    }
     if (cfg->model == FBA_MODEL_BA_FACTORED) {
         CHK(dev_alloc(c, &c->d_fdesc, 1));
         HIPC(hipMemcpyAsync(c->d_fdesc, &c->fdesc, sizeof(FDesc), hipMemcpyHostToDevice, c->stream));

@@ -61,7 +61,44 @@ __device__ __forceinline__ void node_init(const DeviceState& D, int32_t* rec, in
     for (int a = 0; a < A; ++a) rec[1 + a] = 0;
     double* q = reinterpret_cast<double*>(rec + D.cq_off);
     for (int a = 0; a < A; ++a) q[a] = 0.0;
-    for (int k = 0; k < A * O; ++k) rec[D.child_off + k] = -1;
+    if (!D.hash)
+        for (int k = 0; k < A * O; ++k) rec[D.child_off + k] = -1;
+}
+
+// ChanceNode::child / hasChild / addChild (MCTSTreeNodes.cpp:35-50): dense table in the node record,
+// or the epoch-tagged hash table (fba_state.h)
+__device__ __forceinline__ uint32_t child_hash(uint64_t code)
+{
+    code ^= code >> 33; code *= 0xff51afd7ed558ccdull; code ^= code >> 29;
+    return (uint32_t)code;
+}
+__device__ __forceinline__ int child_get(const Problem& P, const DeviceState& D, const int32_t* tree, int4* tab, uint32_t epoch,
+                                         int node, int a, int o)
+{
+    if (!D.hash) return tree[(size_t)node * D.node_words + D.child_off + a * P.O + o];
+    const uint64_t code = ((uint64_t)node * P.A + a) * P.O + o;
+    const uint32_t lo = (uint32_t)code, hi = (uint32_t)(code >> 32) | (epoch << 4);
+    for (uint32_t h = child_hash(code) & D.hmask;; h = (h + 1) & D.hmask) {
+        const int4 e = tab[h];
+        if (((uint32_t)e.y >> 4) != epoch) return -1;  // empty or left over from an earlier search
+        if ((uint32_t)e.x == lo && (uint32_t)e.y == hi) return e.z;
+    }
+}
+__device__ __forceinline__ void child_set(const Problem& P, const DeviceState& D, int32_t* tree, int4* tab, uint32_t epoch, int node,
+                                          int a, int o, int child)
+{
+    if (!D.hash) {
+        tree[(size_t)node * D.node_words + D.child_off + a * P.O + o] = child;
+        return;
+    }
+    const uint64_t code = ((uint64_t)node * P.A + a) * P.O + o;
+    const uint32_t lo = (uint32_t)code, hi = (uint32_t)(code >> 32) | (epoch << 4);
+    for (uint32_t h = child_hash(code) & D.hmask;; h = (h + 1) & D.hmask) {
+        if (((uint32_t)tab[h].y >> 4) != epoch) {
+            tab[h] = make_int4((int)lo, (int)hi, child, 0);
+            return;
+        }
+    }
 }
 
 // POUCT::selectChanceNodeUCB (POUCT.cpp:138-181 = RBAPOUCT.cpp:162-205).
@@ -134,6 +171,13 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
     node_init(D, tree, P.A, P.O);
     int n_nodes = 1, tree_depth = 0;
     unsigned long long steps = 0;
+    int4* tab      = D.hash ? D.hash + (size_t)e * (D.hmask + 1) : nullptr;
+    uint32_t epoch = 0;
+    if (D.hash) {
+        epoch      = (D.epoch[e] + 1) & 0x0fffffffu;
+        if (epoch == 0) epoch = 1;
+        D.epoch[e] = epoch;
+    }
 
     int sim = 0, mode = 0;  // 0 = start a simulation, 1 = in the tree, 2 = rollout
     int s = 0, node = 0, dtg = 0, plen = 0, rdepth = 0;
@@ -185,13 +229,12 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
                 ++plen;
                 if (term) finish = true;
                 else {
-                    int32_t* ch = tree + (size_t)node * W + D.child_off + a * P.O + o;
-                    const int c = *ch;
+                    const int c = child_get(P, D, tree, tab, epoch, node, a, o);
                     if (c >= 0) { node = c; --dtg; }
                     else {  // expand: new leaf, then rollout(depth_to_go - 1)
                         const int nn = n_nodes++;
                         node_init(D, tree + (size_t)nn * W, P.A, P.O);
-                        *ch = nn;
+                        child_set(P, D, tree, tab, epoch, node, a, o, nn);
                         mode = 2; rdepth = dtg - 1; rret = 0; rdisc = 1;
                         if (rdepth == 0) finish = true;
                     }

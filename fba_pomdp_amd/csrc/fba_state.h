@@ -57,6 +57,12 @@ struct DeviceState {
     // --- tree ---
     int32_t* nodes;     // [E][max_nodes][node_words]
     int32_t max_nodes, node_words, cq_off, child_off;
+    // large observation spaces (A*O > 64): children live in a per-slot open-addressing table
+    // of {code_lo, code_hi | epoch << 4, child, -} entries tagged with the slot's search epoch, so
+    // the table is never cleared: an entry of an older search reads as empty
+    int4* hash;         // [E][hmask + 1] or null (dense child table inside the node record)
+    uint32_t hmask;
+    uint32_t* epoch;    // [E]
     const double* log1p_tab; // [sims + 1]
     // --- outputs ---
     double* returns;    // [runs][episodes]

@@ -13,7 +13,7 @@ from oracle import pyorc as orc
 
 pytestmark = pytest.mark.gpu
 
-DOM = {"episodic-tiger": orc.DOM_TIGER_EPISODIC, "continuous-tiger": orc.DOM_TIGER_CONTINUOUS,
+DOM = {"gridworld": orc.DOM_GRIDWORLD, "episodic-tiger": orc.DOM_TIGER_EPISODIC, "continuous-tiger": orc.DOM_TIGER_CONTINUOUS,
        "episodic-factored-tiger": orc.DOM_FTIGER_EPISODIC, "continuous-factored-tiger": orc.DOM_FTIGER_CONTINUOUS}
 
 
@@ -128,6 +128,47 @@ def test_fbapomdp_prior_particles_equal_oracle():
     assert np.array_equal(cnt.view(np.uint32), ocnt.view(np.uint32))   # counts and structure masks
     masks = cnt.view(np.uint32)[:, -1]
     assert np.all(masks & 1 == 1) and len(set(masks.tolist())) > 1       # match-uniform: feature 0 forced, rest random
+
+
+@pytest.mark.parametrize("size", [3, 5])
+def test_planning_gridworld_importance(size):
+    """planning -D gridworld -B importance_sampling: true GridWorld dynamics as simulator, O = N*N*G
+    observations (hashed child table for N = 5), computeObservationProbability in the filter."""
+    eng, o = _pair("gridworld", N.MODEL_POMDP, "importance_sampling", 81, size=size, particles=120, sims=150,
+                   runs=8, horizon=12)
+    _assert_same_experiment(eng, o, ba=False)
+
+
+@pytest.mark.parametrize("size,sp", [(3, 0), (3, 2), (5, 2)])
+def test_fbapomdp_gridworld(size, sp):
+    """fbapomdp -D gridworld -B importance_sampling (BASELINE configs[3] at parity size): factored
+    prior, per-particle structure (goal as extra parent of the x / y nodes), BABNModel step."""
+    eng, o = _pair("gridworld", N.MODEL_BA_FACTORED, "importance_sampling", 83 + sp, size=size, particles=64,
+                   sims=100, runs=4, episodes=3, horizon=10, structure_prior=sp)
+    _assert_same_experiment(eng, o, ba=True)
+
+
+def test_fbapomdp_gridworld_prior_particles_equal_oracle():
+    kw = dict(size=4, particles=32, sims=8, structure_prior=2, belief=1)
+    eng = fba.Engine("gridworld", model=N.MODEL_BA_FACTORED, seed=91, slots=1, **kw)
+    o = orc.Oracle(domain=orc.DOM_GRIDWORLD, model=orc.MODEL_BA_FACTORED, rng_mode=orc.RNG_PHILOX,
+                   arith=orc.ARITH_DEV, philox_seed=91, **kw)
+    assert np.array_equal(eng.prior().view(np.uint32), o.L.orc_counts_len(o.h) and _oracle_base_prior(o).view(np.uint32))
+    orc.lib().orc_rng_episode(o.rng, 0, 0, 0)
+    o.belief_initiate()
+    eng.belief_init()
+    s, _, cnt = eng.belief_get(0)
+    os_, _, ocnt = o.belief_get()
+    assert np.array_equal(s, os_)
+    assert np.array_equal(cnt.view(np.uint32), ocnt.view(np.uint32))
+    masks = cnt.view(np.uint32)[:, -8:]
+    assert set(np.unique(masks).tolist()) == {3, 7}
+
+
+def _oracle_base_prior(o):
+    """the correct-structure prior record: what a particle holds under structure prior '' """
+    base = orc.Oracle(domain=o.cfg.domain, size=o.cfg.size, model=orc.MODEL_BA_FACTORED, structure_prior=0)
+    return base.prior_counts()
 
 
 def test_bapomdp_slots_fewer_than_runs():
