@@ -150,10 +150,16 @@ struct GridDesc {
     float disp[32];
 };
 
-// the "+1"s of one UpdateCounts step, as indices into the particle's count blob
-struct Inc {
-    int n;
-    int idx[MAXINC];
+// Where the "+1"s of one UpdateCounts step go.  A step reports them as (slot k, blob index) pairs;
+// slot k < ninc(model).  The search ignores them (KeepCounts); the belief kernels park them in one
+// LDS column per thread, [k][thread], so nothing is indexed at run time in registers.
+struct NoInc {
+    __device__ __forceinline__ void add(int, int) const {}
+};
+template <int STRIDE>
+struct LdsInc {
+    int32_t* col;  // &s_inc[thread]
+    __device__ __forceinline__ void add(int k, int idx) const { col[k * STRIDE] = idx; }
 };
 
 struct Problem {
@@ -342,22 +348,21 @@ __device__ __forceinline__ int node_row(const FDesc* fd, const FNode& nd, uint32
 // BAPOMDP::step over BABNModel (BABNModel.cpp:292-325) + the indices incrementCountsOf would
 // touch (:354-382).  Quirk kept: observation CPTs are incremented at the row of
 // the PREVIOUS state's parent values.
-template <class View>
-__device__ __forceinline__ bool fact_step(const Problem& P, Rng& g, const View& cnt, int& s, int a, int& o, double& r, Inc& inc)
+template <class View, class Sink>
+__device__ __forceinline__ bool fact_step(const Problem& P, Rng& g, const View& cnt, int& s, int a, int& o, double& r, const Sink& inc)
 {
     const FDesc* fd   = P.fd;
     const int FS = fd->FS, FO = fd->FO;
     const uint64_t fv = pack_features(s, fd->Sstep, FS);
     uint64_t nf = 0;
     int ns = 0;
-    inc.n = FS + FO;
 #pragma unroll
     for (int f = 0; f < MAXF; ++f)
         if (f < FS) {
             const FNode& nd = fd->nodes[a * FS + f];
             const int row   = node_row(fd, nd, node_mask(fd, nd, cnt), fv);
             const int v     = sample_expected_mult(g, cnt, row, nd.out);
-            inc.idx[f]      = row + v;
+            inc.add(f, row + v);
             nf |= (uint64_t)v << (8 * f);
             ns = ns * fd->Ssz[f] + v;  // indexing::project
         }
@@ -369,10 +374,7 @@ __device__ __forceinline__ bool fact_step(const Problem& P, Rng& g, const View& 
             const uint32_t mask = node_mask(fd, nd, cnt);
             const int v         = sample_expected_mult(g, cnt, node_row(fd, nd, mask, nf), nd.out);
             ob = ob * fd->Osz[f] + v;
-            // MAXINC = FS + FO slots: observation feature f uses slot FS + f
-#pragma unroll
-            for (int k = 0; k < MAXINC; ++k)
-                if (k == FS + f) inc.idx[k] = node_row(fd, nd, mask, fv) + v;
+            inc.add(FS + f, node_row(fd, nd, mask, fv) + v);
         }
     o            = ob;
     const bool t = ext_terminal(P, s, a, ns);
@@ -402,13 +404,15 @@ __device__ __forceinline__ double fact_obs_prob(const Problem& P, const View& cn
 }
 
 // ---- simulator.step for the three simulators --------------------------------------------------
-template <class View>
-__device__ __forceinline__ bool sim_step(const Problem& P, Rng& g, const View& cnt, int& s, int a, int& o, double& r, Inc& inc)
+__device__ __forceinline__ int model_ninc(const Problem& P)
 {
-    if (P.model == FBA_MODEL_POMDP) {
-        inc.n = 0;
-        return domain_step(P, g, s, a, o, r);
-    }
+    return P.model == FBA_MODEL_POMDP ? 0 : (P.model == FBA_MODEL_BA_TABLE ? 2 : P.fd->FS + P.fd->FO);
+}
+
+template <class View, class Sink>
+__device__ __forceinline__ bool sim_step(const Problem& P, Rng& g, const View& cnt, int& s, int a, int& o, double& r, const Sink& inc)
+{
+    if (P.model == FBA_MODEL_POMDP) return domain_step(P, g, s, a, o, r);
     if (P.model == FBA_MODEL_BA_FACTORED) return fact_step(P, g, cnt, s, a, o, r, inc);
     const int S = P.S, A = P.A, O = P.O;
     const int t_off = s * A * S + a * S;
@@ -417,9 +421,8 @@ __device__ __forceinline__ bool sim_step(const Problem& P, Rng& g, const View& c
     o               = sample_expected_mult(g, cnt, o_off, O);
     const bool t    = ext_terminal(P, s, a, ns);
     r               = ext_reward(P, s, a, ns);
-    inc.n           = 2;
-    inc.idx[0]      = t_off + ns;
-    inc.idx[1]      = o_off + o;
+    inc.add(0, t_off + ns);
+    inc.add(1, o_off + o);
     s               = ns;
     return t;
 }

@@ -219,9 +219,8 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
             int o;
             double r;
             bool term;
-            Inc inc;
-            if (STAGE) term = sim_step(P, g, LdsView<SEARCH_BLOCK>{stage}, s, a, o, r, inc);
-            else term = sim_step(P, g, GlobalView{cnt}, s, a, o, r, inc);
+            if (STAGE) term = sim_step(P, g, LdsView<SEARCH_BLOCK>{stage}, s, a, o, r, NoInc{});
+            else term = sim_step(P, g, GlobalView{cnt}, s, a, o, r, NoInc{});
             ++steps;
             if (mode == 1) {  // traverseChanceNode
                 path_r[(size_t)plen * SEARCH_BLOCK]  = r;
@@ -395,22 +394,32 @@ __global__ void advance_kernel(Problem P, DeviceState D, int32_t* n_active)
 // A record is C4 float4; a power-of-two group of lanes owns one record so consecutive lanes move
 // consecutive 16-byte pieces: every wave instruction reads and writes whole contiguous records.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void gather_records(float* __restrict__ dst, const float* __restrict__ src, const int32_t* s_src,
-                                               const int32_t* s_inc, int ninc, int inc_stride, const int32_t* s_state, int m,
-                                               int C4, int C, int group, int nthreads)
+__device__ __forceinline__ void bump(float4& v, int d, float add)
+{
+    v.x += (d == 0) ? add : 0.f;
+    v.y += (d == 1) ? add : 0.f;
+    v.z += (d == 2) ? add : 0.f;
+    v.w += (d == 3) ? add : 0.f;
+}
+// s_owner[j] (nullable) = the thread whose LDS columns (s_src, s_state, s_inc) describe output record j
+__device__ __forceinline__ void gather_records(float* __restrict__ dst, const float* __restrict__ src, const int32_t* s_owner,
+                                               const int32_t* s_src, const int32_t* s_inc, int ninc, int inc_stride,
+                                               const int32_t* s_state, int m, int C4, int C, int group, int nthreads)
 {
     const int gid = threadIdx.x / group, part0 = threadIdx.x % group, ngroups = nthreads / group;
     for (int j = gid; j < m; j += ngroups) {
-        const float4* sp = reinterpret_cast<const float4*>(src) + (size_t)s_src[j] * C4;
+        const int t      = s_owner ? s_owner[j] : j;
+        const float4* sp = reinterpret_cast<const float4*>(src) + (size_t)s_src[t] * C4;
         float4* dp       = reinterpret_cast<float4*>(dst) + (size_t)j * C4;
         for (int part = part0; part < C4; part += group) {
             float4 v = sp[part];
             const int lo = part * 4;
-            for (int k = 0; k < ninc; ++k) {
-                const int d = s_inc[k * inc_stride + j] - lo;
-                if ((unsigned)d < 4u) (&v.x)[d] += 1.0f;
+            for (int k = 0; k < ninc; ++k) bump(v, s_inc[k * inc_stride + t] - lo, 1.0f);
+            if (s_state) {  // new domain state in word C
+                const int d = C - lo;
+                const float f = __int_as_float(s_state[t]);
+                if (d == 0) v.x = f; else if (d == 1) v.y = f; else if (d == 2) v.z = f; else if (d == 3) v.w = f;
             }
-            if (s_state && (unsigned)(C - lo) < 4u) (&v.x)[C - lo] = __int_as_float(s_state[j]);  // new domain state
             dp[part] = v;
         }
     }
@@ -432,7 +441,7 @@ __device__ __forceinline__ int record_group(int C4)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(REJECT_BLOCK) reject_kernel(Problem P, DeviceState D)
 {
-    __shared__ int32_t s_src[REJECT_BLOCK], s_ns[REJECT_BLOCK], s_inc[MAXINC * REJECT_BLOCK];
+    __shared__ int32_t s_src[REJECT_BLOCK], s_ns[REJECT_BLOCK], s_owner[REJECT_BLOCK], s_inc[MAXINC * REJECT_BLOCK];
     __shared__ int32_t s_wave[REJECT_BLOCK / 64];
     __shared__ int32_t s_count;
     const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -443,7 +452,7 @@ __global__ void __launch_bounds__(REJECT_BLOCK) reject_kernel(Problem P, DeviceS
     const float* scn   = D.p_rec + sb * (size_t)P.Cs;
     float* dcn         = D.p_rec + db * (size_t)P.Cs;
     const int C4 = P.Cs / 4, group = record_group(C4);
-    const int ninc = P.model == FBA_MODEL_POMDP ? 0 : (P.model == FBA_MODEL_BA_TABLE ? 2 : P.fd->FS + P.fd->FO);
+    const int ninc = model_ninc(P);
     Rng g = slot_rng(P, D, e);
 
     int acc = 0, base = 0;
@@ -454,8 +463,9 @@ __global__ void __launch_bounds__(REJECT_BLOCK) reject_kernel(Problem P, DeviceS
         const float* rec = scn + (size_t)src * P.Cs;
         int s = rec_state(rec, P.C), so;
         double r;
-        Inc inc;
-        sim_step(P, g, GlobalView{rec}, s, a, so, r, inc);  // UpdateCounts: the +1s land in the copy
+        sim_step(P, g, GlobalView{rec}, s, a, so, r, LdsInc<REJECT_BLOCK>{s_inc + tid});  // UpdateCounts: the +1s land in the copy
+        s_src[tid] = src;
+        s_ns[tid]  = s;
         const bool ok = (so == o);
         const unsigned long long ballot = __ballot(ok);
         const int prefix = __popcll(ballot & ((1ull << lane) - 1ull));
@@ -468,15 +478,12 @@ __global__ void __launch_bounds__(REJECT_BLOCK) reject_kernel(Problem P, DeviceS
         }
         const int j = woff + prefix;  // position among this chunk's accepted attempts
         if (ok && acc + j < N) {
-            s_src[j] = src; s_ns[j] = s;
-#pragma unroll
-            for (int q = 0; q < MAXINC; ++q)
-                if (q < inc.n) s_inc[q * REJECT_BLOCK + j] = inc.idx[q];
+            s_owner[j] = tid;
             if (acc + j == N - 1) s_count = k + 1;
         }
         __syncthreads();
         const int m = min(chunk, N - acc);
-        gather_records(dcn + (size_t)acc * P.Cs, scn, s_src, s_inc, ninc, REJECT_BLOCK, s_ns, m, C4, P.C, group, REJECT_BLOCK);
+        gather_records(dcn + (size_t)acc * P.Cs, scn, s_owner, s_src, s_inc, ninc, REJECT_BLOCK, s_ns, m, C4, P.C, group, REJECT_BLOCK);
         acc += m;
         base += REJECT_BLOCK;
         __syncthreads();
@@ -583,7 +590,7 @@ __global__ void __launch_bounds__(IS_BLOCK) uniform_scan_kernel(int n, double* w
 __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceState D)
 {
     __shared__ double s_carry[IS_MAX_CHUNKS + 2];
-    __shared__ int32_t s_src[IS_BLOCK];
+    __shared__ int32_t s_src[IS_BLOCK], s_inc[MAXINC * IS_BLOCK];
     const int e = blockIdx.x, tid = threadIdx.x;
     if (!D.need_update[e]) return;
     const int a = D.action[e], o = D.obs[e], N = P.N;
@@ -595,6 +602,7 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
     float* dcn      = D.p_rec + db * (size_t)P.Cs;
     double* wscan   = D.wscan + (size_t)e * N;
     const int C4 = P.Cs / 4, group = record_group(C4);
+    const int ninc = model_ninc(P);
     Rng g = slot_rng(P, D, e);
 
     for (int i = tid; i < N; i += IS_BLOCK) {
@@ -602,11 +610,8 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
         float* cnt = scn + (size_t)i * P.Cs;
         int s = rec_state(cnt, P.C), so;
         double r;
-        Inc inc;
-        sim_step(P, g, GlobalView{cnt}, s, a, so, r, inc);
-#pragma unroll
-        for (int q = 0; q < MAXINC; ++q)
-            if (q < inc.n) cnt[inc.idx[q]] += 1.0f;  // incrementCountsOf (BAFlatModel.cpp:126-139, BABNModel.cpp:354-382)
+        sim_step(P, g, GlobalView{cnt}, s, a, so, r, LdsInc<IS_BLOCK>{s_inc + tid});
+        for (int q = 0; q < ninc; ++q) cnt[s_inc[q * IS_BLOCK + tid]] += 1.0f;  // incrementCountsOf (BAFlatModel.cpp:126-139, BABNModel.cpp:354-382)
         rec_set_state(cnt, P.C, s);
         sw[i] *= sim_obs_prob(P, GlobalView{cnt}, s, a, o);  // probability from the updated counts
     }
@@ -626,7 +631,7 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
         }
         __syncthreads();
         const int m = min(IS_BLOCK, N - j0);
-        gather_records(dcn + (size_t)j0 * P.Cs, scn, s_src, nullptr, 0, 0, nullptr, m, C4, P.C, group, IS_BLOCK);
+        gather_records(dcn + (size_t)j0 * P.Cs, scn, nullptr, s_src, nullptr, 0, 0, nullptr, m, C4, P.C, group, IS_BLOCK);
         __syncthreads();
     }
     if (tid == 0) {
@@ -709,8 +714,8 @@ __global__ void __launch_bounds__(256) reset_kernel(Problem P, DeviceState D)
         }
         __syncthreads();
         const int m = min(256, P.N - j0);
-        gather_records(D.p_rec + (db + j0) * (size_t)P.Cs, D.p_rec + sb * (size_t)P.Cs, s_src, nullptr, 0, 0, s_ns, m, C4, P.C,
-                       group, 256);
+        gather_records(D.p_rec + (db + j0) * (size_t)P.Cs, D.p_rec + sb * (size_t)P.Cs, nullptr, s_src, nullptr, 0, 0, s_ns, m, C4,
+                       P.C, group, 256);
         __syncthreads();
     }
     if (tid == 0) {
