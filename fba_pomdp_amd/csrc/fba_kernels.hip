@@ -104,28 +104,40 @@ __device__ __forceinline__ void child_set(const Problem& P, const DeviceState& D
 // POUCT::selectChanceNodeUCB (POUCT.cpp:138-181 = RBAPOUCT.cpp:162-205).
 // UCB(m, n) = u * sqrt(log1p(m) / n), DBL_MAX for n = 0 (POUCT.cpp:330-338); ties are collected in
 // action order and one slowRandomInt is ALWAYS drawn, also for a single candidate.
-__device__ __forceinline__ int ucb_select(const Problem& P, const DeviceState& D, Rng& g, const int32_t* rec, bool explore)
+// The node's statistics arrive in registers (cn / cq), L = log1p(visits).
+template <int AMAX>
+__device__ __forceinline__ int ucb_pick(const Problem& P, Rng& g, double L, const int (&cn)[AMAX], const double (&cq)[AMAX], bool explore)
 {
-    const int m      = rec[0];
-    const double L   = explore ? D.log1p_tab[m] : 0.0;
-    const double* cq = reinterpret_cast<const double*>(rec + D.cq_off);
-    double best_q    = -DBL_MAX;
-    uint32_t mask    = 0;
-    for (int a = 0; a < P.A; ++a) {
-        double q = cq[a];
-        if (explore) {
-            const int n = rec[1 + a];
-            q += (n == 0) ? DBL_MAX : P.exploration * sqrt(L / (double)n);
+    double best_q = -DBL_MAX;
+    uint32_t mask = 0;
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a)
+        if (a < P.A) {
+            double q = cq[a];
+            if (explore) q += (cn[a] == 0) ? DBL_MAX : P.exploration * sqrt(L / (double)cn[a]);
+            if (q >= best_q) {
+                if (q > best_q) mask = 0;
+                best_q = q;
+                mask |= 1u << a;
+            }
         }
-        if (q >= best_q) {
-            if (q > best_q) mask = 0;
-            best_q = q;
-            mask |= 1u << a;
-        }
-    }
     int k = g.slow_int(0, __popc(mask));
     while (k-- > 0) mask &= mask - 1;  // drop the k lowest candidates
     return __ffs(mask) - 1;
+}
+
+template <int AMAX>
+__device__ __forceinline__ int ucb_select(const Problem& P, const DeviceState& D, Rng& g, const int32_t* rec, bool explore)
+{
+    int cn[AMAX];
+    double cq[AMAX];
+    const double* q = reinterpret_cast<const double*>(rec + D.cq_off);
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) {
+        cn[a] = a < P.A ? rec[1 + a] : 0;
+        cq[a] = a < P.A ? q[a] : 0.0;
+    }
+    return ucb_pick<AMAX>(P, g, explore ? D.log1p_tab[rec[0]] : 0.0, cn, cq, explore);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -139,7 +151,7 @@ __device__ __forceinline__ int ucb_select(const Problem& P, const DeviceState& D
 // record fits 32 words (STAGE) -- the root particle's whole count blob, [word][lane], fetched with
 // one burst of 16-byte loads per simulation so that no step waits on HBM for its Dirichlet rows.
 // ---------------------------------------------------------------------------------------------
-template <bool STAGE>
+template <bool STAGE, int AMAX>
 __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceState D)
 {
     extern __shared__ double lds[];
@@ -151,6 +163,9 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
     double* path_r      = lds + lane;                                                   // [depth][block]
     int32_t* path_na    = reinterpret_cast<int32_t*>(lds + (size_t)depth_cap * SEARCH_BLOCK) + lane;
     float* stage        = reinterpret_cast<float*>(path_na - lane + (size_t)depth_cap * SEARCH_BLOCK) + lane;  // [Cs][block]
+    // children of the root, [a*O + o][block], when there are at most ROOT_CHILDREN of them
+    const bool root_lds = P.A * P.O <= ROOT_CHILDREN;
+    int32_t* rootch     = reinterpret_cast<int32_t*>(stage - lane + (STAGE ? (size_t)P.Cs * SEARCH_BLOCK : 0)) + lane;
 
     Rng g               = slot_rng(P, D, e);
     const int hist_len  = D.t[e];
@@ -171,6 +186,16 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
     node_init(D, tree, P.A, P.O);
     int n_nodes = 1, tree_depth = 0;
     unsigned long long steps = 0;
+    // The root is on the path of every simulation: its visit counts and Q values live in registers
+    // for the whole search, log1p(root visits) is fetched when the visits change (never waited for
+    // on the critical path), and its child pointers sit in LDS.
+    int r_vis = 0, r_cn[AMAX];
+    double r_cq[AMAX];
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) { r_cn[a] = 0; r_cq[a] = 0.0; }
+    double root_L = D.log1p_tab[0];
+    if (root_lds)
+        for (int k = 0; k < P.A * P.O; ++k) rootch[k * SEARCH_BLOCK] = -1;
     int4* tab      = D.hash ? D.hash + (size_t)e * (D.hmask + 1) : nullptr;
     uint32_t epoch = 0;
     if (D.hash) {
@@ -211,7 +236,8 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
         if (mode == 1) {  // traverseActionNode
             tree_depth = max(tree_depth, max_tree_depth - dtg);
             if (dtg == 0) { finish = true; do_step = false; }
-            else a = ucb_select(P, D, g, tree + (size_t)node * W, true);
+            else if (node == 0) a = ucb_pick<AMAX>(P, g, root_L, r_cn, r_cq, true);
+            else a = ucb_select<AMAX>(P, D, g, tree + (size_t)node * W, true);
         } else {          // rollout: uniformly random action
             a = domain_random_action(P, g, s);
         }
@@ -228,12 +254,14 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
                 ++plen;
                 if (term) finish = true;
                 else {
-                    const int c = child_get(P, D, tree, tab, epoch, node, a, o);
+                    const bool at_root_lds = root_lds && node == 0;
+                    const int c = at_root_lds ? rootch[(a * P.O + o) * SEARCH_BLOCK] : child_get(P, D, tree, tab, epoch, node, a, o);
                     if (c >= 0) { node = c; --dtg; }
                     else {  // expand: new leaf, then rollout(depth_to_go - 1)
                         const int nn = n_nodes++;
                         node_init(D, tree + (size_t)nn * W, P.A, P.O);
-                        child_set(P, D, tree, tab, epoch, node, a, o, nn);
+                        if (at_root_lds) rootch[(a * P.O + o) * SEARCH_BLOCK] = nn;
+                        else child_set(P, D, tree, tab, epoch, node, a, o, nn);
                         mode = 2; rdepth = dtg - 1; rret = 0; rdisc = 1;
                         if (rdepth == 0) finish = true;
                     }
@@ -252,12 +280,23 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
             for (int k = plen - 1; k >= 0; --k) {
                 const int na     = path_na[(size_t)k * SEARCH_BLOCK];
                 const double ret = path_r[(size_t)k * SEARCH_BLOCK] + P.gamma * del;
-                int32_t* rec     = tree + (size_t)(na >> 4) * W;
                 const int act    = na & 15;
-                const int n      = ++rec[1 + act];
-                double* q        = reinterpret_cast<double*>(rec + D.cq_off) + act;
-                *q += (ret - *q) / (double)n;
-                ++rec[0];
+                if ((na >> 4) == 0) {
+#pragma unroll
+                    for (int a2 = 0; a2 < AMAX; ++a2)
+                        if (a2 == act) {
+                            const int n = ++r_cn[a2];
+                            r_cq[a2] += (ret - r_cq[a2]) / (double)n;
+                        }
+                    ++r_vis;
+                    root_L = D.log1p_tab[r_vis];
+                } else {
+                    int32_t* rec = tree + (size_t)(na >> 4) * W;
+                    const int n  = ++rec[1 + act];
+                    double* q    = reinterpret_cast<double*>(rec + D.cq_off) + act;
+                    *q += (ret - *q) / (double)n;
+                    ++rec[0];
+                }
                 del = ret;
             }
             ++sim;
@@ -265,16 +304,16 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
         }
     }
     g.stream(FBA_PHASE_SEARCH, (uint32_t)P.sims + 1u);
-    const int best = ucb_select(P, D, g, tree, false);
+    const int best = ucb_pick<AMAX>(P, g, 0.0, r_cn, r_cq, false);
     D.action[e]    = best;
     D.sim_steps[e] += steps;
     fba_trace_rec& rec = D.cur[e];
     rec.n_nodes    = n_nodes;
     rec.tree_depth = tree_depth;
-    const double* cq = reinterpret_cast<const double*>(tree + D.cq_off);
+#pragma unroll
     for (int a = 0; a < FBA_MAX_ACTIONS; ++a) {
-        rec.root_n[a] = a < P.A ? tree[1 + a] : 0;
-        rec.root_q[a] = a < P.A ? cq[a] : 0.0;
+        rec.root_n[a] = a < AMAX && a < P.A ? r_cn[a < AMAX ? a : 0] : 0;
+        rec.root_q[a] = a < AMAX && a < P.A ? r_cq[a < AMAX ? a : 0] : 0.0;
     }
 }
 
@@ -771,11 +810,14 @@ void launch_search(const Problem& P, const DeviceState& D, hipStream_t st)
     const int depth_cap = P.max_depth > 0 ? P.max_depth : 1;
     const bool stage = P.model != FBA_MODEL_POMDP && P.Cs <= SEARCH_STAGE_WORDS;
     const size_t lds = (size_t)depth_cap * SEARCH_BLOCK * (sizeof(double) + sizeof(int32_t)) +
-                       (stage ? (size_t)P.Cs * SEARCH_BLOCK * sizeof(float) : 0);
-    if (stage)
-        hipLaunchKernelGGL(search_kernel<true>, dim3(ceil_div(P.E, SEARCH_BLOCK)), dim3(SEARCH_BLOCK), lds, st, P, D);
-    else
-        hipLaunchKernelGGL(search_kernel<false>, dim3(ceil_div(P.E, SEARCH_BLOCK)), dim3(SEARCH_BLOCK), lds, st, P, D);
+                       (stage ? (size_t)P.Cs * SEARCH_BLOCK * sizeof(float) : 0) +
+                       (P.A * P.O <= ROOT_CHILDREN ? (size_t)P.A * P.O * SEARCH_BLOCK * sizeof(int32_t) : 0);
+    const dim3 grid(ceil_div(P.E, SEARCH_BLOCK)), block(SEARCH_BLOCK);
+#define FBA_LAUNCH_SEARCH(STG, AM) hipLaunchKernelGGL((search_kernel<STG, AM>), grid, block, lds, st, P, D)
+    if (P.A <= 4) { if (stage) FBA_LAUNCH_SEARCH(true, 4); else FBA_LAUNCH_SEARCH(false, 4); }
+    else if (P.A <= 8) { if (stage) FBA_LAUNCH_SEARCH(true, 8); else FBA_LAUNCH_SEARCH(false, 8); }
+    else { if (stage) FBA_LAUNCH_SEARCH(true, 16); else FBA_LAUNCH_SEARCH(false, 16); }
+#undef FBA_LAUNCH_SEARCH
 }
 void launch_start(const Problem& P, const DeviceState& D, hipStream_t st)
 {
