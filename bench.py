@@ -45,6 +45,20 @@ def cpu_baseline(args):
     }
 
 
+def measured_traffic(args, kname):
+    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes
+    (FETCH_SIZE and WRITE_SIZE in separate runs of this same command; profiles/*.json says how
+    they were collected and corrected).  None when the workload differs from the profiled one."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write.json")
+    if not os.path.exists(path) or args.slots != 131072 or args.sims != 4096 or args.particles != 4096:
+        return None, None
+    with open(path) as f:
+        d = json.load(f)
+    if d.get("kernel") != kname:
+        return None, None
+    return d["traffic_bytes_per_launch_raw"], "profiles/r01_pmc_fetch_write.json"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,6 +129,7 @@ def main():
         achieved = (k.bytes / 1e9) / (k.ms / 1e3) if k.ms > 0 else 0.0
         search = kt["search_kernel"]
         n_ep = tot[2]
+        traffic, traffic_src = measured_traffic(args, kname)
         out = {
             "metric": "simulated env steps/sec (belief+rollout)",
             "value": tot[0] / dt_max,
@@ -135,7 +150,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "launches": int(k.launches), "avg_ms": k.ms / max(int(k.launches), 1),
                 "algorithmic_bytes_per_launch": k.bytes / max(int(k.launches), 1),
             },
