@@ -171,6 +171,74 @@ def _oracle_base_prior(o):
     return base.prior_counts()
 
 
+@pytest.mark.parametrize("kw", [
+    dict(particles=1, sims=1, horizon=1),            # smallest everything
+    dict(particles=3, sims=7, horizon=4, max_depth=0),   # depth 0: every simulation returns at the root
+    dict(particles=5, sims=9, horizon=3, max_depth=50),  # depth cap beyond the horizon
+    dict(particles=2, sims=33, horizon=12, discount=1.0, exploration=0.0),
+])
+def test_edge_sizes(kw):
+    eng, o = _pair("episodic-tiger", N.MODEL_BA_TABLE, "rejection_sampling", 101, runs=6, episodes=3, **kw)
+    _assert_same_experiment(eng, o, ba=True)
+    eng, o = _pair("continuous-tiger", N.MODEL_POMDP, "importance_sampling", 102, runs=6, **kw)
+    _assert_same_experiment(eng, o, ba=False)
+
+
+def test_c3_size_one_search_and_update():
+    """BASELINE configs[2] sizes: factored tiger (K = 3), 16384 simulations, match-uniform structure
+    prior; one selectAction + one updateEstimation per slot, compared with the oracle."""
+    kw = dict(size=3, particles=1024, sims=16384, structure_prior=2)
+    eng = fba.Engine("episodic-factored-tiger", model=N.MODEL_BA_FACTORED, seed=111, slots=2, **kw)
+    L = orc.lib()
+    eng.belief_init()
+    eng.belief_reset_domain_state()
+    acts = eng.select_action(hist_len=0)
+    info = eng.last_step_info()
+    eng.belief_update(2, 1)
+    for e in range(2):
+        o = orc.Oracle(domain=orc.DOM_FTIGER_EPISODIC, model=orc.MODEL_BA_FACTORED, rng_mode=orc.RNG_PHILOX,
+                       arith=orc.ARITH_DEV, philox_seed=111, **kw)
+        L.orc_rng_episode(o.rng, e, 0, 0)
+        o.belief_initiate()
+        o.belief_reset_domain_state()
+        a_ref, rec = o.select_action(0)
+        assert acts[e] == a_ref
+        assert np.array_equal(info[e]["root_n"], rec["root_n"]) and np.array_equal(info[e]["root_q"], rec["root_q"])
+        assert info[e]["n_nodes"] == rec["n_nodes"]
+        o.belief_update(2, 1)
+        s, _, cnt = eng.belief_get(e)
+        os_, _, ocnt = o.belief_get()
+        assert np.array_equal(s, os_) and np.array_equal(cnt.view(np.uint32), ocnt.view(np.uint32))
+
+
+def test_gridworld7_one_search_and_update():
+    """BASELINE configs[3] domain size (N = 7: S = O = 490, hashed child table), parity-sized counts."""
+    kw = dict(size=7, particles=48, sims=600, structure_prior=2, belief=1, horizon=20)
+    eng = fba.Engine("gridworld", model=N.MODEL_BA_FACTORED, seed=113, slots=1, **kw)
+    o = orc.Oracle(domain=orc.DOM_GRIDWORLD, model=orc.MODEL_BA_FACTORED, rng_mode=orc.RNG_PHILOX,
+                   arith=orc.ARITH_DEV, philox_seed=113, **kw)
+    L = orc.lib()
+    L.orc_rng_episode(o.rng, 0, 0, 0)
+    o.belief_initiate()
+    eng.belief_init()
+    o.belief_reset_domain_state()
+    eng.belief_reset_domain_state()
+    for t, (a_fix, ob) in enumerate([(1, 10 * 7 + 0), (0, 10 * 7 * 1 + 10 + 3)]):
+        L.orc_rng_episode(o.rng, 0, 0, t)
+        eng.set_position(run=0, episode=0, t=t)
+        a_ref, rec = o.select_action(t)
+        a = eng.select_action(hist_len=t)[0]
+        info = eng.last_step_info()[0]
+        assert a == a_ref and info["n_nodes"] == rec["n_nodes"]
+        assert np.array_equal(info["root_n"], rec["root_n"]) and np.array_equal(info["root_q"], rec["root_q"])
+        o.belief_update(a_fix, ob)
+        eng.belief_update(a_fix, ob)
+        s, w, cnt = eng.belief_get(0)
+        os_, ow, ocnt = o.belief_get()
+        assert np.array_equal(s, os_) and np.array_equal(w, ow)
+        assert np.array_equal(cnt.view(np.uint32), ocnt.view(np.uint32))
+
+
 def test_bapomdp_slots_fewer_than_runs():
     eng, o = _pair("episodic-tiger", N.MODEL_BA_TABLE, "rejection_sampling", 24, slots=3, particles=64, sims=64,
                    runs=8, episodes=2)
