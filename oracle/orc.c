@@ -67,6 +67,15 @@ struct orc_ctx {
     int32_t gw_N, gw_G, gw_nslow;
     int32_t gw_goal[16][2], gw_slow[8][2];
     float gw_disp[32]; /* _obs_displacement_probs */
+    /* collision avoidance (src/domains/collision-avoidance/CollisionAvoidance.cpp) */
+    int32_t ca_W, ca_H, ca_n, ca_random_start, ca_Hn; /* Hn = H^n */
+    double ca_err[16];        /* _observation_error_probability[d] */
+    double ca_phi[20];        /* Phi(k + .5), k = -9..9: rounded-normal thresholds (Philox mode) */
+    float ca_start_v;         /* probability of each start state (float) */
+    double ca_start_total;    /* categoricalDistr::_total */
+    int32_t ca_start_i0, ca_start_cnt;
+    float nd_saved;           /* std::normal_distribution<float>::_M_saved */
+    int nd_saved_available;
     int32_t ncnt;      /* floats per particle count blob */
     int32_t phi_len;   /* tabular: S*A*S */
     float* prior;      /* tabular prior blob (phi then psi) */
@@ -181,6 +190,73 @@ static int is_episodic(int d)
     return d == ORC_DOM_TIGER_EPISODIC || d == ORC_DOM_FTIGER_EPISODIC;
 }
 static int is_grid(int d) { return d == ORC_DOM_GRIDWORLD; }
+static int is_ca(int d) { return d == ORC_DOM_COLLISION_AVOID; }
+
+/* ---- collision avoidance.  ref: src/domains/collision-avoidance/CollisionAvoidance.cpp
+ * state index = (x*H + y)*H^n + project(obstacles) (ctor :77-92); observation = project(observed
+ * obstacle rows); actions MOVE_DOWN, STAY, MOVE_UP (hpp:91) */
+static double normal_cdf(double x) { return .5 + .5 * erf(x / (1 * sqrt(2))); } /* rnd::normal::cdf random.cpp:119-124 */
+static int ca_keep(const orc_ctx* c, int y) { return y < 0 ? 0 : (y > c->ca_H - 1 ? c->ca_H - 1 : y); }
+static void ca_setup(orc_ctx* c, int W, int H, int n, int random_start)
+{
+    int d, k;
+    c->ca_W = W; c->ca_H = H; c->ca_n = n; c->ca_random_start = random_start;
+    c->ca_Hn = 1;
+    for (k = 0; k < n; ++k) c->ca_Hn *= H;
+    for (d = 0; d < H; ++d) c->ca_err[d] = normal_cdf(d + .5) - normal_cdf(d - .5); /* ctor :100-104 */
+    for (k = 0; k < 19; ++k) c->ca_phi[k] = normal_cdf((k - 9) + .5);
+    if (random_start) { /* ctor :121-133: every state with x = W-1 */
+        c->ca_start_v   = (float)(1.f / pow(H, n + 1));
+        c->ca_start_i0  = (W - 1) * H * c->ca_Hn;
+        c->ca_start_cnt = H * c->ca_Hn;
+        c->ca_start_total = 0;
+        for (k = 0; k < c->ca_start_cnt; ++k) c->ca_start_total += c->ca_start_v; /* setRawValue: _total += v - 0 */
+    } else {            /* :134-142: agent and obstacles in the middle row */
+        int obs = 0;
+        for (k = 0; k < n; ++k) obs = obs * H + H / 2;
+        c->ca_start_v = 1; c->ca_start_total = 1; c->ca_start_cnt = 1;
+        c->ca_start_i0 = ((W - 1) * H + H / 2) * c->ca_Hn + obs;
+    }
+}
+/* std::normal_distribution<float>(0,1) as GNU libstdc++ 11 implements it (bits/random.tcc
+ * normal_distribution::operator(): Marsaglia polar method with one saved variate;
+ * generate_canonical<float,24> takes one 32-bit engine word), then static_cast<int>(std::round()).
+ * Philox mode: the same discrete distribution by inverse CDF on Phi(k + .5). */
+static float mt_canonical_f(orc_rng* g)
+{
+    float ret = (float)orc_mt_next(g) / 4294967296.0f;
+    if (ret >= 1.0f) ret = nextafterf(1.0f, 0.0f);
+    return ret;
+}
+static int ca_rounded_normal(orc_ctx* c)
+{
+    if (c->rng.mode == ORC_RNG_MT) {
+        float ret;
+        if (c->nd_saved_available) {
+            c->nd_saved_available = 0;
+            ret = c->nd_saved;
+        } else {
+            float x, y, r2, mult;
+            do {
+                x  = 2.0f * mt_canonical_f(&c->rng) - 1.0f;
+                y  = 2.0f * mt_canonical_f(&c->rng) - 1.0f;
+                r2 = x * x + y * y;
+            } while (r2 > 1.0f || r2 == 0.0f);
+            mult = sqrtf(-2 * logf(r2) / r2);
+            c->nd_saved = x * mult;
+            c->nd_saved_available = 1;
+            ret = y * mult;
+        }
+        ret = ret * 1.0f + 0.0f;
+        return (int)roundf(ret);
+    } else {
+        double u = orc_u01(&c->rng);
+        int k;
+        for (k = 0; k < 19; ++k)
+            if (u < c->ca_phi[k]) return k - 9;
+        return 10;
+    }
+}
 
 /* ---- gridworld.  ref: src/domains/gridworld/GridWorld.cpp
  * state index = x*N*G + y*G + g (positionsToIndex :329-340); actions UP, RIGHT, DOWN, LEFT */
@@ -254,6 +330,17 @@ static int32_t domain_start(orc_ctx* c)
 {
     if (is_tiger(c->cfg.domain)) return orc_bool(&c->rng) ? 0 : 1;
     if (is_ftiger(c->cfg.domain)) return orc_int(&c->rng, c->S);
+    if (is_ca(c->cfg.domain)) { /* sampleStartState :270-273 -> categoricalDistr::sample -> sampleFromMult<float>(values, S, _total) */
+        double p  = orc_u01(&c->rng) * c->ca_start_total;
+        float sum = 0;
+        int k;
+        /* zero entries before the block leave the float sum at 0; inside the block it grows by v */
+        for (k = 0; k < c->ca_start_cnt; ++k) {
+            sum += c->ca_start_v;
+            if (p < sum) return c->ca_start_i0 + k;
+        }
+        return (c->ca_start_i0 + c->ca_start_cnt == c->S) ? c->S - 1 : c->S - 1;
+    }
     if (is_grid(c->cfg.domain)) { /* GridWorld::sampleStartState :260-266: start_locations = {{0,0}} */
         int agent = orc_slow_int(&c->rng, 0, 1);
         int goal  = orc_slow_int(&c->rng, 0, c->gw_G);
@@ -270,6 +357,7 @@ static int32_t domain_random_action(orc_ctx* c, int32_t s)
     (void)s;
     if (is_tiger(c->cfg.domain) || is_ftiger(c->cfg.domain)) return orc_int(&c->rng, 3);
     if (is_grid(c->cfg.domain)) return orc_slow_int(&c->rng, 0, 4); /* GridWorld::generateRandomAction :220-226 */
+    if (is_ca(c->cfg.domain)) return orc_int(&c->rng, 3); /* integerDistribution(0, NUM_ACTIONS) */
     return 0;
 }
 
@@ -302,6 +390,25 @@ static int domain_step(orc_ctx* c, int32_t* s, int32_t a, int32_t* o, double* r)
             *s = orc_int(&c->rng, c->S);    /* sampleStartState() */
         }
         return is_episodic(d) && a != 2;
+    }
+    if (is_ca(d)) { /* CollisionAvoidance::step :236-270, moveObstacle :330-338, reward :196-208 */
+        int H = c->ca_H, n = c->ca_n, Hn = c->ca_Hn, k;
+        int x = *s / (H * Hn), y = (*s / Hn) % H, obs = *s % Hn;
+        int b[8], ob[8], nx = x - 1, ny = ca_keep(c, y + a - 1), nobs = 0, oobs = 0, crashed;
+        for (k = n - 1; k >= 0; --k) { b[k] = obs % H; obs /= H; }
+        for (k = 0; k < n; ++k) {
+            double prob = orc_u01(&c->rng);
+            int m = (prob < .5) ? 1 : (prob > .5 * (1 + .5)) ? 2 : 0;
+            b[k] = ca_keep(c, b[k] + m - 1);
+        }
+        for (k = 0; k < n; ++k) nobs = nobs * H + b[k];
+        *s = (nx * H + ny) * Hn + nobs;
+        for (k = 0; k < n; ++k) ob[k] = ca_keep(c, b[k] + ca_rounded_normal(c));
+        for (k = 0; k < n; ++k) oobs = oobs * H + ob[k];
+        *o = oobs;
+        crashed = nx < n && nx >= 0 && ny == b[nx];
+        *r = crashed ? -1000 : (a == 1 ? 0 : -1);
+        return crashed || nx == 0;
     }
     if (is_grid(d)) { /* GridWorld::step :272-304, generateObservation :366-394 */
         int N = c->gw_N, G = c->gw_G;
@@ -337,6 +444,15 @@ static double domain_obs_prob(orc_ctx* c, int32_t o, int32_t a, int32_t new_s)
         if (a != 2) return .5;
         return (loc == o) ? .85 : .15;
     }
+    if (is_ca(d)) { /* computeObservationProbability :216-229 */
+        int H = c->ca_H, n = c->ca_n, k, pos = new_s % c->ca_Hn, obs = o;
+        double p = 1;
+        int pb[8], po[8];
+        (void)a;
+        for (k = n - 1; k >= 0; --k) { pb[k] = pos % H; pos /= H; po[k] = obs % H; obs /= H; }
+        for (k = 0; k < n; ++k) p *= c->ca_err[abs(pb[k] - po[k])];
+        return p;
+    }
     if (is_grid(d)) { /* GridWorld::computeObservationProbability :236-250: float * float, goal ignored */
         int N = c->gw_N, G = c->gw_G;
         int x = new_s / (N * G), y = (new_s / G) % N, ox = o / (N * G), oy = (o / G) % N;
@@ -356,14 +472,24 @@ static int gw_on_goal(const orc_ctx* c, int32_t s)
 }
 static int ext_terminal(orc_ctx* c, int32_t s, int32_t a, int32_t ns)
 {
-    (void)ns;
+    if (is_ca(c->cfg.domain)) { /* CollisionAvoidanceBAExtension.cpp:53-63: the NEW state */
+        int H = c->ca_H, Hn = c->ca_Hn, x = ns / (H * Hn), y = (ns / Hn) % H, obs = ns % Hn, k;
+        int b = 0;
+        for (k = c->ca_n - 1; k >= 0; --k) { if (k == x) b = obs % H; obs /= H; }
+        return (x < c->ca_n && y == b) || x == 0;
+    }
     if (is_grid(c->cfg.domain)) return gw_on_goal(c, s); /* GridWorldBAExtension.cpp:74-83: the PRE-state */
     return is_episodic(c->cfg.domain) && a != 2;
 }
 static double ext_reward(orc_ctx* c, int32_t s, int32_t a, int32_t ns)
 {
     int d = c->cfg.domain;
-    (void)ns;
+    if (is_ca(d)) { /* CollisionAvoidanceBAExtension.cpp:65-82 */
+        int H = c->ca_H, Hn = c->ca_Hn, x = ns / (H * Hn), y = (ns / Hn) % H, obs = ns % Hn, k, b = 0;
+        for (k = c->ca_n - 1; k >= 0; --k) { if (k == x) b = obs % H; obs /= H; }
+        if (x < c->ca_n && y == b) return -1000;
+        return a == 1 ? 0 : -1;
+    }
     if (is_grid(d)) return gw_on_goal(c, s) ? 1 : 0; /* GridWorldBAExtension.cpp:85-99 */
     if (a == 2) return -1;
     if (is_tiger(d)) return (a == s) ? 10 : -100;
@@ -1375,6 +1501,16 @@ orc_ctx* orc_create(const orc_config* cfg)
             }
             c->tiger_K = cfg->size; c->S = 2 << cfg->size; c->A = 3; c->O = 2;
             break;
+        case ORC_DOM_COLLISION_AVOID: {
+            int W = cfg->width, H = cfg->height, n = cfg->size, k, Hn = 1;
+            if (W < 1) { snprintf(c->err, sizeof c->err, "Cannot initiate CollisionAvoidance with width %d", W); return c; }
+            if (H < 1 || H % 2 != 1 || H > 15) { snprintf(c->err, sizeof c->err, "Cannot initiate CollisionAvoidance with height %d, must be uneven", H); return c; }
+            if (n > W || n < 1 || n > 6) { snprintf(c->err, sizeof c->err, "cannot initiate collision avoidance with more obstacles (%d ) than columns (%d)!", n, W); return c; }
+            for (k = 0; k < n; ++k) Hn *= H;
+            ca_setup(c, W, H, n, cfg->structure_prior >= 0 && cfg->ca_centered == 0);
+            c->S = W * H * Hn; c->A = 3; c->O = Hn;
+            break;
+        }
         case ORC_DOM_GRIDWORLD:
             if (cfg->size < 3 || cfg->size > 15) {
                 snprintf(c->err, sizeof c->err, "please enter a size larger than 3 to be able to run gridworld (you entered %d)", cfg->size);

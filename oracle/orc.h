@@ -71,6 +71,7 @@ typedef struct orc_config {
     int32_t run_offset;    /* first run index (Philox streams; episode sharding) */
     int32_t trace;         /* 1 = record orc_trace_rec per real step */
     int32_t planner;       /* ORC_PLANNER_* */
+    int32_t ca_centered;   /* collision avoidance: 1 = centered-collision-avoidance, 0 = random-collision-avoidance */
 } orc_config;
 
 /* One record per real time-step; the HIP engine emits the same layout (fba_trace_rec). */

@@ -34,7 +34,7 @@ class Config(C.Structure):
         ("noise", C.c_float), ("counts_total", C.c_float),
         ("structure_prior", C.c_int32), ("rng_mode", C.c_int32), ("arith", C.c_int32),
         ("philox_seed", C.c_uint64), ("seed_str", C.c_char * 64),
-        ("run_offset", C.c_int32), ("trace", C.c_int32), ("planner", C.c_int32),
+        ("run_offset", C.c_int32), ("trace", C.c_int32), ("planner", C.c_int32), ("ca_centered", C.c_int32),
     ]
 
 

@@ -26,6 +26,7 @@
 #include "beliefs/particle_filters/ImportanceSampler.hpp"
 #include "beliefs/particle_filters/RejectionSampling.hpp"
 #include "beliefs/particle_filters/WeightedFilter.hpp"
+#include "domains/collision-avoidance/CollisionAvoidance.hpp"
 #include "domains/gridworld/GridWorld.hpp"
 #include "domains/tiger/FactoredTiger.hpp"
 #include "domains/tiger/Tiger.hpp"
@@ -160,6 +161,24 @@ static void gridworld_obs_table(int size)
                     for (unsigned oy = 0; oy < (unsigned)size; ++oy)
                         for (auto const& og : goals)
                             p.push_back(d.computeObservationProbability(d.getObservation({ox, oy}, og), &a, d.getState({x, y}, g)));
+    arr(p, pd);
+}
+
+static void ca_obs_table(domains::CollisionAvoidance const& d, int W, int H, int n)
+{
+    std::vector<double> p;
+    IndexAction a(1);
+    int O = 1;
+    for (int k = 0; k < n; ++k) O *= H;
+    std::vector<int> range(n, H);
+    for (int x = 0; x < W; ++x)
+        for (int y = 0; y < H; ++y) {
+            std::vector<int> obst(n, 0);
+            do {
+                for (int o = 0; o < O; ++o)
+                    p.push_back(d.computeObservationProbability(d.getObservation(o), &a, d.getState(x, y, obst)));
+            } while (!indexing::increment(obst, range));
+        }
     arr(p, pd);
 }
 
@@ -500,6 +519,15 @@ int main(int argc, char** argv)
     { domains::GridWorld d(7); walk(d, "9", 400); }
     key("gridworld3");
     { domains::GridWorld d(3); walk(d, "10", 200); }
+
+    key("ca_5_3_1_random");
+    { domains::CollisionAvoidance d(5, 3, 1, domains::CollisionAvoidance::INIT_RANDOM_POSITION); walk(d, "30", 300); }
+    key("ca_5_3_3_random");
+    { domains::CollisionAvoidance d(5, 3, 3, domains::CollisionAvoidance::INIT_RANDOM_POSITION); walk(d, "31", 400); }
+    key("ca_7_7_2_centered");
+    { domains::CollisionAvoidance d(7, 7, 2, domains::CollisionAvoidance::INITIALIZE_CENTRE); walk(d, "32", 400); }
+    key("ca_4_5_2_obs_prob");
+    { domains::CollisionAvoidance d(4, 5, 2, domains::CollisionAvoidance::INIT_RANDOM_POSITION); ca_obs_table(d, 4, 5, 2); }
 
     key("tiger_obs_prob");
     { domains::Tiger d(domains::Tiger::EPISODIC); obs_table(d, 2, 3, 2); }
