@@ -27,7 +27,7 @@ MAX_ACTIONS = 16
 K_SEARCH, K_ENV, K_BELIEF_RS, K_BELIEF_IS, K_BELIEF_RESET, K_BELIEF_INIT, K_COUNT = range(7)
 KERNEL_NAMES = ["search_kernel", "env_kernel", "reject_kernel", "importance_kernel", "reset_kernel", "init_kernel"]
 
-DOM_TIGER_EPISODIC, DOM_TIGER_CONTINUOUS, DOM_FTIGER_EPISODIC, DOM_FTIGER_CONTINUOUS, DOM_GRIDWORLD, DOM_COLLISION_AVOID = range(6)
+DOM_TIGER_EPISODIC, DOM_TIGER_CONTINUOUS, DOM_FTIGER_EPISODIC, DOM_FTIGER_CONTINUOUS, DOM_GRIDWORLD, DOM_COLLISION_AVOID, DOM_COLLISION_AVOID_CENTERED = range(7)
 MODEL_POMDP, MODEL_BA_TABLE, MODEL_BA_FACTORED = range(3)
 BELIEF_REJECTION, BELIEF_IMPORTANCE = range(2)
 PLANNER_POUCT, PLANNER_RANDOM = range(2)
@@ -37,6 +37,7 @@ DOMAIN_NAMES = {  # reference -D strings (DomainConf.cpp)
     "episodic-tiger": DOM_TIGER_EPISODIC, "continuous-tiger": DOM_TIGER_CONTINUOUS,
     "episodic-factored-tiger": DOM_FTIGER_EPISODIC, "continuous-factored-tiger": DOM_FTIGER_CONTINUOUS,
     "gridworld": DOM_GRIDWORLD,
+    "random-collision-avoidance": DOM_COLLISION_AVOID, "centered-collision-avoidance": DOM_COLLISION_AVOID_CENTERED,
 }
 BELIEF_NAMES = {"rejection_sampling": BELIEF_REJECTION, "importance_sampling": BELIEF_IMPORTANCE}
 PLANNER_NAMES = {"po-uct": PLANNER_POUCT, "random": PLANNER_RANDOM}

@@ -150,6 +150,18 @@ struct GridDesc {
     float disp[32];
 };
 
+// Collision avoidance (reference src/domains/collision-avoidance/CollisionAvoidance.cpp), tables
+// built on the host with libm: err[d] = Phi(d+.5) - Phi(d-.5) (_observation_error_probability),
+// phi[k] = Phi(k - 9 + .5) (inverse-CDF thresholds of round(N(0,1)), the observation noise)
+struct CADesc {
+    int32_t W, H, n, Hn;
+    int32_t start_i0, start_cnt;
+    float start_v;
+    double start_total;
+    double err[16];
+    double phi[20];
+};
+
 // Where the "+1"s of one UpdateCounts step go.  A step reports them as (slot k, blob index) pairs;
 // slot k < ninc(model).  The search ignores them (KeepCounts); the belief kernels park them in one
 // LDS column per thread, [k][thread], so nothing is indexed at run time in registers.
@@ -165,6 +177,7 @@ struct LdsInc {
 struct Problem {
     const FDesc* fd;  // device pointer; null unless model = BA_FACTORED
     const GridDesc* gw;  // device pointer; null unless domain = gridworld
+    const CADesc* ca;    // device pointer; null unless domain = collision avoidance
     float noise, counts_total;
     int32_t structure_prior;
     int32_t domain, model, belief, planner;
@@ -183,6 +196,22 @@ __device__ __forceinline__ bool dom_is_tiger(int d) { return d == FBA_DOM_TIGER_
 __device__ __forceinline__ bool dom_is_ftiger(int d) { return d == FBA_DOM_FTIGER_EPISODIC || d == FBA_DOM_FTIGER_CONTINUOUS; }
 __device__ __forceinline__ bool dom_is_episodic(int d) { return d == FBA_DOM_TIGER_EPISODIC || d == FBA_DOM_FTIGER_EPISODIC; }
 __device__ __forceinline__ bool dom_is_grid(int d) { return d == FBA_DOM_GRIDWORLD; }
+__device__ __forceinline__ bool dom_is_ca(int d) { return d == FBA_DOM_COLLISION_AVOID || d == FBA_DOM_COLLISION_AVOID_CENTERED; }
+
+// ---- collision avoidance helpers: state = (x*H + y)*H^n + project(obstacle rows) ----
+__device__ __forceinline__ int ca_keep(const CADesc* ca, int y) { return max(0, min(ca->H - 1, y)); }
+// row of obstacle k (0-based, most significant digit first) in the packed obstacle index
+__device__ __forceinline__ int ca_obstacle(const CADesc* ca, int packed, int k)
+{
+    int v = packed;
+    for (int j = ca->n - 1; j > k; --j) v /= ca->H;
+    return v % ca->H;
+}
+__device__ __forceinline__ bool ca_crashed(const CADesc* ca, int s)
+{
+    const int H = ca->H, Hn = ca->Hn, x = s / (H * Hn), y = (s / Hn) % H;
+    return x < ca->n && y == ca_obstacle(ca, s % Hn, x);
+}
 
 // ---- gridworld helpers: state index = x*N*G + y*G + g (GridWorld.cpp:329-340) ----
 __device__ __forceinline__ bool gw_slow_at(const GridDesc* gw, int x, int y)
@@ -218,6 +247,16 @@ __device__ __forceinline__ float gw_obs_displ_prob(const GridDesc* gw, int loc, 
 __device__ __forceinline__ int domain_start(const Problem& P, Rng& g)
 {
     if (dom_is_tiger(P.domain)) return g.boolean() ? 0 : 1;
+    if (dom_is_ca(P.domain)) {  // sampleStartState :270-273 -> categoricalDistr::sample -> sampleFromMult<float>
+        const CADesc* ca = P.ca;
+        const double p = g.u01() * ca->start_total;
+        float sum = 0;
+        for (int k = 0; k < ca->start_cnt; ++k) {
+            sum += ca->start_v;
+            if (p < (double)sum) return ca->start_i0 + k;
+        }
+        return P.S - 1;
+    }
     if (dom_is_grid(P.domain)) {  // GridWorld::sampleStartState :260-266 (start_locations = {{0,0}})
         (void)g.slow_int(0, 1);
         return g.slow_int(0, P.gw->G);
@@ -237,6 +276,33 @@ __device__ __forceinline__ int domain_random_action(const Problem& P, Rng& g, in
 __device__ __forceinline__ bool domain_step(const Problem& P, Rng& g, int& s, int a, int& o, double& r)
 {
     const int d = P.domain;
+    if (dom_is_ca(d)) {  // CollisionAvoidance::step :236-270, moveObstacle :330-338, reward :196-208
+        const CADesc* ca = P.ca;
+        const int H = ca->H, n = ca->n, Hn = ca->Hn;
+        const int x = s / (H * Hn), y = (s / Hn) % H, packed = s % Hn;
+        const int nx = x - 1, ny = ca_keep(ca, y + a - 1);
+        int nobs = 0, hit = -1;
+        for (int k = 0; k < n; ++k) {  // obstacles move first, in order ...
+            const double prob = g.u01();
+            const int m = (prob < .5) ? 1 : (prob > .5 * (1 + .5)) ? 2 : 0;
+            const int b = ca_keep(ca, ca_obstacle(ca, packed, k) + m - 1);
+            nobs = nobs * H + b;
+            if (k == nx) hit = b;
+        }
+        int oobs = 0;
+        for (int k = 0; k < n; ++k) {  // ... then each is observed with rounded N(0,1) noise
+            const double u = g.u01();
+            int noise = 10;
+            for (int j = 18; j >= 0; --j)
+                if (u < ca->phi[j]) noise = j - 9;
+            oobs = oobs * H + ca_keep(ca, ca_obstacle(ca, nobs, k) + noise);
+        }
+        s = (nx * H + ny) * Hn + nobs;
+        o = oobs;
+        const bool crashed = nx < n && nx >= 0 && ny == hit;
+        r = crashed ? -1000 : (a == 1 ? 0 : -1);
+        return crashed || nx == 0;
+    }
     if (dom_is_grid(d)) {  // GridWorld::step :272-304, generateObservation :366-394
         const GridDesc* gw = P.gw;
         const int N = gw->N, G = gw->G;
@@ -284,6 +350,12 @@ __device__ __forceinline__ bool domain_step(const Problem& P, Rng& g, int& s, in
 // Tiger / FactoredTiger::computeObservationProbability (Tiger.cpp:27-38)
 __device__ __forceinline__ double domain_obs_prob(const Problem& P, int o, int a, int new_s)
 {
+    if (dom_is_ca(P.domain)) {  // CollisionAvoidance::computeObservationProbability :216-229
+        const CADesc* ca = P.ca;
+        double p = 1;
+        for (int k = 0; k < ca->n; ++k) p *= ca->err[abs(ca_obstacle(ca, new_s % ca->Hn, k) - ca_obstacle(ca, o, k))];
+        return p;
+    }
     if (dom_is_grid(P.domain)) {  // GridWorld::computeObservationProbability :236-250 (goal part ignored)
         const GridDesc* gw = P.gw;
         const int N = gw->N, G = gw->G;
@@ -296,13 +368,15 @@ __device__ __forceinline__ double domain_obs_prob(const Problem& P, int o, int a
 
 // BADomainExtension::terminal / reward (TigerBAExtension.cpp:21-44, FactoredTigerBAExtension.cpp):
 // the reward is looked up with the PRE-state s.
-__device__ __forceinline__ bool ext_terminal(const Problem& P, int s, int a, int /*ns*/)
+__device__ __forceinline__ bool ext_terminal(const Problem& P, int s, int a, int ns)
 {
+    if (dom_is_ca(P.domain)) return ca_crashed(P.ca, ns) || ns / (P.ca->H * P.ca->Hn) == 0;  // CollisionAvoidanceBAExtension.cpp:53-63 (NEW state)
     if (dom_is_grid(P.domain)) return gw_on_goal(P.gw, s);  // GridWorldBAExtension.cpp:74-83
     return dom_is_episodic(P.domain) && a != 2;
 }
-__device__ __forceinline__ double ext_reward(const Problem& P, int s, int a, int /*ns*/)
+__device__ __forceinline__ double ext_reward(const Problem& P, int s, int a, int ns)
 {
+    if (dom_is_ca(P.domain)) return ca_crashed(P.ca, ns) ? -1000 : (a == 1 ? 0 : -1);  // CollisionAvoidanceBAExtension.cpp:65-82
     if (dom_is_grid(P.domain)) return gw_on_goal(P.gw, s) ? 1 : 0;  // GridWorldBAExtension.cpp:85-99
     if (a == 2) return -1;
     const int loc = dom_is_tiger(P.domain) ? s : ((s < P.S / 2) ? 0 : 1);
@@ -494,6 +568,7 @@ __device__ __forceinline__ void gw_fill_xy_node_with_goal(const Problem& P, floa
 
 __device__ __forceinline__ void factored_prior_sample(const Problem& P, Rng& g, float* rec)
 {
+    if (dom_is_ca(P.domain)) return;  // fixed structures only
     if (dom_is_grid(P.domain)) {  // GridWorldFactBAPrior::sampleFBAPOMDPState :415-441
         if (P.structure_prior != FBA_SP_MATCH_UNIFORM) return;
         for (int a = 0; a < P.A; ++a)

@@ -40,6 +40,8 @@ struct fba_ctx {
     FDesc* d_fdesc       = nullptr;
     GridDesc gdesc{};
     GridDesc* d_gdesc    = nullptr;
+    CADesc cadesc{};
+    CADesc* d_cadesc     = nullptr;
     double* d_uni_scan   = nullptr;
     double* d_log1p      = nullptr;
     int32_t* d_n_active  = nullptr;
@@ -90,6 +92,31 @@ int dev_alloc(fba_ctx* c, T** p, size_t n, bool zero = true)
 
 bool is_tiger(int d) { return d == FBA_DOM_TIGER_EPISODIC || d == FBA_DOM_TIGER_CONTINUOUS; }
 bool is_ftiger(int d) { return d == FBA_DOM_FTIGER_EPISODIC || d == FBA_DOM_FTIGER_CONTINUOUS; }
+
+bool is_ca(int d) { return d == FBA_DOM_COLLISION_AVOID || d == FBA_DOM_COLLISION_AVOID_CENTERED; }
+double normal_cdf(double x) { return .5 + .5 * std::erf(x / (1 * std::sqrt(2.0))); }  // rnd::normal::cdf random.cpp:119-124
+
+// Collision avoidance tables (reference CollisionAvoidance.cpp ctor :100-142)
+void build_collision_avoidance(CADesc& c, int W, int H, int n, bool random_start)
+{
+    std::memset(&c, 0, sizeof c);
+    c.W = W; c.H = H; c.n = n; c.Hn = 1;
+    for (int k = 0; k < n; ++k) c.Hn *= H;
+    for (int d = 0; d < H; ++d) c.err[d] = normal_cdf(d + .5) - normal_cdf(d - .5);
+    for (int k = 0; k < 19; ++k) c.phi[k] = normal_cdf((k - 9) + .5);
+    if (random_start) {  // every state with x = W-1, probability 1.f / pow(H, n + 1) each
+        c.start_v   = (float)(1.f / std::pow(H, n + 1));
+        c.start_i0  = (W - 1) * H * c.Hn;
+        c.start_cnt = H * c.Hn;
+        c.start_total = 0;
+        for (int k = 0; k < c.start_cnt; ++k) c.start_total += c.start_v;  // categoricalDistr::setRawValue
+    } else {             // agent and obstacles in the middle row
+        int obs = 0;
+        for (int k = 0; k < n; ++k) obs = obs * H + H / 2;
+        c.start_v = 1; c.start_total = 1; c.start_cnt = 1;
+        c.start_i0 = ((W - 1) * H + H / 2) * c.Hn + obs;
+    }
+}
 
 // GridWorld geometry (reference src/domains/gridworld/GridWorld.cpp)
 void build_gridworld(GridDesc& g, int N)
@@ -272,10 +299,96 @@ int build_gridworld_factored_prior(fba_ctx* c)
     return FBA_OK;
 }
 
+// CollisionAvoidanceFactoredPrior ctor (reference
+// src/domains/collision-avoidance/CollisionAvoidancePriors.cpp:210-347, obstacleTransition :385-404,
+// observationDistr :46-63) for the fixed structures: "" / match-counts (every obstacle depends on
+// itself) and fully-connected (every obstacle depends on all features).  Features
+// {x, y, obstacle_1..n}; observation features = the n observed obstacle rows.
+int build_ca_factored_prior(fba_ctx* c)
+{
+    Problem& P = c->P;
+    const CADesc& ca = c->cadesc;
+    const int A = P.A, W = ca.W, H = ca.H, n = ca.n, FS = 2 + n;
+    const float noise = c->cfg.noise, total = c->cfg.counts_total;
+    const bool full = c->cfg.structure_prior == FBA_SP_FULLY_CONNECTED;
+    if (noise > .5 || noise < -.5) return fail(c, FBA_EINVAL, "CollisionAvoidanceFactoredPrior must be intiiated with -.5 < noise < .5 (is: %f)", noise);
+    if (c->cfg.structure_prior != FBA_SP_NONE && !full)
+        return fail(c, FBA_EINVAL, "collision avoidance: structure priors 'uniform' / 'match-uniform' are not built (variable-size CPTs)");
+    if (FS > MAXF || A * (FS + n) > MAXNODES) return fail(c, FBA_EINVAL, "too many state features");
+    FDesc& d = c->fdesc;
+    std::memset(&d, 0, sizeof d);
+    d.FS = FS; d.FO = n;
+    d.Ssz[0] = W; d.Ssz[1] = H;
+    for (int f = 0; f < n; ++f) { d.Ssz[2 + f] = H; d.Osz[f] = H; }
+    fdesc_steps(d.Ssz, FS, d.Sstep);
+    fdesc_steps(d.Osz, n, d.Ostep);
+    int off = 0;
+    for (int a = 0; a < A; ++a)
+        for (int f = 0; f < FS; ++f) {
+            FNode& nd = d.nodes[a * FS + f];
+            nd.off = off; nd.out = d.Ssz[f]; nd.var = -1;
+            if (f >= 2 && full) {
+                int rows = 1;
+                nd.nmax = FS;
+                for (int k = 0; k < FS; ++k) { nd.maxp[k] = (uint8_t)k; rows *= d.Ssz[k]; }
+                nd.fixed_mask = (1u << FS) - 1u;
+                off += rows * H;
+            } else {
+                nd.nmax = 1; nd.maxp[0] = (uint8_t)f; nd.fixed_mask = 1;
+                off += d.Ssz[f] * d.Ssz[f];
+            }
+        }
+    for (int a = 0; a < A; ++a)
+        for (int f = 0; f < n; ++f) {
+            FNode& nd = d.nodes[A * FS + a * n + f];
+            nd.off = off; nd.out = H; nd.var = -1; nd.nmax = 1; nd.maxp[0] = (uint8_t)(2 + f); nd.fixed_mask = 1;
+            off += H * H;
+        }
+    d.ncounts = off;
+    d.nvar    = 0;
+    c->prior.assign((size_t)off, 0.f);
+    float* pr = c->prior.data();
+    auto obstacle_transition = [&](int y, float* out) {
+        const float move_prob = (float)(.25 - .5 * noise);
+        const float stay_prob = (y == 0 || y == H - 1) ? (float)(3 * .25 + .5 * noise) : (float)(2 * .25 + noise);
+        for (int k = 0; k < H; ++k) out[k] = 0;
+        if (y != 0) out[y - 1] = move_prob * total;
+        if (y != H - 1) out[y + 1] = move_prob * total;
+        out[y] = stay_prob * total;
+    };
+    for (int a = 0; a < A; ++a) {
+        for (int x = 1; x < W; ++x) pr[d.nodes[a * FS + 0].off + x * W + (x - 1)] = 1;
+        for (int y = 0; y < H; ++y) pr[d.nodes[a * FS + 1].off + y * H + std::max(0, std::min(H - 1, y + a - 1))] += 1;
+        for (int f = 2; f < FS; ++f) {
+            const FNode& nd = d.nodes[a * FS + f];
+            if (!full) {
+                for (int y = 0; y < H; ++y) obstacle_transition(y, pr + nd.off + y * H);
+            } else {
+                int rows = 1;
+                for (int k = 0; k < FS; ++k) rows *= d.Ssz[k];
+                for (int r = 0; r < rows; ++r) obstacle_transition((r / d.Sstep[f]) % d.Ssz[f], pr + nd.off + r * H);
+            }
+        }
+        for (int f = 0; f < n; ++f)
+            for (int y = 0; y < H; ++y) {
+                float* row = pr + d.nodes[A * FS + a * n + f].off + y * H;
+                row[0] = (float)normal_cdf(-y + .5);
+                for (int oy = 1; oy < H - 1; ++oy) {
+                    const int dist = std::abs(oy - y);
+                    row[oy] = (float)(normal_cdf(dist + .5) - normal_cdf(dist - .5));
+                }
+                row[H - 1] = (float)normal_cdf(-(H - 1 - y) + .5);
+                for (int oy = 0; oy < H; ++oy) row[oy] *= 10000;
+            }
+    }
+    return FBA_OK;
+}
+
 int build_ftiger_factored_prior(fba_ctx* c);
 
 int build_factored_prior(fba_ctx* c)
 {
+    if (is_ca(c->P.domain)) return build_ca_factored_prior(c);
     if (c->P.domain == FBA_DOM_GRIDWORLD) return build_gridworld_factored_prior(c);
     return build_ftiger_factored_prior(c);
 }
@@ -574,6 +687,23 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
             }
             P.S = 2 << cfg->size; P.A = 3; P.O = 2;
             break;
+        case FBA_DOM_COLLISION_AVOID:
+        case FBA_DOM_COLLISION_AVOID_CENTERED: {
+            const int W = cfg->width, H = cfg->height, n = cfg->size;
+            const char* bad = nullptr;
+            char msg[160];
+            if (W < 1) { snprintf(msg, sizeof msg, "Cannot initiate CollisionAvoidance with width %d", W); bad = msg; }
+            else if (H < 1 || H % 2 != 1 || H > 15) { snprintf(msg, sizeof msg, "Cannot initiate CollisionAvoidance with height %d, must be uneven", H); bad = msg; }
+            else if (n > W || n < 1 || n > MAXF - 2) { snprintf(msg, sizeof msg, "cannot initiate collision avoidance with more obstacles (%d ) than columns (%d)!", n, W); bad = msg; }
+            if (bad) {
+                fail(nullptr, FBA_EINVAL, "%s", bad);
+                delete c;
+                return FBA_EINVAL;
+            }
+            build_collision_avoidance(c->cadesc, W, H, n, cfg->domain == FBA_DOM_COLLISION_AVOID);
+            P.S = W * H * c->cadesc.Hn; P.A = 3; P.O = c->cadesc.Hn;
+            break;
+        }
         case FBA_DOM_GRIDWORLD:
             if (cfg->size < 3 || cfg->size > 15) {
                 fail(nullptr, FBA_EINVAL, "please enter a size larger than 3 to be able to run gridworld (you entered %d)", cfg->size);
@@ -602,6 +732,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     P.structure_prior = cfg->structure_prior;
     P.fd = nullptr;
     P.gw = nullptr;
+    P.ca = nullptr;
     if (cfg->model == FBA_MODEL_BA_TABLE) {
         P.phi_len = P.S * P.A * P.S;
         P.C       = P.phi_len + P.A * P.S * P.O;
@@ -635,8 +766,8 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         delete c;
         return FBA_EINVAL;
     }
-    if (cfg->model == FBA_MODEL_BA_TABLE && cfg->domain == FBA_DOM_GRIDWORLD) {
-        fail(nullptr, FBA_EINVAL, "the tabular gridworld prior (S*A*S counts per particle) is not built; use the factored model");
+    if (cfg->model == FBA_MODEL_BA_TABLE && (cfg->domain == FBA_DOM_GRIDWORLD || is_ca(cfg->domain))) {
+        fail(nullptr, FBA_EINVAL, "the tabular prior of this domain (S*A*S counts per particle) is not built; use the factored model");
         delete c;
         return FBA_EINVAL;
     }
@@ -754,6 +885,11 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         HIPC(hipStreamSynchronize(c->stream));
     }
     if (cfg->model == FBA_MODEL_BA_TABLE) CHK(build_tabular_prior(c));
+    if (is_ca(cfg->domain)) {
+        CHK(dev_alloc(c, &c->d_cadesc, 1));
+        HIPC(hipMemcpyAsync(c->d_cadesc, &c->cadesc, sizeof(CADesc), hipMemcpyHostToDevice, c->stream));
+        P.ca = c->d_cadesc;
+    }
     if (cfg->domain == FBA_DOM_GRIDWORLD) {
         CHK(dev_alloc(c, &c->d_gdesc, 1));
         HIPC(hipMemcpyAsync(c->d_gdesc, &c->gdesc, sizeof(GridDesc), hipMemcpyHostToDevice, c->stream));

@@ -35,7 +35,8 @@ enum {
     FBA_DOM_FTIGER_EPISODIC   = 2, /* episodic-factored-tiger    src/domains/tiger/FactoredTiger.cpp  */
     FBA_DOM_FTIGER_CONTINUOUS = 3, /* continuous-factored-tiger                                       */
     FBA_DOM_GRIDWORLD         = 4, /* gridworld                  src/domains/gridworld/GridWorld.cpp  */
-    FBA_DOM_COLLISION_AVOID   = 5
+    FBA_DOM_COLLISION_AVOID   = 5, /* random-collision-avoidance src/domains/collision-avoidance/CollisionAvoidance.cpp */
+    FBA_DOM_COLLISION_AVOID_CENTERED = 6 /* centered-collision-avoidance (VERSION INITIALIZE_CENTRE) */
 };
 /* simulator: plain POMDP (planning), tabular BA-POMDP (bapomdp), factored (fbapomdp) */
 enum { FBA_MODEL_POMDP = 0, FBA_MODEL_BA_TABLE = 1, FBA_MODEL_BA_FACTORED = 2 };

@@ -829,8 +829,103 @@ static int build_gridworld_factored_prior(orc_ctx* c)
     return 0;
 }
 
+/* CollisionAvoidanceFactoredPrior ctor (CollisionAvoidancePriors.cpp:210-347), structure priors ""
+ * / "match-counts" (correct graph) and "fully-connected".  Features {x, y, obstacle_1..n};
+ * T parents x:{x}, y:{y}, obstacle f:{f} (or all features when fully connected); O parents
+ * observed obstacle f:{obstacle f}.  The per-particle edge noise ("uniform", "match-uniform")
+ * needs variable-size CPTs and is not built. */
+static void ca_obstacle_transition(const orc_ctx* c, int y, float* out) /* obstacleTransition :385-404 */
+{
+    int H = c->ca_H, k;
+    float move_prob = (float)(.25 - .5 * c->cfg.noise);
+    float stay_prob = (y == 0 || y == H - 1) ? (float)(3 * .25 + .5 * c->cfg.noise) : (float)(2 * .25 + c->cfg.noise);
+    for (k = 0; k < H; ++k) out[k] = 0;
+    if (y != 0) out[y - 1] = move_prob * c->cfg.counts_total;
+    if (y != H - 1) out[y + 1] = move_prob * c->cfg.counts_total;
+    out[y] = stay_prob * c->cfg.counts_total;
+}
+static int build_ca_factored_prior(orc_ctx* c)
+{
+    fdesc* d = &c->fd;
+    int A = c->A, W = c->ca_W, H = c->ca_H, n = c->ca_n, FS = 2 + n, a, f, off = 0, y, k;
+    int full = c->cfg.structure_prior == ORC_SP_FULLY_CONNECTED;
+    if (c->cfg.noise > .5 || c->cfg.noise < -.5) {
+        snprintf(c->err, sizeof c->err, "CollisionAvoidanceFactoredPrior must be intiiated with -.5 < noise < .5 (is: %f)", c->cfg.noise);
+        return -1;
+    }
+    if (c->cfg.structure_prior != ORC_SP_NONE && !full) {
+        snprintf(c->err, sizeof c->err, "collision avoidance: structure priors 'uniform' / 'match-uniform' are not built");
+        return -1;
+    }
+    if (FS > ORC_MAXF) { snprintf(c->err, sizeof c->err, "too many state features"); return -1; }
+    d->FS = FS; d->FO = n;
+    d->Ssz[0] = W; d->Ssz[1] = H;
+    for (f = 0; f < n; ++f) { d->Ssz[2 + f] = H; d->Osz[f] = H; }
+    fdesc_steps(d->Ssz, FS, d->Sstep);
+    fdesc_steps(d->Osz, n, d->Ostep);
+    d->T = (fnode*)calloc((size_t)A * FS, sizeof(fnode));
+    d->O = (fnode*)calloc((size_t)A * n, sizeof(fnode));
+    for (a = 0; a < A; ++a)
+        for (f = 0; f < FS; ++f) {
+            fnode* nd = &d->T[a * FS + f];
+            nd->off = off; nd->out = d->Ssz[f]; nd->var = -1;
+            if (f >= 2 && full) {
+                int rows = 1;
+                nd->nmax = FS;
+                for (k = 0; k < FS; ++k) { nd->maxp[k] = k; rows *= d->Ssz[k]; }
+                nd->fixed_mask = (1u << FS) - 1u;
+                off += rows * H;
+            } else {
+                nd->nmax = 1; nd->maxp[0] = f; nd->fixed_mask = 1;
+                off += d->Ssz[f] * d->Ssz[f];
+            }
+        }
+    for (a = 0; a < A; ++a)
+        for (f = 0; f < n; ++f) {
+            fnode* nd = &d->O[a * n + f];
+            nd->off = off; nd->out = H; nd->var = -1; nd->nmax = 1; nd->maxp[0] = 2 + f; nd->fixed_mask = 1;
+            off += H * H;
+        }
+    d->ncounts = off;
+    d->nvar    = 0;
+    c->ncnt    = off;
+    c->prior   = (float*)calloc((size_t)off, sizeof(float));
+    for (a = 0; a < A; ++a) {
+        int x;
+        for (x = 1; x < W; ++x) c->prior[d->T[a * FS + 0].off + x * W + (x - 1)] = 1; /* agent always moves one column */
+        for (y = 0; y < H; ++y) c->prior[d->T[a * FS + 1].off + y * H + ca_keep(c, y + a - 1)] += 1; /* setAgentYTransition */
+        for (f = 2; f < FS; ++f) {
+            const fnode* nd = &d->T[a * FS + f];
+            if (!full) {
+                for (y = 0; y < H; ++y) ca_obstacle_transition(c, y, c->prior + nd->off + y * H);
+            } else { /* every parent-value combination gets obstacleTransition(value of the obstacle itself) */
+                int rows = 1, r;
+                for (k = 0; k < FS; ++k) rows *= d->Ssz[k];
+                for (r = 0; r < rows; ++r) {
+                    int v = (r / d->Sstep[f]) % d->Ssz[f];
+                    ca_obstacle_transition(c, v, c->prior + nd->off + r * H);
+                }
+            }
+        }
+        for (f = 0; f < n; ++f) /* observationDistr(height, y) * 10000 (:46-63, :289-300) */
+            for (y = 0; y < H; ++y) {
+                float* row = c->prior + d->O[a * n + f].off + y * H;
+                int oy;
+                row[0] = (float)normal_cdf(-y + .5);
+                for (oy = 1; oy < H - 1; ++oy) {
+                    int dist = abs(oy - y);
+                    row[oy]  = (float)(normal_cdf(dist + .5) - normal_cdf(dist - .5));
+                }
+                row[H - 1] = (float)normal_cdf(-(H - 1 - y) + .5);
+                for (oy = 0; oy < H; ++oy) row[oy] *= 10000;
+            }
+    }
+    return 0;
+}
+
 static int build_factored_prior(orc_ctx* c)
 {
+    if (is_ca(c->cfg.domain)) return build_ca_factored_prior(c);
     if (is_ftiger(c->cfg.domain)) return build_ftiger_factored_prior(c);
     if (is_grid(c->cfg.domain)) return build_gridworld_factored_prior(c);
     snprintf(c->err, sizeof c->err, "domain %d has no factored prior in the oracle", c->cfg.domain);
@@ -843,6 +938,7 @@ static int build_factored_prior(orc_ctx* c)
 static void factored_prior_sample(orc_ctx* c, float* cnt)
 {
     memcpy(cnt, c->prior, sizeof(float) * (size_t)c->ncnt);
+    if (is_ca(c->cfg.domain)) return; /* fixed structures only: no draws */
     if (is_grid(c->cfg.domain)) {
         /* GridWorldFactBAPrior::sampleFBAPOMDPState (GridWorldBAPriors.cpp:415-441): per action,
          * one boolean for the x node and one for the y node: add the goal feature as a parent */

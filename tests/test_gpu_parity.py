@@ -13,15 +13,19 @@ from oracle import pyorc as orc
 
 pytestmark = pytest.mark.gpu
 
-DOM = {"gridworld": orc.DOM_GRIDWORLD, "episodic-tiger": orc.DOM_TIGER_EPISODIC, "continuous-tiger": orc.DOM_TIGER_CONTINUOUS,
+DOM = {"random-collision-avoidance": orc.DOM_COLLISION_AVOID, "centered-collision-avoidance": orc.DOM_COLLISION_AVOID,
+       "gridworld": orc.DOM_GRIDWORLD, "episodic-tiger": orc.DOM_TIGER_EPISODIC, "continuous-tiger": orc.DOM_TIGER_CONTINUOUS,
        "episodic-factored-tiger": orc.DOM_FTIGER_EPISODIC, "continuous-factored-tiger": orc.DOM_FTIGER_CONTINUOUS}
 
 
 def _pair(domain, model, belief, seed, slots=None, size=0, **kw):
     runs = kw.get("runs", 1)
     eng = fba.Engine(domain, model=model, belief=belief, seed=seed, slots=slots or runs, trace=1, size=size, **kw)
+    okw = dict(kw)
+    if domain == "centered-collision-avoidance":
+        okw["ca_centered"] = 1
     o = orc.Oracle(domain=DOM[domain], model=model, belief=N.BELIEF_NAMES[belief], rng_mode=orc.RNG_PHILOX,
-                   arith=orc.ARITH_DEV, philox_seed=seed, trace=1, size=size, **kw)
+                   arith=orc.ARITH_DEV, philox_seed=seed, trace=1, size=size, **okw)
     return eng, o
 
 
@@ -237,6 +241,32 @@ def test_gridworld7_one_search_and_update():
         os_, ow, ocnt = o.belief_get()
         assert np.array_equal(s, os_) and np.array_equal(w, ow)
         assert np.array_equal(cnt.view(np.uint32), ocnt.view(np.uint32))
+
+
+@pytest.mark.parametrize("domain", ["random-collision-avoidance", "centered-collision-avoidance"])
+def test_planning_collision_avoidance(domain):
+    """planning -D *-collision-avoidance: true dynamics (obstacle moves, rounded-normal observation
+    noise, crash / arrival termination), importance filter with computeObservationProbability."""
+    eng, o = _pair(domain, N.MODEL_POMDP, "importance_sampling", 121, size=2, width=5, height=3, particles=100,
+                   sims=200, runs=10, horizon=8)
+    _assert_same_experiment(eng, o, ba=False)
+
+
+@pytest.mark.parametrize("sp,W,H,n", [(0, 5, 3, 3), (0, 7, 7, 2), (3, 4, 3, 1)])
+def test_fbapomdp_collision_avoidance(sp, W, H, n):
+    """fbapomdp -D random-collision-avoidance (largest factored domain; BASELINE configs[4] at
+    parity size): correct-graph and fully-connected priors."""
+    eng, o = _pair("random-collision-avoidance", N.MODEL_BA_FACTORED, "importance_sampling", 123 + sp, size=n, width=W,
+                   height=H, particles=80, sims=150, runs=6, episodes=3, structure_prior=sp)
+    _assert_same_experiment(eng, o, ba=True)
+
+
+def test_collision_avoidance_prior_equals_oracle():
+    for sp in (0, 3):
+        kw = dict(width=5, height=5, size=2, structure_prior=sp, noise=0.1, counts_total=500.0)
+        eng = fba.Engine("random-collision-avoidance", model=N.MODEL_BA_FACTORED, particles=4, sims=4, slots=1, belief=1, **kw)
+        o = orc.Oracle(domain=orc.DOM_COLLISION_AVOID, model=orc.MODEL_BA_FACTORED, **kw)
+        assert np.array_equal(eng.prior(), o.prior_counts())
 
 
 def test_bapomdp_slots_fewer_than_runs():
