@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -771,8 +772,8 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         delete c;
         return FBA_EINVAL;
     }
-    if (cfg->belief == FBA_BELIEF_IMPORTANCE && P.N > IS_MAX_CHUNKS * 256) {
-        fail(nullptr, FBA_EINVAL, "importance sampling supports at most %d particles per slot", IS_MAX_CHUNKS * 256);
+    if (cfg->belief == FBA_BELIEF_IMPORTANCE && P.N > (1 << 26)) {
+        fail(nullptr, FBA_EINVAL, "importance sampling supports at most %d particles per slot", 1 << 26);
         delete c;
         return FBA_EINVAL;
     }
@@ -843,7 +844,16 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     CHK(dev_alloc(c, &D.p_weight, is ? (size_t)2 * E * P.N : 1));
     CHK(dev_alloc(c, &D.p_rec, (size_t)2 * E * P.N * P.Cs, false));
     CHK(dev_alloc(c, &D.wscan, is ? (size_t)E * P.N : 1, false));
-    CHK(dev_alloc(c, &D.src_idx, 1));
+    {
+        // one workgroup per slot up to IS_MAX_CHUNKS*256 particles, several launches beyond
+        // (FBA_IS_MULTI_MIN lowers the switch-over so tests can exercise the large-filter path)
+        int multi_min = IS_MAX_CHUNKS * 256 + 1;
+        if (const char* ev = std::getenv("FBA_IS_MULTI_MIN")) multi_min = std::max(1, std::atoi(ev));
+        D.is_multi    = is && P.N >= multi_min;
+        D.ctot_stride = (P.N + 255) / 256 + 2;
+        CHK(dev_alloc(c, &D.ctot, is ? (size_t)E * D.ctot_stride : 1));
+        CHK(dev_alloc(c, &D.is_tot, (size_t)2 * E));
+    }
     CHK(dev_alloc(c, &D.nodes, (size_t)E * D.max_nodes * D.node_words, false));
     if (hashed) {
         CHK(dev_alloc(c, &D.hash, (size_t)E * hcap));
@@ -880,7 +890,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     if (is) {
         double* tmp = nullptr;
         CHK(dev_alloc(c, &tmp, (size_t)P.N + 1));
-        launch_uniform_scan(P.N, tmp, c->d_uni_scan, c->d_uni_scan + P.N, c->stream);
+        launch_uniform_scan(P.N, tmp, c->d_uni_scan, c->d_uni_scan + P.N, D.ctot, c->stream);
         HIPC(hipMemcpyAsync(&D.uni_total, c->d_uni_scan + P.N, sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPC(hipStreamSynchronize(c->stream));
     }

@@ -12,6 +12,8 @@ constexpr int SEARCH_STAGE_WORDS = 32;
 constexpr int ROOT_CHILDREN = 8;       // root child pointers are kept in LDS when A*O is at most this  // particle records up to this many words are staged in LDS
 constexpr int REJECT_BLOCK  = 256;   // attempts per chunk of the rejection filter
 constexpr int IS_BLOCK      = 1024;  // one workgroup per slot in the importance filter
+constexpr int PARTICLE_TILE = 4096;  // particles one workgroup initialises / resets
+constexpr int CARRY_TILE    = 2048;  // chunk totals staged in LDS per step of the carry chain
 constexpr int IS_MAX_CHUNKS = 256;   // 256-element scan chunks per slot => N <= 65536
 
 void launch_search(const Problem& P, const DeviceState& D, hipStream_t st);
@@ -23,6 +25,6 @@ void launch_init(const Problem& P, const DeviceState& D, hipStream_t st);
 void launch_reset(const Problem& P, const DeviceState& D, hipStream_t st);
 void launch_flush(const Problem& P, const DeviceState& D, hipStream_t st);
 void launch_selftest_ucb(const double* L, const int32_t* n, int count, double u, double* out, hipStream_t st);
-void launch_uniform_scan(int n, double* w_tmp, double* out, double* total, hipStream_t st);
+void launch_uniform_scan(int n, double* w_tmp, double* out, double* total, double* ctot, hipStream_t st);
 
 }  // namespace fba

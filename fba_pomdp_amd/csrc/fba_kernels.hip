@@ -685,14 +685,226 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
 }
 
 // ---------------------------------------------------------------------------------------------
+// Multi-workgroup importance filter: the same algorithm and the same device-order sums as
+// importance_kernel, cut at its block-wide synchronisation points into separate launches so that a
+// filter of millions of particles (N > 65536) spreads over the whole chip:
+//   is_multi_step   step + weight + totals of each 256-chunk      (one wave per chunk)
+//   scan_carry      chunk totals -> carries, sequentially          (one lane per slot)
+//   is_multi_norm   w /= total, chunk totals of the normalised w
+//   scan_carry
+//   scan_write      inclusive prefix sums from carries
+//   is_multi_resample  N binary searches + whole-record gather
+//   is_multi_finish flip buffers, counters
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double chunk_lane_sum(const double* __restrict__ in, int n, int i0, double (&x)[4])
+{
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        x[k] = (i0 + k < n) ? in[i0 + k] : 0.0;
+        s    = (k == 0) ? x[k] : s + x[k];
+    }
+    return s;
+}
+
+// totals of every 256-element chunk of w (ctot[c + 1] = total of chunk c); one wave per chunk
+__global__ void __launch_bounds__(256) chunk_totals_kernel(const double* w_base, size_t w_stride, int n, double* ctot_base, int ctot_stride,
+                                                           const uint8_t* need)
+{
+    const int e = blockIdx.y;
+    if (need && !need[e]) return;
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c * 256 >= n) return;
+    double x[4];
+    const double incl = wave_inclusive_scan(chunk_lane_sum(w_base + (size_t)e * w_stride, n, c * 256 + lane * 4, x), lane);
+    if (lane == 63) ctot_base[(size_t)e * ctot_stride + c + 1] = incl;
+}
+
+// One workgroup per slot.  The chain carry_{c+1} = carry_c + total_c is sequential by definition
+// (device-order sums); the totals are staged through LDS in tiles so the one lane that chains them
+// never waits on HBM.
+__global__ void __launch_bounds__(256) scan_carry_kernel(double* ctot_base, int ctot_stride, int nchunks, double* total_base,
+                                                         int total_stride, int which, const uint8_t* need, int count)
+{
+    __shared__ double tile[CARRY_TILE];
+    __shared__ double s_carry0;
+    const int e = blockIdx.x, tid = threadIdx.x;
+    if (e >= count || (need && !need[e])) return;
+    double* ct = ctot_base + (size_t)e * ctot_stride;
+    if (tid == 0) { s_carry0 = 0; ct[0] = 0; }
+    for (int c0 = 0; c0 < nchunks; c0 += CARRY_TILE) {
+        const int m = min(CARRY_TILE, nchunks - c0);
+        __syncthreads();
+        for (int k = tid; k < m; k += 256) tile[k] = ct[c0 + k + 1];
+        __syncthreads();
+        if (tid == 0) {
+            double carry = s_carry0;
+            for (int k = 0; k < m; ++k) {
+                carry   = carry + tile[k];
+                tile[k] = carry;
+            }
+            s_carry0 = carry;
+        }
+        __syncthreads();
+        for (int k = tid; k < m; k += 256) ct[c0 + k + 1] = tile[k];
+    }
+    __syncthreads();
+    if (tid == 0) total_base[(size_t)e * total_stride + which] = s_carry0;
+}
+
+__global__ void __launch_bounds__(256) scan_write_kernel(const double* w_base, size_t w_stride, int n, const double* ctot_base, int ctot_stride,
+                                                         double* out_base, size_t out_stride, const uint8_t* need)
+{
+    const int e = blockIdx.y;
+    if (need && !need[e]) return;
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c * 256 >= n) return;
+    const int i0 = c * 256 + lane * 4;
+    double x[4];
+    const double incl = wave_inclusive_scan(chunk_lane_sum(w_base + (size_t)e * w_stride, n, i0, x), lane);
+    double excl       = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 0.0;
+    double run  = ctot_base[(size_t)e * ctot_stride + c] + excl;
+    double* out = out_base + (size_t)e * out_stride;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (i0 + k < n) {
+            run += x[k];
+            out[i0 + k] = run;
+        }
+}
+
+__global__ void fill_kernel(double* p, int n, double v)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+__global__ void __launch_bounds__(256) is_multi_step_kernel(Problem P, DeviceState D)
+{
+    __shared__ int32_t s_inc[MAXINC * 256];
+    const int e = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    if (!D.need_update[e]) return;
+    const int c = blockIdx.x * 4 + (tid >> 6), N = P.N;
+    if (c * 256 >= N) return;
+    const int a = D.action[e], o = D.obs[e], ninc = model_ninc(P);
+    const size_t sb = pbase(P, e, D.bufsel[e]);
+    double* sw = D.p_weight + sb;
+    float* scn = D.p_rec + sb * (size_t)P.Cs;
+    Rng g = slot_rng(P, D, e);
+    const int i0 = c * 256 + lane * 4;
+    double sum = 0;
+    for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k;
+        double v = 0.0;
+        if (i < N) {
+            g.stream(FBA_PHASE_IS_UPDATE, (uint32_t)i);
+            float* cnt = scn + (size_t)i * P.Cs;
+            int s = rec_state(cnt, P.C), so;
+            double r;
+            sim_step(P, g, GlobalView{cnt}, s, a, so, r, LdsInc<256>{s_inc + tid});
+            for (int q = 0; q < ninc; ++q) cnt[s_inc[q * 256 + tid]] += 1.0f;
+            rec_set_state(cnt, P.C, s);
+            v     = sw[i] * sim_obs_prob(P, GlobalView{cnt}, s, a, o);
+            sw[i] = v;
+        }
+        sum = (k == 0) ? v : sum + v;
+    }
+    const double incl = wave_inclusive_scan(sum, lane);
+    if (lane == 63) D.ctot[(size_t)e * D.ctot_stride + c + 1] = incl;
+}
+
+__global__ void __launch_bounds__(256) is_multi_norm_kernel(Problem P, DeviceState D)
+{
+    const int e = blockIdx.y, lane = threadIdx.x & 63;
+    if (!D.need_update[e]) return;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), N = P.N;
+    if (c * 256 >= N) return;
+    double* sw = D.p_weight + pbase(P, e, D.bufsel[e]);
+    const double total = D.is_tot[2 * e + 0];
+    const int i0 = c * 256 + lane * 4;
+    double sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        double v = 0.0;
+        if (i0 + k < N) {
+            v = sw[i0 + k] / total;
+            sw[i0 + k] = v;
+        }
+        sum = (k == 0) ? v : sum + v;
+    }
+    const double incl = wave_inclusive_scan(sum, lane);
+    if (lane == 63) D.ctot[(size_t)e * D.ctot_stride + c + 1] = incl;
+}
+
+__global__ void __launch_bounds__(256) is_multi_resample_kernel(Problem P, DeviceState D)
+{
+    __shared__ int32_t s_src[256];
+    const int e = blockIdx.y, tid = threadIdx.x;
+    if (!D.need_update[e]) return;
+    const int N = P.N, j0 = blockIdx.x * 256, j = j0 + tid;
+    const int cur = D.bufsel[e];
+    const size_t sb = pbase(P, e, cur), db = pbase(P, e, cur ^ 1);
+    const double* wscan = D.wscan + (size_t)e * N;
+    const int C4 = P.Cs / 4, group = record_group(C4);
+    if (j < N) {
+        Rng g = slot_rng(P, D, e);
+        g.stream(FBA_PHASE_RESAMPLE, (uint32_t)j);
+        s_src[tid] = weighted_pick(wscan, N, g.u01() * D.is_tot[2 * e + 1]);
+        D.p_weight[db + j] = 1.0 / (double)N;
+    }
+    __syncthreads();
+    gather_records(D.p_rec + (db + j0) * (size_t)P.Cs, D.p_rec + sb * (size_t)P.Cs, nullptr, s_src, nullptr, 0, 0, nullptr,
+                   min(256, N - j0), C4, P.C, group, 256);
+}
+
+__global__ void __launch_bounds__(256) is_multi_scan_kernel(Problem P, DeviceState D)
+{
+    const int e = blockIdx.y;
+    if (!D.need_update[e]) return;
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6), N = P.N;
+    if (c * 256 >= N) return;
+    const double* sw = D.p_weight + pbase(P, e, D.bufsel[e]);
+    const int i0 = c * 256 + lane * 4;
+    double x[4];
+    const double incl = wave_inclusive_scan(chunk_lane_sum(sw, N, i0, x), lane);
+    double excl       = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 0.0;
+    double run  = D.ctot[(size_t)e * D.ctot_stride + c] + excl;
+    double* out = D.wscan + (size_t)e * N;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (i0 + k < N) {
+            run += x[k];
+            out[i0 + k] = run;
+        }
+}
+
+__global__ void is_multi_finish_kernel(Problem P, DeviceState D)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= P.E || !D.need_update[e]) return;
+    D.bufsel[e] ^= 1;
+    D.need_update[e] = 0;
+    D.belief_steps[e] += (unsigned long long)P.N;
+    D.upd_attempts[e] += (unsigned long long)P.N;
+    D.upd_particles[e] += (unsigned long long)P.N;
+    D.cur[e].update_count = -1;
+    D.cur[e].weight_total = D.is_tot[2 * e + 0];
+}
+
+// ---------------------------------------------------------------------------------------------
 // init_kernel: Belief::initiate -- N x simulator.sampleStartState()
 // (RejectionSampling.cpp:15-20, ImportanceSampler.cpp:45-55; BAPOMDP::sampleStartState
 // BAPOMDP.cpp:101-104 = prior->sample(domain start state)).  One workgroup per slot.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) init_kernel(Problem P, DeviceState D)
 {
-    const int e = blockIdx.x, tid = threadIdx.x;
+    const int e = blockIdx.y, tid = threadIdx.x;
     if (!D.need_init[e]) return;
+    // this workgroup's tile of the slot's particles (PARTICLE_TILE each, so big filters spread over the chip)
+    const int i_lo = blockIdx.x * PARTICLE_TILE, i_hi = min(P.N, i_lo + PARTICLE_TILE);
+    if (i_lo >= P.N) return;
     const size_t pb = pbase(P, e, D.bufsel[e]);
     float* recs     = D.p_rec + pb * (size_t)P.Cs;
     Rng g = slot_rng(P, D, e);
@@ -700,20 +912,18 @@ __global__ void __launch_bounds__(256) init_kernel(Problem P, DeviceState D)
     // every particle starts from the prior record ...
     const int C4 = P.Cs / 4;
     const float4* pr = reinterpret_cast<const float4*>(D.prior);
-    float4* dp       = reinterpret_cast<float4*>(recs);
-    const size_t tot = (size_t)P.N * C4;
+    float4* dp       = reinterpret_cast<float4*>(recs) + (size_t)i_lo * C4;
+    const size_t tot = (size_t)(i_hi - i_lo) * C4;
     for (size_t f = tid; f < tot; f += 256) dp[f] = pr[f % C4];
     __syncthreads();
     // ... and its own domain start state
     const double w1 = 1.0 / (double)P.N;
-    for (int i = tid; i < P.N; i += 256) {
+    for (int i = i_lo + tid; i < i_hi; i += 256) {
         g.stream(FBA_PHASE_INIT, (uint32_t)i);
         rec_set_state(recs + (size_t)i * P.Cs, P.C, domain_start(P, g));
         if (P.model == FBA_MODEL_BA_FACTORED) factored_prior_sample(P, g, recs + (size_t)i * P.Cs);
         if (P.belief == FBA_BELIEF_IMPORTANCE) D.p_weight[pb + i] = w1;
     }
-    __syncthreads();
-    if (tid == 0) D.need_init[e] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -725,42 +935,52 @@ __global__ void __launch_bounds__(256) init_kernel(Problem P, DeviceState D)
 __global__ void __launch_bounds__(256) reset_kernel(Problem P, DeviceState D)
 {
     __shared__ int32_t s_src[256], s_ns[256];
-    const int e = blockIdx.x, tid = threadIdx.x;
+    const int e = blockIdx.y, tid = threadIdx.x;
     if (D.need_reset[e] != 1) return;
+    const int i_lo = blockIdx.x * PARTICLE_TILE, i_hi = min(P.N, i_lo + PARTICLE_TILE);
+    if (i_lo >= P.N) return;
     const int cur = D.bufsel[e];
     const size_t sb = pbase(P, e, cur), db = pbase(P, e, cur ^ 1);
     Rng g = slot_rng(P, D, e);
     g.position((uint32_t)D.run[e], (uint32_t)D.episode[e], 0);
     if (P.belief == FBA_BELIEF_REJECTION) {
         float* recs = D.p_rec + sb * (size_t)P.Cs;
-        for (int i = tid; i < P.N; i += 256) {
+        for (int i = i_lo + tid; i < i_hi; i += 256) {
             g.stream(FBA_PHASE_RESET, (uint32_t)i);
             rec_set_state(recs + (size_t)i * P.Cs, P.C, domain_start(P, g));
         }
-        __syncthreads();
-        if (tid == 0) D.need_reset[e] = 0;
         return;
     }
     const int C4 = P.Cs / 4, group = record_group(C4);
     const double w1 = 1.0 / (double)P.N;
-    for (int j0 = 0; j0 < P.N; j0 += 256) {
+    for (int j0 = i_lo; j0 < i_hi; j0 += 256) {
         const int j = j0 + tid;
-        if (j < P.N) {
+        if (j < i_hi) {
             g.stream(FBA_PHASE_RESET, (uint32_t)j);
             s_src[tid] = weighted_pick(D.uni_scan, P.N, g.u01() * D.uni_total);
             s_ns[tid]  = domain_start(P, g);
             D.p_weight[db + j] = w1;
         }
         __syncthreads();
-        const int m = min(256, P.N - j0);
+        const int m = min(256, i_hi - j0);
         gather_records(D.p_rec + (db + j0) * (size_t)P.Cs, D.p_rec + sb * (size_t)P.Cs, nullptr, s_src, nullptr, 0, 0, s_ns, m, C4,
                        P.C, group, 256);
         __syncthreads();
     }
-    if (tid == 0) {
-        D.bufsel[e]     = cur ^ 1;
-        D.need_reset[e] = 0;
-    }
+}
+
+// clears the request flags after init_kernel / reset_kernel (several workgroups serve one slot)
+__global__ void post_init_kernel(Problem P, DeviceState D)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < P.E) D.need_init[e] = 0;
+}
+__global__ void post_reset_kernel(Problem P, DeviceState D)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= P.E || D.need_reset[e] != 1) return;
+    if (P.belief == FBA_BELIEF_IMPORTANCE) D.bufsel[e] ^= 1;
+    D.need_reset[e] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -833,18 +1053,33 @@ void launch_advance(const Problem& P, const DeviceState& D, int32_t* n_active, h
 }
 void launch_belief_update(const Problem& P, const DeviceState& D, hipStream_t st)
 {
-    if (P.belief == FBA_BELIEF_REJECTION)
+    if (P.belief == FBA_BELIEF_REJECTION) {
         hipLaunchKernelGGL(reject_kernel, dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D);
-    else
+        return;
+    }
+    if (!D.is_multi) {
         hipLaunchKernelGGL(importance_kernel, dim3(P.E), dim3(IS_BLOCK), 0, st, P, D);
+        return;
+    }
+    const int nchunks = (P.N + 255) / 256;
+    const dim3 cgrid(ceil_div(nchunks, 4), P.E), eg(ceil_div(P.E, 64));
+    hipLaunchKernelGGL(is_multi_step_kernel, cgrid, dim3(256), 0, st, P, D);
+    hipLaunchKernelGGL(scan_carry_kernel, dim3(P.E), dim3(256), 0, st, D.ctot, D.ctot_stride, nchunks, D.is_tot, 2, 0, D.need_update, P.E);
+    hipLaunchKernelGGL(is_multi_norm_kernel, cgrid, dim3(256), 0, st, P, D);
+    hipLaunchKernelGGL(scan_carry_kernel, dim3(P.E), dim3(256), 0, st, D.ctot, D.ctot_stride, nchunks, D.is_tot, 2, 1, D.need_update, P.E);
+    hipLaunchKernelGGL(is_multi_scan_kernel, cgrid, dim3(256), 0, st, P, D);
+    hipLaunchKernelGGL(is_multi_resample_kernel, dim3(ceil_div(P.N, 256), P.E), dim3(256), 0, st, P, D);
+    hipLaunchKernelGGL(is_multi_finish_kernel, eg, dim3(64), 0, st, P, D);
 }
 void launch_init(const Problem& P, const DeviceState& D, hipStream_t st)
 {
-    hipLaunchKernelGGL(init_kernel, dim3(P.E), dim3(256), 0, st, P, D);
+    hipLaunchKernelGGL(init_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), P.E), dim3(256), 0, st, P, D);
+    hipLaunchKernelGGL(post_init_kernel, dim3(ceil_div(P.E, 256)), dim3(256), 0, st, P, D);
 }
 void launch_reset(const Problem& P, const DeviceState& D, hipStream_t st)
 {
-    hipLaunchKernelGGL(reset_kernel, dim3(P.E), dim3(256), 0, st, P, D);
+    hipLaunchKernelGGL(reset_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), P.E), dim3(256), 0, st, P, D);
+    hipLaunchKernelGGL(post_reset_kernel, dim3(ceil_div(P.E, 256)), dim3(256), 0, st, P, D);
 }
 void launch_flush(const Problem& P, const DeviceState& D, hipStream_t st)
 {
@@ -854,9 +1089,18 @@ void launch_selftest_ucb(const double* L, const int32_t* n, int count, double u,
 {
     hipLaunchKernelGGL(selftest_ucb_kernel, dim3(ceil_div(count, 256)), dim3(256), 0, st, L, n, count, u, out);
 }
-void launch_uniform_scan(int n, double* w_tmp, double* out, double* total, hipStream_t st)
+// prefix sums of n uniform weights 1/n; ctot: n/256 + 2 doubles of scratch (multi-workgroup form)
+void launch_uniform_scan(int n, double* w_tmp, double* out, double* total, double* ctot, hipStream_t st)
 {
-    hipLaunchKernelGGL(uniform_scan_kernel, dim3(1), dim3(IS_BLOCK), 0, st, n, w_tmp, out, total);
+    if (n <= IS_MAX_CHUNKS * 256) {
+        hipLaunchKernelGGL(uniform_scan_kernel, dim3(1), dim3(IS_BLOCK), 0, st, n, w_tmp, out, total);
+        return;
+    }
+    const int nchunks = (n + 255) / 256;
+    hipLaunchKernelGGL(fill_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, w_tmp, n, 1.0 / (double)n);
+    hipLaunchKernelGGL(chunk_totals_kernel, dim3(ceil_div(nchunks, 4), 1), dim3(256), 0, st, w_tmp, (size_t)0, n, ctot, 0, nullptr);
+    hipLaunchKernelGGL(scan_carry_kernel, dim3(1), dim3(256), 0, st, ctot, 0, nchunks, total, 0, 0, nullptr, 1);
+    hipLaunchKernelGGL(scan_write_kernel, dim3(ceil_div(nchunks, 4), 1), dim3(256), 0, st, w_tmp, (size_t)0, n, ctot, 0, out, (size_t)0, nullptr);
 }
 
 }  // namespace fba

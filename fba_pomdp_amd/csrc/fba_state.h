@@ -50,7 +50,10 @@ struct DeviceState {
     double* p_weight;   // [2][E][N]
     float* p_rec;       // [2][E][N][Cs] particle records (counts | state | pad)
     double* wscan;      // [E][N] scratch: inclusive device-order prefix sums of normalised weights
-    int32_t* src_idx;   // [E][N] scratch: resample ancestors
+    double* ctot;       // [E][N/256 + 2] scratch: chunk totals / carries of the multi-workgroup filter
+    double* is_tot;     // [E][2] total weight before normalisation, total of the normalised weights
+    int32_t ctot_stride;
+    int32_t is_multi;   // importance filter runs as several launches (N too large for one workgroup)
     const float* prior; // [Cs] prior record (state word unset)
     const double* uni_scan; // [N] prefix sums of N uniform weights 1/N (device order)
     double uni_total;

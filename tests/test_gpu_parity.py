@@ -347,3 +347,38 @@ def test_device_order_sums_equal_reference_order_on_ancestors():
     for name in ("action", "state", "obs", "n_nodes", "root_n"):
         assert np.array_equal(ta[name], tb[name])
     assert np.allclose(ta["weight_total"], tb["weight_total"], rtol=1e-14, atol=0)
+
+
+def test_multi_workgroup_importance_filter_equals_single_workgroup(monkeypatch):
+    """The large-filter path (N > 65536: update, scan and resample as separate launches over the
+    whole chip) computes the same device-order sums as the one-workgroup kernel: forced on at
+    N = 700 it must reproduce the oracle bit for bit."""
+    monkeypatch.setenv("FBA_IS_MULTI_MIN", "1")
+    eng, o = _pair("continuous-tiger", N.MODEL_BA_TABLE, "importance_sampling", 131, particles=700, sims=64, runs=6,
+                   episodes=3, horizon=6)
+    _assert_same_experiment(eng, o, ba=True)
+    eng, o = _pair("random-collision-avoidance", N.MODEL_BA_FACTORED, "importance_sampling", 132, size=2, width=5,
+                   height=5, particles=333, sims=40, runs=4, episodes=2)
+    _assert_same_experiment(eng, o, ba=True)
+
+
+def test_large_importance_filter_properties(monkeypatch):
+    """200 000 particles in ONE belief (collision avoidance, correct-graph prior): the resampled set
+    must consist of updated copies of the old particles (count sums grow by FS + FO per update), all
+    weights 1/N, total weight in (0, 1]."""
+    Np = 200000
+    eng = fba.Engine("random-collision-avoidance", model=N.MODEL_BA_FACTORED, belief="importance_sampling", size=2,
+                     width=7, height=7, particles=Np, sims=4, slots=1, seed=133)
+    eng.belief_init()
+    eng.belief_reset_domain_state()
+    prior = eng.prior()
+    for k, (a, ob) in enumerate([(1, 3 * 7 + 3), (2, 3 * 7 + 4)]):
+        eng.set_position(t=k)
+        eng.belief_update(a, ob)
+        s, w, cnt = eng.belief_get(0)
+        assert np.all(w == 1.0 / Np)
+        assert np.all((s >= 0) & (s < eng.S))
+        d = cnt - prior
+        assert np.all(d >= 0) and np.all(d.sum(axis=1) == (k + 1) * 6)     # FS + FO = 4 + 2 increments per update
+        tot = eng.last_step_info()[0]["weight_total"]
+        assert 0 < tot <= 1.0
