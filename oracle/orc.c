@@ -74,6 +74,9 @@ struct orc_ctx {
     float ca_start_v;         /* probability of each start state (float) */
     double ca_start_total;    /* categoricalDistr::_total */
     int32_t ca_start_i0, ca_start_cnt;
+    /* ziggurat tables of rnd::initiate() (random.cpp:47-74) */
+    unsigned long zig_ul[128];
+    double zig_wn[128], zig_fn[128];
     float nd_saved;           /* std::normal_distribution<float>::_M_saved */
     int nd_saved_available;
     int32_t ncnt;      /* floats per particle count blob */
@@ -496,6 +499,199 @@ static double ext_reward(orc_ctx* c, int32_t s, int32_t a, int32_t ns)
     return (a == ((s < c->S / 2) ? 0 : 1)) ? 10 : -100;
 }
 
+/* ------------------------------------------------------------------ regular Dirichlet mode
+ * ref: src/utils/random.cpp:40-44 (randomLong), :47-74 (tables), :146-213 (ziggurat normal,
+ * Marsaglia-Tsang gamma), :217-242 (sampleFromSampledMult), :281-304 (sampleMult).
+ * Bug-compatible: randomLong32 only yields 31-bit values, so the "normal" is
+ * half-normal.  log / exp / pow come from libm in REF arithmetic (what the reference calls) and
+ * from the deterministic det_log / det_exp below in DEV arithmetic (what the HIP engine evaluates:
+ * plain IEEE +,-,*,/ sequences, bit-identical on host and device). */
+
+/* log and exp in the classic argument-reduction + minimax-polynomial form, IEEE double ops only */
+double orc_det_log(double x)
+{
+    static const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+        Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+        Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+        Lg7 = 1.479819860511658591e-01;
+    uint64_t ix;
+    int k;
+    double f, s, z, w, t1, t2, R, hfsq, dk;
+    if (!(x > 0)) return x == 0 ? -HUGE_VAL : NAN;
+    memcpy(&ix, &x, 8);
+    k = 0;
+    if ((ix >> 52) == 0) { x *= 18014398509481984.0; memcpy(&ix, &x, 8); k = -54; } /* subnormal */
+    k += (int)(ix >> 52) - 1023;
+    ix = (ix & 0x000fffffffffffffull) | 0x3ff0000000000000ull; /* x in [1, 2) */
+    memcpy(&x, &ix, 8);
+    if (x > 1.4142135623730951) { x *= 0.5; k += 1; }              /* x in (sqrt(2)/2, sqrt(2)] */
+    f    = x - 1.0;
+    s    = f / (2.0 + f);
+    z    = s * s;
+    w    = z * z;
+    t1   = w * (Lg2 + w * (Lg4 + w * Lg6));
+    t2   = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    R    = t2 + t1;
+    hfsq = 0.5 * f * f;
+    dk   = (double)k;
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+double orc_det_exp(double x)
+{
+    static const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+        inv_ln2 = 1.44269504088896338700e+00, P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
+        P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    double hi, lo, r, c, y, t;
+    int k;
+    uint64_t bits;
+    if (x > 709.0) return HUGE_VAL;
+    if (x < -745.0) return 0.0;
+    k  = (int)(inv_ln2 * x + (x < 0 ? -0.5 : 0.5));
+    t  = (double)k;
+    hi = x - t * ln2_hi;
+    lo = t * ln2_lo;
+    r  = hi - lo;
+    t  = r * r;
+    c  = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    y  = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    if (k < -1021) { /* result may be subnormal: scale in two steps */
+        bits = (uint64_t)(k + 1000 + 1023) << 52;
+        memcpy(&t, &bits, 8);
+        return y * t * 9.33263618503218878990e-302; /* 2^-1000 */
+    }
+    bits = (uint64_t)(k + 1023) << 52;
+    memcpy(&t, &bits, 8);
+    return y * t;
+}
+
+static double m_log(const orc_ctx* c, double x) { return c->cfg.arith == ORC_ARITH_DEV ? orc_det_log(x) : log(x); }
+static double m_exp(const orc_ctx* c, double x) { return c->cfg.arith == ORC_ARITH_DEV ? orc_det_exp(x) : exp(x); }
+static double m_pow(const orc_ctx* c, double x, double y)
+{
+    if (c->cfg.arith != ORC_ARITH_DEV) return pow(x, y);
+    if (x == 0) return y > 0 ? 0.0 : HUGE_VAL;
+    return orc_det_exp(y * orc_det_log(x));
+}
+
+/* rnd::initiate() tables (random.cpp:47-74); always libm: they are built once on the host */
+static void zig_tables(orc_ctx* c)
+{
+    double tn = 3.442619855899;
+    const double m1 = 2147483648.0, vn = 9.91256303526217e-3, q = vn / exp(-.5 * tn * tn);
+    int i;
+    c->zig_ul[0]   = (unsigned long)((tn / q) * m1);
+    c->zig_ul[1]   = 0;
+    c->zig_wn[0]   = q / m1;
+    c->zig_wn[127] = tn / m1;
+    c->zig_fn[0]   = 1.;
+    c->zig_fn[127] = exp(-.5 * tn * tn);
+    for (i = 126; i > 0; --i) {
+        const double dn  = sqrt(-2 * log(vn / tn + exp(-.5 * tn * tn)));
+        c->zig_ul[i + 1] = (unsigned long)((dn / tn) * m1);
+        c->zig_fn[i]     = exp(-.5 * dn * dn);
+        c->zig_wn[i]     = dn / m1;
+        tn               = dn;
+    }
+}
+
+/* randomLong() (random.cpp:40-44): uniform_int_distribution<unsigned long>(0, 2^31-1) = one engine
+ * word >> 1 on a 32-bit URBG (Lemire with a power-of-two range never rejects) */
+static long random_long(orc_ctx* c)
+{
+    if (c->rng.mode == ORC_RNG_MT) return (long)(orc_mt_next(&c->rng) >> 1);
+    return (long)((uint64_t)(orc_u01(&c->rng) * 2147483648.0)); /* top 31 bits of the draw */
+}
+
+/* normalRejectFix (random.cpp:146-176) */
+static double normal_reject_fix(orc_ctx* c, long h, unsigned long i)
+{
+    const double r = 3.442620, r_inverse = 0.2904764;
+    double y;
+    for (;;) {
+        double x = (double)h * c->zig_wn[i];
+        if (i == 0) {
+            do {
+                x = -m_log(c, orc_u01(&c->rng)) * r_inverse;
+                y = -m_log(c, orc_u01(&c->rng));
+            } while (y + y < x * x);
+            return (h > 0) ? r + x : -r - x;
+        }
+        if (c->zig_fn[i] + orc_u01(&c->rng) * (c->zig_fn[i - 1] - c->zig_fn[i]) < m_exp(c, -.5 * x * x)) return x;
+        h = random_long(c);
+        i = (unsigned long)(h & 127);
+        if ((unsigned long)labs(h) < c->zig_ul[i]) return (double)h * c->zig_wn[i];
+    }
+}
+
+/* randomNormal (random.cpp:181-187) */
+static double random_normal(orc_ctx* c)
+{
+    const long h = random_long(c), i = h & 127;
+    return ((unsigned long)labs(h) < c->zig_ul[i]) ? (double)h * c->zig_wn[i] : normal_reject_fix(c, h, (unsigned long)i);
+}
+
+/* rnd::sample::gamma (random.cpp:189-213) */
+double orc_gamma(orc_ctx* c, double shape)
+{
+    double x, v, d, cc;
+    if (shape < 1.) {
+        double g = orc_gamma(c, shape + 1);
+        return g * m_pow(c, orc_u01(&c->rng), 1 / shape);
+    }
+    d  = shape - 1. / 3.;
+    cc = 1. / sqrt(9. * d);
+    for (;;) {
+        double u, x2;
+        do {
+            x = random_normal(c);
+            v = 1.0 + cc * x;
+        } while (v <= 0.0);
+        v  = v * v * v;
+        u  = orc_u01(&c->rng);
+        x2 = x * x;
+        if (u < 1.0 - 0.0331 * x2 * x2) return d * v;
+        if (m_log(c, u) < .5 * x2 + d * (1. - v + m_log(c, v))) return d * v;
+    }
+}
+
+/* sampleFromSampledMult (random.cpp:217-242): gamma per count, then sampleFromMult<double> */
+int orc_sample_sampled_mult(orc_ctx* c, const float* dir, int n)
+{
+    double probs[64], sum, p, acc;
+    int i;
+    probs[0] = orc_gamma(c, dir[0]);
+    sum      = probs[0];
+    for (i = 1; i < n; ++i) {
+        probs[i] = orc_gamma(c, dir[i]);
+        sum += probs[i];
+    }
+    p   = orc_u01(&c->rng) * sum;
+    acc = probs[0];
+    for (i = 1; i < n; ++i) {
+        if (p < acc) return i - 1;
+        acc += probs[i];
+    }
+    return n - 1;
+}
+
+/* sampleMult (random.cpp:281-304): gammas stored as float, float sum, float division */
+void orc_sample_mult(orc_ctx* c, const float* dir, int n, float* out)
+{
+    float sum = 0;
+    int i;
+    for (i = 0; i < n; ++i) {
+        out[i] = (float)orc_gamma(c, dir[i]);
+        sum += out[i];
+    }
+    for (i = 0; i < n; ++i) out[i] = out[i] / sum;
+}
+
+static int sample_dirichlet_row(orc_ctx* c, const float* row, int n)
+{
+    return c->cfg.dirichlet_regular ? orc_sample_sampled_mult(c, row, n) : orc_sample_expected_mult(&c->rng, row, n);
+}
+
 /* ------------------------------------------------------------------ priors (tabular) */
 
 /* ref: TigerBAPrior src/domains/tiger/TigerPriors.cpp:14-43;
@@ -554,9 +750,9 @@ static int ba_table_step(orc_ctx* c, simstate* st, int32_t a, int32_t* o, double
     float* phi = st->cnt;
     float* psi = st->cnt + c->phi_len;
     int32_t s  = st->s;
-    int32_t ns = orc_sample_expected_mult(&c->rng, &phi[s * A * S + a * S], S);
+    int32_t ns = sample_dirichlet_row(c, &phi[s * A * S + a * S], S);
     int t;
-    *o = orc_sample_expected_mult(&c->rng, &psi[a * S * O + ns * O], O);
+    *o = sample_dirichlet_row(c, &psi[a * S * O + ns * O], O);
     t  = ext_terminal(c, s, a, ns);
     *r = ext_reward(c, s, a, ns);
     if (update) {
@@ -610,12 +806,12 @@ static int ba_fact_step(orc_ctx* c, simstate* st, int32_t a, int32_t* o, double*
     features_of(s, d->Sstep, d->FS, fv);
     for (f = 0; f < d->FS; ++f) {
         const fnode* nd = &d->T[a * d->FS + f];
-        nf[f] = orc_sample_expected_mult(&c->rng, st->cnt + node_row(c, nd, node_mask(c, nd, st->cnt), fv), nd->out);
+        nf[f] = sample_dirichlet_row(c, st->cnt + node_row(c, nd, node_mask(c, nd, st->cnt), fv), nd->out);
     }
     ns = project(nf, d->Ssz, d->FS);
     for (f = 0; f < d->FO; ++f) {
         const fnode* nd = &d->O[a * d->FO + f];
-        of[f] = orc_sample_expected_mult(&c->rng, st->cnt + node_row(c, nd, node_mask(c, nd, st->cnt), nf), nd->out);
+        of[f] = sample_dirichlet_row(c, st->cnt + node_row(c, nd, node_mask(c, nd, st->cnt), nf), nd->out);
     }
     *o = project(of, d->Osz, d->FO);
     t  = ext_terminal(c, s, a, ns);
@@ -647,6 +843,12 @@ static double ba_fact_obs_prob(orc_ctx* c, const simstate* st, int32_t a, int32_
         const fnode* nd  = &d->O[a * d->FO + f];
         const float* row = st->cnt + node_row(c, nd, node_mask(c, nd, st->cnt), fv);
         float sum        = row[0];
+        if (c->cfg.dirichlet_regular) { /* sampleMultinominal = sampleMult: a fresh Dirichlet draw per feature */
+            float tmp[64];
+            orc_sample_mult(c, row, nd->out, tmp);
+            prob *= tmp[of[f]];
+            continue;
+        }
         for (i = 1; i < nd->out; ++i) sum += row[i];
         prob *= (sum <= 1e-300) ? 0.0f : row[of[f]] / sum;
     }
@@ -986,6 +1188,10 @@ static double sim_obs_prob(orc_ctx* c, const simstate* st, int32_t a, int32_t o)
         float tmp[64];
         const float* row = st->cnt + c->phi_len + a * c->S * c->O + st->s * c->O;
         if (c->O == 1) return 1;
+        if (c->cfg.dirichlet_regular) {
+            orc_sample_mult(c, row, c->O, tmp);
+            return tmp[o];
+        }
         if (c->O <= 64) {
             orc_expected_mult(row, c->O, tmp);
             return tmp[o];
@@ -1586,6 +1792,7 @@ orc_ctx* orc_create(const orc_config* cfg)
         orc_rng_init_philox(&c->rng, cfg->philox_seed);
     }
     c->gamma = cfg->discount;
+    zig_tables(c);
     switch (cfg->domain) {
         case ORC_DOM_TIGER_EPISODIC:
         case ORC_DOM_TIGER_CONTINUOUS: c->S = 2; c->A = 3; c->O = 2; break;

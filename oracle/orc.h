@@ -72,6 +72,7 @@ typedef struct orc_config {
     int32_t trace;         /* 1 = record orc_trace_rec per real step */
     int32_t planner;       /* ORC_PLANNER_* */
     int32_t ca_centered;   /* collision avoidance: 1 = centered-collision-avoidance, 0 = random-collision-avoidance */
+    int32_t dirichlet_regular; /* --dirichlet_sampling_method regular (0 = expected, the default) */
 } orc_config;
 
 /* One record per real time-step; the HIP engine emits the same layout (fba_trace_rec). */
@@ -148,6 +149,12 @@ int orc_model_step(orc_ctx* c, float* cnt, int32_t* s, int32_t a, int32_t* o, do
 double orc_model_obs_prob(orc_ctx* c, const float* cnt, int32_t new_s, int32_t a, int32_t o);
 double orc_dev_scan(const double* w, int n, double* incl);
 int orc_ftiger_set_structure(orc_ctx* c, float* cnt, uint32_t mask);
+/* regular-Dirichlet building blocks (reference src/utils/random.cpp:146-304) for golden tests */
+double orc_gamma(orc_ctx* c, double shape);
+int orc_sample_sampled_mult(orc_ctx* c, const float* dir, int n);
+void orc_sample_mult(orc_ctx* c, const float* dir, int n, float* out);
+double orc_det_log(double x);
+double orc_det_exp(double x);
 
 #ifdef __cplusplus
 }

@@ -34,7 +34,7 @@ class Config(C.Structure):
         ("noise", C.c_float), ("counts_total", C.c_float),
         ("structure_prior", C.c_int32), ("rng_mode", C.c_int32), ("arith", C.c_int32),
         ("philox_seed", C.c_uint64), ("seed_str", C.c_char * 64),
-        ("run_offset", C.c_int32), ("trace", C.c_int32), ("planner", C.c_int32), ("ca_centered", C.c_int32),
+        ("run_offset", C.c_int32), ("trace", C.c_int32), ("planner", C.c_int32), ("ca_centered", C.c_int32), ("dirichlet_regular", C.c_int32),
     ]
 
 
@@ -122,6 +122,14 @@ def lib():
         L.orc_model_obs_prob.restype = C.c_double
         L.orc_model_obs_prob.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
         L.orc_ftiger_set_structure.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.orc_gamma.restype = C.c_double
+        L.orc_gamma.argtypes = [C.c_void_p, C.c_double]
+        L.orc_sample_sampled_mult.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_sample_mult.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_det_log.restype = C.c_double
+        L.orc_det_log.argtypes = [C.c_double]
+        L.orc_det_exp.restype = C.c_double
+        L.orc_det_exp.argtypes = [C.c_double]
         L.orc_dev_scan.restype = C.c_double
         L.orc_dev_scan.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         # rng

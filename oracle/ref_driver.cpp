@@ -441,6 +441,32 @@ static void babn_model(char const* s, std::vector<int> parents)
     printf("}");
 }
 
+
+/* regular Dirichlet mode: rnd::sample::gamma, sampleFromSampledMult, sampleMult (random.cpp:189-304) */
+static void regular_dirichlet(char const* s)
+{
+    seed(s);
+    std::vector<double> g;
+    double const shapes[] = {0.3, 1, 5, 5000, 0, 8500, 0.9999, 1500, 2.5, 1e-3};
+    for (int rep = 0; rep < 40; ++rep)
+        for (double sh : shapes) g.push_back(rnd::sample::gamma(sh));
+    std::vector<int> picks;
+    float const rows[4][4] = {{5000, 5000, 0, 0}, {8500, 1500, 3, 0.25f}, {1, 2, 3, 4}, {0, 0, 7, 0}};
+    for (int rep = 0; rep < 60; ++rep)
+        for (auto const& r : rows) picks.push_back(rnd::sample::Dir::sampleFromSampledMult(r, 4));
+    std::vector<double> mults;
+    for (int rep = 0; rep < 10; ++rep)
+        for (auto const& r : rows)
+            for (float v : rnd::sample::Dir::sampleMult(r, 4)) mults.push_back(v);
+    printf("{\"seed\": \"%s\", \"gamma\": ", s);
+    arr(g, pd);
+    printf(", \"picks\": ");
+    arr(picks, pi);
+    printf(", \"mults\": ");
+    arr(mults, pd);
+    printf(", \"next_u01\": %.17g}", rnd::uniform_rand01());
+}
+
 /* episode::run with the reference's RandomPlanner and RejectionSampling belief */
 static void random_planner_episodes(char const* s, int n, int episodes)
 {
@@ -574,6 +600,9 @@ int main(int argc, char** argv)
     printf(",");
     babn_model("21", {0, 1, 2});
     printf("]");
+
+    key("regular_dirichlet");
+    regular_dirichlet("40");
 
     key("random_planner_episodes");
     random_planner_episodes("16", 32, 60);
