@@ -52,7 +52,7 @@ class Config(C.Structure):
         ("runs", C.c_int32), ("episodes", C.c_int32),
         ("noise", C.c_float), ("counts_total", C.c_float), ("structure_prior", C.c_int32),
         ("seed", C.c_uint64), ("run_offset", C.c_int32), ("slots", C.c_int32),
-        ("device", C.c_int32), ("trace", C.c_int32),
+        ("device", C.c_int32), ("trace", C.c_int32), ("dirichlet_regular", C.c_int32),
     ]
 
 

@@ -178,6 +178,8 @@ struct Problem {
     const FDesc* fd;  // device pointer; null unless model = BA_FACTORED
     const GridDesc* gw;  // device pointer; null unless domain = gridworld
     const CADesc* ca;    // device pointer; null unless domain = collision avoidance
+    const struct ZigDesc* zig;  // ziggurat tables (regular Dirichlet mode only)
+    int32_t dirichlet_regular;  // --dirichlet_sampling_method regular
     float noise, counts_total;
     int32_t structure_prior;
     int32_t domain, model, belief, planner;
@@ -391,6 +393,152 @@ __device__ __forceinline__ double ext_reward(const Problem& P, int s, int a, int
 // caller decides where the +1 lands (in place for importance sampling, in the copy for
 // rejection sampling).
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// `regular` Dirichlet mode (reference src/utils/random.cpp:40-44, 146-304), bug-compatible: the
+// reference's randomLong32 yields 31-bit values only, so its ziggurat "normal" is a half-normal and
+// its gammas are biased upward -- reproduced, not repaired.
+// log / exp are the deterministic sequences of IEEE operations that oracle/orc.c calls det_log /
+// det_exp (argument reduction + minimax polynomial): bit-identical on host and device, < 2 ulp from
+// libm.  The ziggurat tables are built on the host with libm, as rnd::initiate() does.
+// ---------------------------------------------------------------------------------------------
+struct ZigDesc {
+    uint32_t ul[128];
+    double wn[128], fn[128];
+};
+constexpr int MAXROW = 16;  // longest Dirichlet row the regular mode samples in registers/scratch
+
+__device__ __forceinline__ double det_log(double x)
+{
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                 Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    if (!(x > 0)) return x == 0 ? -HUGE_VAL : NAN;
+    uint64_t ix = (uint64_t)__double_as_longlong(x);
+    int k = 0;
+    if ((ix >> 52) == 0) { x *= 18014398509481984.0; ix = (uint64_t)__double_as_longlong(x); k = -54; }
+    k += (int)(ix >> 52) - 1023;
+    ix = (ix & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
+    x  = __longlong_as_double((long long)ix);
+    if (x > 1.4142135623730951) { x *= 0.5; k += 1; }
+    const double f = x - 1.0, s = f / (2.0 + f), z = s * s, w = z * z;
+    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double R = t2 + t1, hfsq = 0.5 * f * f, dk = (double)k;
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+__device__ __forceinline__ double det_exp(double x)
+{
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                 inv_ln2 = 1.44269504088896338700e+00, P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
+                 P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    if (x > 709.0) return HUGE_VAL;
+    if (x < -745.0) return 0.0;
+    const int k = (int)(inv_ln2 * x + (x < 0 ? -0.5 : 0.5));
+    double t = (double)k;
+    const double hi = x - t * ln2_hi, lo = t * ln2_lo, r = hi - lo;
+    t = r * r;
+    const double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    if (k < -1021) return y * __longlong_as_double((long long)((uint64_t)(k + 1000 + 1023) << 52)) * 9.33263618503218878990e-302;
+    return y * __longlong_as_double((long long)((uint64_t)(k + 1023) << 52));
+}
+
+__device__ __forceinline__ double det_pow(double x, double y)
+{
+    if (x == 0) return y > 0 ? 0.0 : HUGE_VAL;
+    return det_exp(y * det_log(x));
+}
+
+// randomLong (random.cpp:40-44): 31 random bits, never negative
+__device__ __forceinline__ long long random_long(Rng& g) { return (long long)(g.next64() >> 33); }
+
+// randomNormal + normalRejectFix (random.cpp:146-187)
+__device__ __noinline__ double random_normal(const ZigDesc* z, Rng& g)
+{
+    long long h = random_long(g);
+    uint32_t i  = (uint32_t)(h & 127);
+    if ((uint64_t)h < z->ul[i]) return (double)h * z->wn[i];
+    const double r = 3.442620, r_inverse = 0.2904764;
+    for (;;) {
+        double x = (double)h * z->wn[i];
+        if (i == 0) {
+            double y;
+            do {
+                x = -det_log(g.u01()) * r_inverse;
+                y = -det_log(g.u01());
+            } while (y + y < x * x);
+            return (h > 0) ? r + x : -r - x;
+        }
+        if (z->fn[i] + g.u01() * (z->fn[i - 1] - z->fn[i]) < det_exp(-.5 * x * x)) return x;
+        h = random_long(g);
+        i = (uint32_t)(h & 127);
+        if ((uint64_t)h < z->ul[i]) return (double)h * z->wn[i];
+    }
+}
+
+// rnd::sample::gamma (random.cpp:189-213): Marsaglia-Tsang; shape < 1 goes through shape + 1
+__device__ __noinline__ double sample_gamma(const ZigDesc* z, Rng& g, double shape)
+{
+    const double sh = shape < 1. ? shape + 1 : shape;
+    const double d = sh - 1. / 3., cc = 1. / sqrt(9. * d);
+    double res;
+    for (;;) {
+        double x, v;
+        do {
+            x = random_normal(z, g);
+            v = 1.0 + cc * x;
+        } while (v <= 0.0);
+        v = v * v * v;
+        const double u = g.u01(), x2 = x * x;
+        if (u < 1.0 - 0.0331 * x2 * x2) { res = d * v; break; }
+        if (det_log(u) < .5 * x2 + d * (1. - v + det_log(v))) { res = d * v; break; }
+    }
+    if (shape < 1.) res = res * det_pow(g.u01(), 1 / shape);
+    return res;
+}
+
+// sampleFromSampledMult (random.cpp:217-242)
+template <class View>
+__device__ __forceinline__ int sample_sampled_mult(const ZigDesc* z, Rng& g, const View& row, int off, int n)
+{
+    double probs[MAXROW];
+    double sum = 0;
+    for (int i = 0; i < n; ++i) {
+        probs[i] = sample_gamma(z, g, (double)row.at(off + i));
+        sum      = (i == 0) ? probs[0] : sum + probs[i];
+    }
+    const double p = g.u01() * sum;
+    double acc     = probs[0];
+    for (int i = 1; i < n; ++i) {
+        if (p < acc) return i - 1;
+        acc += probs[i];
+    }
+    return n - 1;
+}
+
+// sampleMult(row)[o] (random.cpp:281-304): gammas stored as float, float sum, float division
+template <class View>
+__device__ __forceinline__ double sample_mult_at(const ZigDesc* z, Rng& g, const View& row, int off, int n, int o)
+{
+    float sum = 0, mine = 0;
+    for (int i = 0; i < n; ++i) {
+        const float v = (float)sample_gamma(z, g, (double)row.at(off + i));
+        sum += v;
+        if (i == o) mine = v;
+    }
+    return (double)(mine / sum);
+}
+
+// one Dirichlet-row draw in the configured mode
+template <bool REG, class View>
+__device__ __forceinline__ int sample_row(const Problem& P, Rng& g, const View& row, int off, int n)
+{
+    if (REG) return sample_sampled_mult(P.zig, g, row, off, n);
+    return sample_expected_mult(g, row, off, n);
+}
+
 // ---- factored model ---------------------------------------------------------------------------
 // feature values travel packed, 8 bits each, so no runtime-indexed register arrays are needed
 __device__ __forceinline__ uint64_t pack_features(int v, const int32_t* step, int n)
@@ -422,7 +570,7 @@ __device__ __forceinline__ int node_row(const FDesc* fd, const FNode& nd, uint32
 // BAPOMDP::step over BABNModel (BABNModel.cpp:292-325) + the indices incrementCountsOf would
 // touch (:354-382).  Quirk kept: observation CPTs are incremented at the row of
 // the PREVIOUS state's parent values.
-template <class View, class Sink>
+template <bool REG, class View, class Sink>
 __device__ __forceinline__ bool fact_step(const Problem& P, Rng& g, const View& cnt, int& s, int a, int& o, double& r, const Sink& inc)
 {
     const FDesc* fd   = P.fd;
@@ -435,7 +583,7 @@ __device__ __forceinline__ bool fact_step(const Problem& P, Rng& g, const View& 
         if (f < FS) {
             const FNode& nd = fd->nodes[a * FS + f];
             const int row   = node_row(fd, nd, node_mask(fd, nd, cnt), fv);
-            const int v     = sample_expected_mult(g, cnt, row, nd.out);
+            const int v     = sample_row<REG>(P, g, cnt, row, nd.out);
             inc.add(f, row + v);
             nf |= (uint64_t)v << (8 * f);
             ns = ns * fd->Ssz[f] + v;  // indexing::project
@@ -446,7 +594,7 @@ __device__ __forceinline__ bool fact_step(const Problem& P, Rng& g, const View& 
         if (f < FO) {
             const FNode& nd     = fd->nodes[P.A * FS + a * FO + f];
             const uint32_t mask = node_mask(fd, nd, cnt);
-            const int v         = sample_expected_mult(g, cnt, node_row(fd, nd, mask, nf), nd.out);
+            const int v         = sample_row<REG>(P, g, cnt, node_row(fd, nd, mask, nf), nd.out);
             ob = ob * fd->Osz[f] + v;
             inc.add(FS + f, node_row(fd, nd, mask, fv) + v);
         }
@@ -458,8 +606,8 @@ __device__ __forceinline__ bool fact_step(const Problem& P, Rng& g, const View& 
 }
 
 // BABNModel::computeObservationProbability (BABNModel.cpp:328-352)
-template <class View>
-__device__ __forceinline__ double fact_obs_prob(const Problem& P, const View& cnt, int new_s, int a, int o)
+template <bool REG, class View>
+__device__ __forceinline__ double fact_obs_prob(const Problem& P, Rng& g, const View& cnt, int new_s, int a, int o)
 {
     const FDesc* fd   = P.fd;
     const uint64_t fv = pack_features(new_s, fd->Sstep, fd->FS);
@@ -470,9 +618,13 @@ __device__ __forceinline__ double fact_obs_prob(const Problem& P, const View& cn
         if (f < fd->FO) {
             const FNode& nd = fd->nodes[P.A * fd->FS + a * fd->FO + f];
             const int row   = node_row(fd, nd, node_mask(fd, nd, cnt), fv);
-            float sum       = cnt.at(row);
-            for (int i = 1; i < nd.out; ++i) sum += cnt.at(row + i);
-            prob *= ((double)sum <= 1e-300) ? 0.0f : cnt.at(row + feat(of, f)) / sum;
+            if (REG) {  // sampleMultinominal = sampleMult: a fresh Dirichlet draw per observation feature
+                prob *= (float)sample_mult_at(P.zig, g, cnt, row, nd.out, feat(of, f));
+            } else {
+                float sum = cnt.at(row);
+                for (int i = 1; i < nd.out; ++i) sum += cnt.at(row + i);
+                prob *= ((double)sum <= 1e-300) ? 0.0f : cnt.at(row + feat(of, f)) / sum;
+            }
         }
     return prob;
 }
@@ -483,16 +635,16 @@ __device__ __forceinline__ int model_ninc(const Problem& P)
     return P.model == FBA_MODEL_POMDP ? 0 : (P.model == FBA_MODEL_BA_TABLE ? 2 : P.fd->FS + P.fd->FO);
 }
 
-template <class View, class Sink>
+template <bool REG, class View, class Sink>
 __device__ __forceinline__ bool sim_step(const Problem& P, Rng& g, const View& cnt, int& s, int a, int& o, double& r, const Sink& inc)
 {
     if (P.model == FBA_MODEL_POMDP) return domain_step(P, g, s, a, o, r);
-    if (P.model == FBA_MODEL_BA_FACTORED) return fact_step(P, g, cnt, s, a, o, r, inc);
+    if (P.model == FBA_MODEL_BA_FACTORED) return fact_step<REG>(P, g, cnt, s, a, o, r, inc);
     const int S = P.S, A = P.A, O = P.O;
     const int t_off = s * A * S + a * S;
-    const int ns    = sample_expected_mult(g, cnt, t_off, S);
+    const int ns    = sample_row<REG>(P, g, cnt, t_off, S);
     const int o_off = P.phi_len + a * S * O + ns * O;
-    o               = sample_expected_mult(g, cnt, o_off, O);
+    o               = sample_row<REG>(P, g, cnt, o_off, O);
     const bool t    = ext_terminal(P, s, a, ns);
     r               = ext_reward(P, s, a, ns);
     inc.add(0, t_off + ns);
@@ -503,12 +655,13 @@ __device__ __forceinline__ bool sim_step(const Problem& P, Rng& g, const View& c
 
 // POMDP::computeObservationProbability of the simulator in use
 // (BAPOMDP.cpp:93-99 -> BAFlatModel::computeObservationProbability BAFlatModel.cpp:106-124)
-template <class View>
-__device__ __forceinline__ double sim_obs_prob(const Problem& P, const View& cnt, int new_s, int a, int o)
+template <bool REG, class View>
+__device__ __forceinline__ double sim_obs_prob(const Problem& P, Rng& g, const View& cnt, int new_s, int a, int o)
 {
     if (P.model == FBA_MODEL_POMDP) return domain_obs_prob(P, o, a, new_s);
-    if (P.model == FBA_MODEL_BA_FACTORED) return fact_obs_prob(P, cnt, new_s, a, o);
+    if (P.model == FBA_MODEL_BA_FACTORED) return fact_obs_prob<REG>(P, g, cnt, new_s, a, o);
     if (P.O == 1) return 1.0;
+    if (REG) return sample_mult_at(P.zig, g, cnt, P.phi_len + a * P.S * P.O + new_s * P.O, P.O, o);
     return expected_mult_at(cnt, P.phi_len + a * P.S * P.O + new_s * P.O, P.O, o);
 }
 

@@ -43,6 +43,7 @@ struct fba_ctx {
     GridDesc* d_gdesc    = nullptr;
     CADesc cadesc{};
     CADesc* d_cadesc     = nullptr;
+    ZigDesc* d_zig       = nullptr;
     double* d_uni_scan   = nullptr;
     double* d_log1p      = nullptr;
     int32_t* d_n_active  = nullptr;
@@ -116,6 +117,26 @@ void build_collision_avoidance(CADesc& c, int W, int H, int n, bool random_start
         for (int k = 0; k < n; ++k) obs = obs * H + H / 2;
         c.start_v = 1; c.start_total = 1; c.start_cnt = 1;
         c.start_i0 = ((W - 1) * H + H / 2) * c.Hn + obs;
+    }
+}
+
+// ziggurat tables of rnd::initiate() (reference src/utils/random.cpp:47-74), libm on the host
+void build_ziggurat(ZigDesc& z)
+{
+    double tn = 3.442619855899;
+    const double m1 = 2147483648.0, vn = 9.91256303526217e-3, q = vn / std::exp(-.5 * tn * tn);
+    z.ul[0]   = (uint32_t)(unsigned long)((tn / q) * m1);
+    z.ul[1]   = 0;
+    z.wn[0]   = q / m1;
+    z.wn[127] = tn / m1;
+    z.fn[0]   = 1.;
+    z.fn[127] = std::exp(-.5 * tn * tn);
+    for (int i = 126; i > 0; --i) {
+        const double dn = std::sqrt(-2 * std::log(vn / tn + std::exp(-.5 * tn * tn)));
+        z.ul[i + 1]     = (uint32_t)(unsigned long)((dn / tn) * m1);
+        z.fn[i]         = std::exp(-.5 * dn * dn);
+        z.wn[i]         = dn / m1;
+        tn              = dn;
     }
 }
 
@@ -734,6 +755,8 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     P.fd = nullptr;
     P.gw = nullptr;
     P.ca = nullptr;
+    P.zig = nullptr;
+    P.dirichlet_regular = cfg->dirichlet_regular ? 1 : 0;
     if (cfg->model == FBA_MODEL_BA_TABLE) {
         P.phi_len = P.S * P.A * P.S;
         P.C       = P.phi_len + P.A * P.S * P.O;
@@ -895,6 +918,32 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         HIPC(hipStreamSynchronize(c->stream));
     }
     if (cfg->model == FBA_MODEL_BA_TABLE) CHK(build_tabular_prior(c));
+    if (P.dirichlet_regular) {
+        if (cfg->model == FBA_MODEL_POMDP) {
+            fail(c, FBA_EINVAL, "the Dirichlet sampling method only exists for Bayes-adaptive models");
+            g_create_error = c->err;
+            fba_destroy(c);
+            return FBA_EINVAL;
+        }
+        int longest = std::max(P.S, P.O);
+        if (cfg->model == FBA_MODEL_BA_FACTORED) {
+            longest = 0;
+            for (int f = 0; f < c->fdesc.FS; ++f) longest = std::max(longest, c->fdesc.Ssz[f]);
+            for (int f = 0; f < c->fdesc.FO; ++f) longest = std::max(longest, c->fdesc.Osz[f]);
+        }
+        if (longest > MAXROW) {
+            fail(c, FBA_EINVAL, "regular Dirichlet mode samples rows of at most %d counts (this model has %d)", MAXROW, longest);
+            g_create_error = c->err;
+            fba_destroy(c);
+            return FBA_EINVAL;
+        }
+        ZigDesc z;
+        build_ziggurat(z);
+        CHK(dev_alloc(c, &c->d_zig, 1));
+        HIPC(hipMemcpyAsync(c->d_zig, &z, sizeof z, hipMemcpyHostToDevice, c->stream));
+        HIPC(hipStreamSynchronize(c->stream));
+        P.zig = c->d_zig;
+    }
     if (is_ca(cfg->domain)) {
         CHK(dev_alloc(c, &c->d_cadesc, 1));
         HIPC(hipMemcpyAsync(c->d_cadesc, &c->cadesc, sizeof(CADesc), hipMemcpyHostToDevice, c->stream));

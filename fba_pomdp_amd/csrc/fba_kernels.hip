@@ -151,7 +151,7 @@ __device__ __forceinline__ int ucb_select(const Problem& P, const DeviceState& D
 // record fits 32 words (STAGE) -- the root particle's whole count blob, [word][lane], fetched with
 // one burst of 16-byte loads per simulation so that no step waits on HBM for its Dirichlet rows.
 // ---------------------------------------------------------------------------------------------
-template <bool STAGE, int AMAX>
+template <bool STAGE, int AMAX, bool REG>
 __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceState D)
 {
     extern __shared__ double lds[];
@@ -245,8 +245,8 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
             int o;
             double r;
             bool term;
-            if (STAGE) term = sim_step(P, g, LdsView<SEARCH_BLOCK>{stage}, s, a, o, r, NoInc{});
-            else term = sim_step(P, g, GlobalView{cnt}, s, a, o, r, NoInc{});
+            if (STAGE) term = sim_step<REG>(P, g, LdsView<SEARCH_BLOCK>{stage}, s, a, o, r, NoInc{});
+            else term = sim_step<REG>(P, g, GlobalView{cnt}, s, a, o, r, NoInc{});
             ++steps;
             if (mode == 1) {  // traverseChanceNode
                 path_r[(size_t)plen * SEARCH_BLOCK]  = r;
@@ -478,6 +478,7 @@ __device__ __forceinline__ int record_group(int C4)
 // reference's result: the new filter is the first N accepted attempts, in order, and the
 // reported loop count is the index of the N-th accepted attempt + 1.
 // ---------------------------------------------------------------------------------------------
+template <bool REG>
 __global__ void __launch_bounds__(REJECT_BLOCK) reject_kernel(Problem P, DeviceState D)
 {
     __shared__ int32_t s_src[REJECT_BLOCK], s_ns[REJECT_BLOCK], s_owner[REJECT_BLOCK], s_inc[MAXINC * REJECT_BLOCK];
@@ -502,7 +503,7 @@ __global__ void __launch_bounds__(REJECT_BLOCK) reject_kernel(Problem P, DeviceS
         const float* rec = scn + (size_t)src * P.Cs;
         int s = rec_state(rec, P.C), so;
         double r;
-        sim_step(P, g, GlobalView{rec}, s, a, so, r, LdsInc<REJECT_BLOCK>{s_inc + tid});  // UpdateCounts: the +1s land in the copy
+        sim_step<REG>(P, g, GlobalView{rec}, s, a, so, r, LdsInc<REJECT_BLOCK>{s_inc + tid});  // UpdateCounts: the +1s land in the copy
         s_src[tid] = src;
         s_ns[tid]  = s;
         const bool ok = (so == o);
@@ -626,6 +627,7 @@ __global__ void __launch_bounds__(IS_BLOCK) uniform_scan_kernel(int n, double* w
 //   3. N multinomial draws by binary search on the prefix sums
 //   4. whole-record gather into the other buffer, weights reset to 1/N
 // ---------------------------------------------------------------------------------------------
+template <bool REG>
 __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceState D)
 {
     __shared__ double s_carry[IS_MAX_CHUNKS + 2];
@@ -649,10 +651,10 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
         float* cnt = scn + (size_t)i * P.Cs;
         int s = rec_state(cnt, P.C), so;
         double r;
-        sim_step(P, g, GlobalView{cnt}, s, a, so, r, LdsInc<IS_BLOCK>{s_inc + tid});
+        sim_step<REG>(P, g, GlobalView{cnt}, s, a, so, r, LdsInc<IS_BLOCK>{s_inc + tid});
         for (int q = 0; q < ninc; ++q) cnt[s_inc[q * IS_BLOCK + tid]] += 1.0f;  // incrementCountsOf (BAFlatModel.cpp:126-139, BABNModel.cpp:354-382)
         rec_set_state(cnt, P.C, s);
-        sw[i] *= sim_obs_prob(P, GlobalView{cnt}, s, a, o);  // probability from the updated counts
+        sw[i] *= sim_obs_prob<REG>(P, g, GlobalView{cnt}, s, a, o);  // probability from the updated counts
     }
     __syncthreads();
     const double total = block_device_scan(sw, N, nullptr, s_carry);
@@ -780,6 +782,7 @@ __global__ void fill_kernel(double* p, int n, double v)
     if (i < n) p[i] = v;
 }
 
+template <bool REG>
 __global__ void __launch_bounds__(256) is_multi_step_kernel(Problem P, DeviceState D)
 {
     __shared__ int32_t s_inc[MAXINC * 256];
@@ -802,10 +805,10 @@ __global__ void __launch_bounds__(256) is_multi_step_kernel(Problem P, DeviceSta
             float* cnt = scn + (size_t)i * P.Cs;
             int s = rec_state(cnt, P.C), so;
             double r;
-            sim_step(P, g, GlobalView{cnt}, s, a, so, r, LdsInc<256>{s_inc + tid});
+            sim_step<REG>(P, g, GlobalView{cnt}, s, a, so, r, LdsInc<256>{s_inc + tid});
             for (int q = 0; q < ninc; ++q) cnt[s_inc[q * 256 + tid]] += 1.0f;
             rec_set_state(cnt, P.C, s);
-            v     = sw[i] * sim_obs_prob(P, GlobalView{cnt}, s, a, o);
+            v     = sw[i] * sim_obs_prob<REG>(P, g, GlobalView{cnt}, s, a, o);
             sw[i] = v;
         }
         sum = (k == 0) ? v : sum + v;
@@ -1033,7 +1036,11 @@ void launch_search(const Problem& P, const DeviceState& D, hipStream_t st)
                        (stage ? (size_t)P.Cs * SEARCH_BLOCK * sizeof(float) : 0) +
                        (P.A * P.O <= ROOT_CHILDREN ? (size_t)P.A * P.O * SEARCH_BLOCK * sizeof(int32_t) : 0);
     const dim3 grid(ceil_div(P.E, SEARCH_BLOCK)), block(SEARCH_BLOCK);
-#define FBA_LAUNCH_SEARCH(STG, AM) hipLaunchKernelGGL((search_kernel<STG, AM>), grid, block, lds, st, P, D)
+#define FBA_LAUNCH_SEARCH(STG, AM)                                                                  \
+    do {                                                                                            \
+        if (P.dirichlet_regular) hipLaunchKernelGGL((search_kernel<STG, AM, true>), grid, block, lds, st, P, D);   \
+        else hipLaunchKernelGGL((search_kernel<STG, AM, false>), grid, block, lds, st, P, D);       \
+    } while (0)
     if (P.A <= 4) { if (stage) FBA_LAUNCH_SEARCH(true, 4); else FBA_LAUNCH_SEARCH(false, 4); }
     else if (P.A <= 8) { if (stage) FBA_LAUNCH_SEARCH(true, 8); else FBA_LAUNCH_SEARCH(false, 8); }
     else { if (stage) FBA_LAUNCH_SEARCH(true, 16); else FBA_LAUNCH_SEARCH(false, 16); }
@@ -1054,16 +1061,19 @@ void launch_advance(const Problem& P, const DeviceState& D, int32_t* n_active, h
 void launch_belief_update(const Problem& P, const DeviceState& D, hipStream_t st)
 {
     if (P.belief == FBA_BELIEF_REJECTION) {
-        hipLaunchKernelGGL(reject_kernel, dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D);
+        if (P.dirichlet_regular) hipLaunchKernelGGL(reject_kernel<true>, dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D);
+        else hipLaunchKernelGGL(reject_kernel<false>, dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D);
         return;
     }
     if (!D.is_multi) {
-        hipLaunchKernelGGL(importance_kernel, dim3(P.E), dim3(IS_BLOCK), 0, st, P, D);
+        if (P.dirichlet_regular) hipLaunchKernelGGL(importance_kernel<true>, dim3(P.E), dim3(IS_BLOCK), 0, st, P, D);
+        else hipLaunchKernelGGL(importance_kernel<false>, dim3(P.E), dim3(IS_BLOCK), 0, st, P, D);
         return;
     }
     const int nchunks = (P.N + 255) / 256;
     const dim3 cgrid(ceil_div(nchunks, 4), P.E), eg(ceil_div(P.E, 64));
-    hipLaunchKernelGGL(is_multi_step_kernel, cgrid, dim3(256), 0, st, P, D);
+    if (P.dirichlet_regular) hipLaunchKernelGGL(is_multi_step_kernel<true>, cgrid, dim3(256), 0, st, P, D);
+    else hipLaunchKernelGGL(is_multi_step_kernel<false>, cgrid, dim3(256), 0, st, P, D);
     hipLaunchKernelGGL(scan_carry_kernel, dim3(P.E), dim3(256), 0, st, D.ctot, D.ctot_stride, nchunks, D.is_tot, 2, 0, D.need_update, P.E);
     hipLaunchKernelGGL(is_multi_norm_kernel, cgrid, dim3(256), 0, st, P, D);
     hipLaunchKernelGGL(scan_carry_kernel, dim3(P.E), dim3(256), 0, st, D.ctot, D.ctot_stride, nchunks, D.is_tot, 2, 1, D.need_update, P.E);

@@ -93,6 +93,9 @@ typedef struct fba_config {
     int32_t slots;           /* concurrent runs on the device; 0 => min(runs, auto)          */
     int32_t device;          /* HIP device ordinal                                           */
     int32_t trace;           /* 1 => record one fba_trace_rec per real time-step             */
+    int32_t dirichlet_regular; /* --dirichlet_sampling_method regular (0 = expected, default);
+                                * bug-compatible with the reference's biased sampler (BAConf.hpp:22,
+                                * random.cpp:146-242) */
 } fba_config;
 
 /* One record per real time-step: the information the reference prints at -v 2 / -v 3

@@ -382,3 +382,21 @@ def test_large_importance_filter_properties(monkeypatch):
         assert np.all(d >= 0) and np.all(d.sum(axis=1) == (k + 1) * 6)     # FS + FO = 4 + 2 increments per update
         tot = eng.last_step_info()[0]["weight_total"]
         assert 0 < tot <= 1.0
+
+
+@pytest.mark.parametrize("domain,model,belief,kw", [
+    ("episodic-tiger", N.MODEL_BA_TABLE, "rejection_sampling", dict(particles=60, sims=80, runs=5, episodes=3)),
+    ("continuous-tiger", N.MODEL_BA_TABLE, "importance_sampling", dict(particles=60, sims=60, runs=4, episodes=2, horizon=5)),
+    ("episodic-factored-tiger", N.MODEL_BA_FACTORED, "importance_sampling",
+     dict(size=2, particles=50, sims=60, runs=4, episodes=2, structure_prior=2)),
+])
+def test_regular_dirichlet_mode(domain, model, belief, kw):
+    """--dirichlet_sampling_method regular on the device: ziggurat half-normal, Marsaglia-Tsang gamma,
+    sampleFromSampledMult / sampleMult with the deterministic log / exp, bit-equal to the oracle."""
+    eng, o = _pair(domain, model, belief, 141, dirichlet_regular=1, **kw)
+    _assert_same_experiment(eng, o, ba=True)
+
+
+def test_regular_mode_rejects_long_rows():
+    with pytest.raises(ValueError, match="rows of at most"):
+        fba.Engine("episodic-factored-tiger", model=N.MODEL_BA_TABLE, size=4, particles=4, sims=4, slots=1, dirichlet_regular=1)
