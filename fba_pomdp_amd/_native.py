@@ -110,6 +110,21 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+CLI_PATH = os.path.join(HERE, "fba_experiment")
+CLI_SOURCE = os.path.join(HERE, "csrc", "host", "fba_cli.cpp")
+
+
+def build_cli(force=False):
+    """g++ the reference-compatible command line (planning / bapomdp / fbapomdp) against the C-ABI."""
+    if (not force and os.path.exists(CLI_PATH)
+            and os.path.getmtime(CLI_SOURCE) <= os.path.getmtime(CLI_PATH)
+            and os.path.getmtime(LIB_PATH) <= os.path.getmtime(CLI_PATH)):
+        return CLI_PATH
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), CLI_SOURCE,
+                           "-L" + HERE, "-lfba_hip", "-Wl,-rpath,$ORIGIN", "-o", CLI_PATH])
+    return CLI_PATH
+
+
 _lib = None
 
 

@@ -1,0 +1,71 @@
+"""The reference-compatible command line (fba_experiment planning|bapomdp|fbapomdp): flag names and
+result-file format of src/planning.cpp / src/bapomdp.cpp / src/fbapomdp.cpp."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import fba_pomdp_amd as fba
+from fba_pomdp_amd import _native as N
+
+
+@pytest.fixture(scope="module")
+def cli():
+    fba.build()
+    return fba.build_cli()
+
+
+def test_cli_help_and_argument_errors(cli):
+    r = subprocess.run([cli, "--help"], capture_output=True, text=True)
+    assert r.returncode == 0
+    for flag in ("--runs", "--horizon", "--discount", "--planner", "--belief", "--seed", "--simulation-amount",
+                 "--mcts-max-depth", "--exploration-constant", "--particle-amount", "--domain", "--size", "--episodes",
+                 "--dirichlet_sampling_method", "--noise", "--counts-total", "--structure-prior", "--output-file"):
+        assert flag in r.stdout                                  # the reference's flag names (Conf.cpp, BAConf.cpp, ...)
+    for args, msg in ((["planning", "-D", "nope"], "legit domain"), (["planning", "-D", "episodic-tiger", "--bogus", "1"], "unrecognised"),
+                      (["planning", "-D", "episodic-tiger", "--runs"], "missing"), (["frobnicate"], "unknown mode"),
+                      (["planning", "-D", "episodic-tiger", "-s", "abc"], "invalid")):
+        r = subprocess.run([cli] + args, capture_output=True, text=True)
+        assert r.returncode == 1 and msg in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_planning_result_file_matches_library(cli, tmp_path):
+    out = tmp_path / "planning.res"
+    r = subprocess.run([cli, "planning", "-D", "episodic-tiger", "-s", "200", "--particle-amount", "64", "--runs", "50",
+                        "--seed", "abc", "-f", str(out), "-v", "2"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = out.read_text().splitlines()
+    assert lines[0] == "# version 1:"
+    assert lines[1] == "# return mean, return var, return count, return stder, step duration mean"
+    mean, var, count, stder, dur = (float(x) for x in lines[2].split(", "))
+    h = 1469598103934665603
+    for ch in b"abc":
+        h = ((h ^ ch) * 1099511628211) % 2 ** 64
+    eng = fba.Engine("episodic-tiger", sims=200, particles=64, runs=50, seed=h)
+    st = eng.run_planning()
+    assert count == 50 and float("%g" % st.mean) == mean and float("%g" % st.var) == var and float("%g" % st.stder) == stder
+    assert dur > 0
+    steps = [l for l in r.stdout.splitlines() if l.startswith("V2: T=")]
+    assert len(steps) == eng.counters().env_steps
+    assert re.match(r"V2: T=0\ta=\d\ts'=\d\to=\d\tr=-?\d+", steps[0])
+
+
+@pytest.mark.gpu
+def test_cli_bapomdp_and_fbapomdp_write_one_line_per_episode(cli, tmp_path):
+    out = tmp_path / "ba.res"
+    r = subprocess.run([cli, "bapomdp", "-D", "episodic-tiger", "-s", "100", "--particle-amount", "50", "--runs", "8",
+                        "--episodes", "4", "--seed", "1", "-f", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rows = [l for l in out.read_text().splitlines() if l and not l.startswith("#")]
+    assert len(rows) == 4 and all(len(l.split(", ")) == 5 and float(l.split(", ")[2]) == 8 for l in rows)
+    out2 = tmp_path / "fba.res"
+    r = subprocess.run([cli, "fbapomdp", "-D", "gridworld", "--size", "3", "-B", "importance_sampling", "-s", "50",
+                        "--particle-amount", "32", "--runs", "4", "--episodes", "2", "-H", "8", "--structure-prior", "match-uniform",
+                        "-f", str(out2)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert len([l for l in out2.read_text().splitlines() if l and not l.startswith("#")]) == 2
+    r = subprocess.run([cli, "bapomdp", "-D", "episodic-tiger", "--noise", "0.9"], capture_output=True, text=True)
+    assert r.returncode == 1 and "noise has to be between" in r.stderr      # TigerPriors.cpp:22-25
