@@ -27,30 +27,60 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(args):
-    """The oracle (CPU restatement, mt19937 mode = the reference's own arithmetic and draw order)
-    timed on one host core on a bounded sample of the same workload."""
+def cpu_worker(args):
+    """One process of the CPU baseline (`bench.py --cpu-worker SEED`): the oracle in mt19937 mode (the
+    reference's own arithmetic and draw order) on its own seed; prints one JSON line."""
     from oracle import pyorc as orc
     o = orc.Oracle(domain=orc.DOM_TIGER_EPISODIC, model=orc.MODEL_BA_TABLE, belief=orc.BELIEF_REJECTION,
                    sims=args.sims, particles=args.particles, horizon=args.horizon,
-                   runs=args.cpu_runs, episodes=args.cpu_episodes, seed_str="bench")
+                   runs=args.cpu_runs, episodes=args.cpu_episodes, seed_str=args.cpu_worker)
     t0 = time.perf_counter()
     _, res = o.run_bapomdp()
-    dt = time.perf_counter() - t0
-    steps = res.sim_steps + res.belief_steps
+    print(json.dumps({"steps": res.sim_steps + res.belief_steps, "env_steps": res.env_steps,
+                      "seconds": time.perf_counter() - t0}), flush=True)
+
+
+def cpu_baseline(args):
+    """The oracle (CPU restatement of the reference path) timed on the host cores of this box on a
+    bounded sample of the same workload: one PROCESS per available core (the reference algorithm is
+    built on global RNG / static scratch state, SURVEY section 5, so no threads), disjoint seeds;
+    aggregate = total simulated steps / longest process time.  Plain child processes with a hard
+    timeout: they never touch the GPU."""
+    import subprocess
+    cores = max(1, min(len(os.sched_getaffinity(0)), args.cpu_cores or 10 ** 6))
+    cmd = [sys.executable, os.path.abspath(__file__), "--sims", str(args.sims), "--particles", str(args.particles),
+           "--horizon", str(args.horizon), "--cpu-runs", str(args.cpu_runs), "--cpu-episodes", str(args.cpu_episodes)]
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen(cmd + ["--cpu-worker", f"bench-{k}"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+             for k in range(cores)]
+    out = []
+    for p in procs:
+        try:
+            stdout, _ = p.communicate(timeout=max(5.0, 120.0 - (time.perf_counter() - t0)))
+            out.append(json.loads(stdout.strip().splitlines()[-1]))
+        except Exception:
+            p.kill()
+    wall = time.perf_counter() - t0
+    if not out:
+        return {"value": None, "unit": "simulated env steps/s", "cores": cores, "kind": "port", "sample": "CPU baseline workers failed"}
+    steps = sum(o["steps"] for o in out)
+    longest = max(o["seconds"] for o in out)
+    per_core = sorted(o["steps"] / o["seconds"] for o in out)[len(out) // 2]
     return {
-        "value": steps / dt, "unit": "simulated env steps/s", "cores": 1, "kind": "port",
-        "sample": f"{args.cpu_runs} runs x {args.cpu_episodes} episodes of the same config "
-                  f"({res.env_steps} real steps, {steps} simulated steps, {dt:.1f} s, gcc -O2, 1 thread)",
+        "value": steps / longest, "unit": "simulated env steps/s", "cores": len(out), "kind": "port",
+        "per_core": per_core,
+        "sample": f"{len(out)} processes x {args.cpu_runs} runs x {args.cpu_episodes} episodes of the same config "
+                  f"({sum(o['env_steps'] for o in out)} real steps, {steps} simulated steps, longest process {longest:.1f} s, "
+                  f"{wall:.1f} s wall, gcc -O2)",
     }
 
 
-def measured_traffic(args, kname):
+def measured_traffic(args, kname, slots):
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes
     (FETCH_SIZE and WRITE_SIZE in separate runs of this same command; profiles/*.json says how
     they were collected and corrected).  None when the workload differs from the profiled one."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write.json")
-    if not os.path.exists(path) or args.slots != 131072 or args.sims != 4096 or args.particles != 4096:
+    if not os.path.exists(path) or slots != 131072 or args.sims != 4096 or args.particles != 4096:
         return None, None
     with open(path) as f:
         d = json.load(f)
@@ -69,10 +99,17 @@ def main():
     ap.add_argument("--particles", type=int, default=4096)
     ap.add_argument("--horizon", type=int, default=10)
     ap.add_argument("--belief", default="rejection_sampling", choices=["rejection_sampling", "importance_sampling"])
-    ap.add_argument("--cpu-runs", type=int, default=8)
+    ap.add_argument("--cpu-cores", type=int, default=0, help="processes of the CPU baseline (0 = every core this process may use)")
+    ap.add_argument("--cpu-runs", type=int, default=4)
     ap.add_argument("--cpu-episodes", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--all-ranks-on-device", type=int, default=None,
+                    help="rehearsal only: put every rank on this one GPU (a 1-GPU box cannot give each rank its own)")
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker is not None:
+        cpu_worker(args)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -84,19 +121,36 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: fba_pomdp_amd has no CPU path")
+    if args.all_ranks_on_device is not None:
+        local_rank = args.all_ranks_on_device
     torch.cuda.set_device(local_rank)
     collective = None
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # nccl = RCCL on ROCm
-        collective = "rccl"
+        try:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # nccl = RCCL on ROCm
+            collective = "rccl"
+        except Exception as e:  # the statistics reduce is 5 doubles: never lose a scaling run to the transport
+            print(f"[bench] RCCL process group failed ({e}); reducing over gloo instead", file=sys.stderr)
+            dist.init_process_group(backend="gloo")
+            collective = "gloo"
 
     import fba_pomdp_amd as fba
-    eng = fba.Engine("episodic-tiger", model=fba.MODEL_BA_TABLE, belief=args.belief,
-                     sims=args.sims, particles=args.particles, horizon=args.horizon,
-                     episodes=64, runs=1 << 30, slots=args.slots, run_offset=rank * args.slots,
-                     seed=20261003, device=local_rank)
+    slots = args.slots
+    while True:  # 1.3 MB of HBM per slot: halve if this GPU cannot give 170 GB right now
+        try:
+            eng = fba.Engine("episodic-tiger", model=fba.MODEL_BA_TABLE, belief=args.belief,
+                             sims=args.sims, particles=args.particles, horizon=args.horizon,
+                             episodes=64, runs=1 << 30, slots=slots, run_offset=rank * args.slots,
+                             seed=20261003, device=local_rank)
+            break
+        except fba.FbaError as e:
+            if "out of memory" not in str(e) or slots <= 1024:
+                raise
+            print(f"[bench] {slots} slots do not fit ({e}); retrying with {slots // 2}", file=sys.stderr)
+            slots //= 2
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -114,9 +168,10 @@ def main():
     steps = (c1.sim_steps - c0.sim_steps) + (c1.belief_steps - c0.belief_steps)
     rets = eng.return_sums()
 
+    red_dev = "cpu" if collective == "gloo" else "cuda"
     tot = torch.tensor([float(steps), float(c1.sim_steps - c0.sim_steps), rets[0], rets[1], rets[2]],
-                       dtype=torch.float64, device="cuda")
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+                       dtype=torch.float64, device=red_dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -129,7 +184,7 @@ def main():
         achieved = (k.bytes / 1e9) / (k.ms / 1e3) if k.ms > 0 else 0.0
         search = kt["search_kernel"]
         n_ep = tot[2]
-        traffic, traffic_src = measured_traffic(args, kname)
+        traffic, traffic_src = measured_traffic(args, kname, eng.slots)
         out = {
             "metric": "simulated env steps/sec (belief+rollout)",
             "value": tot[0] / dt_max,
