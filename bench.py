@@ -99,7 +99,8 @@ def main():
     ap.add_argument("--particles", type=int, default=4096)
     ap.add_argument("--horizon", type=int, default=10)
     ap.add_argument("--belief", default="rejection_sampling", choices=["rejection_sampling", "importance_sampling"])
-    ap.add_argument("--cpu-cores", type=int, default=0, help="processes of the CPU baseline (0 = every core this process may use)")
+    ap.add_argument("--cpu-cores", type=int, default=16,
+                    help="processes of the CPU baseline (a 1-GPU box's CPU share is 16 cores, whatever the affinity mask says)")
     ap.add_argument("--cpu-runs", type=int, default=4)
     ap.add_argument("--cpu-episodes", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
