@@ -151,9 +151,19 @@ __device__ __forceinline__ int ucb_select(const Problem& P, const DeviceState& D
 // record fits 32 words (STAGE) -- the root particle's whole count blob, [word][lane], fetched with
 // one burst of 16-byte loads per simulation so that no step waits on HBM for its Dirichlet rows.
 // ---------------------------------------------------------------------------------------------
-template <bool STAGE, int AMAX, bool REG>
+template <bool STAGE, int AMAX, bool REG, bool TIGER_TABLE>
 __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceState D)
 {
+    // TIGER_TABLE: the launcher has checked that this is the tabular BA-POMDP over (episodic or
+    // continuous) tiger; restating its sizes as literals lets the compiler unroll the two-entry
+    // Dirichlet rows and fold every model / domain branch.  Same code, same results.
+    if (TIGER_TABLE) {
+        P.model = FBA_MODEL_BA_TABLE; P.planner = FBA_PLANNER_POUCT;
+        P.S = 2; P.A = 3; P.O = 2; P.phi_len = 12; P.C = 24; P.Cs = 32;
+        if (P.domain != FBA_DOM_TIGER_CONTINUOUS) P.domain = FBA_DOM_TIGER_EPISODIC;
+        P.belief = P.belief == FBA_BELIEF_IMPORTANCE ? FBA_BELIEF_IMPORTANCE : FBA_BELIEF_REJECTION;
+        D.cq_off = 4; D.child_off = 10; D.node_words = 16; D.hash = nullptr;  // node layout of A = 3, O = 2 (fba_engine.hip)
+    }
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
     const int e    = blockIdx.x * SEARCH_BLOCK + lane;
@@ -478,9 +488,14 @@ __device__ __forceinline__ int record_group(int C4)
 // reference's result: the new filter is the first N accepted attempts, in order, and the
 // reported loop count is the index of the N-th accepted attempt + 1.
 // ---------------------------------------------------------------------------------------------
-template <bool REG>
+template <bool REG, bool TIGER_TABLE>
 __global__ void __launch_bounds__(REJECT_BLOCK) reject_kernel(Problem P, DeviceState D)
 {
+    if (TIGER_TABLE) {  // sizes restated as literals (see search_kernel)
+        P.model = FBA_MODEL_BA_TABLE;
+        P.S = 2; P.A = 3; P.O = 2; P.phi_len = 12; P.C = 24; P.Cs = 32;
+        if (P.domain != FBA_DOM_TIGER_CONTINUOUS) P.domain = FBA_DOM_TIGER_EPISODIC;
+    }
     __shared__ int32_t s_src[REJECT_BLOCK], s_ns[REJECT_BLOCK], s_owner[REJECT_BLOCK], s_inc[MAXINC * REJECT_BLOCK];
     __shared__ int32_t s_wave[REJECT_BLOCK / 64];
     __shared__ int32_t s_count;
@@ -1038,9 +1053,15 @@ void launch_search(const Problem& P, const DeviceState& D, hipStream_t st)
     const dim3 grid(ceil_div(P.E, SEARCH_BLOCK)), block(SEARCH_BLOCK);
 #define FBA_LAUNCH_SEARCH(STG, AM)                                                                  \
     do {                                                                                            \
-        if (P.dirichlet_regular) hipLaunchKernelGGL((search_kernel<STG, AM, true>), grid, block, lds, st, P, D);   \
-        else hipLaunchKernelGGL((search_kernel<STG, AM, false>), grid, block, lds, st, P, D);       \
+        if (P.dirichlet_regular) hipLaunchKernelGGL((search_kernel<STG, AM, true, false>), grid, block, lds, st, P, D);   \
+        else hipLaunchKernelGGL((search_kernel<STG, AM, false, false>), grid, block, lds, st, P, D); \
     } while (0)
+    const bool tiger_table = P.model == FBA_MODEL_BA_TABLE && P.planner == FBA_PLANNER_POUCT && !P.dirichlet_regular && stage &&
+                             (P.domain == FBA_DOM_TIGER_EPISODIC || P.domain == FBA_DOM_TIGER_CONTINUOUS) && !D.hash;
+    if (tiger_table) {
+        hipLaunchKernelGGL((search_kernel<true, 4, false, true>), grid, block, lds, st, P, D);
+        return;
+    }
     if (P.A <= 4) { if (stage) FBA_LAUNCH_SEARCH(true, 4); else FBA_LAUNCH_SEARCH(false, 4); }
     else if (P.A <= 8) { if (stage) FBA_LAUNCH_SEARCH(true, 8); else FBA_LAUNCH_SEARCH(false, 8); }
     else { if (stage) FBA_LAUNCH_SEARCH(true, 16); else FBA_LAUNCH_SEARCH(false, 16); }
@@ -1061,8 +1082,11 @@ void launch_advance(const Problem& P, const DeviceState& D, int32_t* n_active, h
 void launch_belief_update(const Problem& P, const DeviceState& D, hipStream_t st)
 {
     if (P.belief == FBA_BELIEF_REJECTION) {
-        if (P.dirichlet_regular) hipLaunchKernelGGL(reject_kernel<true>, dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D);
-        else hipLaunchKernelGGL(reject_kernel<false>, dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D);
+        const bool tiger_table = P.model == FBA_MODEL_BA_TABLE && !P.dirichlet_regular &&
+                                 (P.domain == FBA_DOM_TIGER_EPISODIC || P.domain == FBA_DOM_TIGER_CONTINUOUS);
+        if (P.dirichlet_regular) hipLaunchKernelGGL((reject_kernel<true, false>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D);
+        else if (tiger_table) hipLaunchKernelGGL((reject_kernel<false, true>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D);
+        else hipLaunchKernelGGL((reject_kernel<false, false>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D);
         return;
     }
     if (!D.is_multi) {
