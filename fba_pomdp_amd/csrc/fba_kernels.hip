@@ -642,9 +642,14 @@ __global__ void __launch_bounds__(IS_BLOCK) uniform_scan_kernel(int n, double* w
 //   3. N multinomial draws by binary search on the prefix sums
 //   4. whole-record gather into the other buffer, weights reset to 1/N
 // ---------------------------------------------------------------------------------------------
-template <bool REG>
+template <bool REG, bool TIGER_TABLE>
 __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceState D)
 {
+    if (TIGER_TABLE) {  // sizes restated as literals (see search_kernel)
+        P.model = FBA_MODEL_BA_TABLE;
+        P.S = 2; P.A = 3; P.O = 2; P.phi_len = 12; P.C = 24; P.Cs = 32;
+        if (P.domain != FBA_DOM_TIGER_CONTINUOUS) P.domain = FBA_DOM_TIGER_EPISODIC;
+    }
     __shared__ double s_carry[IS_MAX_CHUNKS + 2];
     __shared__ int32_t s_src[IS_BLOCK], s_inc[MAXINC * IS_BLOCK];
     const int e = blockIdx.x, tid = threadIdx.x;
@@ -1090,8 +1095,11 @@ void launch_belief_update(const Problem& P, const DeviceState& D, hipStream_t st
         return;
     }
     if (!D.is_multi) {
-        if (P.dirichlet_regular) hipLaunchKernelGGL(importance_kernel<true>, dim3(P.E), dim3(IS_BLOCK), 0, st, P, D);
-        else hipLaunchKernelGGL(importance_kernel<false>, dim3(P.E), dim3(IS_BLOCK), 0, st, P, D);
+        const bool tiger_table = P.model == FBA_MODEL_BA_TABLE && !P.dirichlet_regular &&
+                                 (P.domain == FBA_DOM_TIGER_EPISODIC || P.domain == FBA_DOM_TIGER_CONTINUOUS);
+        if (P.dirichlet_regular) hipLaunchKernelGGL((importance_kernel<true, false>), dim3(P.E), dim3(IS_BLOCK), 0, st, P, D);
+        else if (tiger_table) hipLaunchKernelGGL((importance_kernel<false, true>), dim3(P.E), dim3(IS_BLOCK), 0, st, P, D);
+        else hipLaunchKernelGGL((importance_kernel<false, false>), dim3(P.E), dim3(IS_BLOCK), 0, st, P, D);
         return;
     }
     const int nchunks = (P.N + 255) / 256;
