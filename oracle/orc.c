@@ -90,6 +90,12 @@ struct orc_ctx {
     particle* Pnew;
     float* pool;
     float* pool_new;
+    /* ReinvigoratingRejectionSampling::_fully_connected_belief (second FlatFilter) */
+    particle* F;
+    particle* Fnew;
+    float* fpool;
+    float* fpool_new;
+    float* breed_tmp;
     double total_w; /* WeightedFilter::_total_weight */
     double* wscratch;
     double* wscan;
@@ -1452,7 +1458,7 @@ static void weighted_refresh_scan(orc_ctx* c)
 
 static int32_t belief_sample(orc_ctx* c)
 {
-    return c->cfg.belief == ORC_BELIEF_REJECTION ? flat_sample(c) : weighted_sample(c);
+    return c->cfg.belief != ORC_BELIEF_IMPORTANCE ? flat_sample(c) : weighted_sample(c);
 }
 
 static void swap_pools(orc_ctx* c)
@@ -1488,10 +1494,22 @@ static void belief_initiate(orc_ctx* c)
         c->total_w += w; /* WeightedFilter::add(T, w) WeightedFilter.cpp:60-66 */
     }
     if (c->cfg.belief == ORC_BELIEF_IMPORTANCE) weighted_refresh_scan(c);
+    if (c->cfg.belief == ORC_BELIEF_REINVIGORATION) {
+        /* ReinvigoratingRejectionSampling::initiate (ReinvigoratingRejectionSampling.cpp:55-76):
+         * after the n start states, n x FBAPOMDP::sampleFullyConnectedState (FBAPOMDP.cpp:63-67 ->
+         * FactoredTigerFactoredPrior::sampleFullyConnectedState FactoredTigerPriors.cpp:324-337) */
+        for (i = 0; i < n; ++i) {
+            orc_rng_stream(&c->rng, ORC_PH_INIT_FC, (uint32_t)i);
+            c->F[i].s = domain_start(c);
+            c->F[i].w = 0;
+            memcpy(c->F[i].cnt, c->prior, sizeof(float) * (size_t)c->ncnt);
+            ftiger_set_observation_model(c, c->F[i].cnt, (1u << c->fd.FS) - 1u);
+        }
+    }
 }
 
 /* beliefs::rejectSample.  ref: src/beliefs/particle_filters/RejectionSampling.hpp:26-72 */
-static void reject_sample(orc_ctx* c, int32_t a, int32_t o)
+static void reject_sample(orc_ctx* c, int32_t a, int32_t o, int phase)
 {
     int n = c->cfg.particles, acc = 0, count = 0;
     c->step_counter = &c->belief_steps;
@@ -1500,7 +1518,7 @@ static void reject_sample(orc_ctx* c, int32_t a, int32_t o)
         double r;
         simstate st;
         particle* dst = &c->Pnew[acc];
-        orc_rng_stream(&c->rng, ORC_PH_REJECT, (uint32_t)count);
+        orc_rng_stream(&c->rng, phase, (uint32_t)count);
         src  = flat_sample(c);
         st.s = c->P[src].s;
         st.cnt = dst->cnt;
@@ -1573,11 +1591,99 @@ static void is_resample(orc_ctx* c)
     c->last_update_count = -1;
 }
 
+/* the main filter <-> the fully connected filter */
+static void swap_main_fc(orc_ctx* c)
+{
+    particle* p; float* q;
+    p = c->P; c->P = c->F; c->F = p;
+    p = c->Pnew; c->Pnew = c->Fnew; c->Fnew = p;
+    q = c->pool; c->pool = c->fpool; c->fpool = q;
+    q = c->pool_new; c->pool_new = c->fpool_new; c->fpool_new = q;
+}
+
+/* DBNNode::marginalizeOut (DBNNode.cpp:40-80) on a max-layout node: `src` holds the node's CPT
+ * under parent mask `om`, `dst` receives the CPT under mask `nm`.  Rows of the source are visited
+ * in ascending order and added (float) into the row the new node's cptIndex maps their parent
+ * values to; the reference reads those parent values as graph input (DBNNode.cpp:62), so the
+ * source must hold every parent of the target: nm is a subset of om. */
+static void node_marginalize(const orc_ctx* c, const fnode* nd, const float* src, uint32_t om, float* dst, uint32_t nm)
+{
+    int j, v, r, rows_old = 1, rows_max = 1, fv[ORC_MAXF] = {0};
+    for (j = 0; j < nd->nmax; ++j) {
+        rows_max *= c->fd.Ssz[nd->maxp[j]];
+        if ((om >> j) & 1u) rows_old *= c->fd.Ssz[nd->maxp[j]];
+    }
+    memset(dst + nd->off, 0, sizeof(float) * (size_t)rows_max * nd->out);
+    for (r = 0; r < rows_old; ++r) {
+        int rem = r, nr;
+        for (j = nd->nmax - 1; j >= 0; --j) /* last parent is the fastest digit (index.cpp:51-83) */
+            if ((om >> j) & 1u) {
+                fv[nd->maxp[j]] = rem % c->fd.Ssz[nd->maxp[j]];
+                rem /= c->fd.Ssz[nd->maxp[j]];
+            }
+        nr = node_row(c, nd, nm, fv);
+        for (v = 0; v < nd->out; ++v) dst[nr + v] += src[nd->off + r * nd->out + v];
+    }
+}
+
+/* breed (ReinvigoratingRejectionSampling.cpp:24-35): BABNModel::marginalizeOut (BABNModel.cpp:205-229)
+ * of the counts particle onto the mutated structure.  Nodes whose parents are fixed keep the counts
+ * particle's CPT ("exactly same parents need no marginalizing", DBNNode.cpp:45-48). */
+static void breed_counts(const orc_ctx* c, const float* counts_cnt, const uint32_t* new_masks, float* out)
+{
+    const fdesc* d = &c->fd;
+    int k, nn = c->A * d->FS + c->A * d->FO;
+    memcpy(out, counts_cnt, sizeof(float) * (size_t)c->ncnt);
+    for (k = 0; k < nn; ++k) {
+        const fnode* nd = k < c->A * d->FS ? &d->T[k] : &d->O[k - c->A * d->FS];
+        if (nd->var < 0) continue;
+        node_marginalize(c, nd, counts_cnt, f2u(counts_cnt[d->ncounts + nd->var]), out, new_masks[nd->var]);
+        out[d->ncounts + nd->var] = u2f(new_masks[nd->var]);
+    }
+}
+
+/* ReinvigoratingRejectionSampling::reinvigorateParticles (ReinvigoratingRejectionSampling.cpp:121-131).
+ * Draw order of one iteration: g++ evaluates breed's arguments right to left, so
+ * _fully_connected_belief.sample() comes first, then _belief.sample(); then the mutation
+ * (FactoredTigerFactoredPrior::mutate FactoredTigerPriors.cpp:353-381 ->
+ * BABNModel::Structure::flip_random_edge BABNModel.cpp:16-31: one slowRandomInt over the state
+ * features, flips that parent of the listen observation node); then FlatFilter::replace picks the
+ * victim (FlatFilter.cpp:39-46).  Iterations are sequential: a bred particle can be sampled by the next. */
+static void reinvigorate(orc_ctx* c)
+{
+    int i, k, n = c->cfg.particles;
+    const fdesc* d = &c->fd;
+    for (i = 0; i < c->cfg.resample_amount; ++i) {
+        uint32_t masks[ORC_MAXF];
+        int32_t fc, b, edge, victim;
+        orc_rng_stream(&c->rng, ORC_PH_REINVIG, (uint32_t)i);
+        fc = orc_int(&c->rng, n);
+        b  = orc_int(&c->rng, n);
+        for (k = 0; k < d->nvar; ++k) masks[k] = f2u(c->P[b].cnt[d->ncounts + k]);
+        edge = orc_slow_int(&c->rng, 0, d->FS);
+        masks[0] ^= 1u << edge;
+        breed_counts(c, c->F[fc].cnt, masks, c->breed_tmp);
+        victim = orc_int(&c->rng, n);
+        c->P[victim].s = c->P[b].s; /* copyDomainState(structure_state->_domain_state) */
+        memcpy(c->P[victim].cnt, c->breed_tmp, sizeof(float) * (size_t)c->ncnt);
+    }
+}
+
 static void belief_update(orc_ctx* c, int32_t a, int32_t o)
 {
     c->last_weight_total = 0;
-    if (c->cfg.belief == ORC_BELIEF_REJECTION) reject_sample(c, a, o);
-    else {
+    if (c->cfg.belief == ORC_BELIEF_REJECTION) reject_sample(c, a, o, ORC_PH_REJECT);
+    else if (c->cfg.belief == ORC_BELIEF_REINVIGORATION) {
+        /* ReinvigoratingRejectionSampling::updateEstimation (ReinvigoratingRejectionSampling.cpp:89-107) */
+        int count;
+        reinvigorate(c);
+        reject_sample(c, a, o, ORC_PH_REJECT);
+        count = c->last_update_count;
+        swap_main_fc(c);
+        reject_sample(c, a, o, ORC_PH_REJECT_FC);
+        swap_main_fc(c);
+        c->last_update_count = count;
+    } else {
         is_update(c, a, o);
         is_resample(c);
     }
@@ -1589,11 +1695,16 @@ static void belief_update(orc_ctx* c, int32_t a, int32_t o)
 static void belief_reset_domain_state(orc_ctx* c)
 {
     int i, n = c->cfg.particles;
-    if (c->cfg.belief == ORC_BELIEF_REJECTION) {
+    if (c->cfg.belief != ORC_BELIEF_IMPORTANCE) {
         for (i = 0; i < n; ++i) {
             orc_rng_stream(&c->rng, ORC_PH_RESET, (uint32_t)i);
             c->P[i].s = domain_start(c);
         }
+        if (c->cfg.belief == ORC_BELIEF_REINVIGORATION) /* ReinvigoratingRejectionSampling.cpp:109-119 */
+            for (i = 0; i < n; ++i) {
+                orc_rng_stream(&c->rng, ORC_PH_RESET_FC, (uint32_t)i);
+                c->F[i].s = domain_start(c);
+            }
     } else {
         double w1 = 1.0 / (double)n, new_total = 0;
         for (i = 0; i < n; ++i) {
@@ -1854,6 +1965,27 @@ orc_ctx* orc_create(const orc_config* cfg)
             c->Pnew[i].cnt = c->pool_new + (size_t)i * c->ncnt;
         }
     }
+    if (cfg->belief == ORC_BELIEF_REINVIGORATION) {
+        if (cfg->model != ORC_MODEL_BA_FACTORED || !is_ftiger(cfg->domain)) {
+            /* the reference has fully connected priors for factored tiger, collision avoidance and
+             * sysadmin; GridWorldFactBAPrior::sampleFullyConnectedState throws "nyi" */
+            snprintf(c->err, sizeof c->err, "reinvigoration belief: built for the factored-tiger FBA-POMDP only");
+            return c;
+        }
+        if (cfg->resample_amount < 1) { /* ReinvigoratingRejectionSampling.cpp:43-49 */
+            snprintf(c->err, sizeof c->err, "ReinvigoratingRejectionSampling::cannot initiate belief of size < 1 (%d), or resample size of < 1 (%d)", n, cfg->resample_amount);
+            return c;
+        }
+        c->F     = (particle*)calloc((size_t)n, sizeof(particle));
+        c->Fnew  = (particle*)calloc((size_t)n, sizeof(particle));
+        c->fpool     = (float*)malloc(sizeof(float) * (size_t)n * c->ncnt);
+        c->fpool_new = (float*)malloc(sizeof(float) * (size_t)n * c->ncnt);
+        c->breed_tmp = (float*)malloc(sizeof(float) * (size_t)c->ncnt);
+        for (i = 0; i < n; ++i) {
+            c->F[i].cnt    = c->fpool + (size_t)i * c->ncnt;
+            c->Fnew[i].cnt = c->fpool_new + (size_t)i * c->ncnt;
+        }
+    }
     c->step_counter = &c->sim_steps;
     return c;
 }
@@ -1865,6 +1997,7 @@ void orc_destroy(orc_ctx* c)
     free(c->tr.visits); free(c->tr.cn); free(c->tr.cq); free(c->tr.child);
     free(c->tr.hkey); free(c->tr.hval);
     free(c->P); free(c->Pnew); free(c->pool); free(c->pool_new);
+    free(c->F); free(c->Fnew); free(c->fpool); free(c->fpool_new); free(c->breed_tmp);
     free(c->wscratch); free(c->wscan); free(c->trace);
     free(c);
 }
@@ -1911,6 +2044,23 @@ void orc_belief_get(const orc_ctx* c, int32_t* s, double* w, float* cnt)
         if (w) w[i] = c->P[i].w;
         if (cnt && c->ncnt) memcpy(cnt + (size_t)i * c->ncnt, c->P[i].cnt, sizeof(float) * c->ncnt);
     }
+}
+/* the fully connected filter of the reinvigoration belief */
+void orc_belief_get_fc(const orc_ctx* c, int32_t* s, float* cnt)
+{
+    int i;
+    if (!c->F) return;
+    for (i = 0; i < c->cfg.particles; ++i) {
+        if (s) s[i] = c->F[i].s;
+        if (cnt) memcpy(cnt + (size_t)i * c->ncnt, c->F[i].cnt, sizeof(float) * c->ncnt);
+    }
+}
+/* BABNModel::marginalizeOut of a caller-owned count blob onto new parent masks (one per variable node) */
+int orc_marginalize(orc_ctx* c, const float* cnt, const uint32_t* new_masks, float* out)
+{
+    if (c->cfg.model != ORC_MODEL_BA_FACTORED) return -1;
+    breed_counts(c, cnt, new_masks, out);
+    return 0;
 }
 void orc_belief_set(orc_ctx* c, const int32_t* s, const double* w, const float* cnt)
 {

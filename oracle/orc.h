@@ -35,7 +35,8 @@ enum {
 /* simulator model */
 enum { ORC_MODEL_POMDP = 0, ORC_MODEL_BA_TABLE = 1, ORC_MODEL_BA_FACTORED = 2 };
 /* belief */
-enum { ORC_BELIEF_REJECTION = 0, ORC_BELIEF_IMPORTANCE = 1 };
+/* REINVIGORATION = beliefs::bayes_adaptive::factored::ReinvigoratingRejectionSampling (-B reinvigoration) */
+enum { ORC_BELIEF_REJECTION = 0, ORC_BELIEF_IMPORTANCE = 1, ORC_BELIEF_REINVIGORATION = 2 };
 /* floating-point summation order of the importance-sampling filter:
  * REF = the reference's sequential loops; DEV = the HIP engine's fixed reduction tree */
 enum { ORC_ARITH_REF = 0, ORC_ARITH_DEV = 1 };
@@ -73,6 +74,7 @@ typedef struct orc_config {
     int32_t planner;       /* ORC_PLANNER_* */
     int32_t ca_centered;   /* collision avoidance: 1 = centered-collision-avoidance, 0 = random-collision-avoidance */
     int32_t dirichlet_regular; /* --dirichlet_sampling_method regular (0 = expected, the default) */
+    int32_t resample_amount;   /* --resample-amount: particles bred per update (reinvigoration belief) */
 } orc_config;
 
 /* One record per real time-step; the HIP engine emits the same layout (fba_trace_rec). */
@@ -144,6 +146,8 @@ int orc_select_action(orc_ctx* c, int hist_len, orc_trace_rec* rec);
 uint64_t orc_belief_hash(orc_ctx* c);
 int orc_last_update_count(const orc_ctx* c);
 void orc_belief_get(const orc_ctx* c, int32_t* s, double* w, float* cnt);
+void orc_belief_get_fc(const orc_ctx* c, int32_t* s, float* cnt);
+int orc_marginalize(orc_ctx* c, const float* cnt, const uint32_t* new_masks, float* out);
 void orc_belief_set(orc_ctx* c, const int32_t* s, const double* w, const float* cnt);
 int orc_model_step(orc_ctx* c, float* cnt, int32_t* s, int32_t a, int32_t* o, double* r, int update);
 double orc_model_obs_prob(orc_ctx* c, const float* cnt, int32_t new_s, int32_t a, int32_t o);

@@ -15,7 +15,7 @@ _LIB = os.path.join(_HERE, "liborc.so")
 # enums (oracle/orc.h)
 DOM_TIGER_EPISODIC, DOM_TIGER_CONTINUOUS, DOM_FTIGER_EPISODIC, DOM_FTIGER_CONTINUOUS, DOM_GRIDWORLD, DOM_COLLISION_AVOID = range(6)
 MODEL_POMDP, MODEL_BA_TABLE, MODEL_BA_FACTORED = range(3)
-BELIEF_REJECTION, BELIEF_IMPORTANCE = range(2)
+BELIEF_REJECTION, BELIEF_IMPORTANCE, BELIEF_REINVIGORATION = range(3)
 ARITH_REF, ARITH_DEV = range(2)
 RNG_MT, RNG_PHILOX = range(2)
 PLANNER_POUCT, PLANNER_RANDOM = range(2)
@@ -35,6 +35,7 @@ class Config(C.Structure):
         ("structure_prior", C.c_int32), ("rng_mode", C.c_int32), ("arith", C.c_int32),
         ("philox_seed", C.c_uint64), ("seed_str", C.c_char * 64),
         ("run_offset", C.c_int32), ("trace", C.c_int32), ("planner", C.c_int32), ("ca_centered", C.c_int32), ("dirichlet_regular", C.c_int32),
+        ("resample_amount", C.c_int32),
     ]
 
 
@@ -117,6 +118,8 @@ def lib():
         L.orc_belief_hash.argtypes = [C.c_void_p]
         L.orc_last_update_count.argtypes = [C.c_void_p]
         L.orc_belief_get.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_belief_get_fc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_marginalize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_belief_set.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_model_step.argtypes = [C.c_void_p, C.c_void_p, P(C.c_int32), C.c_int32, P(C.c_int32), P(C.c_double), C.c_int]
         L.orc_model_obs_prob.restype = C.c_double
@@ -272,6 +275,21 @@ class Oracle:
         cnt = np.zeros((n, self.ncnt), np.float32)
         self.L.orc_belief_get(self.h, s.ctypes.data, w.ctypes.data, cnt.ctypes.data if self.ncnt else None)
         return s, w, cnt
+
+    def belief_get_fc(self):
+        n = self.cfg.particles
+        s = np.zeros(n, np.int32)
+        cnt = np.zeros((n, self.ncnt), np.float32)
+        self.L.orc_belief_get_fc(self.h, s.ctypes.data, cnt.ctypes.data)
+        return s, cnt
+
+    def marginalize(self, cnt, masks):
+        cnt = np.ascontiguousarray(cnt, np.float32)
+        masks = np.ascontiguousarray(masks, np.uint32)
+        out = np.zeros(self.ncnt, np.float32)
+        if self.L.orc_marginalize(self.h, cnt.ctypes.data, masks.ctypes.data, out.ctypes.data):
+            raise RuntimeError("marginalize: factored model only")
+        return out
 
     def belief_set(self, s=None, w=None, cnt=None):
         s = None if s is None else np.ascontiguousarray(s, np.int32)

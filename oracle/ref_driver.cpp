@@ -442,6 +442,90 @@ static void babn_model(char const* s, std::vector<int> parents)
 }
 
 
+/* BABNModel::marginalizeOut (BABNModel.cpp:205-229) / DBNNode::marginalizeOut (DBNNode.cpp:40-80) of a
+ * fully connected listen observation node onto every parent subset, and
+ * BABNModel::Structure::flip_random_edge (BABNModel.cpp:16-31) */
+static void marginalize(char const* s)
+{
+    using bayes_adaptive::factored::BABNModel;
+    Domain_Size sz(8, 3, 2);
+    Domain_Feature_Size fsz({2, 2, 2}, {2});
+    BABNModel::Indexing_Steps steps(indexing::stepSize(fsz._S), indexing::stepSize(fsz._O));
+    BABNModel m(&sz, &fsz, &steps);
+    IndexAction listen(2);
+    for (int f = 0; f < 3; ++f) {
+        m.resetTransitionNode(&listen, f, std::vector<int>({f}));
+        for (int v = 0; v < 2; ++v) m.transitionNode(&listen, f).count(std::vector<int>({v}), v) = 5000.25f + (float)f;
+    }
+    for (int a = 0; a < 2; ++a) {
+        IndexAction act(a);
+        for (int f = 0; f < 3; ++f)
+            for (int v = 0; v < 2; ++v) m.transitionNode(&act, f).count({}, v) = 5000 + 11.f * (float)(a + f + 2 * v);
+        m.observationNode(&act, 0).count({}, 0) = 5000;
+        m.observationNode(&act, 0).count({}, 1) = 4000;
+    }
+    m.resetObservationNode(&listen, 0, std::vector<int>({0, 1, 2}));
+    std::vector<double> full;
+    {
+        std::vector<int> pv(3, 0), pr(3, 2);
+        int row = 0;
+        do { /* counts whose float sums depend on the order of addition */
+            for (int v = 0; v < 2; ++v) {
+                float c = 1000.1f * (float)(row + 1) + 0.37f * (float)v + (row == 5 ? 1.e-3f : 0.f);
+                m.observationNode(&listen, 0).count(pv, v) = c;
+                full.push_back(c);
+            }
+            ++row;
+        } while (!indexing::increment(pv, pr));
+    }
+    printf("{\"full\": ");
+    arr(full, pd);
+    printf(", \"onto\": [");
+    for (int mask = 0; mask < 8; ++mask) {
+        auto st = m.structure();
+        std::vector<int> parents;
+        for (int f = 0; f < 3; ++f)
+            if ((mask >> f) & 1) parents.push_back(f);
+        st.O[2][0] = parents;
+        auto mm = m.marginalizeOut(st);
+        std::vector<double> cpt;
+        std::vector<int> pv(parents.size(), 0), pr(parents.size(), 2);
+        if (parents.empty()) {
+            cpt.push_back(mm.observationNode(&listen, 0).count(pv, 0));
+            cpt.push_back(mm.observationNode(&listen, 0).count(pv, 1));
+        } else {
+            do {
+                cpt.push_back(mm.observationNode(&listen, 0).count(pv, 0));
+                cpt.push_back(mm.observationNode(&listen, 0).count(pv, 1));
+            } while (!indexing::increment(pv, pr));
+        }
+        std::vector<double> tl;
+        for (int f = 0; f < 3; ++f)
+            for (int v = 0; v < 2; ++v)
+                for (int w = 0; w < 2; ++w) tl.push_back(mm.transitionNode(&listen, f).count(std::vector<int>({v}), w));
+        IndexAction open0(0);
+        tl.push_back(mm.observationNode(&open0, 0).count({}, 1));
+        printf("%s{\"mask\": %d, \"listen_O\": ", mask ? "," : "", mask);
+        arr(cpt, pd);
+        printf(", \"rest\": ");
+        arr(tl, pd);
+        printf("}");
+    }
+    printf("], ");
+    seed(s);
+    std::vector<int> edges = {0}, masks;
+    for (int i = 0; i < 64; ++i) {
+        BABNModel::Structure::flip_random_edge(&edges, 3);
+        int mk = 0;
+        for (int e : edges) mk |= 1 << e;
+        masks.push_back(mk);
+    }
+    printf("\"seed\": \"%s\", \"flip_masks\": ", s);
+    arr(masks, pi);
+    printf("}");
+}
+
+
 /* regular Dirichlet mode: rnd::sample::gamma, sampleFromSampledMult, sampleMult (random.cpp:189-304) */
 static void regular_dirichlet(char const* s)
 {
@@ -600,6 +684,9 @@ int main(int argc, char** argv)
     printf(",");
     babn_model("21", {0, 1, 2});
     printf("]");
+
+    key("marginalize");
+    marginalize("23");
 
     key("regular_dirichlet");
     regular_dirichlet("40");
