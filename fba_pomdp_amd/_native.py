@@ -29,7 +29,7 @@ KERNEL_NAMES = ["search_kernel", "env_kernel", "reject_kernel", "importance_kern
 
 DOM_TIGER_EPISODIC, DOM_TIGER_CONTINUOUS, DOM_FTIGER_EPISODIC, DOM_FTIGER_CONTINUOUS, DOM_GRIDWORLD, DOM_COLLISION_AVOID, DOM_COLLISION_AVOID_CENTERED = range(7)
 MODEL_POMDP, MODEL_BA_TABLE, MODEL_BA_FACTORED = range(3)
-BELIEF_REJECTION, BELIEF_IMPORTANCE = range(2)
+BELIEF_REJECTION, BELIEF_IMPORTANCE, BELIEF_REINVIGORATION = range(3)
 PLANNER_POUCT, PLANNER_RANDOM = range(2)
 OK, EINVAL, EHIP, ENODEVICE, ESTATE = 0, -1, -2, -3, -4
 
@@ -39,7 +39,8 @@ DOMAIN_NAMES = {  # reference -D strings (DomainConf.cpp)
     "gridworld": DOM_GRIDWORLD,
     "random-collision-avoidance": DOM_COLLISION_AVOID, "centered-collision-avoidance": DOM_COLLISION_AVOID_CENTERED,
 }
-BELIEF_NAMES = {"rejection_sampling": BELIEF_REJECTION, "importance_sampling": BELIEF_IMPORTANCE}
+BELIEF_NAMES = {"rejection_sampling": BELIEF_REJECTION, "importance_sampling": BELIEF_IMPORTANCE,
+                "reinvigoration": BELIEF_REINVIGORATION}
 PLANNER_NAMES = {"po-uct": PLANNER_POUCT, "random": PLANNER_RANDOM}
 
 
@@ -53,6 +54,7 @@ class Config(C.Structure):
         ("noise", C.c_float), ("counts_total", C.c_float), ("structure_prior", C.c_int32),
         ("seed", C.c_uint64), ("run_offset", C.c_int32), ("slots", C.c_int32),
         ("device", C.c_int32), ("trace", C.c_int32), ("dirichlet_regular", C.c_int32),
+        ("resample_amount", C.c_int32),
     ]
 
 
@@ -90,7 +92,7 @@ EXPORTS = [
     "fba_abi_version", "fba_default_config", "fba_create", "fba_destroy", "fba_last_error",
     "fba_domain_sizes", "fba_counts_len", "fba_slots", "fba_set_model_tabular", "fba_get_prior",
     "fba_set_position", "fba_belief_init", "fba_belief_reset_domain_state", "fba_select_action",
-    "fba_belief_update", "fba_belief_get", "fba_belief_set", "fba_last_step_info",
+    "fba_belief_update", "fba_belief_get", "fba_belief_set", "fba_belief_get_fully_connected", "fba_last_step_info",
     "fba_run_planning", "fba_run_bapomdp", "fba_run_ticks", "fba_get_returns", "fba_get_counters", "fba_get_return_sums",
     "fba_get_kernel_times", "fba_reset_kernel_times", "fba_trace_count", "fba_get_trace",
     "fba_selftest_ucb", "fba_stat_add", "fba_stat_var", "fba_stat_stder",
@@ -157,6 +159,7 @@ def load():
     L.fba_belief_update.argtypes = [vp, vp, vp, vp]
     L.fba_belief_get.argtypes = [vp, C.c_int32, vp, vp, vp]
     L.fba_belief_set.argtypes = [vp, C.c_int32, vp, vp, vp]
+    L.fba_belief_get_fully_connected.argtypes = [vp, C.c_int32, vp, vp]
     L.fba_last_step_info.argtypes = [vp, vp]
     L.fba_run_planning.argtypes = [vp, P(Stat)]
     L.fba_run_bapomdp.argtypes = [vp, P(Stat)]

@@ -183,6 +183,7 @@ struct Problem {
     float noise, counts_total;
     int32_t structure_prior;
     int32_t domain, model, belief, planner;
+    int32_t reinvig;    // reinvigoration belief: particles bred per update (belief = REJECTION then); 0 = off
     int32_t S, A, O;
     int32_t N;          // particles per slot
     int32_t C;          // floats per particle count blob
@@ -397,8 +398,8 @@ __device__ __forceinline__ double ext_reward(const Problem& P, int s, int a, int
 // `regular` Dirichlet mode (reference src/utils/random.cpp:40-44, 146-304), bug-compatible: the
 // reference's randomLong32 yields 31-bit values only, so its ziggurat "normal" is a half-normal and
 // its gammas are biased upward -- reproduced, not repaired.
-// log / exp are the deterministic sequences of IEEE operations that oracle/orc.c calls det_log /
-// det_exp (argument reduction + minimax polynomial): bit-identical on host and device, < 2 ulp from
+// log / exp are fixed sequences of IEEE operations, det_log / det_exp (argument reduction +
+// minimax polynomial; the CPU checker carries the same sequences): bit-identical on host and device, < 2 ulp from
 // libm.  The ziggurat tables are built on the host with libm, as rnd::initiate() does.
 // ---------------------------------------------------------------------------------------------
 struct ZigDesc {

@@ -584,6 +584,7 @@ int start_experiment(fba_ctx* c, int runs_total)
     const int32_t n_active = runs_total < 0 ? c->P.E : std::min(c->P.E, runs_total);
     HIPCHK(c, hipMemcpyAsync(c->d_n_active, &n_active, sizeof n_active, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->D.bufsel, 0, (size_t)c->P.E, c->stream));
+    if (c->D.bufsel_fc) HIPCHK(c, hipMemsetAsync(c->D.bufsel_fc, 0, (size_t)c->P.E, c->stream));
     launch_start(c->P, c->D, c->stream);
     if ((rc = timed(c, FBA_K_BELIEF_INIT, [&] { launch_init(c->P, c->D, c->stream); }))) return rc;
     if (c->P.model != FBA_MODEL_POMDP)
@@ -697,6 +698,25 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     c->cfg     = *cfg;
     Problem& P = c->P;
     P.domain = cfg->domain; P.model = cfg->model; P.belief = cfg->belief; P.planner = cfg->planner;
+    P.reinvig = 0;
+    if (cfg->belief == FBA_BELIEF_REINVIGORATION) {
+        // two rejection filters + breeding (ReinvigoratingRejectionSampling.hpp); the reference has fully
+        // connected priors for factored tiger, collision avoidance and sysadmin
+        // (GridWorldFactBAPrior::sampleFullyConnectedState throws "nyi"); built here: factored tiger
+        if (cfg->model != FBA_MODEL_BA_FACTORED || (cfg->domain != FBA_DOM_FTIGER_EPISODIC && cfg->domain != FBA_DOM_FTIGER_CONTINUOUS)) {
+            fail(nullptr, FBA_EINVAL, "reinvigoration belief: built for the factored-tiger FBA-POMDP only");
+            delete c;
+            return FBA_EINVAL;
+        }
+        if (cfg->particles < 1 || cfg->resample_amount < 1) {  // ReinvigoratingRejectionSampling.cpp:43-49
+            fail(nullptr, FBA_EINVAL, "ReinvigoratingRejectionSampling::cannot initiate belief of size < 1 (%d), or resample size of < 1 (%d)",
+                 cfg->particles, cfg->resample_amount);
+            delete c;
+            return FBA_EINVAL;
+        }
+        P.belief  = FBA_BELIEF_REJECTION;
+        P.reinvig = cfg->resample_amount;
+    }
     switch (cfg->domain) {
         case FBA_DOM_TIGER_EPISODIC:
         case FBA_DOM_TIGER_CONTINUOUS: P.S = 2; P.A = 3; P.O = 2; break;
@@ -838,7 +858,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     }
 
     // slots
-    const size_t per_slot = (size_t)P.N * (2 * 8 + 8 + 2 * (size_t)P.Cs * 4) + (size_t)D.max_nodes * D.node_words * 4 + (size_t)hcap * 16 + 1024;
+    const size_t per_slot = (size_t)P.N * (2 * 8 + 8 + (P.reinvig ? 4 : 2) * (size_t)P.Cs * 4) + (size_t)D.max_nodes * D.node_words * 4 + (size_t)hcap * 16 + 1024;
     int E = cfg->slots;
     if (E <= 0) {
         size_t free_b = 0, total_b = 0;
@@ -866,6 +886,10 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     const bool is = cfg->belief == FBA_BELIEF_IMPORTANCE;
     CHK(dev_alloc(c, &D.p_weight, is ? (size_t)2 * E * P.N : 1));
     CHK(dev_alloc(c, &D.p_rec, (size_t)2 * E * P.N * P.Cs, false));
+    if (P.reinvig) {
+        CHK(dev_alloc(c, &D.p_rec_fc, (size_t)2 * E * P.N * P.Cs, false));
+        CHK(dev_alloc(c, &D.bufsel_fc, E));
+    }
     CHK(dev_alloc(c, &D.wscan, is ? (size_t)E * P.N : 1, false));
     {
         // one workgroup per slot up to IS_MAX_CHUNKS*256 particles, several launches beyond
@@ -1086,6 +1110,24 @@ int fba_belief_get(fba_ctx* c, int32_t slot, int32_t* state, double* weight, flo
             if (state) std::memcpy(&state[i], &rec[P.C], 4);
             if (counts && P.C) std::copy(rec, rec + P.C, counts + (size_t)i * P.C);
         }
+    }
+    return FBA_OK;
+}
+
+int fba_belief_get_fully_connected(fba_ctx* c, int32_t slot, int32_t* state, float* counts)
+{
+    if (!c || slot < 0 || slot >= c->P.E) return FBA_EINVAL;
+    const Problem& P = c->P;
+    if (!P.reinvig) return fail(c, FBA_EINVAL, "only the reinvigoration belief has a fully connected filter");
+    uint8_t sel = 0;
+    HIPCHK(c, hipMemcpy(&sel, c->D.bufsel_fc + slot, 1, hipMemcpyDeviceToHost));
+    const size_t pb = ((size_t)sel * P.E + slot) * (size_t)P.N;
+    std::vector<float> tmp((size_t)P.N * P.Cs);
+    HIPCHK(c, hipMemcpy(tmp.data(), c->D.p_rec_fc + pb * P.Cs, tmp.size() * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < P.N; ++i) {
+        const float* rec = tmp.data() + (size_t)i * P.Cs;
+        if (state) std::memcpy(&state[i], &rec[P.C], 4);
+        if (counts) std::copy(rec, rec + P.C, counts + (size_t)i * P.C);
     }
     return FBA_OK;
 }

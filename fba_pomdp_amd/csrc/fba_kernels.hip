@@ -3,6 +3,7 @@
 //   search_kernel        POUCT / RBAPOUCT tree search            (P1-P8)
 //   env_kernel           true-environment step + episode loop    (E1-E3, D1/D2)
 //   reject_kernel        rejection-sampling belief update        (B4)
+//   reinvigorate_kernel  structure reinvigoration (breed + replace) before the rejection update (8f-3)
 //   importance_kernel    importance update + scan + resample     (B5, B6, B3)
 //   reset_kernel         resetDomainStateDistribution            (B7)
 //   init_kernel          Belief::initiate                        (B7)
@@ -488,10 +489,13 @@ __device__ __forceinline__ int record_group(int C4)
 // reference's result: the new filter is the first N accepted attempts, in order, and the
 // reported loop count is the index of the N-th accepted attempt + 1.
 // ---------------------------------------------------------------------------------------------
+// `fc` = 1 runs the update on the reinvigoration belief's fully connected filter (launched before
+// the main filter's update, which is the one that clears the request flag).
 template <bool REG, bool TIGER_TABLE>
-__global__ void __launch_bounds__(REJECT_BLOCK) reject_kernel(Problem P, DeviceState D)
+__global__ void __launch_bounds__(REJECT_BLOCK) reject_kernel(Problem P, DeviceState D, int fc)
 {
     if (TIGER_TABLE) {  // sizes restated as literals (see search_kernel)
+        fc = 0;
         P.model = FBA_MODEL_BA_TABLE;
         P.S = 2; P.A = 3; P.O = 2; P.phi_len = 12; P.C = 24; P.Cs = 32;
         if (P.domain != FBA_DOM_TIGER_CONTINUOUS) P.domain = FBA_DOM_TIGER_EPISODIC;
@@ -502,18 +506,21 @@ __global__ void __launch_bounds__(REJECT_BLOCK) reject_kernel(Problem P, DeviceS
     const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (!D.need_update[e]) return;
     const int a = D.action[e], o = D.obs[e], N = P.N;
-    const int cur = D.bufsel[e];
+    uint8_t* bufsel = fc ? D.bufsel_fc : D.bufsel;
+    float* recs     = fc ? D.p_rec_fc : D.p_rec;
+    const int cur = bufsel[e];
     const size_t sb = pbase(P, e, cur), db = pbase(P, e, cur ^ 1);
-    const float* scn   = D.p_rec + sb * (size_t)P.Cs;
-    float* dcn         = D.p_rec + db * (size_t)P.Cs;
+    const float* scn   = recs + sb * (size_t)P.Cs;
+    float* dcn         = recs + db * (size_t)P.Cs;
     const int C4 = P.Cs / 4, group = record_group(C4);
     const int ninc = model_ninc(P);
+    const uint32_t phase = fc ? FBA_PHASE_REJECT_FC : FBA_PHASE_REJECT;
     Rng g = slot_rng(P, D, e);
 
     int acc = 0, base = 0;
     while (acc < N) {
         const int k = base + tid;
-        g.stream(FBA_PHASE_REJECT, (uint32_t)k);
+        g.stream(phase, (uint32_t)k);
         const int src = g.uniform_int(N);                       // FlatFilter::sample
         const float* rec = scn + (size_t)src * P.Cs;
         int s = rec_state(rec, P.C), so;
@@ -544,12 +551,92 @@ __global__ void __launch_bounds__(REJECT_BLOCK) reject_kernel(Problem P, DeviceS
         __syncthreads();
     }
     if (tid == 0) {
-        D.bufsel[e]      = cur ^ 1;
-        D.need_update[e] = 0;
+        bufsel[e] = cur ^ 1;
         D.belief_steps[e] += (unsigned long long)s_count;
         D.upd_attempts[e] += (unsigned long long)s_count;
         D.upd_particles[e] += (unsigned long long)N;
-        D.cur[e].update_count = s_count;
+        if (!fc) {
+            D.need_update[e]      = 0;
+            D.cur[e].update_count = s_count;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// reinvigorate_kernel: ReinvigoratingRejectionSampling::reinvigorateParticles
+// (ReinvigoratingRejectionSampling.cpp:121-131), one workgroup per slot, before the two rejection
+// updates.  Iteration i breeds one particle (breed, :24-35): the structure of a random particle
+// of the main filter with one random edge flipped (FactoredTigerFactoredPrior::mutate
+// FactoredTigerPriors.cpp:353-381 -> BABNModel::Structure::flip_random_edge BABNModel.cpp:16-31),
+// the counts of a random particle of the fully connected filter marginalised onto that structure
+// (BABNModel::marginalizeOut BABNModel.cpp:205-229, DBNNode::marginalizeOut DBNNode.cpp:40-80:
+// source rows added in ascending order, in float), the domain state of the structure particle;
+// it replaces a random particle of the main filter (FlatFilter::replace FlatFilter.cpp:39-46).
+// Iterations are sequential -- a bred particle may be picked by the next one -- and R is small,
+// so the draws are made by one thread and the workgroup only shares the record copy.
+// Draw order within stream (REINVIG, i): fully connected pick, main pick, edge, victim (g++
+// evaluates breed's arguments right to left).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) reinvigorate_kernel(Problem P, DeviceState D)
+{
+    __shared__ int32_t s_fc, s_victim, s_state;
+    __shared__ uint32_t s_mask[MAXF];
+    const int e = blockIdx.x, tid = threadIdx.x;
+    if (!D.need_update[e]) return;
+    const FDesc* fd = P.fd;
+    float* recs      = D.p_rec + pbase(P, e, D.bufsel[e]) * (size_t)P.Cs;
+    const float* fcs = D.p_rec_fc + pbase(P, e, D.bufsel_fc[e]) * (size_t)P.Cs;
+    const int nnodes = P.A * (fd->FS + fd->FO);
+    Rng g = slot_rng(P, D, e);
+    for (int i = 0; i < P.reinvig; ++i) {
+        if (tid == 0) {
+            g.stream(FBA_PHASE_REINVIG, (uint32_t)i);
+            s_fc = g.uniform_int(P.N);
+            const volatile float* srec = recs + (size_t)g.uniform_int(P.N) * P.Cs;  // may have been written an iteration ago
+            for (int k = 0; k < fd->nvar; ++k) s_mask[k] = __float_as_uint(srec[fd->ncounts + k]);
+            s_mask[0] ^= 1u << g.slow_int(0, fd->FS);
+            s_state  = __float_as_int(srec[P.C]);
+            s_victim = g.uniform_int(P.N);
+        }
+        __syncthreads();
+        const float* src = fcs + (size_t)s_fc * P.Cs;
+        float* dst       = recs + (size_t)s_victim * P.Cs;
+        for (int w = tid; w < P.C; w += 256) dst[w] = src[w];  // nodes with fixed parents: the counts particle's CPTs
+        __syncthreads();
+        for (int k = 0; k < nnodes; ++k) {
+            const FNode& nd = fd->nodes[k];
+            if (nd.var < 0) continue;
+            const uint32_t om = __float_as_uint(src[fd->ncounts + nd.var]), nm = s_mask[nd.var];
+            int rows_max = 1, rows_old = 1, rows_new = 1;
+            for (int j = 0; j < nd.nmax; ++j) {
+                const int sz = fd->Ssz[nd.maxp[j]];
+                rows_max *= sz;
+                if ((om >> j) & 1u) rows_old *= sz;
+                if ((nm >> j) & 1u) rows_new *= sz;
+            }
+            for (int idx = tid; idx < rows_max * nd.out; idx += 256) {
+                const int row = idx / nd.out, v = idx - row * nd.out;
+                float acc = 0.f;
+                if (row < rows_new)
+                    for (int r = 0; r < rows_old; ++r) {  // ascending source rows, as the reference adds them
+                        int rem = r, nr = 0, mul = 1;
+                        for (int j = nd.nmax - 1; j >= 0; --j) {
+                            const int sz = fd->Ssz[nd.maxp[j]];
+                            if ((om >> j) & 1u) {
+                                const int digit = rem % sz;
+                                rem /= sz;
+                                if ((nm >> j) & 1u) { nr += digit * mul; mul *= sz; }
+                            }
+                        }
+                        if (nr == row) acc += src[nd.off + r * nd.out + v];
+                    }
+                dst[nd.off + idx] = acc;
+            }
+            if (tid == 0) dst[fd->ncounts + nd.var] = __uint_as_float(nm);
+        }
+        if (tid == 0) rec_set_state(dst, P.C, s_state);
+        __threadfence_block();
+        __syncthreads();
     }
 }
 
@@ -921,15 +1008,17 @@ __global__ void is_multi_finish_kernel(Problem P, DeviceState D)
 // (RejectionSampling.cpp:15-20, ImportanceSampler.cpp:45-55; BAPOMDP::sampleStartState
 // BAPOMDP.cpp:101-104 = prior->sample(domain start state)).  One workgroup per slot.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) init_kernel(Problem P, DeviceState D)
+// `fc` = 1: the reinvigoration belief's fully connected filter (ReinvigoratingRejectionSampling.cpp:
+// 55-76: N x FBAPOMDP::sampleFullyConnectedState after the N start states).
+__global__ void __launch_bounds__(256) init_kernel(Problem P, DeviceState D, int fc)
 {
     const int e = blockIdx.y, tid = threadIdx.x;
     if (!D.need_init[e]) return;
     // this workgroup's tile of the slot's particles (PARTICLE_TILE each, so big filters spread over the chip)
     const int i_lo = blockIdx.x * PARTICLE_TILE, i_hi = min(P.N, i_lo + PARTICLE_TILE);
     if (i_lo >= P.N) return;
-    const size_t pb = pbase(P, e, D.bufsel[e]);
-    float* recs     = D.p_rec + pb * (size_t)P.Cs;
+    const size_t pb = pbase(P, e, fc ? D.bufsel_fc[e] : D.bufsel[e]);
+    float* recs     = (fc ? D.p_rec_fc : D.p_rec) + pb * (size_t)P.Cs;
     Rng g = slot_rng(P, D, e);
     g.position((uint32_t)D.run[e], 0, 0);
     // every particle starts from the prior record ...
@@ -942,8 +1031,12 @@ __global__ void __launch_bounds__(256) init_kernel(Problem P, DeviceState D)
     // ... and its own domain start state
     const double w1 = 1.0 / (double)P.N;
     for (int i = i_lo + tid; i < i_hi; i += 256) {
-        g.stream(FBA_PHASE_INIT, (uint32_t)i);
+        g.stream(fc ? FBA_PHASE_INIT_FC : FBA_PHASE_INIT, (uint32_t)i);
         rec_set_state(recs + (size_t)i * P.Cs, P.C, domain_start(P, g));
+        if (fc) {  // FactoredTigerFactoredPrior::sampleFullyConnectedState FactoredTigerPriors.cpp:324-337
+            ftiger_set_observation_model(P, recs + (size_t)i * P.Cs, (1u << P.fd->FS) - 1u);
+            continue;
+        }
         if (P.model == FBA_MODEL_BA_FACTORED) factored_prior_sample(P, g, recs + (size_t)i * P.Cs);
         if (P.belief == FBA_BELIEF_IMPORTANCE) D.p_weight[pb + i] = w1;
     }
@@ -955,21 +1048,22 @@ __global__ void __launch_bounds__(256) init_kernel(Problem P, DeviceState D)
 // fresh domain start state.  Importance filter (BAImportanceSampling.cpp:90-111): N particles are
 // re-drawn from the (uniformly weighted) filter, copied, and given a fresh start state.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) reset_kernel(Problem P, DeviceState D)
+// `fc` = 1: the reinvigoration belief's fully connected filter (ReinvigoratingRejectionSampling.cpp:109-119).
+__global__ void __launch_bounds__(256) reset_kernel(Problem P, DeviceState D, int fc)
 {
     __shared__ int32_t s_src[256], s_ns[256];
     const int e = blockIdx.y, tid = threadIdx.x;
     if (D.need_reset[e] != 1) return;
     const int i_lo = blockIdx.x * PARTICLE_TILE, i_hi = min(P.N, i_lo + PARTICLE_TILE);
     if (i_lo >= P.N) return;
-    const int cur = D.bufsel[e];
+    const int cur = fc ? D.bufsel_fc[e] : D.bufsel[e];
     const size_t sb = pbase(P, e, cur), db = pbase(P, e, cur ^ 1);
     Rng g = slot_rng(P, D, e);
     g.position((uint32_t)D.run[e], (uint32_t)D.episode[e], 0);
     if (P.belief == FBA_BELIEF_REJECTION) {
-        float* recs = D.p_rec + sb * (size_t)P.Cs;
+        float* recs = (fc ? D.p_rec_fc : D.p_rec) + sb * (size_t)P.Cs;
         for (int i = i_lo + tid; i < i_hi; i += 256) {
-            g.stream(FBA_PHASE_RESET, (uint32_t)i);
+            g.stream(fc ? FBA_PHASE_RESET_FC : FBA_PHASE_RESET, (uint32_t)i);
             rec_set_state(recs + (size_t)i * P.Cs, P.C, domain_start(P, g));
         }
         return;
@@ -1089,9 +1183,12 @@ void launch_belief_update(const Problem& P, const DeviceState& D, hipStream_t st
     if (P.belief == FBA_BELIEF_REJECTION) {
         const bool tiger_table = P.model == FBA_MODEL_BA_TABLE && !P.dirichlet_regular &&
                                  (P.domain == FBA_DOM_TIGER_EPISODIC || P.domain == FBA_DOM_TIGER_CONTINUOUS);
-        if (P.dirichlet_regular) hipLaunchKernelGGL((reject_kernel<true, false>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D);
-        else if (tiger_table) hipLaunchKernelGGL((reject_kernel<false, true>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D);
-        else hipLaunchKernelGGL((reject_kernel<false, false>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D);
+        if (P.reinvig) hipLaunchKernelGGL(reinvigorate_kernel, dim3(P.E), dim3(256), 0, st, P, D);
+        for (int fc = P.reinvig ? 1 : 0; fc >= 0; --fc) {  // the main filter's launch clears the request flag: last
+            if (P.dirichlet_regular) hipLaunchKernelGGL((reject_kernel<true, false>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
+            else if (tiger_table) hipLaunchKernelGGL((reject_kernel<false, true>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
+            else hipLaunchKernelGGL((reject_kernel<false, false>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
+        }
         return;
     }
     if (!D.is_multi) {
@@ -1115,12 +1212,14 @@ void launch_belief_update(const Problem& P, const DeviceState& D, hipStream_t st
 }
 void launch_init(const Problem& P, const DeviceState& D, hipStream_t st)
 {
-    hipLaunchKernelGGL(init_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), P.E), dim3(256), 0, st, P, D);
+    hipLaunchKernelGGL(init_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), P.E), dim3(256), 0, st, P, D, 0);
+    if (P.reinvig) hipLaunchKernelGGL(init_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), P.E), dim3(256), 0, st, P, D, 1);
     hipLaunchKernelGGL(post_init_kernel, dim3(ceil_div(P.E, 256)), dim3(256), 0, st, P, D);
 }
 void launch_reset(const Problem& P, const DeviceState& D, hipStream_t st)
 {
-    hipLaunchKernelGGL(reset_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), P.E), dim3(256), 0, st, P, D);
+    hipLaunchKernelGGL(reset_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), P.E), dim3(256), 0, st, P, D, 0);
+    if (P.reinvig) hipLaunchKernelGGL(reset_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), P.E), dim3(256), 0, st, P, D, 1);
     hipLaunchKernelGGL(post_reset_kernel, dim3(ceil_div(P.E, 256)), dim3(256), 0, st, P, D);
 }
 void launch_flush(const Problem& P, const DeviceState& D, hipStream_t st)

@@ -49,6 +49,8 @@ struct DeviceState {
     uint8_t* bufsel;    // [E]
     double* p_weight;   // [2][E][N]
     float* p_rec;       // [2][E][N][Cs] particle records (counts | state | pad)
+    float* p_rec_fc;    // same shape: the reinvigoration belief's fully connected filter (else null)
+    uint8_t* bufsel_fc; // [E]
     double* wscan;      // [E][N] scratch: inclusive device-order prefix sums of normalised weights
     double* ctot;       // [E][N/256 + 2] scratch: chunk totals / carries of the multi-workgroup filter
     double* is_tot;     // [E][2] total weight before normalisation, total of the normalised weights

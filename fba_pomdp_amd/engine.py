@@ -165,6 +165,14 @@ class Engine:
                                         cnt.ctypes.data if self.ncnt else None))
         return s, w, cnt
 
+    def belief_get_fully_connected(self, slot=0):
+        """The second filter of the reinvigoration belief (ReinvigoratingRejectionSampling.hpp)."""
+        n = self.cfg.particles
+        s = np.zeros(n, np.int32)
+        cnt = np.zeros((n, self.ncnt), np.float32)
+        self._chk(self.L.fba_belief_get_fully_connected(self.h, slot, s.ctypes.data, cnt.ctypes.data))
+        return s, cnt
+
     def belief_set(self, slot, state=None, weight=None, counts=None):
         s = None if state is None else np.ascontiguousarray(state, np.int32)
         w = None if weight is None else np.ascontiguousarray(weight, np.float64)

@@ -40,8 +40,9 @@ enum {
 };
 /* simulator: plain POMDP (planning), tabular BA-POMDP (bapomdp), factored (fbapomdp) */
 enum { FBA_MODEL_POMDP = 0, FBA_MODEL_BA_TABLE = 1, FBA_MODEL_BA_FACTORED = 2 };
-/* -B rejection_sampling | importance_sampling (BeliefConf.hpp, Belief.cpp:13-24) */
-enum { FBA_BELIEF_REJECTION = 0, FBA_BELIEF_IMPORTANCE = 1 };
+/* -B rejection_sampling | importance_sampling (BeliefConf.hpp, Belief.cpp:13-24) | reinvigoration
+ * (BABelief.cpp:28-31: ReinvigoratingRejectionSampling, factored models only) */
+enum { FBA_BELIEF_REJECTION = 0, FBA_BELIEF_IMPORTANCE = 1, FBA_BELIEF_REINVIGORATION = 2 };
 /* -P po-uct | random (Planner.cpp:12-19) */
 enum { FBA_PLANNER_POUCT = 0, FBA_PLANNER_RANDOM = 1 };
 /* --structure-prior (FBAConf.hpp) */
@@ -56,7 +57,11 @@ enum {
     FBA_PHASE_ENV       = 4,
     FBA_PHASE_REJECT    = 5,
     FBA_PHASE_IS_UPDATE = 6,
-    FBA_PHASE_RESAMPLE  = 7
+    FBA_PHASE_RESAMPLE  = 7,
+    FBA_PHASE_REINVIG   = 8,  /* reinvigoration: unit = index of the bred particle            */
+    FBA_PHASE_INIT_FC   = 9,  /* fully connected filter of the reinvigoration belief: initiate */
+    FBA_PHASE_RESET_FC  = 10, /*   ... resetDomainStateDistribution                            */
+    FBA_PHASE_REJECT_FC = 11  /*   ... rejection sampling, unit = attempt index                */
 };
 
 enum {
@@ -96,6 +101,8 @@ typedef struct fba_config {
     int32_t dirichlet_regular; /* --dirichlet_sampling_method regular (0 = expected, default);
                                 * bug-compatible with the reference's biased sampler (BAConf.hpp:22,
                                 * random.cpp:146-242) */
+    int32_t resample_amount; /* --resample-amount: particles bred per update by the reinvigoration
+                              * belief (BeliefConf.cpp:17-21) */
 } fba_config;
 
 /* One record per real time-step: the information the reference prints at -v 2 / -v 3
@@ -182,6 +189,9 @@ int fba_belief_update(fba_ctx* ctx, const int32_t* action, const int32_t* obs, c
  * state[particles], weight[particles] (may be NULL), counts[particles * counts_len] (may be NULL) */
 int fba_belief_get(fba_ctx* ctx, int32_t slot, int32_t* state, double* weight, float* counts);
 int fba_belief_set(fba_ctx* ctx, int32_t slot, const int32_t* state, const double* weight, const float* counts);
+/* the second filter of the reinvigoration belief (ReinvigoratingRejectionSampling.hpp:
+ * _fully_connected_belief), for tests */
+int fba_belief_get_fully_connected(fba_ctx* ctx, int32_t slot, int32_t* state, float* counts);
 /* per-slot record of the last select_action / belief_update (root statistics, rejection count,
  * belief checksum) */
 int fba_last_step_info(fba_ctx* ctx, fba_trace_rec* recs /* [slots] */);

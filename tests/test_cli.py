@@ -22,11 +22,14 @@ def test_cli_help_and_argument_errors(cli):
     assert r.returncode == 0
     for flag in ("--runs", "--horizon", "--discount", "--planner", "--belief", "--seed", "--simulation-amount",
                  "--mcts-max-depth", "--exploration-constant", "--particle-amount", "--domain", "--size", "--episodes",
-                 "--dirichlet_sampling_method", "--noise", "--counts-total", "--structure-prior", "--output-file"):
+                 "--resample-amount", "--dirichlet_sampling_method", "--noise", "--counts-total", "--structure-prior", "--output-file"):
         assert flag in r.stdout                                  # the reference's flag names (Conf.cpp, BAConf.cpp, ...)
     for args, msg in ((["planning", "-D", "nope"], "legit domain"), (["planning", "-D", "episodic-tiger", "--bogus", "1"], "unrecognised"),
                       (["planning", "-D", "episodic-tiger", "--runs"], "missing"), (["frobnicate"], "unknown mode"),
-                      (["planning", "-D", "episodic-tiger", "-s", "abc"], "invalid")):
+                      (["planning", "-D", "episodic-tiger", "-s", "abc"], "invalid"),
+                      (["fbapomdp", "-D", "episodic-factored-tiger", "--size", "2", "--resample-amount", "3"], "resample amount"),  # BeliefConf.cpp:40-49
+                      (["fbapomdp", "-D", "episodic-factored-tiger", "--size", "2", "-B", "reinvigoration"], "resample amount"),
+                      (["bapomdp", "-D", "episodic-tiger", "-B", "reinvigoration", "--resample-amount", "3"], "legit state stimator")):
         r = subprocess.run([cli] + args, capture_output=True, text=True)
         assert r.returncode == 1 and msg in r.stderr
 
@@ -67,5 +70,11 @@ def test_cli_bapomdp_and_fbapomdp_write_one_line_per_episode(cli, tmp_path):
                         "-f", str(out2)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert len([l for l in out2.read_text().splitlines() if l and not l.startswith("#")]) == 2
+    out3 = tmp_path / "reinvig.res"
+    r = subprocess.run([cli, "fbapomdp", "-D", "episodic-factored-tiger", "--size", "3", "-B", "reinvigoration", "--resample-amount", "6",
+                        "-s", "64", "--particle-amount", "48", "--runs", "5", "--episodes", "3", "--structure-prior", "match-uniform",
+                        "-f", str(out3)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert len([l for l in out3.read_text().splitlines() if l and not l.startswith("#")]) == 3
     r = subprocess.run([cli, "bapomdp", "-D", "episodic-tiger", "--noise", "0.9"], capture_output=True, text=True)
     assert r.returncode == 1 and "noise has to be between" in r.stderr      # TigerPriors.cpp:22-25

@@ -118,6 +118,67 @@ def test_fbapomdp_factored_tiger(sp, belief, size):
     _assert_same_experiment(eng, o, ba=True)
 
 
+@pytest.mark.parametrize("sp,size,amount,domain", [
+    (2, 3, 8, "episodic-factored-tiger"),       # match-uniform structure prior, the C3 domain
+    (1, 2, 40, "episodic-factored-tiger"),      # uniform prior, many bred particles per update (victims collide)
+    (0, 3, 1, "continuous-factored-tiger"),     # correct-structure prior, one bred particle
+])
+def test_fbapomdp_reinvigoration_belief(sp, size, amount, domain):
+    """-B reinvigoration (ReinvigoratingRejectionSampling): breed = flip one edge of a sampled structure,
+    marginalise a fully connected particle's counts onto it, replace a random particle; then rejection
+    sampling on both filters."""
+    eng, o = _pair(domain, N.MODEL_BA_FACTORED, "reinvigoration", 131 + sp, size=size, particles=120,
+                   sims=150, runs=7, episodes=4, structure_prior=sp, resample_amount=amount, slots=4)
+    _assert_same_experiment(eng, o, ba=True)
+
+
+def test_reinvigoration_belief_both_filters_equal_oracle_step_by_step():
+    kw = dict(size=3, particles=96, sims=32, structure_prior=2, resample_amount=12)
+    eng = fba.Engine("episodic-factored-tiger", model=N.MODEL_BA_FACTORED, belief="reinvigoration", seed=19, slots=1, **kw)
+    o = orc.Oracle(domain=orc.DOM_FTIGER_EPISODIC, model=orc.MODEL_BA_FACTORED, belief=orc.BELIEF_REINVIGORATION,
+                   rng_mode=orc.RNG_PHILOX, arith=orc.ARITH_DEV, philox_seed=19, **kw)
+    L = orc.lib()
+
+    def same():
+        s, _, cnt = eng.belief_get(0)
+        os_, _, ocnt = o.belief_get()
+        assert np.array_equal(s, os_) and np.array_equal(cnt.view(np.uint32), ocnt.view(np.uint32))
+        fs, fcnt = eng.belief_get_fully_connected(0)
+        ofs, ofcnt = o.belief_get_fc()
+        assert np.array_equal(fs, ofs) and np.array_equal(fcnt.view(np.uint32), ofcnt.view(np.uint32))
+        return cnt.view(np.uint32)[:, -1], fcnt.view(np.uint32)[:, -1]
+
+    L.orc_rng_episode(o.rng, 0, 0, 0)
+    o.belief_initiate()
+    eng.belief_init()
+    o.belief_reset_domain_state()
+    eng.belief_reset_domain_state()
+    masks, fmasks = same()
+    assert np.all(fmasks == 15) and np.all(masks & 1 == 1)
+    seen_unforced = False
+    for t, ob in enumerate([0, 1, 0, 0, 1]):
+        L.orc_rng_episode(o.rng, 0, 0, t)
+        eng.set_position(run=0, episode=0, t=t)
+        o.belief_update(2, ob)
+        eng.belief_update(2, ob)
+        masks, fmasks = same()
+        assert np.all(fmasks == 15)
+        seen_unforced |= bool(np.any(masks & 1 == 0))     # mutate() may drop the tiger-location parent
+        assert eng.last_step_info()[0]["update_count"] == L.orc_last_update_count(o.h)
+    assert seen_unforced
+
+
+def test_reinvigoration_belief_argument_checks():
+    with pytest.raises(ValueError, match="factored-tiger"):
+        fba.Engine("episodic-tiger", model=N.MODEL_BA_TABLE, belief="reinvigoration", resample_amount=4, particles=8, sims=4)
+    with pytest.raises(ValueError, match="resample size of < 1"):
+        fba.Engine("episodic-factored-tiger", model=N.MODEL_BA_FACTORED, belief="reinvigoration", size=2, particles=8, sims=4)
+    eng = fba.Engine("episodic-factored-tiger", model=N.MODEL_BA_FACTORED, size=2, particles=8, sims=4, slots=1)
+    eng.belief_init()
+    with pytest.raises(ValueError, match="fully connected"):
+        eng.belief_get_fully_connected(0)
+
+
 def test_fbapomdp_prior_particles_equal_oracle():
     kw = dict(size=3, particles=64, sims=16, structure_prior=2)
     eng = fba.Engine("episodic-factored-tiger", model=N.MODEL_BA_FACTORED, seed=71, slots=1, **kw)
