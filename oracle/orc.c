@@ -67,6 +67,9 @@ struct orc_ctx {
     int32_t gw_N, gw_G, gw_nslow;
     int32_t gw_goal[16][2], gw_slow[8][2];
     float gw_disp[32]; /* _obs_displacement_probs */
+    /* sysadmin (src/domains/sysadmin/SysAdmin.cpp); bit c of the state = computer c operational */
+    int32_t sys_N;
+    double sys_keep[3]; /* (1 - fail_prob) * pow(1 - fail_neighbour_factor, #failing neighbours) */
     /* collision avoidance (src/domains/collision-avoidance/CollisionAvoidance.cpp) */
     int32_t ca_W, ca_H, ca_n, ca_random_start, ca_Hn; /* Hn = H^n */
     double ca_err[16];        /* _observation_error_probability[d] */
@@ -200,6 +203,7 @@ static int is_episodic(int d)
 }
 static int is_grid(int d) { return d == ORC_DOM_GRIDWORLD; }
 static int is_ca(int d) { return d == ORC_DOM_COLLISION_AVOID; }
+static int is_sys(int d) { return d == ORC_DOM_SYSADMIN_INDEPENDENT || d == ORC_DOM_SYSADMIN_LINEAR; }
 
 /* ---- collision avoidance.  ref: src/domains/collision-avoidance/CollisionAvoidance.cpp
  * state index = (x*H + y)*H^n + project(obstacles) (ctor :77-92); observation = project(observed
@@ -333,12 +337,37 @@ static float gw_obs_displ_prob(const orc_ctx* c, int loc, int observed)
     return res;
 }
 
+/* SysAdmin parameters (SysAdmin.cpp:12): fail .025f, observe .95f, reboot success .95f, reboot
+ * cost 1.0f, neighbour factor .075f -- floats, promoted where the reference promotes them */
+#define SYS_FAIL_PROB .025f
+#define SYS_OBSERVE_PROB .95f
+#define SYS_REBOOT_RATE .95f
+#define SYS_NEIGHBOUR_FACTOR .075f
+static void sys_setup(orc_ctx* c, int n)
+{
+    int k;
+    c->sys_N = n;
+    for (k = 0; k < 3; ++k) /* float * pow(double(float), n): SysAdmin.cpp:116-118 */
+        c->sys_keep[k] = (double)(1 - SYS_FAIL_PROB) * pow((double)(1 - SYS_NEIGHBOUR_FACTOR), (double)k);
+}
+/* SysAdmin::numFailingNeighbours (SysAdmin.cpp:221-246).  isOperational(n) reads bit n of the index
+ * whatever n is, which matters where the flat prior passes an action index for `comp` */
+static int sys_failing_neighbours(const orc_ctx* c, int comp, int32_t s)
+{
+    int n = 0;
+    if (c->cfg.domain == ORC_DOM_SYSADMIN_INDEPENDENT) return 0;
+    if (comp > 0 && !((s >> (comp - 1)) & 1)) n++;
+    if (comp < c->sys_N - 1 && !((s >> (comp + 1)) & 1)) n++;
+    return n;
+}
+
 /* ref: Tiger::sampleStartState src/domains/tiger/Tiger.cpp:16-19 (LEFT=0 iff boolean()),
  *      FactoredTiger::sampleStartState src/domains/tiger/FactoredTiger.cpp (uniform_int{0,S-1}) */
 static int32_t domain_start(orc_ctx* c)
 {
     if (is_tiger(c->cfg.domain)) return orc_bool(&c->rng) ? 0 : 1;
     if (is_ftiger(c->cfg.domain)) return orc_int(&c->rng, c->S);
+    if (is_sys(c->cfg.domain)) return c->S - 1; /* SysAdmin::sampleStartState :102-105: all computers on, no draw */
     if (is_ca(c->cfg.domain)) { /* sampleStartState :270-273 -> categoricalDistr::sample -> sampleFromMult<float>(values, S, _total) */
         double p  = orc_u01(&c->rng) * c->ca_start_total;
         float sum = 0;
@@ -367,6 +396,7 @@ static int32_t domain_random_action(orc_ctx* c, int32_t s)
     if (is_tiger(c->cfg.domain) || is_ftiger(c->cfg.domain)) return orc_int(&c->rng, 3);
     if (is_grid(c->cfg.domain)) return orc_slow_int(&c->rng, 0, 4); /* GridWorld::generateRandomAction :220-226 */
     if (is_ca(c->cfg.domain)) return orc_int(&c->rng, 3); /* integerDistribution(0, NUM_ACTIONS) */
+    if (is_sys(c->cfg.domain)) return orc_int(&c->rng, c->A); /* SysAdmin.cpp:167-170: integerDistribution(0, A) */
     return 0;
 }
 
@@ -399,6 +429,17 @@ static int domain_step(orc_ctx* c, int32_t* s, int32_t a, int32_t* o, double* r)
             *s = orc_int(&c->rng, c->S);    /* sampleStartState() */
         }
         return is_episodic(d) && a != 2;
+    }
+    if (is_sys(d)) { /* SysAdmin::step :107-152 */
+        int N = c->sys_N, rebooting = a >= N, op = rebooting ? a - N : a, k;
+        int32_t index = *s;
+        for (k = 0; k < N; ++k) /* one draw per computer, failing ones included; neighbours of the OLD state */
+            if (orc_u01(&c->rng) > c->sys_keep[sys_failing_neighbours(c, k, *s)]) index &= ~(1 << k);
+        if (rebooting && orc_u01(&c->rng) < (double)SYS_REBOOT_RATE) index |= 1 << op;
+        *s = index;
+        *o = ((orc_u01(&c->rng) < (double)SYS_OBSERVE_PROB) == (((index >> op) & 1) != 0)) ? 1 : 0; /* OPERATIONAL = 1 */
+        *r = (double)((float)__builtin_popcount((unsigned)index) - 1.0f * (float)rebooting);
+        return 0;
     }
     if (is_ca(d)) { /* CollisionAvoidance::step :236-270, moveObstacle :330-338, reward :196-208 */
         int H = c->ca_H, n = c->ca_n, Hn = c->ca_Hn, k;
@@ -453,6 +494,10 @@ static double domain_obs_prob(orc_ctx* c, int32_t o, int32_t a, int32_t new_s)
         if (a != 2) return .5;
         return (loc == o) ? .85 : .15;
     }
+    if (is_sys(d)) { /* SysAdmin::computeObservationProbability :154-165: float results */
+        int op = a >= c->sys_N ? a - c->sys_N : a;
+        return (o == ((new_s >> op) & 1)) ? (double)SYS_OBSERVE_PROB : (double)(1 - SYS_OBSERVE_PROB);
+    }
     if (is_ca(d)) { /* computeObservationProbability :216-229 */
         int H = c->ca_H, n = c->ca_n, k, pos = new_s % c->ca_Hn, obs = o;
         double p = 1;
@@ -488,6 +533,7 @@ static int ext_terminal(orc_ctx* c, int32_t s, int32_t a, int32_t ns)
         return (x < c->ca_n && y == b) || x == 0;
     }
     if (is_grid(c->cfg.domain)) return gw_on_goal(c, s); /* GridWorldBAExtension.cpp:74-83: the PRE-state */
+    if (is_sys(c->cfg.domain)) return 0; /* SysAdminBAExtension.cpp:31-37 */
     return is_episodic(c->cfg.domain) && a != 2;
 }
 static double ext_reward(orc_ctx* c, int32_t s, int32_t a, int32_t ns)
@@ -500,6 +546,8 @@ static double ext_reward(orc_ctx* c, int32_t s, int32_t a, int32_t ns)
         return a == 1 ? 0 : -1;
     }
     if (is_grid(d)) return gw_on_goal(c, s) ? 1 : 0; /* GridWorldBAExtension.cpp:85-99 */
+    if (is_sys(d)) /* SysAdminBAExtension.cpp:39-50: operational computers of the NEW state, minus the reboot cost */
+        return (double)((float)__builtin_popcount((unsigned)ns) - 1.0f * (float)(a >= c->sys_N));
     if (a == 2) return -1;
     if (is_tiger(d)) return (a == s) ? 10 : -100;
     return (a == ((s < c->S / 2) ? 0 : 1)) ? 10 : -100;
@@ -703,6 +751,76 @@ static int sample_dirichlet_row(orc_ctx* c, const float* row, int n)
 /* ref: TigerBAPrior src/domains/tiger/TigerPriors.cpp:14-43;
  *      FactoredTigerFlatPrior src/domains/tiger/FactoredTigerPriors.cpp:18-88;
  *      layout BAFlatModel: phi[s*A*S + a*S + s'], psi[a*S*O + s'*O + o] (utils/index.cpp:13-16) */
+
+/* SysAdminFlatPrior (SysAdminFlatPrior.cpp:24-247): the true transition probabilities times 10000,
+ * enumerated by recursion over the computers from N-1 down to 0.  Restated with the reference's
+ * evaluation order, because later leaves overwrite earlier ones, and with its arithmetic types
+ * (double accumulated probability, float parameters, float counts).  Quirk kept: setTrueTCounts
+ * (:168-172) asks numFailingNeighbours about "computer" a = the ACTION index. */
+static void sys_flat_leaf_reboot(orc_ctx* c, int32_t s, int32_t ns, double prob, int reb) /* :236-245 */
+{
+    c->prior[s * c->A * c->S + (c->sys_N + reb) * c->S + ns] = (float)prob * 10000.0f;
+}
+static void sys_flat_recur_reboot(orc_ctx* c, int32_t s, int32_t ns, int comp, double acc, int reb) /* :188-234 */
+{
+    int32_t ns_fail;
+    if (comp == -1) { sys_flat_leaf_reboot(c, s, ns, acc, reb); return; }
+    ns_fail = ns & ~(1 << comp);
+    if (!((s >> comp) & 1)) {
+        sys_flat_recur_reboot(c, s, ns_fail, comp - 1, acc, reb);
+    } else {
+        double fail_prob = 1 - c->sys_keep[sys_failing_neighbours(c, comp, s)];
+        sys_flat_recur_reboot(c, s, ns, comp - 1, acc * (1 - fail_prob), reb);
+        sys_flat_recur_reboot(c, s, ns_fail, comp - 1, acc * fail_prob, reb);
+    }
+}
+static void sys_flat_leaf(orc_ctx* c, int32_t s, int32_t ns, double prob) /* setTrueTCounts :150-186 */
+{
+    int N = c->sys_N, a;
+    float* phi = c->prior + (size_t)s * c->A * c->S;
+    for (a = 0; a < N; ++a) phi[a * c->S + ns] = (float)prob * 10000.0f;
+    for (a = N; a < 2 * N; ++a) {
+        if ((ns >> (a - N)) & 1) {
+            double fail_prob = 1 - c->sys_keep[sys_failing_neighbours(c, a, s)];
+            phi[a * c->S + ns] = 10000.0f * (float)(prob + (prob * fail_prob / (1 - fail_prob) * SYS_REBOOT_RATE));
+        } else {
+            phi[a * c->S + ns] = 10000.0f * (float)(prob * (1 - SYS_REBOOT_RATE));
+        }
+    }
+}
+static void sys_flat_recur(orc_ctx* c, int32_t s, int32_t ns, int comp, double acc) /* :93-148 */
+{
+    int32_t ns_fail;
+    if (comp == -1) { sys_flat_leaf(c, s, ns, acc); return; }
+    ns_fail = ns & ~(1 << comp);
+    if (!((s >> comp) & 1)) {
+        sys_flat_recur(c, s, ns_fail, comp - 1, acc);
+        sys_flat_recur_reboot(c, s, ns_fail, comp - 1, acc * (1 - SYS_REBOOT_RATE), comp);
+        sys_flat_recur_reboot(c, s, ns, comp - 1, acc * SYS_REBOOT_RATE, comp);
+    } else {
+        double fail_prob = 1 - c->sys_keep[sys_failing_neighbours(c, comp, s)];
+        sys_flat_recur(c, s, ns, comp - 1, acc * (1 - fail_prob));
+        sys_flat_recur(c, s, ns_fail, comp - 1, acc * fail_prob);
+    }
+}
+static int build_sysadmin_flat_prior(orc_ctx* c) /* precomputeFlatPrior :38-91 */
+{
+    int S = c->S, O = c->O, N = c->sys_N, s, ns, k;
+    float* psi = c->prior + c->phi_len;
+    float high = 10000.0f * SYS_OBSERVE_PROB, low = 10000.0f * (1 - SYS_OBSERVE_PROB);
+    memset(c->prior, 0, sizeof(float) * (size_t)c->ncnt); /* BAFlatModel(&domain_size): zero counts */
+    for (s = 0; s < S; ++s) sys_flat_recur(c, s, S - 1, N - 1, 1);
+    for (ns = 0; ns < S; ++ns)
+        for (k = 0; k < N; ++k) {
+            int hi = (ns >> k) & 1;
+            psi[k * S * O + ns * O + hi]           = high;
+            psi[k * S * O + ns * O + (1 - hi)]     = low;
+            psi[(k + N) * S * O + ns * O + hi]     = high;
+            psi[(k + N) * S * O + ns * O + 1 - hi] = low;
+        }
+    return 0;
+}
+
 static int build_tabular_prior(orc_ctx* c)
 {
     int S = c->S, A = c->A, O = c->O, i, s, ns;
@@ -716,6 +834,7 @@ static int build_tabular_prior(orc_ctx* c)
     c->prior   = (float*)malloc(sizeof(float) * (size_t)c->ncnt);
     phi        = c->prior;
     psi        = c->prior + c->phi_len;
+    if (is_sys(c->cfg.domain)) return build_sysadmin_flat_prior(c); /* ignores --noise / -C */
     if (noise <= -.15 || noise > .3) {
         snprintf(c->err, sizeof c->err, "noise has to be between -.15 and .3");
         return -1;
@@ -1131,8 +1250,93 @@ static int build_ca_factored_prior(orc_ctx* c)
     return 0;
 }
 
+
+/* SysAdminFactoredPrior (SysAdminFactoredPrior.cpp:17-45, 129-247, 279-333): one state feature per
+ * computer (feature c is the model's computer c; in the state index it is bit N-1-c, last feature
+ * fastest), transition node (a, c) with parents {c} (independent) or {c-1, c, c+1} (linear),
+ * observation node (a) with parent {a mod N}.  No structure prior ("Structure noise is not
+ * enabled for the Sysadmin problem"), so no per-particle draws. */
+static float sys_failure_probability(const orc_ctx* c, int a, int comp, const int* parents, const int* pv, int np) /* :279-333 */
+{
+    int k, own = -1, nfn = 0, rebooting = (a == c->sys_N + comp);
+    double fail_prob;
+    for (k = 0; k < np; ++k)
+        if (parents[k] == comp) own = k;
+    if (own >= 0 && pv[own] == 0) return rebooting ? 1 - SYS_REBOOT_RATE : 1;
+    if (c->cfg.domain == ORC_DOM_SYSADMIN_LINEAR)
+        for (k = 0; k < np; ++k)
+            if ((parents[k] == comp - 1 || parents[k] == comp + 1) && pv[k] == 0) nfn++;
+    fail_prob = 1 - c->sys_keep[nfn];
+    if (rebooting) fail_prob *= (1 - SYS_REBOOT_RATE);
+    if (own < 0) { /* computer is not its own input: not reached by the two built structures */
+        fail_prob += rebooting ? (1 - SYS_REBOOT_RATE) : 1;
+        fail_prob *= .5;
+    }
+    return (float)fail_prob;
+}
+static int build_sysadmin_factored_prior(orc_ctx* c)
+{
+    fdesc* d = &c->fd;
+    int A = c->A, N = c->sys_N, a, f, k, r, off = 0;
+    int linear = c->cfg.domain == ORC_DOM_SYSADMIN_LINEAR;
+    if (c->cfg.structure_prior != ORC_SP_NONE) {
+        snprintf(c->err, sizeof c->err, "Structure noise is not enabled for the Sysadmin problem");
+        return -1;
+    }
+    if (N > ORC_MAXF) { snprintf(c->err, sizeof c->err, "too many state features"); return -1; }
+    d->FS = N;
+    d->FO = 1;
+    for (f = 0; f < N; ++f) d->Ssz[f] = 2;
+    d->Osz[0] = 2;
+    fdesc_steps(d->Ssz, d->FS, d->Sstep);
+    fdesc_steps(d->Osz, d->FO, d->Ostep);
+    d->T = (fnode*)calloc((size_t)A * N, sizeof(fnode));
+    d->O = (fnode*)calloc((size_t)A, sizeof(fnode));
+    for (a = 0; a < A; ++a)
+        for (f = 0; f < N; ++f) {
+            fnode* nd = &d->T[a * N + f];
+            nd->off = off; nd->out = 2; nd->var = -1; nd->nmax = 0;
+            if (linear && f > 0) nd->maxp[nd->nmax++] = f - 1;
+            nd->maxp[nd->nmax++] = f;
+            if (linear && f < N - 1) nd->maxp[nd->nmax++] = f + 1;
+            nd->fixed_mask = (1u << nd->nmax) - 1u;
+            off += 2 << nd->nmax;
+        }
+    for (a = 0; a < A; ++a) {
+        fnode* nd = &d->O[a];
+        nd->off = off; nd->out = 2; nd->var = -1; nd->nmax = 1; nd->maxp[0] = a % N; nd->fixed_mask = 1;
+        off += 4;
+    }
+    d->ncounts = off;
+    d->nvar    = 0;
+    c->ncnt    = off;
+    c->prior   = (float*)calloc((size_t)c->ncnt, sizeof(float));
+    for (a = 0; a < A; ++a)
+        for (f = 0; f < N; ++f) { /* disconnectedTransitions :186-216 / linearTransitions :218-257 */
+            const fnode* nd = &d->T[a * N + f];
+            int parents[3], pv[3];
+            for (k = 0; k < nd->nmax; ++k) parents[k] = nd->maxp[k];
+            for (r = 0; r < (1 << nd->nmax); ++r) {
+                float p;
+                for (k = 0; k < nd->nmax; ++k) pv[k] = (r >> (nd->nmax - 1 - k)) & 1; /* last parent fastest */
+                p = sys_failure_probability(c, a, f, parents, pv, nd->nmax);
+                c->prior[nd->off + 2 * r + 0] = p * 10000.0f;
+                c->prior[nd->off + 2 * r + 1] = (1 - p) * 10000.0f;
+            }
+        }
+    for (a = 0; a < A; ++a) { /* precomputeFactoredPrior :148-183: output 0 = FAILING */
+        const fnode* nd = &d->O[a];
+        c->prior[nd->off + 0] = 10000.0f * SYS_OBSERVE_PROB;       /* parent failing */
+        c->prior[nd->off + 1] = 10000.0f * (1 - SYS_OBSERVE_PROB);
+        c->prior[nd->off + 2] = 10000.0f * (1 - SYS_OBSERVE_PROB); /* parent working */
+        c->prior[nd->off + 3] = 10000.0f * SYS_OBSERVE_PROB;
+    }
+    return 0;
+}
+
 static int build_factored_prior(orc_ctx* c)
 {
+    if (is_sys(c->cfg.domain)) return build_sysadmin_factored_prior(c);
     if (is_ca(c->cfg.domain)) return build_ca_factored_prior(c);
     if (is_ftiger(c->cfg.domain)) return build_ftiger_factored_prior(c);
     if (is_grid(c->cfg.domain)) return build_gridworld_factored_prior(c);
@@ -1146,7 +1350,7 @@ static int build_factored_prior(orc_ctx* c)
 static void factored_prior_sample(orc_ctx* c, float* cnt)
 {
     memcpy(cnt, c->prior, sizeof(float) * (size_t)c->ncnt);
-    if (is_ca(c->cfg.domain)) return; /* fixed structures only: no draws */
+    if (is_ca(c->cfg.domain) || is_sys(c->cfg.domain)) return; /* fixed structures only: no draws */
     if (is_grid(c->cfg.domain)) {
         /* GridWorldFactBAPrior::sampleFBAPOMDPState (GridWorldBAPriors.cpp:415-441): per action,
          * one boolean for the x node and one for the y node: add the goal feature as a parent */
@@ -1925,6 +2129,13 @@ orc_ctx* orc_create(const orc_config* cfg)
             c->S = W * H * Hn; c->A = 3; c->O = Hn;
             break;
         }
+        case ORC_DOM_SYSADMIN_INDEPENDENT:
+        case ORC_DOM_SYSADMIN_LINEAR:
+            if (cfg->size < 1) { snprintf(c->err, sizeof c->err, "Cannot initiate Sysadmin with n %d", cfg->size); return c; }
+            if (cfg->size > 8) { snprintf(c->err, sizeof c->err, "sysadmin: at most 8 computers (2N <= %d actions)", ORC_MAX_ACTIONS); return c; }
+            sys_setup(c, cfg->size);
+            c->S = 1 << cfg->size; c->A = 2 * cfg->size; c->O = 2;
+            break;
         case ORC_DOM_GRIDWORLD:
             if (cfg->size < 3 || cfg->size > 15) {
                 snprintf(c->err, sizeof c->err, "please enter a size larger than 3 to be able to run gridworld (you entered %d)", cfg->size);

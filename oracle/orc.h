@@ -30,7 +30,10 @@ enum {
     ORC_DOM_FTIGER_EPISODIC   = 2,
     ORC_DOM_FTIGER_CONTINUOUS = 3,
     ORC_DOM_GRIDWORLD         = 4,
-    ORC_DOM_COLLISION_AVOID   = 5
+    ORC_DOM_COLLISION_AVOID   = 5,
+    /* 6 is the HIP engine's centered-collision-avoidance (here: ca_centered) */
+    ORC_DOM_SYSADMIN_INDEPENDENT = 7, /* -D independent-sysadmin --size N */
+    ORC_DOM_SYSADMIN_LINEAR      = 8  /* -D linear-sysadmin --size N      */
 };
 /* simulator model */
 enum { ORC_MODEL_POMDP = 0, ORC_MODEL_BA_TABLE = 1, ORC_MODEL_BA_FACTORED = 2 };

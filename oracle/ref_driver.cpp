@@ -28,6 +28,8 @@
 #include "beliefs/particle_filters/WeightedFilter.hpp"
 #include "domains/collision-avoidance/CollisionAvoidance.hpp"
 #include "domains/gridworld/GridWorld.hpp"
+#include "domains/sysadmin/SysAdmin.hpp"
+#include "domains/sysadmin/SysAdminBAExtension.hpp"
 #include "domains/tiger/FactoredTiger.hpp"
 #include "domains/tiger/Tiger.hpp"
 #include "environment/Action.hpp"
@@ -145,6 +147,34 @@ static void obs_table(POMDP const& d, int S, int A, int O)
                 p.push_back(d.computeObservationProbability(&io, &ia, &is));
             }
     arr(p, pd);
+}
+
+/* SysAdmin static_casts its states: P(o | a, s') through SysAdminBAExtension's state objects, plus
+ * the extension's reward (SysAdminBAExtension.cpp:39-50) for every (a, s') */
+static void sysadmin_tables(int n, char const* version)
+{
+    domains::SysAdmin d(n, version);
+    bayes_adaptive::domain_extensions::SysAdminBAExtension ext(n);
+    std::vector<double> p, rw;
+    std::vector<int> nfn;
+    for (int a = 0; a < 2 * n; ++a)
+        for (int s = 0; s < (1 << n); ++s) {
+            IndexAction ia(a);
+            for (int o = 0; o < 2; ++o) {
+                IndexObservation io(o);
+                p.push_back(d.computeObservationProbability(&io, &ia, ext.getState(s)));
+            }
+            rw.push_back(ext.reward(ext.getState(0), &ia, ext.getState(s)).toDouble());
+        }
+    for (int c = 0; c < n; ++c)
+        for (int s = 0; s < (1 << n); ++s) nfn.push_back((int)d.numFailingNeighbours(c, ext.getState(s)));
+    printf("{\"obs_prob\": ");
+    arr(p, pd);
+    printf(", \"ext_reward\": ");
+    arr(rw, pd);
+    printf(", \"failing_neighbours\": ");
+    arr(nfn, pi);
+    printf("}");
 }
 
 /* GridWorld needs its own state / observation objects (it static_casts them) */
@@ -638,6 +668,15 @@ int main(int argc, char** argv)
     { domains::CollisionAvoidance d(7, 7, 2, domains::CollisionAvoidance::INITIALIZE_CENTRE); walk(d, "32", 400); }
     key("ca_4_5_2_obs_prob");
     { domains::CollisionAvoidance d(4, 5, 2, domains::CollisionAvoidance::INIT_RANDOM_POSITION); ca_obs_table(d, 4, 5, 2); }
+
+    key("sysadmin3_independent");
+    { domains::SysAdmin d(3, "independent"); walk(d, "50", 300); }
+    key("sysadmin5_linear");
+    { domains::SysAdmin d(5, "linear"); walk(d, "51", 400); }
+    key("sysadmin8_linear");
+    { domains::SysAdmin d(8, "linear"); walk(d, "52", 400); }
+    key("sysadmin4_linear_tables");
+    sysadmin_tables(4, "linear");
 
     key("tiger_obs_prob");
     { domains::Tiger d(domains::Tiger::EPISODIC); obs_table(d, 2, 3, 2); }
