@@ -28,6 +28,7 @@ K_SEARCH, K_ENV, K_BELIEF_RS, K_BELIEF_IS, K_BELIEF_RESET, K_BELIEF_INIT, K_COUN
 KERNEL_NAMES = ["search_kernel", "env_kernel", "reject_kernel", "importance_kernel", "reset_kernel", "init_kernel"]
 
 DOM_TIGER_EPISODIC, DOM_TIGER_CONTINUOUS, DOM_FTIGER_EPISODIC, DOM_FTIGER_CONTINUOUS, DOM_GRIDWORLD, DOM_COLLISION_AVOID, DOM_COLLISION_AVOID_CENTERED = range(7)
+DOM_SYSADMIN_INDEPENDENT, DOM_SYSADMIN_LINEAR = 7, 8
 MODEL_POMDP, MODEL_BA_TABLE, MODEL_BA_FACTORED = range(3)
 BELIEF_REJECTION, BELIEF_IMPORTANCE, BELIEF_REINVIGORATION = range(3)
 PLANNER_POUCT, PLANNER_RANDOM = range(2)
@@ -38,6 +39,7 @@ DOMAIN_NAMES = {  # reference -D strings (DomainConf.cpp)
     "episodic-factored-tiger": DOM_FTIGER_EPISODIC, "continuous-factored-tiger": DOM_FTIGER_CONTINUOUS,
     "gridworld": DOM_GRIDWORLD,
     "random-collision-avoidance": DOM_COLLISION_AVOID, "centered-collision-avoidance": DOM_COLLISION_AVOID_CENTERED,
+    "independent-sysadmin": DOM_SYSADMIN_INDEPENDENT, "linear-sysadmin": DOM_SYSADMIN_LINEAR,
 }
 BELIEF_NAMES = {"rejection_sampling": BELIEF_REJECTION, "importance_sampling": BELIEF_IMPORTANCE,
                 "reinvigoration": BELIEF_REINVIGORATION}

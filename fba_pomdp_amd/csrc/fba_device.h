@@ -129,8 +129,8 @@ __device__ __forceinline__ double expected_mult_at(const View& row, int off, int
 // stored right after the counts -- and rows are indexed compactly by the actual parents, exactly
 // as DBNNode::cptIndex (DBNNode.cpp:171-205).
 constexpr int MAXF     = 8;   // state / observation features
-constexpr int MAXNODES = 96;  // A * (FS + FO)
-constexpr int MAXINC   = 8;   // count increments of one UpdateCounts step (FS + FO)
+constexpr int MAXNODES = 160; // A * (FS + FO)
+constexpr int MAXINC   = 9;   // count increments of one UpdateCounts step (FS + FO)
 struct FNode {
     int32_t off, out, nmax, var;
     uint32_t fixed_mask;
@@ -183,6 +183,8 @@ struct Problem {
     float noise, counts_total;
     int32_t structure_prior;
     int32_t domain, model, belief, planner;
+    int32_t sys_N;      // sysadmin: number of computers (bit c of the state = computer c operational)
+    double sys_keep[3]; // sysadmin: (1 - fail_prob) * pow(1 - fail_neighbour_factor, #failing neighbours), built on the host
     int32_t reinvig;    // reinvigoration belief: particles bred per update (belief = REJECTION then); 0 = off
     int32_t S, A, O;
     int32_t N;          // particles per slot
@@ -200,6 +202,17 @@ __device__ __forceinline__ bool dom_is_ftiger(int d) { return d == FBA_DOM_FTIGE
 __device__ __forceinline__ bool dom_is_episodic(int d) { return d == FBA_DOM_TIGER_EPISODIC || d == FBA_DOM_FTIGER_EPISODIC; }
 __device__ __forceinline__ bool dom_is_grid(int d) { return d == FBA_DOM_GRIDWORLD; }
 __device__ __forceinline__ bool dom_is_ca(int d) { return d == FBA_DOM_COLLISION_AVOID || d == FBA_DOM_COLLISION_AVOID_CENTERED; }
+__device__ __forceinline__ bool dom_is_sys(int d) { return d == FBA_DOM_SYSADMIN_INDEPENDENT || d == FBA_DOM_SYSADMIN_LINEAR; }
+
+// SysAdmin::numFailingNeighbours (SysAdmin.cpp:221-246): linear topology, neighbours c-1 and c+1
+__device__ __forceinline__ int sys_failing_neighbours(const Problem& P, int comp, int s)
+{
+    if (P.domain == FBA_DOM_SYSADMIN_INDEPENDENT) return 0;
+    int n = 0;
+    if (comp > 0 && !((s >> (comp - 1)) & 1)) n++;
+    if (comp < P.sys_N - 1 && !((s >> (comp + 1)) & 1)) n++;
+    return n;
+}
 
 // ---- collision avoidance helpers: state = (x*H + y)*H^n + project(obstacle rows) ----
 __device__ __forceinline__ int ca_keep(const CADesc* ca, int y) { return max(0, min(ca->H - 1, y)); }
@@ -250,6 +263,7 @@ __device__ __forceinline__ float gw_obs_displ_prob(const GridDesc* gw, int loc, 
 __device__ __forceinline__ int domain_start(const Problem& P, Rng& g)
 {
     if (dom_is_tiger(P.domain)) return g.boolean() ? 0 : 1;
+    if (dom_is_sys(P.domain)) return P.S - 1;  // SysAdmin::sampleStartState :102-105: all computers on, no draw
     if (dom_is_ca(P.domain)) {  // sampleStartState :270-273 -> categoricalDistr::sample -> sampleFromMult<float>
         const CADesc* ca = P.ca;
         const double p = g.u01() * ca->start_total;
@@ -279,6 +293,17 @@ __device__ __forceinline__ int domain_random_action(const Problem& P, Rng& g, in
 __device__ __forceinline__ bool domain_step(const Problem& P, Rng& g, int& s, int a, int& o, double& r)
 {
     const int d = P.domain;
+    if (dom_is_sys(d)) {  // SysAdmin::step :107-152
+        const int N = P.sys_N, op = a >= N ? a - N : a;
+        int index = s;
+        for (int k = 0; k < N; ++k)  // one draw per computer (failing ones too); neighbours of the OLD state
+            if (g.u01() > P.sys_keep[sys_failing_neighbours(P, k, s)]) index &= ~(1 << k);
+        if (a >= N && g.u01() < (double).95f) index |= 1 << op;  // _reboot_success_rate
+        s = index;
+        o = ((g.u01() < (double).95f) == (((index >> op) & 1) != 0)) ? 1 : 0;  // _observe_prob; OPERATIONAL = 1
+        r = (double)((int)__popc((unsigned)index) - (a >= N ? 1 : 0));     // operational computers - reboot cost (1.0f)
+        return false;
+    }
     if (dom_is_ca(d)) {  // CollisionAvoidance::step :236-270, moveObstacle :330-338, reward :196-208
         const CADesc* ca = P.ca;
         const int H = ca->H, n = ca->n, Hn = ca->Hn;
@@ -353,6 +378,10 @@ __device__ __forceinline__ bool domain_step(const Problem& P, Rng& g, int& s, in
 // Tiger / FactoredTiger::computeObservationProbability (Tiger.cpp:27-38)
 __device__ __forceinline__ double domain_obs_prob(const Problem& P, int o, int a, int new_s)
 {
+    if (dom_is_sys(P.domain)) {  // SysAdmin::computeObservationProbability :154-165 (float results)
+        const int op = a >= P.sys_N ? a - P.sys_N : a;
+        return (o == ((new_s >> op) & 1)) ? (double).95f : (double)(1 - .95f);
+    }
     if (dom_is_ca(P.domain)) {  // CollisionAvoidance::computeObservationProbability :216-229
         const CADesc* ca = P.ca;
         double p = 1;
@@ -375,12 +404,14 @@ __device__ __forceinline__ bool ext_terminal(const Problem& P, int s, int a, int
 {
     if (dom_is_ca(P.domain)) return ca_crashed(P.ca, ns) || ns / (P.ca->H * P.ca->Hn) == 0;  // CollisionAvoidanceBAExtension.cpp:53-63 (NEW state)
     if (dom_is_grid(P.domain)) return gw_on_goal(P.gw, s);  // GridWorldBAExtension.cpp:74-83
+    if (dom_is_sys(P.domain)) return false;                 // SysAdminBAExtension.cpp:31-37
     return dom_is_episodic(P.domain) && a != 2;
 }
 __device__ __forceinline__ double ext_reward(const Problem& P, int s, int a, int ns)
 {
     if (dom_is_ca(P.domain)) return ca_crashed(P.ca, ns) ? -1000 : (a == 1 ? 0 : -1);  // CollisionAvoidanceBAExtension.cpp:65-82
     if (dom_is_grid(P.domain)) return gw_on_goal(P.gw, s) ? 1 : 0;  // GridWorldBAExtension.cpp:85-99
+    if (dom_is_sys(P.domain)) return (double)((int)__popc((unsigned)ns) - (a >= P.sys_N ? 1 : 0));  // SysAdminBAExtension.cpp:39-50 (NEW state)
     if (a == 2) return -1;
     const int loc = dom_is_tiger(P.domain) ? s : ((s < P.S / 2) ? 0 : 1);
     return (a == loc) ? 10 : -100;
@@ -722,7 +753,7 @@ __device__ __forceinline__ void gw_fill_xy_node_with_goal(const Problem& P, floa
 
 __device__ __forceinline__ void factored_prior_sample(const Problem& P, Rng& g, float* rec)
 {
-    if (dom_is_ca(P.domain)) return;  // fixed structures only
+    if (dom_is_ca(P.domain) || dom_is_sys(P.domain)) return;  // fixed structures only
     if (dom_is_grid(P.domain)) {  // GridWorldFactBAPrior::sampleFBAPOMDPState :415-441
         if (P.structure_prior != FBA_SP_MATCH_UNIFORM) return;
         for (int a = 0; a < P.A; ++a)

@@ -96,6 +96,72 @@ bool is_tiger(int d) { return d == FBA_DOM_TIGER_EPISODIC || d == FBA_DOM_TIGER_
 bool is_ftiger(int d) { return d == FBA_DOM_FTIGER_EPISODIC || d == FBA_DOM_FTIGER_CONTINUOUS; }
 
 bool is_ca(int d) { return d == FBA_DOM_COLLISION_AVOID || d == FBA_DOM_COLLISION_AVOID_CENTERED; }
+bool is_sys(int d) { return d == FBA_DOM_SYSADMIN_INDEPENDENT || d == FBA_DOM_SYSADMIN_LINEAR; }
+
+// SysAdmin (reference src/domains/sysadmin/SysAdmin.cpp:12: parameters .025f, .95f, .95f, 1.0f, .075f).
+// keep[n] = (1 - fail_prob) * pow(1 - fail_neighbour_factor, n) as SysAdmin::step (:116-118)
+// evaluates it: float factor times a double pow, libm on the host so the device only looks it up.
+constexpr float SYS_FAIL = .025f, SYS_OBSERVE = .95f, SYS_REBOOT = .95f, SYS_NEIGHBOUR = .075f;
+void build_sysadmin(Problem& P, int n)
+{
+    P.sys_N = n;
+    for (int k = 0; k < 3; ++k) P.sys_keep[k] = (double)(1 - SYS_FAIL) * std::pow((double)(1 - SYS_NEIGHBOUR), (double)k);
+}
+int sys_failing_neighbours(const Problem& P, int comp, int s)  // SysAdmin::numFailingNeighbours :221-246
+{
+    if (P.domain == FBA_DOM_SYSADMIN_INDEPENDENT) return 0;
+    int n = 0;
+    if (comp > 0 && !((s >> (comp - 1)) & 1)) n++;
+    if (comp < P.sys_N - 1 && !((s >> (comp + 1)) & 1)) n++;
+    return n;
+}
+
+// SysAdminFlatPrior::precomputeFlatPrior (SysAdminFlatPrior.cpp:38-247): every transition
+// probability times 10000, enumerated by a recursion over the computers N-1 .. 0 that multiplies
+// the per-computer outcomes in double and writes float counts at its leaves.  The order of the
+// leaves is the reference's, because reboot-branch leaves overwrite counts written earlier; so is
+// the quirk that setTrueTCounts (:168-172) hands numFailingNeighbours the ACTION index.
+struct SysFlat {
+    const Problem& P;
+    float* phi;
+    void leaf_reboot(int s, int ns, double prob, int reb) { phi[(s * P.A + P.sys_N + reb) * P.S + ns] = (float)prob * 10000.f; }
+    void recur_reboot(int s, int ns, int comp, double acc, int reb)  // :188-234
+    {
+        if (comp < 0) return leaf_reboot(s, ns, acc, reb);
+        const int ns_fail = ns & ~(1 << comp);
+        if (!((s >> comp) & 1)) return recur_reboot(s, ns_fail, comp - 1, acc, reb);
+        const double fail = 1 - P.sys_keep[sys_failing_neighbours(P, comp, s)];
+        recur_reboot(s, ns, comp - 1, acc * (1 - fail), reb);
+        recur_reboot(s, ns_fail, comp - 1, acc * fail, reb);
+    }
+    void leaf(int s, int ns, double prob)  // setTrueTCounts :150-186
+    {
+        const int N = P.sys_N;
+        for (int a = 0; a < N; ++a) phi[(s * P.A + a) * P.S + ns] = (float)prob * 10000.f;
+        for (int a = N; a < 2 * N; ++a) {
+            if ((ns >> (a - N)) & 1) {
+                const double fail = 1 - P.sys_keep[sys_failing_neighbours(P, a, s)];
+                phi[(s * P.A + a) * P.S + ns] = 10000.f * (float)(prob + (prob * fail / (1 - fail) * SYS_REBOOT));
+            } else {
+                phi[(s * P.A + a) * P.S + ns] = 10000.f * (float)(prob * (1 - SYS_REBOOT));
+            }
+        }
+    }
+    void recur(int s, int ns, int comp, double acc)  // :93-148
+    {
+        if (comp < 0) return leaf(s, ns, acc);
+        const int ns_fail = ns & ~(1 << comp);
+        if (!((s >> comp) & 1)) {
+            recur(s, ns_fail, comp - 1, acc);
+            recur_reboot(s, ns_fail, comp - 1, acc * (1 - SYS_REBOOT), comp);
+            recur_reboot(s, ns, comp - 1, acc * SYS_REBOOT, comp);
+        } else {
+            const double fail = 1 - P.sys_keep[sys_failing_neighbours(P, comp, s)];
+            recur(s, ns, comp - 1, acc * (1 - fail));
+            recur(s, ns_fail, comp - 1, acc * fail);
+        }
+    }
+};
 double normal_cdf(double x) { return .5 + .5 * std::erf(x / (1 * std::sqrt(2.0))); }  // rnd::normal::cdf random.cpp:119-124
 
 // Collision avoidance tables (reference CollisionAvoidance.cpp ctor :100-142)
@@ -212,6 +278,20 @@ int build_tabular_prior(fba_ctx* c)
     const Problem& P = c->P;
     const int S = P.S, A = P.A, O = P.O;
     const float noise = c->cfg.noise, total = c->cfg.counts_total;
+    if (is_sys(P.domain)) {  // SysAdminFlatPrior: zero-initialised BAFlatModel, --noise / -C unused
+        c->prior.assign((size_t)P.C, 0.f);
+        SysFlat flat{P, c->prior.data()};
+        for (int s = 0; s < S; ++s) flat.recur(s, S - 1, P.sys_N - 1, 1);
+        float* psi = c->prior.data() + P.phi_len;  // :60-90: the observation tells the operated computer's bit
+        const float high = 10000.f * SYS_OBSERVE, low = 10000.f * (1 - SYS_OBSERVE);
+        for (int a = 0; a < A; ++a)
+            for (int ns = 0; ns < S; ++ns) {
+                const int up = (ns >> (a % P.sys_N)) & 1;
+                psi[(a * S + ns) * O + up]     = high;
+                psi[(a * S + ns) * O + 1 - up] = low;
+            }
+        return FBA_OK;
+    }
     if (noise <= -.15 || noise > .3) return fail(c, FBA_EINVAL, "noise has to be between -.15 and .3");
     const float acc = (.85f - noise) * total, inacc = (.15f + noise) * total;
     c->prior.assign((size_t)P.C, 5000.f);
@@ -408,8 +488,78 @@ int build_ca_factored_prior(fba_ctx* c)
 
 int build_ftiger_factored_prior(fba_ctx* c);
 
+// SysAdminFactoredPrior (SysAdminFactoredPrior.cpp:17-45, 129-257, 279-333).  One binary feature per
+// computer; transition node (a, c): parents {c} (independent) or {c-1, c, c+1} (linear), counts
+// {p, 1-p} * 10000 with p = computeFailureProbability; observation node (a): parent {a mod N}.
+// "Structure noise is not enabled for the Sysadmin problem": nothing is drawn per particle.
+int build_sysadmin_factored_prior(fba_ctx* c)
+{
+    Problem& P = c->P;
+    const int A = P.A, N = P.sys_N;
+    const bool linear = P.domain == FBA_DOM_SYSADMIN_LINEAR;
+    if (c->cfg.structure_prior != FBA_SP_NONE) return fail(c, FBA_EINVAL, "Structure noise is not enabled for the Sysadmin problem");
+    if (N > MAXF || A * (N + 1) > MAXNODES) return fail(c, FBA_EINVAL, "too many state features");
+    FDesc& d = c->fdesc;
+    std::memset(&d, 0, sizeof d);
+    d.FS = N; d.FO = 1;
+    for (int f = 0; f < N; ++f) d.Ssz[f] = 2;
+    d.Osz[0] = 2;
+    fdesc_steps(d.Ssz, N, d.Sstep);
+    fdesc_steps(d.Osz, 1, d.Ostep);
+    int off = 0;
+    for (int a = 0; a < A; ++a)
+        for (int f = 0; f < N; ++f) {
+            FNode& nd = d.nodes[a * N + f];
+            nd.off = off; nd.out = 2; nd.var = -1; nd.nmax = 0;
+            if (linear && f > 0) nd.maxp[nd.nmax++] = (uint8_t)(f - 1);
+            nd.maxp[nd.nmax++] = (uint8_t)f;
+            if (linear && f < N - 1) nd.maxp[nd.nmax++] = (uint8_t)(f + 1);
+            nd.fixed_mask = (1u << nd.nmax) - 1u;
+            off += 2 << nd.nmax;
+        }
+    for (int a = 0; a < A; ++a) {
+        FNode& nd = d.nodes[A * N + a];
+        nd.off = off; nd.out = 2; nd.var = -1; nd.nmax = 1; nd.maxp[0] = (uint8_t)(a % N); nd.fixed_mask = 1;
+        off += 4;
+    }
+    d.ncounts = off;
+    d.nvar    = 0;
+    c->prior.assign((size_t)off, 0.f);
+    float* pr = c->prior.data();
+    for (int a = 0; a < A; ++a)
+        for (int f = 0; f < N; ++f) {
+            const FNode& nd = d.nodes[a * N + f];
+            const bool rebooting = a == N + f;
+            for (int r = 0; r < (1 << nd.nmax); ++r) {  // row r: parent values, last parent the fastest digit
+                int failing = 0;
+                bool own_up = true;
+                for (int k = 0; k < nd.nmax; ++k) {
+                    const int v = (r >> (nd.nmax - 1 - k)) & 1;
+                    if (nd.maxp[k] == f) own_up = v != 0;
+                    else if (!v) failing++;              // parents other than f are its linear neighbours
+                }
+                float p;
+                if (!own_up) p = rebooting ? 1 - SYS_REBOOT : 1;   // :295-298
+                else {
+                    double fail = 1 - P.sys_keep[failing];          // :313-315
+                    if (rebooting) fail *= (1 - SYS_REBOOT);
+                    p = (float)fail;
+                }
+                pr[nd.off + 2 * r + 0] = p * 10000.f;
+                pr[nd.off + 2 * r + 1] = (1 - p) * 10000.f;
+            }
+        }
+    for (int a = 0; a < A; ++a) {  // precomputeFactoredPrior :148-183: output 0 = FAILING
+        float* o = pr + d.nodes[A * N + a].off;
+        o[0] = 10000.f * SYS_OBSERVE; o[1] = 10000.f * (1 - SYS_OBSERVE);   // operated computer failing
+        o[2] = 10000.f * (1 - SYS_OBSERVE); o[3] = 10000.f * SYS_OBSERVE;   // operated computer working
+    }
+    return FBA_OK;
+}
+
 int build_factored_prior(fba_ctx* c)
 {
+    if (is_sys(c->P.domain)) return build_sysadmin_factored_prior(c);
     if (is_ca(c->P.domain)) return build_ca_factored_prior(c);
     if (c->P.domain == FBA_DOM_GRIDWORLD) return build_gridworld_factored_prior(c);
     return build_ftiger_factored_prior(c);
@@ -728,6 +878,16 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
                 return FBA_EINVAL;
             }
             P.S = 2 << cfg->size; P.A = 3; P.O = 2;
+            break;
+        case FBA_DOM_SYSADMIN_INDEPENDENT:
+        case FBA_DOM_SYSADMIN_LINEAR:
+            if (cfg->size < 1 || cfg->size > 8) {  // SysAdmin.cpp:17-21; 2N actions <= FBA_MAX_ACTIONS
+                fail(nullptr, FBA_EINVAL, cfg->size < 1 ? "Cannot initiate Sysadmin with n %d" : "sysadmin: at most 8 computers (n = %d)", cfg->size);
+                delete c;
+                return FBA_EINVAL;
+            }
+            build_sysadmin(P, cfg->size);
+            P.S = 1 << cfg->size; P.A = 2 * cfg->size; P.O = 2;
             break;
         case FBA_DOM_COLLISION_AVOID:
         case FBA_DOM_COLLISION_AVOID_CENTERED: {

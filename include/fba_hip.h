@@ -36,7 +36,9 @@ enum {
     FBA_DOM_FTIGER_CONTINUOUS = 3, /* continuous-factored-tiger                                       */
     FBA_DOM_GRIDWORLD         = 4, /* gridworld                  src/domains/gridworld/GridWorld.cpp  */
     FBA_DOM_COLLISION_AVOID   = 5, /* random-collision-avoidance src/domains/collision-avoidance/CollisionAvoidance.cpp */
-    FBA_DOM_COLLISION_AVOID_CENTERED = 6 /* centered-collision-avoidance (VERSION INITIALIZE_CENTRE) */
+    FBA_DOM_COLLISION_AVOID_CENTERED = 6, /* centered-collision-avoidance (VERSION INITIALIZE_CENTRE) */
+    FBA_DOM_SYSADMIN_INDEPENDENT = 7, /* independent-sysadmin --size N  src/domains/sysadmin/SysAdmin.cpp */
+    FBA_DOM_SYSADMIN_LINEAR      = 8  /* linear-sysadmin --size N                                         */
 };
 /* simulator: plain POMDP (planning), tabular BA-POMDP (bapomdp), factored (fbapomdp) */
 enum { FBA_MODEL_POMDP = 0, FBA_MODEL_BA_TABLE = 1, FBA_MODEL_BA_FACTORED = 2 };

@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 
 DOM = {"random-collision-avoidance": orc.DOM_COLLISION_AVOID, "centered-collision-avoidance": orc.DOM_COLLISION_AVOID,
        "gridworld": orc.DOM_GRIDWORLD, "episodic-tiger": orc.DOM_TIGER_EPISODIC, "continuous-tiger": orc.DOM_TIGER_CONTINUOUS,
-       "episodic-factored-tiger": orc.DOM_FTIGER_EPISODIC, "continuous-factored-tiger": orc.DOM_FTIGER_CONTINUOUS}
+       "episodic-factored-tiger": orc.DOM_FTIGER_EPISODIC, "continuous-factored-tiger": orc.DOM_FTIGER_CONTINUOUS,
+       "independent-sysadmin": orc.DOM_SYSADMIN_INDEPENDENT, "linear-sysadmin": orc.DOM_SYSADMIN_LINEAR}
 
 
 def _pair(domain, model, belief, seed, slots=None, size=0, **kw):
@@ -328,6 +329,39 @@ def test_collision_avoidance_prior_equals_oracle():
         eng = fba.Engine("random-collision-avoidance", model=N.MODEL_BA_FACTORED, particles=4, sims=4, slots=1, belief=1, **kw)
         o = orc.Oracle(domain=orc.DOM_COLLISION_AVOID, model=orc.MODEL_BA_FACTORED, **kw)
         assert np.array_equal(eng.prior(), o.prior_counts())
+
+
+@pytest.mark.parametrize("domain,size,belief", [
+    ("independent-sysadmin", 3, "rejection_sampling"), ("linear-sysadmin", 5, "importance_sampling"),
+    ("linear-sysadmin", 8, "rejection_sampling")])
+def test_planning_sysadmin(domain, size, belief):
+    """planning -D *-sysadmin: 2N actions (ucb_pick<16> at N = 8), never terminal."""
+    eng, o = _pair(domain, N.MODEL_POMDP, belief, 151 + size, size=size, particles=100, sims=160, runs=9, horizon=7, slots=4)
+    _assert_same_experiment(eng, o, ba=False)
+
+
+@pytest.mark.parametrize("domain,size,model,belief", [
+    ("independent-sysadmin", 3, N.MODEL_BA_TABLE, "rejection_sampling"),
+    ("linear-sysadmin", 4, N.MODEL_BA_TABLE, "importance_sampling"),
+    ("independent-sysadmin", 4, N.MODEL_BA_FACTORED, "importance_sampling"),
+    ("linear-sysadmin", 5, N.MODEL_BA_FACTORED, "rejection_sampling"),
+    ("linear-sysadmin", 8, N.MODEL_BA_FACTORED, "rejection_sampling"),     # FS + FO = 9 increments per step
+])
+def test_bapomdp_and_fbapomdp_sysadmin(domain, size, model, belief):
+    eng, o = _pair(domain, model, belief, 171 + size, size=size, particles=80, sims=96, runs=6, episodes=3, horizon=6, slots=3)
+    _assert_same_experiment(eng, o, ba=True)
+
+
+def test_sysadmin_priors_equal_oracle():
+    for dom, size in (("independent-sysadmin", 3), ("linear-sysadmin", 5)):
+        for model in (N.MODEL_BA_TABLE, N.MODEL_BA_FACTORED):
+            eng = fba.Engine(dom, model=model, size=size, particles=4, sims=4, slots=1)
+            o = orc.Oracle(domain=DOM[dom], model=model, size=size)
+            assert np.array_equal(eng.prior().view(np.uint32), o.prior_counts().view(np.uint32)), (dom, model)
+    with pytest.raises(ValueError, match="Structure noise is not enabled"):
+        fba.Engine("linear-sysadmin", model=N.MODEL_BA_FACTORED, size=3, structure_prior=2, particles=4, sims=4)
+    with pytest.raises(ValueError, match="Sysadmin with n 0"):
+        fba.Engine("linear-sysadmin", size=0, particles=4, sims=4)
 
 
 def test_bapomdp_slots_fewer_than_runs():
