@@ -162,6 +162,14 @@ struct CADesc {
     double phi[20];
 };
 
+// SysAdmin (reference src/domains/sysadmin/SysAdmin.cpp): bit c of the state = computer c operational;
+// keep[n] = (1 - fail_prob) * pow(1 - fail_neighbour_factor, n), n failing neighbours, built on the
+// host with libm exactly as SysAdmin::step (:116-118) evaluates it
+struct SysDesc {
+    int32_t N, pad;
+    double keep[3];
+};
+
 // Where the "+1"s of one UpdateCounts step go.  A step reports them as (slot k, blob index) pairs;
 // slot k < ninc(model).  The search ignores them (KeepCounts); the belief kernels park them in one
 // LDS column per thread, [k][thread], so nothing is indexed at run time in registers.
@@ -178,13 +186,12 @@ struct Problem {
     const FDesc* fd;  // device pointer; null unless model = BA_FACTORED
     const GridDesc* gw;  // device pointer; null unless domain = gridworld
     const CADesc* ca;    // device pointer; null unless domain = collision avoidance
+    const struct SysDesc* sys;  // device pointer; null unless domain = sysadmin
     const struct ZigDesc* zig;  // ziggurat tables (regular Dirichlet mode only)
     int32_t dirichlet_regular;  // --dirichlet_sampling_method regular
     float noise, counts_total;
     int32_t structure_prior;
     int32_t domain, model, belief, planner;
-    int32_t sys_N;      // sysadmin: number of computers (bit c of the state = computer c operational)
-    double sys_keep[3]; // sysadmin: (1 - fail_prob) * pow(1 - fail_neighbour_factor, #failing neighbours), built on the host
     int32_t reinvig;    // reinvigoration belief: particles bred per update (belief = REJECTION then); 0 = off
     int32_t S, A, O;
     int32_t N;          // particles per slot
@@ -210,7 +217,7 @@ __device__ __forceinline__ int sys_failing_neighbours(const Problem& P, int comp
     if (P.domain == FBA_DOM_SYSADMIN_INDEPENDENT) return 0;
     int n = 0;
     if (comp > 0 && !((s >> (comp - 1)) & 1)) n++;
-    if (comp < P.sys_N - 1 && !((s >> (comp + 1)) & 1)) n++;
+    if (comp < P.sys->N - 1 && !((s >> (comp + 1)) & 1)) n++;
     return n;
 }
 
@@ -294,10 +301,10 @@ __device__ __forceinline__ bool domain_step(const Problem& P, Rng& g, int& s, in
 {
     const int d = P.domain;
     if (dom_is_sys(d)) {  // SysAdmin::step :107-152
-        const int N = P.sys_N, op = a >= N ? a - N : a;
+        const int N = P.sys->N, op = a >= N ? a - N : a;
         int index = s;
         for (int k = 0; k < N; ++k)  // one draw per computer (failing ones too); neighbours of the OLD state
-            if (g.u01() > P.sys_keep[sys_failing_neighbours(P, k, s)]) index &= ~(1 << k);
+            if (g.u01() > P.sys->keep[sys_failing_neighbours(P, k, s)]) index &= ~(1 << k);
         if (a >= N && g.u01() < (double).95f) index |= 1 << op;  // _reboot_success_rate
         s = index;
         o = ((g.u01() < (double).95f) == (((index >> op) & 1) != 0)) ? 1 : 0;  // _observe_prob; OPERATIONAL = 1
@@ -379,7 +386,7 @@ __device__ __forceinline__ bool domain_step(const Problem& P, Rng& g, int& s, in
 __device__ __forceinline__ double domain_obs_prob(const Problem& P, int o, int a, int new_s)
 {
     if (dom_is_sys(P.domain)) {  // SysAdmin::computeObservationProbability :154-165 (float results)
-        const int op = a >= P.sys_N ? a - P.sys_N : a;
+        const int op = a >= P.sys->N ? a - P.sys->N : a;
         return (o == ((new_s >> op) & 1)) ? (double).95f : (double)(1 - .95f);
     }
     if (dom_is_ca(P.domain)) {  // CollisionAvoidance::computeObservationProbability :216-229
@@ -411,7 +418,7 @@ __device__ __forceinline__ double ext_reward(const Problem& P, int s, int a, int
 {
     if (dom_is_ca(P.domain)) return ca_crashed(P.ca, ns) ? -1000 : (a == 1 ? 0 : -1);  // CollisionAvoidanceBAExtension.cpp:65-82
     if (dom_is_grid(P.domain)) return gw_on_goal(P.gw, s) ? 1 : 0;  // GridWorldBAExtension.cpp:85-99
-    if (dom_is_sys(P.domain)) return (double)((int)__popc((unsigned)ns) - (a >= P.sys_N ? 1 : 0));  // SysAdminBAExtension.cpp:39-50 (NEW state)
+    if (dom_is_sys(P.domain)) return (double)((int)__popc((unsigned)ns) - (a >= P.sys->N ? 1 : 0));  // SysAdminBAExtension.cpp:39-50 (NEW state)
     if (a == 2) return -1;
     const int loc = dom_is_tiger(P.domain) ? s : ((s < P.S / 2) ? 0 : 1);
     return (a == loc) ? 10 : -100;

@@ -43,6 +43,8 @@ struct fba_ctx {
     GridDesc* d_gdesc    = nullptr;
     CADesc cadesc{};
     CADesc* d_cadesc     = nullptr;
+    SysDesc sysdesc{};
+    SysDesc* d_sysdesc   = nullptr;
     ZigDesc* d_zig       = nullptr;
     double* d_uni_scan   = nullptr;
     double* d_log1p      = nullptr;
@@ -102,17 +104,17 @@ bool is_sys(int d) { return d == FBA_DOM_SYSADMIN_INDEPENDENT || d == FBA_DOM_SY
 // keep[n] = (1 - fail_prob) * pow(1 - fail_neighbour_factor, n) as SysAdmin::step (:116-118)
 // evaluates it: float factor times a double pow, libm on the host so the device only looks it up.
 constexpr float SYS_FAIL = .025f, SYS_OBSERVE = .95f, SYS_REBOOT = .95f, SYS_NEIGHBOUR = .075f;
-void build_sysadmin(Problem& P, int n)
+void build_sysadmin(SysDesc& d, int n)
 {
-    P.sys_N = n;
-    for (int k = 0; k < 3; ++k) P.sys_keep[k] = (double)(1 - SYS_FAIL) * std::pow((double)(1 - SYS_NEIGHBOUR), (double)k);
+    d.N = n; d.pad = 0;
+    for (int k = 0; k < 3; ++k) d.keep[k] = (double)(1 - SYS_FAIL) * std::pow((double)(1 - SYS_NEIGHBOUR), (double)k);
 }
-int sys_failing_neighbours(const Problem& P, int comp, int s)  // SysAdmin::numFailingNeighbours :221-246
+int sys_failing_neighbours(const SysDesc& d, bool linear, int comp, int s)  // SysAdmin::numFailingNeighbours :221-246
 {
-    if (P.domain == FBA_DOM_SYSADMIN_INDEPENDENT) return 0;
+    if (!linear) return 0;
     int n = 0;
     if (comp > 0 && !((s >> (comp - 1)) & 1)) n++;
-    if (comp < P.sys_N - 1 && !((s >> (comp + 1)) & 1)) n++;
+    if (comp < d.N - 1 && !((s >> (comp + 1)) & 1)) n++;
     return n;
 }
 
@@ -123,24 +125,26 @@ int sys_failing_neighbours(const Problem& P, int comp, int s)  // SysAdmin::numF
 // the quirk that setTrueTCounts (:168-172) hands numFailingNeighbours the ACTION index.
 struct SysFlat {
     const Problem& P;
+    const SysDesc& d;
     float* phi;
-    void leaf_reboot(int s, int ns, double prob, int reb) { phi[(s * P.A + P.sys_N + reb) * P.S + ns] = (float)prob * 10000.f; }
+    double keep(int comp, int s) const { return d.keep[sys_failing_neighbours(d, P.domain == FBA_DOM_SYSADMIN_LINEAR, comp, s)]; }
+    void leaf_reboot(int s, int ns, double prob, int reb) { phi[(s * P.A + d.N + reb) * P.S + ns] = (float)prob * 10000.f; }
     void recur_reboot(int s, int ns, int comp, double acc, int reb)  // :188-234
     {
         if (comp < 0) return leaf_reboot(s, ns, acc, reb);
         const int ns_fail = ns & ~(1 << comp);
         if (!((s >> comp) & 1)) return recur_reboot(s, ns_fail, comp - 1, acc, reb);
-        const double fail = 1 - P.sys_keep[sys_failing_neighbours(P, comp, s)];
+        const double fail = 1 - keep(comp, s);
         recur_reboot(s, ns, comp - 1, acc * (1 - fail), reb);
         recur_reboot(s, ns_fail, comp - 1, acc * fail, reb);
     }
     void leaf(int s, int ns, double prob)  // setTrueTCounts :150-186
     {
-        const int N = P.sys_N;
+        const int N = d.N;
         for (int a = 0; a < N; ++a) phi[(s * P.A + a) * P.S + ns] = (float)prob * 10000.f;
         for (int a = N; a < 2 * N; ++a) {
             if ((ns >> (a - N)) & 1) {
-                const double fail = 1 - P.sys_keep[sys_failing_neighbours(P, a, s)];
+                const double fail = 1 - keep(a, s);
                 phi[(s * P.A + a) * P.S + ns] = 10000.f * (float)(prob + (prob * fail / (1 - fail) * SYS_REBOOT));
             } else {
                 phi[(s * P.A + a) * P.S + ns] = 10000.f * (float)(prob * (1 - SYS_REBOOT));
@@ -156,7 +160,7 @@ struct SysFlat {
             recur_reboot(s, ns_fail, comp - 1, acc * (1 - SYS_REBOOT), comp);
             recur_reboot(s, ns, comp - 1, acc * SYS_REBOOT, comp);
         } else {
-            const double fail = 1 - P.sys_keep[sys_failing_neighbours(P, comp, s)];
+            const double fail = 1 - keep(comp, s);
             recur(s, ns, comp - 1, acc * (1 - fail));
             recur(s, ns_fail, comp - 1, acc * fail);
         }
@@ -280,13 +284,13 @@ int build_tabular_prior(fba_ctx* c)
     const float noise = c->cfg.noise, total = c->cfg.counts_total;
     if (is_sys(P.domain)) {  // SysAdminFlatPrior: zero-initialised BAFlatModel, --noise / -C unused
         c->prior.assign((size_t)P.C, 0.f);
-        SysFlat flat{P, c->prior.data()};
-        for (int s = 0; s < S; ++s) flat.recur(s, S - 1, P.sys_N - 1, 1);
+        SysFlat flat{P, c->sysdesc, c->prior.data()};
+        for (int s = 0; s < S; ++s) flat.recur(s, S - 1, c->sysdesc.N - 1, 1);
         float* psi = c->prior.data() + P.phi_len;  // :60-90: the observation tells the operated computer's bit
         const float high = 10000.f * SYS_OBSERVE, low = 10000.f * (1 - SYS_OBSERVE);
         for (int a = 0; a < A; ++a)
             for (int ns = 0; ns < S; ++ns) {
-                const int up = (ns >> (a % P.sys_N)) & 1;
+                const int up = (ns >> (a % c->sysdesc.N)) & 1;
                 psi[(a * S + ns) * O + up]     = high;
                 psi[(a * S + ns) * O + 1 - up] = low;
             }
@@ -495,7 +499,7 @@ int build_ftiger_factored_prior(fba_ctx* c);
 int build_sysadmin_factored_prior(fba_ctx* c)
 {
     Problem& P = c->P;
-    const int A = P.A, N = P.sys_N;
+    const int A = P.A, N = c->sysdesc.N;
     const bool linear = P.domain == FBA_DOM_SYSADMIN_LINEAR;
     if (c->cfg.structure_prior != FBA_SP_NONE) return fail(c, FBA_EINVAL, "Structure noise is not enabled for the Sysadmin problem");
     if (N > MAXF || A * (N + 1) > MAXNODES) return fail(c, FBA_EINVAL, "too many state features");
@@ -541,7 +545,7 @@ int build_sysadmin_factored_prior(fba_ctx* c)
                 float p;
                 if (!own_up) p = rebooting ? 1 - SYS_REBOOT : 1;   // :295-298
                 else {
-                    double fail = 1 - P.sys_keep[failing];          // :313-315
+                    double fail = 1 - c->sysdesc.keep[failing];          // :313-315
                     if (rebooting) fail *= (1 - SYS_REBOOT);
                     p = (float)fail;
                 }
@@ -886,7 +890,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
                 delete c;
                 return FBA_EINVAL;
             }
-            build_sysadmin(P, cfg->size);
+            build_sysadmin(c->sysdesc, cfg->size);
             P.S = 1 << cfg->size; P.A = 2 * cfg->size; P.O = 2;
             break;
         case FBA_DOM_COLLISION_AVOID:
@@ -935,6 +939,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     P.fd = nullptr;
     P.gw = nullptr;
     P.ca = nullptr;
+    P.sys = nullptr;
     P.zig = nullptr;
     P.dirichlet_regular = cfg->dirichlet_regular ? 1 : 0;
     if (cfg->model == FBA_MODEL_BA_TABLE) {
@@ -1132,6 +1137,11 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         CHK(dev_alloc(c, &c->d_cadesc, 1));
         HIPC(hipMemcpyAsync(c->d_cadesc, &c->cadesc, sizeof(CADesc), hipMemcpyHostToDevice, c->stream));
         P.ca = c->d_cadesc;
+    }
+    if (is_sys(cfg->domain)) {
+        CHK(dev_alloc(c, &c->d_sysdesc, 1));
+        HIPC(hipMemcpyAsync(c->d_sysdesc, &c->sysdesc, sizeof(SysDesc), hipMemcpyHostToDevice, c->stream));
+        P.sys = c->d_sysdesc;
     }
     if (cfg->domain == FBA_DOM_GRIDWORLD) {
         CHK(dev_alloc(c, &c->d_gdesc, 1));

@@ -293,12 +293,17 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
                 const double ret = path_r[(size_t)k * SEARCH_BLOCK] + P.gamma * del;
                 const int act    = na & 15;
                 if ((na >> 4) == 0) {
+                    // register-array element `act`: select, ONE division, write back
+                    int n = 0;
+                    double q = 0.0;
 #pragma unroll
                     for (int a2 = 0; a2 < AMAX; ++a2)
-                        if (a2 == act) {
-                            const int n = ++r_cn[a2];
-                            r_cq[a2] += (ret - r_cq[a2]) / (double)n;
-                        }
+                        if (a2 == act) { n = r_cn[a2]; q = r_cq[a2]; }
+                    ++n;
+                    q += (ret - q) / (double)n;
+#pragma unroll
+                    for (int a2 = 0; a2 < AMAX; ++a2)
+                        if (a2 == act) { r_cn[a2] = n; r_cq[a2] = q; }
                     ++r_vis;
                     root_L = D.log1p_tab[r_vis];
                 } else {

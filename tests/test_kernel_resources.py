@@ -1,0 +1,33 @@
+"""The constant-folded tiger instantiations (the bench workload's kernels) must stay free of scratch:
+an indexed array or a double added to `Problem` once pinned the whole by-value struct to private
+memory and tripled their register count.  Checked on the code-object metadata hipcc emits (no GPU)."""
+import os
+import re
+import subprocess
+
+from fba_pomdp_amd import _native as N
+
+
+def test_tiger_kernels_use_no_scratch(tmp_path):
+    out = tmp_path / "kernels.s"
+    src = os.path.join(N.HERE, "csrc", "fba_kernels.hip")
+    flags = [f for f in N.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+    subprocess.check_call(["hipcc"] + flags + ["-I" + os.path.join(N.ROOT, "include"), "-S", "--cuda-device-only", "-o", str(out), src],
+                          stderr=subprocess.DEVNULL)
+    meta = out.read_text()
+    meta = meta[meta.index("amdhsa.kernels:"):]
+    seen = {}
+    for blk in meta.split("  - .agpr_count")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        get = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1))
+        seen[name] = (get("private_segment_fixed_size"), get("vgpr_count"), get("vgpr_spill_count"))
+    tiger = {n: v for n, v in seen.items()
+             if re.search(r"search_kernelILb1ELi4ELb0ELb1E|reject_kernelILb0ELb1E|importance_kernelILb0ELb1E", n)}
+    assert len(tiger) == 3, sorted(seen)
+    for name, (scratch, vgprs, spills) in tiger.items():
+        assert scratch == 0 and spills == 0, (name, scratch, spills)
+        assert vgprs <= 128, (name, vgprs)       # four waves per SIMD stay possible
+    regular = re.compile(r"search_kernelILb[01]ELi\d+ELb1E|(reject|importance)_kernelILb1E|is_multi_step_kernelILb1E")
+    for name, (scratch, vgprs, spills) in seen.items():
+        if not regular.search(name):              # (the `regular` Dirichlet instantiations carry the gamma sampler)
+            assert spills == 0, (name, spills)    # no expected-mode kernel spills vector registers
