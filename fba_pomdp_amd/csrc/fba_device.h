@@ -131,10 +131,12 @@ __device__ __forceinline__ double expected_mult_at(const View& row, int off, int
 constexpr int MAXF     = 8;   // state / observation features
 constexpr int MAXNODES = 160; // A * (FS + FO)
 constexpr int MAXINC   = 9;   // count increments of one UpdateCounts step (FS + FO)
-struct FNode {
+struct alignas(16) FNode {  // 48 bytes: three 16-byte loads bring a whole node description
     int32_t off, out, nmax, var;
     uint32_t fixed_mask;
-    uint8_t maxp[MAXF];
+    uint8_t maxp[MAXF];  // candidate parents (state features), in order
+    uint8_t psz[MAXF];   // psz[j] = number of values of parent maxp[j] (filled by the engine after the build)
+    uint32_t pad[3];
 };
 struct FDesc {
     int32_t FS, FO, nvar, ncounts;
@@ -192,6 +194,7 @@ struct Problem {
     float noise, counts_total;
     int32_t structure_prior;
     int32_t domain, model, belief, planner;
+    int32_t fd_bytes;   // bytes of *fd in use (header + A*(FS+FO) nodes): what a kernel stages in LDS
     int32_t reinvig;    // reinvigoration belief: particles bred per update (belief = REJECTION then); 0 = off
     int32_t S, A, O;
     int32_t N;          // particles per slot
@@ -602,7 +605,7 @@ __device__ __forceinline__ int node_row(const FDesc* fd, const FNode& nd, uint32
     int idx = 0;
 #pragma unroll
     for (int j = 0; j < MAXF; ++j)
-        if (j < nd.nmax && ((mask >> j) & 1u)) idx = idx * fd->Ssz[nd.maxp[j]] + feat(fv, nd.maxp[j]);
+        if (j < nd.nmax && ((mask >> j) & 1u)) idx = idx * nd.psz[j] + feat(fv, nd.maxp[j]);
     return nd.off + idx * nd.out;
 }
 

@@ -940,6 +940,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     P.gw = nullptr;
     P.ca = nullptr;
     P.sys = nullptr;
+    P.fd_bytes = 0;
     P.zig = nullptr;
     P.dirichlet_regular = cfg->dirichlet_regular ? 1 : 0;
     if (cfg->model == FBA_MODEL_BA_TABLE) {
@@ -1149,6 +1150,11 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         P.gw = c->d_gdesc;
     }
     if (cfg->model == FBA_MODEL_BA_FACTORED) {
+        FDesc& fdh = c->fdesc;
+        const int nnodes = P.A * (fdh.FS + fdh.FO);
+        for (int k = 0; k < nnodes; ++k)
+            for (int j = 0; j < fdh.nodes[k].nmax; ++j) fdh.nodes[k].psz[j] = (uint8_t)fdh.Ssz[fdh.nodes[k].maxp[j]];
+        P.fd_bytes = (int32_t)(offsetof(FDesc, nodes) + (size_t)nnodes * sizeof(FNode));
         CHK(dev_alloc(c, &c->d_fdesc, 1));
         HIPC(hipMemcpyAsync(c->d_fdesc, &c->fdesc, sizeof(FDesc), hipMemcpyHostToDevice, c->stream));
         P.fd = c->d_fdesc;

@@ -152,9 +152,13 @@ __device__ __forceinline__ int ucb_select(const Problem& P, const DeviceState& D
 // record fits 32 words (STAGE) -- the root particle's whole count blob, [word][lane], fetched with
 // one burst of 16-byte loads per simulation so that no step waits on HBM for its Dirichlet rows.
 // ---------------------------------------------------------------------------------------------
-template <bool STAGE, int AMAX, bool REG, bool TIGER_TABLE>
+template <bool STAGE, int AMAX, bool REG, bool TIGER_TABLE, int MODEL>
 __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceState D)
 {
+    // one instantiation per simulator: the launcher passes the model it read from P, so restating it
+    // here drops the other simulators' code (a plain-POMDP search carries every domain's step(),
+    // the Bayes-adaptive ones none of them) from this instantiation
+    P.model = MODEL;
     // TIGER_TABLE: the launcher has checked that this is the tabular BA-POMDP over (episodic or
     // continuous) tiger; restating its sizes as literals lets the compiler unroll the two-entry
     // Dirichlet rows and fold every model / domain branch.  Same code, same results.
@@ -168,6 +172,20 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
     const int e    = blockIdx.x * SEARCH_BLOCK + lane;
+    if (MODEL == FBA_MODEL_BA_FACTORED) {
+        // the factored model's description (which parents, how many values, where the rows start) is
+        // consulted several times per sampled feature: keep the part in use in LDS, at the end of
+        // this workgroup's allocation, instead of chasing it through global memory
+        const int depth_cap0 = P.max_depth > 0 ? P.max_depth : 1;
+        size_t words = (size_t)depth_cap0 * SEARCH_BLOCK * 3 + (STAGE ? (size_t)P.Cs * SEARCH_BLOCK : 0) +
+                       (P.A * P.O <= ROOT_CHILDREN ? (size_t)P.A * P.O * SEARCH_BLOCK : 0);
+        words = (words + 3) & ~(size_t)3;  // 16-byte aligned
+        uint4* dst       = reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(lds) + words);
+        const uint4* src = reinterpret_cast<const uint4*>(P.fd);
+        for (int k = lane; k < (P.fd_bytes + 15) / 16; k += SEARCH_BLOCK) dst[k] = src[k];
+        __syncthreads();
+        P.fd = reinterpret_cast<const FDesc*>(dst);
+    }
     if (e >= P.E || !D.active[e]) return;
 
     const int depth_cap = P.max_depth > 0 ? P.max_depth : 1;
@@ -1151,24 +1169,33 @@ void launch_search(const Problem& P, const DeviceState& D, hipStream_t st)
 {
     const int depth_cap = P.max_depth > 0 ? P.max_depth : 1;
     const bool stage = P.model != FBA_MODEL_POMDP && P.Cs <= SEARCH_STAGE_WORDS;
-    const size_t lds = (size_t)depth_cap * SEARCH_BLOCK * (sizeof(double) + sizeof(int32_t)) +
-                       (stage ? (size_t)P.Cs * SEARCH_BLOCK * sizeof(float) : 0) +
-                       (P.A * P.O <= ROOT_CHILDREN ? (size_t)P.A * P.O * SEARCH_BLOCK * sizeof(int32_t) : 0);
+    size_t lds = (size_t)depth_cap * SEARCH_BLOCK * (sizeof(double) + sizeof(int32_t)) +
+                 (stage ? (size_t)P.Cs * SEARCH_BLOCK * sizeof(float) : 0) +
+                 (P.A * P.O <= ROOT_CHILDREN ? (size_t)P.A * P.O * SEARCH_BLOCK * sizeof(int32_t) : 0);
+    if (P.model == FBA_MODEL_BA_FACTORED) lds = ((lds + 15) & ~(size_t)15) + (((size_t)P.fd_bytes + 15) & ~(size_t)15);  // + the model description
     const dim3 grid(ceil_div(P.E, SEARCH_BLOCK)), block(SEARCH_BLOCK);
+#define FBA_LAUNCH_SEARCH_M(STG, AM, MODEL)                                                                              \
+    do {                                                                                                                 \
+        if (P.dirichlet_regular && MODEL != FBA_MODEL_POMDP)                                                             \
+            hipLaunchKernelGGL((search_kernel<STG, AM, (MODEL != FBA_MODEL_POMDP), false, MODEL>), grid, block, lds, st, P, D); \
+        else hipLaunchKernelGGL((search_kernel<STG, AM, false, false, MODEL>), grid, block, lds, st, P, D);             \
+    } while (0)
 #define FBA_LAUNCH_SEARCH(STG, AM)                                                                  \
     do {                                                                                            \
-        if (P.dirichlet_regular) hipLaunchKernelGGL((search_kernel<STG, AM, true, false>), grid, block, lds, st, P, D);   \
-        else hipLaunchKernelGGL((search_kernel<STG, AM, false, false>), grid, block, lds, st, P, D); \
+        if (P.model == FBA_MODEL_BA_FACTORED) FBA_LAUNCH_SEARCH_M(STG, AM, FBA_MODEL_BA_FACTORED);  \
+        else if (P.model == FBA_MODEL_BA_TABLE) FBA_LAUNCH_SEARCH_M(STG, AM, FBA_MODEL_BA_TABLE);   \
+        else FBA_LAUNCH_SEARCH_M(false, AM, FBA_MODEL_POMDP);                                       \
     } while (0)
     const bool tiger_table = P.model == FBA_MODEL_BA_TABLE && P.planner == FBA_PLANNER_POUCT && !P.dirichlet_regular && stage &&
                              (P.domain == FBA_DOM_TIGER_EPISODIC || P.domain == FBA_DOM_TIGER_CONTINUOUS) && !D.hash;
     if (tiger_table) {
-        hipLaunchKernelGGL((search_kernel<true, 4, false, true>), grid, block, lds, st, P, D);
+        hipLaunchKernelGGL((search_kernel<true, 4, false, true, FBA_MODEL_BA_TABLE>), grid, block, lds, st, P, D);
         return;
     }
     if (P.A <= 4) { if (stage) FBA_LAUNCH_SEARCH(true, 4); else FBA_LAUNCH_SEARCH(false, 4); }
     else if (P.A <= 8) { if (stage) FBA_LAUNCH_SEARCH(true, 8); else FBA_LAUNCH_SEARCH(false, 8); }
     else { if (stage) FBA_LAUNCH_SEARCH(true, 16); else FBA_LAUNCH_SEARCH(false, 16); }
+#undef FBA_LAUNCH_SEARCH_M
 #undef FBA_LAUNCH_SEARCH
 }
 void launch_start(const Problem& P, const DeviceState& D, hipStream_t st)
