@@ -296,6 +296,43 @@ int build_tabular_prior(fba_ctx* c)
             }
         return FBA_OK;
     }
+    if (P.domain == FBA_DOM_GRIDWORLD) {
+        // GridWorldFlatBAPrior (GridWorldBAPriors.cpp:21-156).  Transition counts accumulate (a move
+        // into a wall and a failed move are the same cell; on a goal the next goal is uniform);
+        // observation counts = P(o | s') * 100000 for the observations that carry s' own goal.
+        const GridDesc& g = c->gdesc;
+        const int N = g.N, G = g.G;
+        if (noise < 0 || noise > (1 - .15))
+            return fail(c, FBA_EINVAL, "Gridworld expects noise in between 0 and %f (received %f)", 1 - .15, noise);
+        c->prior.assign((size_t)P.C, 0.f);
+        float* phi = c->prior.data();
+        float* psi = c->prior.data() + P.phi_len;
+        for (int a = 0; a < A; ++a)
+            for (int s = 0; s < S; ++s) {
+                const int ax = s / (N * G), ay = (s / G) % N, gl = s % G;
+                const bool on_goal = g.goal[gl][0] == ax && g.goal[gl][1] == ay;
+                const float success = gw_slow_at_h(g, ax, ay) ? (float)(.15 + noise) : (float).95;
+                const float goal_prob = (float)1 / (float)G;
+                float* row = phi + ((size_t)s * A + a) * S;
+                int nx = ax, ny = ay;
+                gw_move_h(g, a, nx, ny);
+                if (on_goal) {  // the move fails / succeeds, then the goal is re-drawn uniformly (:76-88, :104-117)
+                    const float stay = (1 - success) * goal_prob, go = success * goal_prob;
+                    for (int g2 = 0; g2 < G; ++g2) row[(ax * N + ay) * G + g2] += stay * total;
+                    for (int g2 = 0; g2 < G; ++g2) row[(nx * N + ny) * G + g2] += go * total;
+                } else {
+                    const float stay = 1 - success;
+                    row[s] += stay * total;
+                    row[(nx * N + ny) * G + gl] += success * total;
+                }
+                for (int x = 0; x < N; ++x)
+                    for (int y = 0; y < N; ++y) {
+                        const double prob = (double)(gw_obs_displ_prob_h(g, ax, x) * gw_obs_displ_prob_h(g, ay, y));
+                        psi[((size_t)a * S + s) * O + (x * N + y) * G + gl] = (float)(prob * 100000.0f);
+                    }
+            }
+        return FBA_OK;
+    }
     if (noise <= -.15 || noise > .3) return fail(c, FBA_EINVAL, "noise has to be between -.15 and .3");
     const float acc = (.85f - noise) * total, inacc = (.15f + noise) * total;
     c->prior.assign((size_t)P.C, 5000.f);
@@ -976,7 +1013,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         delete c;
         return FBA_EINVAL;
     }
-    if (cfg->model == FBA_MODEL_BA_TABLE && (cfg->domain == FBA_DOM_GRIDWORLD || is_ca(cfg->domain))) {
+    if (cfg->model == FBA_MODEL_BA_TABLE && is_ca(cfg->domain)) {
         fail(nullptr, FBA_EINVAL, "the tabular prior of this domain (S*A*S counts per particle) is not built; use the factored model");
         delete c;
         return FBA_EINVAL;

@@ -821,6 +821,53 @@ static int build_sysadmin_flat_prior(orc_ctx* c) /* precomputeFlatPrior :38-91 *
     return 0;
 }
 
+/* GridWorldFlatBAPrior (GridWorldBAPriors.cpp:21-156): tabular counts of the true gridworld.
+ * Transition counts are ADDED (a blocked move and a failed move land in the same cell); observation
+ * counts = P(o | s') * 100000 for the observations that show s' own goal, 0 elsewhere. */
+static int build_gridworld_flat_prior(orc_ctx* c)
+{
+    int S = c->S, A = c->A, N = c->gw_N, G = c->gw_G, a, s, g2, x, y;
+    float noise = c->cfg.noise, total = c->cfg.counts_total;
+    float* phi = c->prior;
+    float* psi = c->prior + c->phi_len;
+    if (noise < 0 || noise > (1 - .15)) {
+        snprintf(c->err, sizeof c->err, "Gridworld expects noise in between 0 and %f (received %f)", 1 - .15, noise);
+        return -1;
+    }
+    memset(c->prior, 0, sizeof(float) * (size_t)c->ncnt);
+    for (a = 0; a < A; ++a)
+        for (s = 0; s < S; ++s) {
+            int ax = s / (N * G), ay = (s / G) % N, gl = s % G, nx = ax, ny = ay;
+            int on_goal = c->gw_goal[gl][0] == ax && c->gw_goal[gl][1] == ay;
+            float success_prob = gw_slow_at(c, ax, ay) ? (float)(.15 + noise) : (float).95;
+            float goal_prob    = (float)1 / (float)G;
+            float* row         = phi + (size_t)s * A * S + (size_t)a * S;
+            /* setPriorTransitionProbabilities :62-126 */
+            if (on_goal) {
+                float prob = (1 - success_prob) * goal_prob;
+                for (g2 = 0; g2 < G; ++g2) row[ax * N * G + ay * G + g2] += prob * total;
+            } else {
+                float prob = 1 - success_prob;
+                row[s] += prob * total;
+            }
+            gw_move(c, a, &nx, &ny);
+            if (on_goal) {
+                float prob = success_prob * goal_prob;
+                for (g2 = 0; g2 < G; ++g2) row[nx * N * G + ny * G + g2] += prob * total;
+            } else {
+                row[nx * N * G + ny * G + gl] += success_prob * total;
+            }
+            /* setPriorObservationProbabilities :128-150 (s plays the role of new_s) */
+            for (x = 0; x < N; ++x)
+                for (y = 0; y < N; ++y) {
+                    int o       = x * N * G + y * G + gl;
+                    double prob = domain_obs_prob(c, o, a, s);
+                    psi[(size_t)a * S * c->O + (size_t)s * c->O + o] = (float)(prob * 100000.0f);
+                }
+        }
+    return 0;
+}
+
 static int build_tabular_prior(orc_ctx* c)
 {
     int S = c->S, A = c->A, O = c->O, i, s, ns;
@@ -835,6 +882,7 @@ static int build_tabular_prior(orc_ctx* c)
     phi        = c->prior;
     psi        = c->prior + c->phi_len;
     if (is_sys(c->cfg.domain)) return build_sysadmin_flat_prior(c); /* ignores --noise / -C */
+    if (is_grid(c->cfg.domain)) return build_gridworld_flat_prior(c);
     if (noise <= -.15 || noise > .3) {
         snprintf(c->err, sizeof c->err, "noise has to be between -.15 and .3");
         return -1;

@@ -214,6 +214,18 @@ def test_fbapomdp_gridworld(size, sp):
     _assert_same_experiment(eng, o, ba=True)
 
 
+@pytest.mark.parametrize("size,belief,noise", [(3, "rejection_sampling", 0.0), (3, "importance_sampling", 0.1), (4, "rejection_sampling", 0.05)])
+def test_bapomdp_gridworld_flat_prior(size, belief, noise):
+    """bapomdp -D gridworld: GridWorldFlatBAPrior (S*A*S + A*S*O counts per particle: 23 KB at --size 3,
+    131 KB at --size 4), rows of S entries sampled with the float CDF."""
+    eng, o = _pair("gridworld", N.MODEL_BA_TABLE, belief, 211 + size, size=size, particles=48, sims=80, runs=5, episodes=3,
+                   horizon=8, slots=3, noise=noise)
+    assert np.array_equal(eng.prior().view(np.uint32), o.prior_counts().view(np.uint32))
+    _assert_same_experiment(eng, o, ba=True)
+    with pytest.raises(ValueError, match="Gridworld expects noise"):
+        fba.Engine("gridworld", model=N.MODEL_BA_TABLE, size=3, noise=-0.1, particles=4, sims=4)
+
+
 def test_fbapomdp_gridworld_prior_particles_equal_oracle():
     kw = dict(size=4, particles=32, sims=8, structure_prior=2, belief=1)
     eng = fba.Engine("gridworld", model=N.MODEL_BA_FACTORED, seed=91, slots=1, **kw)
