@@ -761,9 +761,70 @@ __device__ __forceinline__ void gw_fill_xy_node_with_goal(const Problem& P, floa
     rec[P.fd->ncounts + nd.var] = __uint_as_float(7u);
 }
 
+// CollisionAvoidanceFactoredPrior::obstacleTransition (CollisionAvoidancePriors.cpp:402-427): the H
+// counts of an obstacle at row y
+__device__ __forceinline__ void ca_obstacle_transition(const Problem& P, int y, float* out)
+{
+    const int H = P.ca->H;
+    const float move_prob = (float)(.25 - .5 * (double)P.noise);
+    const float stay_prob = (y == 0 || y == H - 1) ? (float)(3 * .25 + .5 * (double)P.noise) : (float)(2 * .25 + (double)P.noise);
+    for (int k = 0; k < H; ++k) out[k] = 0.f;
+    if (y != 0) out[y - 1] = move_prob * P.counts_total;
+    if (y != H - 1) out[y + 1] = move_prob * P.counts_total;
+    out[y] = stay_prob * P.counts_total;
+}
+// CollisionAvoidanceFactoredPrior::sampleBlockTModel (:528-590) for one (action, obstacle feature):
+// the node's CPT under parent set `mask`.  With the obstacle among its own parents every row is
+// obstacleTransition(its own value), otherwise every row is uniform, counts_total / H.
+__device__ __forceinline__ void ca_fill_obstacle_node(const Problem& P, float* rec, int a, int f, uint32_t mask)
+{
+    const FDesc* fd = P.fd;
+    const FNode& nd = fd->nodes[a * fd->FS + f];
+    const int H = P.ca->H, FS = fd->FS;
+    int rows = 1, rows_max = 1;
+    for (int k = 0; k < FS; ++k) {
+        rows_max *= fd->Ssz[k];
+        if ((mask >> k) & 1u) rows *= fd->Ssz[k];
+    }
+    float* base = rec + nd.off;
+    for (int r = 0; r < rows; ++r) {
+        float* row = base + r * H;
+        if ((mask >> f) & 1u) {
+            int rem = r, own = 0;
+            for (int k = FS - 1; k >= 0; --k)  // last parent is the fastest digit
+                if ((mask >> k) & 1u) {
+                    if (k == f) own = rem % fd->Ssz[k];
+                    rem /= fd->Ssz[k];
+                }
+            ca_obstacle_transition(P, own, row);
+        } else {
+            const float u = P.counts_total / (float)H;
+            for (int y = 0; y < H; ++y) row[y] = u;
+        }
+    }
+    for (int k = rows * H; k < rows_max * H; ++k) base[k] = 0.f;
+    rec[fd->ncounts + nd.var] = __uint_as_float(mask);
+}
+
 __device__ __forceinline__ void factored_prior_sample(const Problem& P, Rng& g, float* rec)
 {
-    if (dom_is_ca(P.domain) || dom_is_sys(P.domain)) return;  // fixed structures only
+    if (dom_is_sys(P.domain)) return;  // fixed structures only
+    if (dom_is_ca(P.domain)) {
+        // CollisionAvoidanceFactoredPrior::sampleFBAPOMDPState (:349-383): per obstacle, per action, one
+        // boolean per state feature (always drawn); match-uniform forces the obstacle's own edge
+        if (P.structure_prior != FBA_SP_UNIFORM && P.structure_prior != FBA_SP_MATCH_UNIFORM) return;
+        const int FS = P.fd->FS;
+        for (int f = 2; f < FS; ++f)
+            for (int a = 0; a < P.A; ++a) {
+                uint32_t mask = 0;
+                for (int fp = 0; fp < FS; ++fp) {
+                    const bool b = g.boolean();
+                    if (b || (fp == f && P.structure_prior == FBA_SP_MATCH_UNIFORM)) mask |= 1u << fp;
+                }
+                ca_fill_obstacle_node(P, rec, a, f, mask);
+            }
+        return;
+    }
     if (dom_is_grid(P.domain)) {  // GridWorldFactBAPrior::sampleFBAPOMDPState :415-441
         if (P.structure_prior != FBA_SP_MATCH_UNIFORM) return;
         for (int a = 0; a < P.A; ++a)

@@ -455,8 +455,9 @@ int build_ca_factored_prior(fba_ctx* c)
     const float noise = c->cfg.noise, total = c->cfg.counts_total;
     const bool full = c->cfg.structure_prior == FBA_SP_FULLY_CONNECTED;
     if (noise > .5 || noise < -.5) return fail(c, FBA_EINVAL, "CollisionAvoidanceFactoredPrior must be intiiated with -.5 < noise < .5 (is: %f)", noise);
-    if (c->cfg.structure_prior != FBA_SP_NONE && !full)
-        return fail(c, FBA_EINVAL, "collision avoidance: structure priors 'uniform' / 'match-uniform' are not built (variable-size CPTs)");
+    // edge noise "uniform" / "match-uniform" (:349-383): every obstacle node's parents are drawn per particle
+    // (on the device, factored_prior_sample); the node owns room for every state feature as a parent
+    const bool noisy = c->cfg.structure_prior == FBA_SP_UNIFORM || c->cfg.structure_prior == FBA_SP_MATCH_UNIFORM;
     if (FS > MAXF || A * (FS + n) > MAXNODES) return fail(c, FBA_EINVAL, "too many state features");
     FDesc& d = c->fdesc;
     std::memset(&d, 0, sizeof d);
@@ -470,11 +471,12 @@ int build_ca_factored_prior(fba_ctx* c)
         for (int f = 0; f < FS; ++f) {
             FNode& nd = d.nodes[a * FS + f];
             nd.off = off; nd.out = d.Ssz[f]; nd.var = -1;
-            if (f >= 2 && full) {
+            if (f >= 2 && (full || noisy)) {
                 int rows = 1;
                 nd.nmax = FS;
                 for (int k = 0; k < FS; ++k) { nd.maxp[k] = (uint8_t)k; rows *= d.Ssz[k]; }
                 nd.fixed_mask = (1u << FS) - 1u;
+                if (noisy) nd.var = a * n + (f - 2);
                 off += rows * H;
             } else {
                 nd.nmax = 1; nd.maxp[0] = (uint8_t)f; nd.fixed_mask = 1;
@@ -488,8 +490,8 @@ int build_ca_factored_prior(fba_ctx* c)
             off += H * H;
         }
     d.ncounts = off;
-    d.nvar    = 0;
-    c->prior.assign((size_t)off, 0.f);
+    d.nvar    = noisy ? A * n : 0;
+    c->prior.assign((size_t)off + d.nvar, 0.f);
     float* pr = c->prior.data();
     auto obstacle_transition = [&](int y, float* out) {
         const float move_prob = (float)(.25 - .5 * noise);
@@ -504,7 +506,11 @@ int build_ca_factored_prior(fba_ctx* c)
         for (int y = 0; y < H; ++y) pr[d.nodes[a * FS + 1].off + y * H + std::max(0, std::min(H - 1, y + a - 1))] += 1;
         for (int f = 2; f < FS; ++f) {
             const FNode& nd = d.nodes[a * FS + f];
-            if (!full) {
+            if (noisy) {  // the base record carries the correct graph {f}; every particle overwrites it
+                for (int y = 0; y < H; ++y) obstacle_transition(y, pr + nd.off + y * H);
+                const uint32_t own = 1u << f;
+                std::memcpy(&pr[off + nd.var], &own, 4);
+            } else if (!full) {
                 for (int y = 0; y < H; ++y) obstacle_transition(y, pr + nd.off + y * H);
             } else {
                 int rows = 1;

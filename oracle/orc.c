@@ -1219,17 +1219,46 @@ static void ca_obstacle_transition(const orc_ctx* c, int y, float* out) /* obsta
     if (y != H - 1) out[y + 1] = move_prob * c->cfg.counts_total;
     out[y] = stay_prob * c->cfg.counts_total;
 }
+
+/* CollisionAvoidanceFactoredPrior::sampleBlockTModel (CollisionAvoidancePriors.cpp:528-590) for one
+ * (action, obstacle feature): the node's CPT under parent set `mask` (bit k = state feature k).  With
+ * the obstacle itself among the parents every row is obstacleTransition(its own value), otherwise
+ * every row is uniform, counts_total / H. */
+static void ca_fill_obstacle_node(orc_ctx* c, float* cnt, int a, int f, uint32_t mask)
+{
+    const fdesc* d  = &c->fd;
+    const fnode* nd = &d->T[a * d->FS + f];
+    int H = c->ca_H, rows = 1, rows_max = 1, k, r, y;
+    for (k = 0; k < d->FS; ++k) {
+        rows_max *= d->Ssz[k];
+        if ((mask >> k) & 1u) rows *= d->Ssz[k];
+    }
+    memset(cnt + nd->off, 0, sizeof(float) * (size_t)rows_max * H);
+    for (r = 0; r < rows; ++r) {
+        float* row = cnt + nd->off + r * H;
+        if ((mask >> f) & 1u) {
+            int rem = r, own = 0;
+            for (k = d->FS - 1; k >= 0; --k) /* last parent is the fastest digit */
+                if ((mask >> k) & 1u) {
+                    if (k == f) own = rem % d->Ssz[k];
+                    rem /= d->Ssz[k];
+                }
+            ca_obstacle_transition(c, own, row);
+        } else {
+            for (y = 0; y < H; ++y) row[y] = c->cfg.counts_total / (float)H;
+        }
+    }
+    if (nd->var >= 0) cnt[d->ncounts + nd->var] = u2f(mask);
+}
 static int build_ca_factored_prior(orc_ctx* c)
 {
     fdesc* d = &c->fd;
     int A = c->A, W = c->ca_W, H = c->ca_H, n = c->ca_n, FS = 2 + n, a, f, off = 0, y, k;
     int full = c->cfg.structure_prior == ORC_SP_FULLY_CONNECTED;
+    /* edge noise "uniform" / "match-uniform" (:349-383): every obstacle node's parents are drawn per particle */
+    int noisy = c->cfg.structure_prior == ORC_SP_UNIFORM || c->cfg.structure_prior == ORC_SP_MATCH_UNIFORM;
     if (c->cfg.noise > .5 || c->cfg.noise < -.5) {
         snprintf(c->err, sizeof c->err, "CollisionAvoidanceFactoredPrior must be intiiated with -.5 < noise < .5 (is: %f)", c->cfg.noise);
-        return -1;
-    }
-    if (c->cfg.structure_prior != ORC_SP_NONE && !full) {
-        snprintf(c->err, sizeof c->err, "collision avoidance: structure priors 'uniform' / 'match-uniform' are not built");
         return -1;
     }
     if (FS > ORC_MAXF) { snprintf(c->err, sizeof c->err, "too many state features"); return -1; }
@@ -1244,11 +1273,12 @@ static int build_ca_factored_prior(orc_ctx* c)
         for (f = 0; f < FS; ++f) {
             fnode* nd = &d->T[a * FS + f];
             nd->off = off; nd->out = d->Ssz[f]; nd->var = -1;
-            if (f >= 2 && full) {
+            if (f >= 2 && (full || noisy)) {
                 int rows = 1;
                 nd->nmax = FS;
                 for (k = 0; k < FS; ++k) { nd->maxp[k] = k; rows *= d->Ssz[k]; }
                 nd->fixed_mask = (1u << FS) - 1u;
+                if (noisy) nd->var = a * n + (f - 2);
                 off += rows * H;
             } else {
                 nd->nmax = 1; nd->maxp[0] = f; nd->fixed_mask = 1;
@@ -1262,16 +1292,18 @@ static int build_ca_factored_prior(orc_ctx* c)
             off += H * H;
         }
     d->ncounts = off;
-    d->nvar    = 0;
-    c->ncnt    = off;
-    c->prior   = (float*)calloc((size_t)off, sizeof(float));
+    d->nvar    = noisy ? A * n : 0;
+    c->ncnt    = off + d->nvar;
+    c->prior   = (float*)calloc((size_t)c->ncnt, sizeof(float));
     for (a = 0; a < A; ++a) {
         int x;
         for (x = 1; x < W; ++x) c->prior[d->T[a * FS + 0].off + x * W + (x - 1)] = 1; /* agent always moves one column */
         for (y = 0; y < H; ++y) c->prior[d->T[a * FS + 1].off + y * H + ca_keep(c, y + a - 1)] += 1; /* setAgentYTransition */
         for (f = 2; f < FS; ++f) {
             const fnode* nd = &d->T[a * FS + f];
-            if (!full) {
+            if (noisy) { /* the base record carries the correct graph; every particle overwrites it */
+                ca_fill_obstacle_node(c, c->prior, a, f, 1u << f);
+            } else if (!full) {
                 for (y = 0; y < H; ++y) ca_obstacle_transition(c, y, c->prior + nd->off + y * H);
             } else { /* every parent-value combination gets obstacleTransition(value of the obstacle itself) */
                 int rows = 1, r;
@@ -1398,7 +1430,24 @@ static int build_factored_prior(orc_ctx* c)
 static void factored_prior_sample(orc_ctx* c, float* cnt)
 {
     memcpy(cnt, c->prior, sizeof(float) * (size_t)c->ncnt);
-    if (is_ca(c->cfg.domain) || is_sys(c->cfg.domain)) return; /* fixed structures only: no draws */
+    if (is_sys(c->cfg.domain)) return; /* fixed structures only: no draws */
+    if (is_ca(c->cfg.domain)) {
+        /* CollisionAvoidanceFactoredPrior::sampleFBAPOMDPState (:349-383): per obstacle, per action, one
+         * boolean per state feature (always drawn: it is the left operand of the ||); under
+         * match-uniform the obstacle is always its own parent */
+        int f, a, fp;
+        if (c->cfg.structure_prior != ORC_SP_UNIFORM && c->cfg.structure_prior != ORC_SP_MATCH_UNIFORM) return;
+        for (f = 2; f < c->fd.FS; ++f)
+            for (a = 0; a < c->A; ++a) {
+                uint32_t mask = 0;
+                for (fp = 0; fp < c->fd.FS; ++fp) {
+                    int b = orc_bool(&c->rng);
+                    if (b || (fp == f && c->cfg.structure_prior == ORC_SP_MATCH_UNIFORM)) mask |= 1u << fp;
+                }
+                ca_fill_obstacle_node(c, cnt, a, f, mask);
+            }
+        return;
+    }
     if (is_grid(c->cfg.domain)) {
         /* GridWorldFactBAPrior::sampleFBAPOMDPState (GridWorldBAPriors.cpp:415-441): per action,
          * one boolean for the x node and one for the y node: add the goal feature as a parent */

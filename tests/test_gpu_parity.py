@@ -326,13 +326,36 @@ def test_planning_collision_avoidance(domain):
     _assert_same_experiment(eng, o, ba=False)
 
 
-@pytest.mark.parametrize("sp,W,H,n", [(0, 5, 3, 3), (0, 7, 7, 2), (3, 4, 3, 1)])
+@pytest.mark.parametrize("sp,W,H,n", [(0, 5, 3, 3), (0, 7, 7, 2), (3, 4, 3, 1), (1, 4, 3, 1), (2, 5, 3, 2), (1, 4, 5, 2)])
 def test_fbapomdp_collision_avoidance(sp, W, H, n):
     """fbapomdp -D random-collision-avoidance (largest factored domain; BASELINE configs[4] at
-    parity size): correct-graph and fully-connected priors."""
+    parity size): correct-graph and fully-connected priors, and the edge-noise priors uniform (1) /
+    match-uniform (2), whose obstacle nodes draw their parent sets per particle."""
     eng, o = _pair("random-collision-avoidance", N.MODEL_BA_FACTORED, "importance_sampling", 123 + sp, size=n, width=W,
                    height=H, particles=80, sims=150, runs=6, episodes=3, structure_prior=sp)
     _assert_same_experiment(eng, o, ba=True)
+
+
+def test_collision_avoidance_edge_noise_prior_particles_equal_oracle():
+    """CollisionAvoidanceFactoredPrior::sampleFBAPOMDPState / sampleBlockTModel on the device."""
+    for sp in (1, 2):
+        kw = dict(width=4, height=3, size=2, structure_prior=sp, noise=0.1, counts_total=90.0, particles=96, sims=8)
+        eng = fba.Engine("random-collision-avoidance", model=N.MODEL_BA_FACTORED, seed=29, slots=1, **kw)
+        o = orc.Oracle(domain=orc.DOM_COLLISION_AVOID, model=orc.MODEL_BA_FACTORED, rng_mode=orc.RNG_PHILOX,
+                       arith=orc.ARITH_DEV, philox_seed=29, **kw)
+        orc.lib().orc_rng_episode(o.rng, 0, 0, 0)
+        o.belief_initiate()
+        eng.belief_init()
+        s, _, cnt = eng.belief_get(0)
+        os_, _, ocnt = o.belief_get()
+        assert np.array_equal(s, os_)
+        assert np.array_equal(cnt.view(np.uint32), ocnt.view(np.uint32))
+        masks = cnt.view(np.uint32)[:, -6:]                       # var (a, obstacle) = a * n + obstacle
+        assert len({tuple(m) for m in masks.tolist()}) > 50       # per-particle structures
+        if sp == 2:
+            assert np.all(masks[:, 0::2] & 4) and np.all(masks[:, 1::2] & 8)   # own edge forced
+        else:
+            assert not np.all(masks[:, 0::2] & 4)
 
 
 def test_collision_avoidance_prior_equals_oracle():
