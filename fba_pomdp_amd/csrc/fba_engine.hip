@@ -457,7 +457,9 @@ int build_ca_factored_prior(fba_ctx* c)
     if (noise > .5 || noise < -.5) return fail(c, FBA_EINVAL, "CollisionAvoidanceFactoredPrior must be intiiated with -.5 < noise < .5 (is: %f)", noise);
     // edge noise "uniform" / "match-uniform" (:349-383): every obstacle node's parents are drawn per particle
     // (on the device, factored_prior_sample); the node owns room for every state feature as a parent
-    const bool noisy = c->cfg.structure_prior == FBA_SP_UNIFORM || c->cfg.structure_prior == FBA_SP_MATCH_UNIFORM;
+    // (the reinvigoration belief breeds particles with structures of their own: same layout)
+    const bool noisy = c->cfg.structure_prior == FBA_SP_UNIFORM || c->cfg.structure_prior == FBA_SP_MATCH_UNIFORM ||
+                       (c->cfg.belief == FBA_BELIEF_REINVIGORATION && !full);
     if (FS > MAXF || A * (FS + n) > MAXNODES) return fail(c, FBA_EINVAL, "too many state features");
     FDesc& d = c->fdesc;
     std::memset(&d, 0, sizeof d);
@@ -899,9 +901,11 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     if (cfg->belief == FBA_BELIEF_REINVIGORATION) {
         // two rejection filters + breeding (ReinvigoratingRejectionSampling.hpp); the reference has fully
         // connected priors for factored tiger, collision avoidance and sysadmin
-        // (GridWorldFactBAPrior::sampleFullyConnectedState throws "nyi"); built here: factored tiger
-        if (cfg->model != FBA_MODEL_BA_FACTORED || (cfg->domain != FBA_DOM_FTIGER_EPISODIC && cfg->domain != FBA_DOM_FTIGER_CONTINUOUS)) {
-            fail(nullptr, FBA_EINVAL, "reinvigoration belief: built for the factored-tiger FBA-POMDP only");
+        // (GridWorldFactBAPrior::sampleFullyConnectedState throws "nyi"); built here: the first two
+        const bool ftiger = cfg->domain == FBA_DOM_FTIGER_EPISODIC || cfg->domain == FBA_DOM_FTIGER_CONTINUOUS;
+        if (cfg->model != FBA_MODEL_BA_FACTORED || !(ftiger || is_ca(cfg->domain)) ||
+            (is_ca(cfg->domain) && cfg->structure_prior == FBA_SP_FULLY_CONNECTED)) {
+            fail(nullptr, FBA_EINVAL, "reinvigoration belief: built for the factored-tiger and collision-avoidance FBA-POMDPs");
             delete c;
             return FBA_EINVAL;
         }

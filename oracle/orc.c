@@ -1256,7 +1256,8 @@ static int build_ca_factored_prior(orc_ctx* c)
     int A = c->A, W = c->ca_W, H = c->ca_H, n = c->ca_n, FS = 2 + n, a, f, off = 0, y, k;
     int full = c->cfg.structure_prior == ORC_SP_FULLY_CONNECTED;
     /* edge noise "uniform" / "match-uniform" (:349-383): every obstacle node's parents are drawn per particle */
-    int noisy = c->cfg.structure_prior == ORC_SP_UNIFORM || c->cfg.structure_prior == ORC_SP_MATCH_UNIFORM;
+    int noisy = c->cfg.structure_prior == ORC_SP_UNIFORM || c->cfg.structure_prior == ORC_SP_MATCH_UNIFORM ||
+                (c->cfg.belief == ORC_BELIEF_REINVIGORATION && !full); /* bred particles carry their own structures */
     if (c->cfg.noise > .5 || c->cfg.noise < -.5) {
         snprintf(c->err, sizeof c->err, "CollisionAvoidanceFactoredPrior must be intiiated with -.5 < noise < .5 (is: %f)", c->cfg.noise);
         return -1;
@@ -1804,7 +1805,13 @@ static void belief_initiate(orc_ctx* c)
             c->F[i].s = domain_start(c);
             c->F[i].w = 0;
             memcpy(c->F[i].cnt, c->prior, sizeof(float) * (size_t)c->ncnt);
-            ftiger_set_observation_model(c, c->F[i].cnt, (1u << c->fd.FS) - 1u);
+            if (is_ca(c->cfg.domain)) { /* CollisionAvoidanceFactoredPrior::sampleFullyConnectedState :429-440 */
+                int a, f;
+                for (a = 0; a < c->A; ++a)
+                    for (f = 2; f < c->fd.FS; ++f) ca_fill_obstacle_node(c, c->F[i].cnt, a, f, (1u << c->fd.FS) - 1u);
+            } else {
+                ftiger_set_observation_model(c, c->F[i].cnt, (1u << c->fd.FS) - 1u);
+            }
         }
     }
 }
@@ -1955,14 +1962,20 @@ static void reinvigorate(orc_ctx* c)
     int i, k, n = c->cfg.particles;
     const fdesc* d = &c->fd;
     for (i = 0; i < c->cfg.resample_amount; ++i) {
-        uint32_t masks[ORC_MAXF];
+        uint32_t masks[32];
         int32_t fc, b, edge, victim;
         orc_rng_stream(&c->rng, ORC_PH_REINVIG, (uint32_t)i);
         fc = orc_int(&c->rng, n);
         b  = orc_int(&c->rng, n);
         for (k = 0; k < d->nvar; ++k) masks[k] = f2u(c->P[b].cnt[d->ncounts + k]);
-        edge = orc_slow_int(&c->rng, 0, d->FS);
-        masks[0] ^= 1u << edge;
+        if (is_ca(c->cfg.domain)) { /* CollisionAvoidanceFactoredPrior::mutate :455-488: action, obstacle, then the edge */
+            int ma = orc_int(&c->rng, c->A), mo = orc_int(&c->rng, c->ca_n);
+            edge = orc_slow_int(&c->rng, 0, d->FS);
+            masks[ma * c->ca_n + mo] ^= 1u << edge;
+        } else {
+            edge = orc_slow_int(&c->rng, 0, d->FS);
+            masks[0] ^= 1u << edge;
+        }
         breed_counts(c, c->F[fc].cnt, masks, c->breed_tmp);
         victim = orc_int(&c->rng, n);
         c->P[victim].s = c->P[b].s; /* copyDomainState(structure_state->_domain_state) */
@@ -2274,10 +2287,11 @@ orc_ctx* orc_create(const orc_config* cfg)
         }
     }
     if (cfg->belief == ORC_BELIEF_REINVIGORATION) {
-        if (cfg->model != ORC_MODEL_BA_FACTORED || !is_ftiger(cfg->domain)) {
+        if (cfg->model != ORC_MODEL_BA_FACTORED || !(is_ftiger(cfg->domain) || is_ca(cfg->domain)) ||
+            (is_ca(cfg->domain) && cfg->structure_prior == ORC_SP_FULLY_CONNECTED)) {
             /* the reference has fully connected priors for factored tiger, collision avoidance and
              * sysadmin; GridWorldFactBAPrior::sampleFullyConnectedState throws "nyi" */
-            snprintf(c->err, sizeof c->err, "reinvigoration belief: built for the factored-tiger FBA-POMDP only");
+            snprintf(c->err, sizeof c->err, "reinvigoration belief: built for the factored-tiger and collision-avoidance FBA-POMDPs");
             return c;
         }
         if (cfg->resample_amount < 1) { /* ReinvigoratingRejectionSampling.cpp:43-49 */

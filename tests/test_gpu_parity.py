@@ -133,6 +133,21 @@ def test_fbapomdp_reinvigoration_belief(sp, size, amount, domain):
     _assert_same_experiment(eng, o, ba=True)
 
 
+@pytest.mark.parametrize("sp,W,H,n,amount", [(0, 4, 3, 1, 5), (2, 5, 3, 2, 9), (1, 4, 3, 2, 3)])
+def test_fbapomdp_reinvigoration_belief_collision_avoidance(sp, W, H, n, amount):
+    """-B reinvigoration on collision avoidance: CollisionAvoidanceFactoredPrior::mutate picks an action and
+    an obstacle and flips one of that node's edges; the fully connected filter has every state feature as
+    a parent of every obstacle node."""
+    eng, o = _pair("random-collision-avoidance", N.MODEL_BA_FACTORED, "reinvigoration", 231 + sp, size=n, width=W, height=H,
+                   particles=60, sims=64, runs=5, episodes=3, structure_prior=sp, resample_amount=amount, slots=3)
+    _assert_same_experiment(eng, o, ba=True)
+    s, _, cnt = eng.belief_get(0)
+    fs, fcnt = eng.belief_get_fully_connected(0)
+    nvar = 3 * n
+    assert np.all(fcnt.view(np.uint32)[:, -nvar:] == (1 << (2 + n)) - 1)
+    assert len({tuple(m) for m in cnt.view(np.uint32)[:, -nvar:].tolist()}) > 1
+
+
 def test_reinvigoration_belief_both_filters_equal_oracle_step_by_step():
     kw = dict(size=3, particles=96, sims=32, structure_prior=2, resample_amount=12)
     eng = fba.Engine("episodic-factored-tiger", model=N.MODEL_BA_FACTORED, belief="reinvigoration", seed=19, slots=1, **kw)
@@ -170,7 +185,7 @@ def test_reinvigoration_belief_both_filters_equal_oracle_step_by_step():
 
 
 def test_reinvigoration_belief_argument_checks():
-    with pytest.raises(ValueError, match="factored-tiger"):
+    with pytest.raises(ValueError, match="factored-tiger and collision-avoidance"):
         fba.Engine("episodic-tiger", model=N.MODEL_BA_TABLE, belief="reinvigoration", resample_amount=4, particles=8, sims=4)
     with pytest.raises(ValueError, match="resample size of < 1"):
         fba.Engine("episodic-factored-tiger", model=N.MODEL_BA_FACTORED, belief="reinvigoration", size=2, particles=8, sims=4)
