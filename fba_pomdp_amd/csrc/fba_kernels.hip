@@ -132,13 +132,26 @@ __device__ __forceinline__ int ucb_select(const Problem& P, const DeviceState& D
 {
     int cn[AMAX];
     double cq[AMAX];
-    const double* q = reinterpret_cast<const double*>(rec + D.cq_off);
+    int visits;
+    if (AMAX >= 3 && P.A == 3) {  // header {visits, n0, n1, n2} and the three Q values: one 16-byte, one 16-byte, one 8-byte load
+        const int4 h = *reinterpret_cast<const int4*>(rec);
+        const double2 q01 = *reinterpret_cast<const double2*>(rec + 4);
+        const double q2   = *reinterpret_cast<const double*>(rec + 8);
+        visits = h.x;
 #pragma unroll
-    for (int a = 0; a < AMAX; ++a) {
-        cn[a] = a < P.A ? rec[1 + a] : 0;
-        cq[a] = a < P.A ? q[a] : 0.0;
+        for (int a = 0; a < AMAX; ++a) { cn[a] = 0; cq[a] = 0.0; }
+        cn[0] = h.y; cn[1] = h.z; cn[2] = h.w;
+        cq[0] = q01.x; cq[1] = q01.y; cq[2] = q2;
+    } else {
+        const double* q = reinterpret_cast<const double*>(rec + D.cq_off);
+        visits = rec[0];
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a) {
+            cn[a] = a < P.A ? rec[1 + a] : 0;
+            cq[a] = a < P.A ? q[a] : 0.0;
+        }
     }
-    return ucb_pick<AMAX>(P, g, explore ? D.log1p_tab[rec[0]] : 0.0, cn, cq, explore);
+    return ucb_pick<AMAX>(P, g, explore ? D.log1p_tab[visits] : 0.0, cn, cq, explore);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -326,10 +339,19 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
                     root_L = D.log1p_tab[r_vis];
                 } else {
                     int32_t* rec = tree + (size_t)(na >> 4) * W;
-                    const int n  = ++rec[1 + act];
                     double* q    = reinterpret_cast<double*>(rec + D.cq_off) + act;
+                    int n;
+                    if (P.A == 3) {  // {visits, n0, n1, n2} is one 16-byte word: one load, one store
+                        int4* hp = reinterpret_cast<int4*>(rec);
+                        int4 h   = *hp;
+                        n = act == 0 ? ++h.y : (act == 1 ? ++h.z : ++h.w);
+                        ++h.x;
+                        *hp = h;
+                    } else {
+                        n = ++rec[1 + act];
+                        ++rec[0];
+                    }
                     *q += (ret - *q) / (double)n;
-                    ++rec[0];
                 }
                 del = ret;
             }
