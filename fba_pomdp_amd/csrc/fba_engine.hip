@@ -296,6 +296,50 @@ int build_tabular_prior(fba_ctx* c)
             }
         return FBA_OK;
     }
+    if (is_ca(P.domain)) {
+        // CollisionAvoidanceTablePrior (CollisionAvoidancePriors.cpp:65-208).  For state (x, y, b) and every
+        // obstacle configuration b': transition count to (x-1, y', b') = prod_i obstacleTransProb(b_i, b'_i) * -C
+        // (none from x = 0; the product stops at its first zero), observation count of b' in that state =
+        // prod_i observationDistr(H, b_i)[b'_i] * 10000.
+        const CADesc& ca = c->cadesc;
+        const int W = ca.W, H = ca.H, n = ca.n, Hn = ca.Hn;
+        if (!(noise < .5 && noise > -.5)) return fail(c, FBA_EINVAL, "CollisionAvoidanceTablePrior needs -.5 < noise < .5 (is: %f)", noise);
+        c->prior.assign((size_t)P.C, 0.f);
+        float* phi = c->prior.data();
+        float* psi = c->prior.data() + P.phi_len;
+        auto trans = [&](int y, int ny) -> double {  // obstacleTransProb :136-170
+            const int dist = std::abs(y - ny);
+            if (dist > 1) return 0;
+            if (y == 0 || y == H - 1) return dist == 0 ? .75 + .5 * noise : .25 - .5 * noise;
+            return dist == 0 ? .5 + noise : .25 - .5 * noise;
+        };
+        auto seen = [&](int pos, int oy) -> float {  // observationDistr(height, obstacle_pos) :46-63
+            if (oy == 0) return (float)normal_cdf(-pos + .5);
+            if (oy == H - 1) return (float)normal_cdf(-(H - 1 - pos) + .5);
+            const int dist = std::abs(oy - pos);
+            return (float)(normal_cdf(dist + .5) - normal_cdf(dist - .5));
+        };
+        for (int ob = 0; ob < Hn; ++ob)
+            for (int nob = 0; nob < Hn; ++nob) {
+                int b[MAXF], nb[MAXF], r1 = ob, r2 = nob;
+                for (int i = n - 1; i >= 0; --i) { b[i] = r1 % H; r1 /= H; nb[i] = r2 % H; r2 /= H; }
+                double tprob = 1, oprob = 1;
+                for (int i = 0; i < n && tprob != 0; ++i) tprob *= trans(b[i], nb[i]);
+                for (int i = 0; i < n; ++i) oprob *= seen(b[i], nb[i]);
+                for (int x = 0; x < W; ++x)
+                    for (int y = 0; y < H; ++y) {
+                        const int s = (x * H + y) * Hn + ob;
+                        for (int a = 0; a < A; ++a) {
+                            psi[((size_t)a * S + s) * O + nob] = (float)(oprob * 10000);
+                            if (x == 0 || tprob == 0) continue;
+                            int ny = y + a - 1;
+                            if (ny == -1 || ny == H) ny = y;
+                            phi[((size_t)s * A + a) * S + ((x - 1) * H + ny) * Hn + nob] = (float)(tprob * total);
+                        }
+                    }
+            }
+        return FBA_OK;
+    }
     if (P.domain == FBA_DOM_GRIDWORLD) {
         // GridWorldFlatBAPrior (GridWorldBAPriors.cpp:21-156).  Transition counts accumulate (a move
         // into a wall and a failed move are the same cell; on a goal the next goal is uniform);
@@ -1020,11 +1064,6 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     }
     if (P.A > FBA_MAX_ACTIONS) {
         fail(nullptr, FBA_EINVAL, "more than %d actions", FBA_MAX_ACTIONS);
-        delete c;
-        return FBA_EINVAL;
-    }
-    if (cfg->model == FBA_MODEL_BA_TABLE && is_ca(cfg->domain)) {
-        fail(nullptr, FBA_EINVAL, "the tabular prior of this domain (S*A*S counts per particle) is not built; use the factored model");
         delete c;
         return FBA_EINVAL;
     }

@@ -868,6 +868,61 @@ static int build_gridworld_flat_prior(orc_ctx* c)
     return 0;
 }
 
+/* CollisionAvoidanceTablePrior (CollisionAvoidancePriors.cpp:65-208): tabular counts.  For every
+ * state s = (x, y, obstacles) and every obstacle configuration b': the transition count to
+ * (x-1, y', b') is prod_i obstacleTransProb(b_i, b'_i) * -C (nothing from x = 0), and the
+ * observation count of b' "in" s is prod_i observationDistr(H, b_i)[b'_i] * 10000. */
+static double ca_obstacle_trans_prob(const orc_ctx* c, int y, int ny) /* :136-170 */
+{
+    int dist = abs(y - ny);
+    if (dist > 1) return 0;
+    if (y == 0 || y == c->ca_H - 1) return dist == 0 ? .75 + .5 * c->cfg.noise : .25 - .5 * c->cfg.noise;
+    return dist == 0 ? .5 + c->cfg.noise : .25 - .5 * c->cfg.noise;
+}
+static float ca_observation_distr(const orc_ctx* c, int pos, int oy) /* observationDistr(height, obstacle_pos) :46-63 */
+{
+    int H = c->ca_H;
+    if (oy == 0) return (float)normal_cdf(-pos + .5);
+    if (oy == H - 1) return (float)normal_cdf(-(H - 1 - pos) + .5);
+    { int dist = abs(oy - pos); return (float)(normal_cdf(dist + .5) - normal_cdf(dist - .5)); }
+}
+static int build_ca_flat_prior(orc_ctx* c)
+{
+    int S = c->S, A = c->A, O = c->O, W = c->ca_W, H = c->ca_H, n = c->ca_n, Hn = c->ca_Hn;
+    int ob, nob, x, y, a, i;
+    float* phi = c->prior;
+    float* psi = c->prior + c->phi_len;
+    if (!(c->cfg.noise < .5 && c->cfg.noise > -.5)) { /* assert(c.noise < .5 && c.noise > -.5) :80 */
+        snprintf(c->err, sizeof c->err, "CollisionAvoidanceTablePrior needs -.5 < noise < .5 (is: %f)", c->cfg.noise);
+        return -1;
+    }
+    memset(c->prior, 0, sizeof(float) * (size_t)c->ncnt);
+    for (ob = 0; ob < Hn; ++ob)
+        for (nob = 0; nob < Hn; ++nob) {
+            int b[8], nb[8], r1 = ob, r2 = nob;
+            double tprob = 1, oprob = 1;
+            for (i = n - 1; i >= 0; --i) { b[i] = r1 % H; r1 /= H; nb[i] = r2 % H; r2 /= H; }
+            for (i = 0; i < n; ++i) { /* stops at the first zero factor (:191-199) */
+                tprob *= ca_obstacle_trans_prob(c, b[i], nb[i]);
+                if (tprob == 0) break;
+            }
+            for (i = 0; i < n; ++i) oprob *= ca_observation_distr(c, b[i], nb[i]);
+            for (x = 0; x < W; ++x)
+                for (y = 0; y < H; ++y) {
+                    int s = (x * H + y) * Hn + ob;
+                    for (a = 0; a < A; ++a) {
+                        psi[(size_t)a * S * O + (size_t)s * O + nob] = (float)(oprob * 10000);
+                        if (x > 0 && tprob != 0) {
+                            int ny = y + a - 1;
+                            if (ny == -1 || ny == H) ny = y;
+                            phi[(size_t)s * A * S + (size_t)a * S + ((x - 1) * H + ny) * Hn + nob] = (float)(tprob * c->cfg.counts_total);
+                        }
+                    }
+                }
+        }
+    return 0;
+}
+
 static int build_tabular_prior(orc_ctx* c)
 {
     int S = c->S, A = c->A, O = c->O, i, s, ns;
@@ -883,6 +938,7 @@ static int build_tabular_prior(orc_ctx* c)
     psi        = c->prior + c->phi_len;
     if (is_sys(c->cfg.domain)) return build_sysadmin_flat_prior(c); /* ignores --noise / -C */
     if (is_grid(c->cfg.domain)) return build_gridworld_flat_prior(c);
+    if (is_ca(c->cfg.domain)) return build_ca_flat_prior(c);
     if (noise <= -.15 || noise > .3) {
         snprintf(c->err, sizeof c->err, "noise has to be between -.15 and .3");
         return -1;

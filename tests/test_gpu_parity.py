@@ -351,6 +351,16 @@ def test_fbapomdp_collision_avoidance(sp, W, H, n):
     _assert_same_experiment(eng, o, ba=True)
 
 
+@pytest.mark.parametrize("domain,W,H,n,belief", [("random-collision-avoidance", 4, 3, 1, "rejection_sampling"),
+                                                 ("centered-collision-avoidance", 3, 3, 2, "importance_sampling")])
+def test_bapomdp_collision_avoidance_table_prior(domain, W, H, n, belief):
+    """bapomdp -D *-collision-avoidance: CollisionAvoidanceTablePrior (S*A*S + A*S*O counts per particle)."""
+    eng, o = _pair(domain, N.MODEL_BA_TABLE, belief, 251 + n, size=n, width=W, height=H, particles=40, sims=64, runs=5,
+                   episodes=3, slots=3, noise=0.1, counts_total=500.0)
+    assert np.array_equal(eng.prior().view(np.uint32), o.prior_counts().view(np.uint32))
+    _assert_same_experiment(eng, o, ba=True)
+
+
 def test_collision_avoidance_edge_noise_prior_particles_equal_oracle():
     """CollisionAvoidanceFactoredPrior::sampleFBAPOMDPState / sampleBlockTModel on the device."""
     for sp in (1, 2):
