@@ -806,6 +806,29 @@ __device__ __forceinline__ void ca_fill_obstacle_node(const Problem& P, float* r
     rec[fd->ncounts + nd.var] = __uint_as_float(mask);
 }
 
+// SysAdminFactoredPrior::fullyConnectedT (SysAdminFactoredPrior.cpp:249-277): every transition node with
+// all N computers as parents, counts {p, 1 - p} (a total of ONE per row), p = SysAdmin::failProbability
+// of the state the parent values spell (SysAdmin.cpp:84-100, a float)
+__device__ __forceinline__ void sys_fill_fully_connected(const Problem& P, float* rec)
+{
+    const FDesc* fd = P.fd;
+    const int N = P.sys->N;
+    for (int a = 0; a < P.A; ++a)
+        for (int f = 0; f < N; ++f) {
+            const FNode& nd = fd->nodes[a * N + f];
+            for (int r = 0; r < (1 << N); ++r) {
+                int st = 0;  // SysAdmin::getState(parent values): bit k = value of feature k
+                for (int k = 0; k < N; ++k) st |= ((r >> (N - 1 - k)) & 1) << k;
+                double fail = ((st >> f) & 1) ? 1 - P.sys->keep[sys_failing_neighbours(P, f, st)] : 1;
+                if (a == N + f) fail *= (1 - .95f);
+                const float p = (float)fail;
+                rec[nd.off + 2 * r + 0] = p;
+                rec[nd.off + 2 * r + 1] = 1 - p;
+            }
+            rec[fd->ncounts + nd.var] = __uint_as_float((1u << N) - 1u);
+        }
+}
+
 __device__ __forceinline__ void factored_prior_sample(const Problem& P, Rng& g, float* rec)
 {
     if (dom_is_sys(P.domain)) return;  // fixed structures only

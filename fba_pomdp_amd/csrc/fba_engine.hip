@@ -590,6 +590,7 @@ int build_sysadmin_factored_prior(fba_ctx* c)
     Problem& P = c->P;
     const int A = P.A, N = c->sysdesc.N;
     const bool linear = P.domain == FBA_DOM_SYSADMIN_LINEAR;
+    const bool reinvig = c->cfg.belief == FBA_BELIEF_REINVIGORATION;
     if (c->cfg.structure_prior != FBA_SP_NONE) return fail(c, FBA_EINVAL, "Structure noise is not enabled for the Sysadmin problem");
     if (N > MAXF || A * (N + 1) > MAXNODES) return fail(c, FBA_EINVAL, "too many state features");
     FDesc& d = c->fdesc;
@@ -604,6 +605,15 @@ int build_sysadmin_factored_prior(fba_ctx* c)
         for (int f = 0; f < N; ++f) {
             FNode& nd = d.nodes[a * N + f];
             nd.off = off; nd.out = 2; nd.var = -1; nd.nmax = 0;
+            if (reinvig) {  // bred particles choose any parent set: room for all N, the prior's set as the base mask
+                uint32_t m = 1u << f;
+                if (linear && f > 0) m |= 1u << (f - 1);
+                if (linear && f < N - 1) m |= 1u << (f + 1);
+                for (int k = 0; k < N; ++k) nd.maxp[k] = (uint8_t)k;
+                nd.nmax = N; nd.var = a * N + f; nd.fixed_mask = m;
+                off += 2 << N;
+                continue;
+            }
             if (linear && f > 0) nd.maxp[nd.nmax++] = (uint8_t)(f - 1);
             nd.maxp[nd.nmax++] = (uint8_t)f;
             if (linear && f < N - 1) nd.maxp[nd.nmax++] = (uint8_t)(f + 1);
@@ -616,19 +626,23 @@ int build_sysadmin_factored_prior(fba_ctx* c)
         off += 4;
     }
     d.ncounts = off;
-    d.nvar    = 0;
-    c->prior.assign((size_t)off, 0.f);
+    d.nvar    = reinvig ? A * N : 0;
+    c->prior.assign((size_t)off + d.nvar, 0.f);
     float* pr = c->prior.data();
     for (int a = 0; a < A; ++a)
         for (int f = 0; f < N; ++f) {
             const FNode& nd = d.nodes[a * N + f];
             const bool rebooting = a == N + f;
-            for (int r = 0; r < (1 << nd.nmax); ++r) {  // row r: parent values, last parent the fastest digit
+            int parents[MAXF], np = 0;
+            for (int k = 0; k < nd.nmax; ++k)
+                if ((nd.fixed_mask >> k) & 1u) parents[np++] = nd.maxp[k];
+            if (reinvig) std::memcpy(&pr[off + nd.var], &nd.fixed_mask, 4);
+            for (int r = 0; r < (1 << np); ++r) {  // row r: parent values, last parent the fastest digit
                 int failing = 0;
                 bool own_up = true;
-                for (int k = 0; k < nd.nmax; ++k) {
-                    const int v = (r >> (nd.nmax - 1 - k)) & 1;
-                    if (nd.maxp[k] == f) own_up = v != 0;
+                for (int k = 0; k < np; ++k) {
+                    const int v = (r >> (np - 1 - k)) & 1;
+                    if (parents[k] == f) own_up = v != 0;
                     else if (!v) failing++;              // parents other than f are its linear neighbours
                 }
                 float p;
@@ -945,11 +959,11 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     if (cfg->belief == FBA_BELIEF_REINVIGORATION) {
         // two rejection filters + breeding (ReinvigoratingRejectionSampling.hpp); the reference has fully
         // connected priors for factored tiger, collision avoidance and sysadmin
-        // (GridWorldFactBAPrior::sampleFullyConnectedState throws "nyi"); built here: the first two
+        // (GridWorldFactBAPrior::sampleFullyConnectedState throws "nyi"): all three are built
         const bool ftiger = cfg->domain == FBA_DOM_FTIGER_EPISODIC || cfg->domain == FBA_DOM_FTIGER_CONTINUOUS;
-        if (cfg->model != FBA_MODEL_BA_FACTORED || !(ftiger || is_ca(cfg->domain)) ||
+        if (cfg->model != FBA_MODEL_BA_FACTORED || !(ftiger || is_ca(cfg->domain) || is_sys(cfg->domain)) ||
             (is_ca(cfg->domain) && cfg->structure_prior == FBA_SP_FULLY_CONNECTED)) {
-            fail(nullptr, FBA_EINVAL, "reinvigoration belief: built for the factored-tiger and collision-avoidance FBA-POMDPs");
+            fail(nullptr, FBA_EINVAL, "reinvigoration belief: needs a factored model (fbapomdp) of factored tiger, collision avoidance or sysadmin");
             delete c;
             return FBA_EINVAL;
         }

@@ -625,7 +625,7 @@ __global__ void __launch_bounds__(REJECT_BLOCK) reject_kernel(Problem P, DeviceS
 __global__ void __launch_bounds__(256) reinvigorate_kernel(Problem P, DeviceState D)
 {
     __shared__ int32_t s_fc, s_victim, s_state;
-    __shared__ uint32_t s_mask[32];  // one parent mask per variable node (collision avoidance: A * obstacles <= 18)
+    __shared__ uint32_t s_mask[128];  // one parent mask per variable node (collision avoidance: A * obstacles <= 18; sysadmin: 2N * N <= 128)
     const int e = blockIdx.x, tid = threadIdx.x;
     if (!D.need_update[e]) return;
     const FDesc* fd = P.fd;
@@ -639,7 +639,12 @@ __global__ void __launch_bounds__(256) reinvigorate_kernel(Problem P, DeviceStat
             s_fc = g.uniform_int(P.N);
             const volatile float* srec = recs + (size_t)g.uniform_int(P.N) * P.Cs;  // may have been written an iteration ago
             for (int k = 0; k < fd->nvar; ++k) s_mask[k] = __float_as_uint(srec[fd->ncounts + k]);
-            if (dom_is_ca(P.domain)) {  // CollisionAvoidanceFactoredPrior::mutate :455-488: action, obstacle, then the edge
+            if (dom_is_sys(P.domain)) {
+                // SysAdminFactoredPrior::mutate (:47-55): flip_random_edge(&T[action()][computer()], N); under the
+                // reference's --std=c++11 g++ evaluates the second subscript first: computer, action, then the edge
+                const int mc = g.uniform_int(P.sys->N), ma = g.uniform_int(P.A);
+                s_mask[ma * P.sys->N + mc] ^= 1u << g.slow_int(0, fd->FS);
+            } else if (dom_is_ca(P.domain)) {  // CollisionAvoidanceFactoredPrior::mutate :455-488: action, obstacle, then the edge
                 const int ma = g.uniform_int(P.A), mo = g.uniform_int(P.ca->n);
                 s_mask[ma * P.ca->n + mo] ^= 1u << g.slow_int(0, fd->FS);
             } else {                    // FactoredTigerFactoredPrior::mutate: the listen observation node
@@ -1083,8 +1088,10 @@ __global__ void __launch_bounds__(256) init_kernel(Problem P, DeviceState D, int
     for (int i = i_lo + tid; i < i_hi; i += 256) {
         g.stream(fc ? FBA_PHASE_INIT_FC : FBA_PHASE_INIT, (uint32_t)i);
         rec_set_state(recs + (size_t)i * P.Cs, P.C, domain_start(P, g));
-        if (fc) {  // sampleFullyConnectedState: FactoredTigerPriors.cpp:324-337, CollisionAvoidancePriors.cpp:429-440
-            if (dom_is_ca(P.domain)) {
+        if (fc) {  // sampleFullyConnectedState: FactoredTigerPriors.cpp:324-337, CollisionAvoidancePriors.cpp:429-440, SysAdminFactoredPrior.cpp:57-69
+            if (dom_is_sys(P.domain)) {
+                sys_fill_fully_connected(P, recs + (size_t)i * P.Cs);
+            } else if (dom_is_ca(P.domain)) {
                 for (int a = 0; a < P.A; ++a)
                     for (int f = 2; f < P.fd->FS; ++f) ca_fill_obstacle_node(P, recs + (size_t)i * P.Cs, a, f, (1u << P.fd->FS) - 1u);
             } else {

@@ -1411,11 +1411,37 @@ static float sys_failure_probability(const orc_ctx* c, int a, int comp, const in
     }
     return (float)fail_prob;
 }
+
+/* SysAdminFactoredPrior::fullyConnectedT (SysAdminFactoredPrior.cpp:249-277): every transition node
+ * with all N computers as parents, counts {p, 1 - p} (a total of ONE per row) with
+ * p = SysAdmin::failProbability(state of the parent values, a, c) (SysAdmin.cpp:84-100, float) */
+static void sys_fill_fully_connected(orc_ctx* c, float* cnt)
+{
+    const fdesc* d = &c->fd;
+    int A = c->A, N = c->sys_N, a, f, r, k;
+    for (a = 0; a < A; ++a)
+        for (f = 0; f < N; ++f) {
+            const fnode* nd = &d->T[a * N + f];
+            for (r = 0; r < (1 << N); ++r) {
+                int32_t st = 0; /* SysAdmin::getState(parent values): bit k = value of feature k */
+                double fail;
+                float p;
+                for (k = 0; k < N; ++k) st |= ((r >> (N - 1 - k)) & 1) << k;
+                fail = ((st >> f) & 1) ? 1 - c->sys_keep[sys_failing_neighbours(c, f, st)] : 1;
+                if (a == N + f) fail *= (1 - SYS_REBOOT_RATE);
+                p = (float)fail;
+                cnt[nd->off + 2 * r + 0] = p;
+                cnt[nd->off + 2 * r + 1] = 1 - p;
+            }
+            cnt[d->ncounts + nd->var] = u2f((1u << N) - 1u);
+        }
+}
 static int build_sysadmin_factored_prior(orc_ctx* c)
 {
     fdesc* d = &c->fd;
     int A = c->A, N = c->sys_N, a, f, k, r, off = 0;
     int linear = c->cfg.domain == ORC_DOM_SYSADMIN_LINEAR;
+    int reinvig = c->cfg.belief == ORC_BELIEF_REINVIGORATION;
     if (c->cfg.structure_prior != ORC_SP_NONE) {
         snprintf(c->err, sizeof c->err, "Structure noise is not enabled for the Sysadmin problem");
         return -1;
@@ -1433,6 +1459,15 @@ static int build_sysadmin_factored_prior(orc_ctx* c)
         for (f = 0; f < N; ++f) {
             fnode* nd = &d->T[a * N + f];
             nd->off = off; nd->out = 2; nd->var = -1; nd->nmax = 0;
+            if (reinvig) { /* bred particles choose any parent set: room for all N, the prior's set as a mask */
+                uint32_t m = 1u << f;
+                if (linear && f > 0) m |= 1u << (f - 1);
+                if (linear && f < N - 1) m |= 1u << (f + 1);
+                for (k = 0; k < N; ++k) nd->maxp[k] = k;
+                nd->nmax = N; nd->var = a * N + f; nd->fixed_mask = m;
+                off += 2 << N;
+                continue;
+            }
             if (linear && f > 0) nd->maxp[nd->nmax++] = f - 1;
             nd->maxp[nd->nmax++] = f;
             if (linear && f < N - 1) nd->maxp[nd->nmax++] = f + 1;
@@ -1445,18 +1480,20 @@ static int build_sysadmin_factored_prior(orc_ctx* c)
         off += 4;
     }
     d->ncounts = off;
-    d->nvar    = 0;
-    c->ncnt    = off;
+    d->nvar    = reinvig ? A * N : 0;
+    c->ncnt    = off + d->nvar;
     c->prior   = (float*)calloc((size_t)c->ncnt, sizeof(float));
     for (a = 0; a < A; ++a)
         for (f = 0; f < N; ++f) { /* disconnectedTransitions :186-216 / linearTransitions :218-257 */
             const fnode* nd = &d->T[a * N + f];
-            int parents[3], pv[3];
-            for (k = 0; k < nd->nmax; ++k) parents[k] = nd->maxp[k];
-            for (r = 0; r < (1 << nd->nmax); ++r) {
+            int parents[3], pv[3], np = 0;
+            for (k = 0; k < nd->nmax; ++k)
+                if ((nd->fixed_mask >> k) & 1u) parents[np++] = nd->maxp[k];
+            if (reinvig) c->prior[d->ncounts + nd->var] = u2f(nd->fixed_mask);
+            for (r = 0; r < (1 << np); ++r) {
                 float p;
-                for (k = 0; k < nd->nmax; ++k) pv[k] = (r >> (nd->nmax - 1 - k)) & 1; /* last parent fastest */
-                p = sys_failure_probability(c, a, f, parents, pv, nd->nmax);
+                for (k = 0; k < np; ++k) pv[k] = (r >> (np - 1 - k)) & 1; /* last parent fastest */
+                p = sys_failure_probability(c, a, f, parents, pv, np);
                 c->prior[nd->off + 2 * r + 0] = p * 10000.0f;
                 c->prior[nd->off + 2 * r + 1] = (1 - p) * 10000.0f;
             }
@@ -1861,7 +1898,9 @@ static void belief_initiate(orc_ctx* c)
             c->F[i].s = domain_start(c);
             c->F[i].w = 0;
             memcpy(c->F[i].cnt, c->prior, sizeof(float) * (size_t)c->ncnt);
-            if (is_ca(c->cfg.domain)) { /* CollisionAvoidanceFactoredPrior::sampleFullyConnectedState :429-440 */
+            if (is_sys(c->cfg.domain)) { /* SysAdminFactoredPrior::sampleFullyConnectedState :57-69 */
+                sys_fill_fully_connected(c, c->F[i].cnt);
+            } else if (is_ca(c->cfg.domain)) { /* CollisionAvoidanceFactoredPrior::sampleFullyConnectedState :429-440 */
                 int a, f;
                 for (a = 0; a < c->A; ++a)
                     for (f = 2; f < c->fd.FS; ++f) ca_fill_obstacle_node(c, c->F[i].cnt, a, f, (1u << c->fd.FS) - 1u);
@@ -2018,13 +2057,19 @@ static void reinvigorate(orc_ctx* c)
     int i, k, n = c->cfg.particles;
     const fdesc* d = &c->fd;
     for (i = 0; i < c->cfg.resample_amount; ++i) {
-        uint32_t masks[32];
+        uint32_t masks[128];
         int32_t fc, b, edge, victim;
         orc_rng_stream(&c->rng, ORC_PH_REINVIG, (uint32_t)i);
         fc = orc_int(&c->rng, n);
         b  = orc_int(&c->rng, n);
         for (k = 0; k < d->nvar; ++k) masks[k] = f2u(c->P[b].cnt[d->ncounts + k]);
-        if (is_ca(c->cfg.domain)) { /* CollisionAvoidanceFactoredPrior::mutate :455-488: action, obstacle, then the edge */
+        if (is_sys(c->cfg.domain)) {
+            /* SysAdminFactoredPrior::mutate (:47-55): flip_random_edge(&T[action()][computer()], N).  Under the
+             * reference's --std=c++11 g++ evaluates the second subscript first: computer, action, edge */
+            int mc = orc_int(&c->rng, c->sys_N), ma = orc_int(&c->rng, c->A);
+            edge = orc_slow_int(&c->rng, 0, d->FS);
+            masks[ma * c->sys_N + mc] ^= 1u << edge;
+        } else if (is_ca(c->cfg.domain)) { /* CollisionAvoidanceFactoredPrior::mutate :455-488: action, obstacle, then the edge */
             int ma = orc_int(&c->rng, c->A), mo = orc_int(&c->rng, c->ca_n);
             edge = orc_slow_int(&c->rng, 0, d->FS);
             masks[ma * c->ca_n + mo] ^= 1u << edge;
@@ -2343,11 +2388,11 @@ orc_ctx* orc_create(const orc_config* cfg)
         }
     }
     if (cfg->belief == ORC_BELIEF_REINVIGORATION) {
-        if (cfg->model != ORC_MODEL_BA_FACTORED || !(is_ftiger(cfg->domain) || is_ca(cfg->domain)) ||
+        if (cfg->model != ORC_MODEL_BA_FACTORED || !(is_ftiger(cfg->domain) || is_ca(cfg->domain) || is_sys(cfg->domain)) ||
             (is_ca(cfg->domain) && cfg->structure_prior == ORC_SP_FULLY_CONNECTED)) {
             /* the reference has fully connected priors for factored tiger, collision avoidance and
              * sysadmin; GridWorldFactBAPrior::sampleFullyConnectedState throws "nyi" */
-            snprintf(c->err, sizeof c->err, "reinvigoration belief: built for the factored-tiger and collision-avoidance FBA-POMDPs");
+            snprintf(c->err, sizeof c->err, "reinvigoration belief: needs a factored model (fbapomdp) of factored tiger, collision avoidance or sysadmin");
             return c;
         }
         if (cfg->resample_amount < 1) { /* ReinvigoratingRejectionSampling.cpp:43-49 */

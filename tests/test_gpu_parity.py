@@ -148,6 +148,21 @@ def test_fbapomdp_reinvigoration_belief_collision_avoidance(sp, W, H, n, amount)
     assert len({tuple(m) for m in cnt.view(np.uint32)[:, -nvar:].tolist()}) > 1
 
 
+@pytest.mark.parametrize("domain,size,amount", [("linear-sysadmin", 3, 6), ("independent-sysadmin", 4, 2), ("linear-sysadmin", 5, 20)])
+def test_fbapomdp_reinvigoration_belief_sysadmin(domain, size, amount):
+    """-B reinvigoration on sysadmin: every transition node may take any set of computers as parents
+    (SysAdminFactoredPrior::mutate flips an edge of T[action][computer]); the fully connected filter
+    starts from SysAdmin::failProbability with a total count of one per row."""
+    eng, o = _pair(domain, N.MODEL_BA_FACTORED, "reinvigoration", 271 + size, size=size, particles=50, sims=64, runs=5,
+                   episodes=3, horizon=6, resample_amount=amount, slots=3)
+    _assert_same_experiment(eng, o, ba=True)
+    fs, fcnt = eng.belief_get_fully_connected(0)
+    nvar = 2 * size * size
+    assert np.all(fcnt.view(np.uint32)[:, -nvar:] == (1 << size) - 1)
+    s, _, cnt = eng.belief_get(0)
+    assert len({tuple(m) for m in cnt.view(np.uint32)[:, -nvar:].tolist()}) > 1
+
+
 def test_reinvigoration_belief_both_filters_equal_oracle_step_by_step():
     kw = dict(size=3, particles=96, sims=32, structure_prior=2, resample_amount=12)
     eng = fba.Engine("episodic-factored-tiger", model=N.MODEL_BA_FACTORED, belief="reinvigoration", seed=19, slots=1, **kw)
@@ -185,7 +200,7 @@ def test_reinvigoration_belief_both_filters_equal_oracle_step_by_step():
 
 
 def test_reinvigoration_belief_argument_checks():
-    with pytest.raises(ValueError, match="factored-tiger and collision-avoidance"):
+    with pytest.raises(ValueError, match="needs a factored model"):
         fba.Engine("episodic-tiger", model=N.MODEL_BA_TABLE, belief="reinvigoration", resample_amount=4, particles=8, sims=4)
     with pytest.raises(ValueError, match="resample size of < 1"):
         fba.Engine("episodic-factored-tiger", model=N.MODEL_BA_FACTORED, belief="reinvigoration", size=2, particles=8, sims=4)
