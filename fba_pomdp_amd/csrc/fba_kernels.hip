@@ -162,7 +162,7 @@ __device__ __forceinline__ int ucb_select(const Problem& P, const DeviceState& D
 // into a state machine whose every iteration performs exactly one simulator.step, so the 64
 // trees of a wave execute the expensive part (Philox + Dirichlet-row sampling) in lock-step.
 // LDS per lane: the path needed for the bottom-up back-up, [depth][lane], and -- when a particle
-// record fits 32 words (STAGE) -- the root particle's whole count blob, [word][lane], fetched with
+// record fits SEARCH_STAGE_WORDS (STAGE) -- the root particle's whole count blob, [word][lane], fetched with
 // one burst of 16-byte loads per simulation so that no step waits on HBM for its Dirichlet rows.
 // ---------------------------------------------------------------------------------------------
 template <bool STAGE, int AMAX, bool REG, bool TIGER_TABLE, int MODEL>
