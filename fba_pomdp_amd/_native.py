@@ -30,7 +30,7 @@ KERNEL_NAMES = ["search_kernel", "env_kernel", "reject_kernel", "importance_kern
 DOM_TIGER_EPISODIC, DOM_TIGER_CONTINUOUS, DOM_FTIGER_EPISODIC, DOM_FTIGER_CONTINUOUS, DOM_GRIDWORLD, DOM_COLLISION_AVOID, DOM_COLLISION_AVOID_CENTERED = range(7)
 DOM_SYSADMIN_INDEPENDENT, DOM_SYSADMIN_LINEAR = 7, 8
 MODEL_POMDP, MODEL_BA_TABLE, MODEL_BA_FACTORED = range(3)
-BELIEF_REJECTION, BELIEF_IMPORTANCE, BELIEF_REINVIGORATION = range(3)
+BELIEF_REJECTION, BELIEF_IMPORTANCE, BELIEF_REINVIGORATION, BELIEF_CHEATING = range(4)
 PLANNER_POUCT, PLANNER_RANDOM = range(2)
 OK, EINVAL, EHIP, ENODEVICE, ESTATE = 0, -1, -2, -3, -4
 
@@ -42,7 +42,7 @@ DOMAIN_NAMES = {  # reference -D strings (DomainConf.cpp)
     "independent-sysadmin": DOM_SYSADMIN_INDEPENDENT, "linear-sysadmin": DOM_SYSADMIN_LINEAR,
 }
 BELIEF_NAMES = {"rejection_sampling": BELIEF_REJECTION, "importance_sampling": BELIEF_IMPORTANCE,
-                "reinvigoration": BELIEF_REINVIGORATION}
+                "reinvigoration": BELIEF_REINVIGORATION, "cheating-reinvigoration": BELIEF_CHEATING}
 PLANNER_NAMES = {"po-uct": PLANNER_POUCT, "random": PLANNER_RANDOM}
 
 
@@ -56,7 +56,7 @@ class Config(C.Structure):
         ("noise", C.c_float), ("counts_total", C.c_float), ("structure_prior", C.c_int32),
         ("seed", C.c_uint64), ("run_offset", C.c_int32), ("slots", C.c_int32),
         ("device", C.c_int32), ("trace", C.c_int32), ("dirichlet_regular", C.c_int32),
-        ("resample_amount", C.c_int32),
+        ("resample_amount", C.c_int32), ("threshold", C.c_double),
     ]
 
 

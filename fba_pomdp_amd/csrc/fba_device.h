@@ -195,6 +195,7 @@ struct Problem {
     int32_t structure_prior;
     int32_t domain, model, belief, planner;
     int32_t fd_bytes;   // bytes of *fd in use (header + A*(FS+FO) nodes): what a kernel stages in LDS
+    int32_t cheat;      // cheating belief: particles copied from the correct-graph filter per cheat (belief = IMPORTANCE then); 0 = off
     int32_t reinvig;    // reinvigoration belief: particles bred per update (belief = REJECTION then); 0 = off
     int32_t S, A, O;
     int32_t N;          // particles per slot

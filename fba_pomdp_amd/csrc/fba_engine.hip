@@ -956,6 +956,29 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     Problem& P = c->P;
     P.domain = cfg->domain; P.model = cfg->model; P.belief = cfg->belief; P.planner = cfg->planner;
     P.reinvig = 0;
+    P.cheat   = 0;
+    if (cfg->belief == FBA_BELIEF_CHEATING) {
+        // a weighted (importance) filter + a rejection filter of correct-graph particles it copies from when
+        // its log likelihood drops below --threshold (prototypes/CheatingReinvigoration.cpp)
+        if (cfg->model != FBA_MODEL_BA_FACTORED) {
+            fail(nullptr, FBA_EINVAL, "cheating-reinvigoration belief: needs a factored model (fbapomdp)");
+            delete c;
+            return FBA_EINVAL;
+        }
+        if (cfg->particles < 1 || cfg->resample_amount < 1) {  // CheatingReinvigoration.cpp:30-34
+            fail(nullptr, FBA_EINVAL, "CheatingReinvigoration::cannot initiate belief of size < 1 (%d), or resample size of < 1 (%d)",
+                 cfg->particles, cfg->resample_amount);
+            delete c;
+            return FBA_EINVAL;
+        }
+        if (cfg->threshold >= 0) {  // :36-40
+            fail(nullptr, FBA_EINVAL, "CheatingReinvigoration::cannot initiate with resample_threshold >= 0 (is:%f)", cfg->threshold);
+            delete c;
+            return FBA_EINVAL;
+        }
+        P.belief = FBA_BELIEF_IMPORTANCE;
+        P.cheat  = cfg->resample_amount;
+    }
     if (cfg->belief == FBA_BELIEF_REINVIGORATION) {
         // two rejection filters + breeding (ReinvigoratingRejectionSampling.hpp); the reference has fully
         // connected priors for factored tiger, collision avoidance and sysadmin
@@ -1124,7 +1147,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     }
 
     // slots
-    const size_t per_slot = (size_t)P.N * (2 * 8 + 8 + (P.reinvig ? 4 : 2) * (size_t)P.Cs * 4) + (size_t)D.max_nodes * D.node_words * 4 + (size_t)hcap * 16 + 1024;
+    const size_t per_slot = (size_t)P.N * (2 * 8 + 8 + ((P.reinvig || P.cheat) ? 4 : 2) * (size_t)P.Cs * 4) + (size_t)D.max_nodes * D.node_words * 4 + (size_t)hcap * 16 + 1024;
     int E = cfg->slots;
     if (E <= 0) {
         size_t free_b = 0, total_b = 0;
@@ -1149,10 +1172,10 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     CHK(dev_alloc(c, &D.action, E));
     CHK(dev_alloc(c, &D.obs, E));
     CHK(dev_alloc(c, &D.bufsel, E));
-    const bool is = cfg->belief == FBA_BELIEF_IMPORTANCE;
+    const bool is = P.belief == FBA_BELIEF_IMPORTANCE;
     CHK(dev_alloc(c, &D.p_weight, is ? (size_t)2 * E * P.N : 1));
     CHK(dev_alloc(c, &D.p_rec, (size_t)2 * E * P.N * P.Cs, false));
-    if (P.reinvig) {
+    if (P.reinvig || P.cheat) {
         CHK(dev_alloc(c, &D.p_rec_fc, (size_t)2 * E * P.N * P.Cs, false));
         CHK(dev_alloc(c, &D.bufsel_fc, E));
     }
@@ -1166,6 +1189,18 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         D.ctot_stride = (P.N + 255) / 256 + 2;
         CHK(dev_alloc(c, &D.ctot, is ? (size_t)E * D.ctot_stride : 1));
         CHK(dev_alloc(c, &D.is_tot, (size_t)2 * E));
+    }
+    if (P.cheat) {
+        if (D.is_multi) {
+            fail(c, FBA_EINVAL, "cheating-reinvigoration belief: at most %d particles per slot", IS_MAX_CHUNKS * 256);
+            g_create_error = c->err;
+            fba_destroy(c);
+            return FBA_EINVAL;
+        }
+        CHK(dev_alloc(c, &D.lik, (size_t)E + 1));
+        CHK(dev_alloc(c, &D.cheat_pending, E));
+        const double thr = cfg->threshold;
+        HIPC(hipMemcpy(D.lik + E, &thr, sizeof thr, hipMemcpyHostToDevice));
     }
     CHK(dev_alloc(c, &D.nodes, (size_t)E * D.max_nodes * D.node_words, false));
     if (hashed) {
@@ -1394,7 +1429,7 @@ int fba_belief_get_fully_connected(fba_ctx* c, int32_t slot, int32_t* state, flo
 {
     if (!c || slot < 0 || slot >= c->P.E) return FBA_EINVAL;
     const Problem& P = c->P;
-    if (!P.reinvig) return fail(c, FBA_EINVAL, "only the reinvigoration belief has a fully connected filter");
+    if (!P.reinvig && !P.cheat) return fail(c, FBA_EINVAL, "only the reinvigoration and cheating beliefs have a second filter");
     uint8_t sel = 0;
     HIPCHK(c, hipMemcpy(&sel, c->D.bufsel_fc + slot, 1, hipMemcpyDeviceToHost));
     const size_t pb = ((size_t)sel * P.E + slot) * (size_t)P.N;

@@ -696,6 +696,37 @@ __global__ void __launch_bounds__(256) reinvigorate_kernel(Problem P, DeviceStat
 }
 
 // ---------------------------------------------------------------------------------------------
+// cheat_kernel: CheatingReinvigoration::cheat (CheatingReinvigoration.cpp:130-143), after the importance
+// update of a slot whose log likelihood fell below the threshold: `cheat` times, a random particle of
+// the correct-graph filter is copied over a random particle of the weighted filter (which keeps its
+// weight).  Draw order within stream (REINVIG, k): the correct filter's sample, then slowRandomInt for
+// the victim (g++ evaluates replace's arguments right to left).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) cheat_kernel(Problem P, DeviceState D)
+{
+    __shared__ int32_t s_src, s_victim;
+    const int e = blockIdx.x, tid = threadIdx.x;
+    if (!D.cheat_pending[e]) return;
+    float* recs      = D.p_rec + pbase(P, e, D.bufsel[e]) * (size_t)P.Cs;
+    const float* aux = D.p_rec_fc + pbase(P, e, D.bufsel_fc[e]) * (size_t)P.Cs;
+    Rng g = slot_rng(P, D, e);
+    for (int k = 0; k < P.cheat; ++k) {
+        if (tid == 0) {
+            g.stream(FBA_PHASE_REINVIG, (uint32_t)k);
+            s_src    = g.uniform_int(P.N);
+            s_victim = g.slow_int(0, P.N);
+        }
+        __syncthreads();
+        const float* src = aux + (size_t)s_src * P.Cs;
+        float* dst       = recs + (size_t)s_victim * P.Cs;
+        for (int w = tid; w <= P.C; w += 256) dst[w] = src[w];  // counts and the state word
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (tid == 0) D.cheat_pending[e] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Device-order prefix sums (DESIGN.md "device-order sums"; oracle/orc.c dev_scan is the CPU twin):
 // each lane sums 4 consecutive elements sequentially, a 64-lane Kogge-Stone scan combines the
 // lane sums of one 256-element chunk, chunks are chained sequentially.
@@ -845,6 +876,14 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
         D.upd_particles[e] += (unsigned long long)N;
         D.cur[e].update_count = -1;
         D.cur[e].weight_total = total;
+        if (P.cheat) {  // CheatingReinvigoration::updateEstimation (CheatingReinvigoration.cpp:117-124)
+            double lik = D.lik[e] * total;
+            if (det_log(lik) < D.lik[P.E]) {
+                D.cheat_pending[e] = 1;
+                lik = 1;
+            }
+            D.lik[e] = lik;
+        }
     }
 }
 
@@ -1085,9 +1124,11 @@ __global__ void __launch_bounds__(256) init_kernel(Problem P, DeviceState D, int
     __syncthreads();
     // ... and its own domain start state
     const double w1 = 1.0 / (double)P.N;
+    if (P.cheat && !fc && blockIdx.x == 0 && tid == 0) D.lik[e] = 1.0;  // _likelihood = 1
     for (int i = i_lo + tid; i < i_hi; i += 256) {
         g.stream(fc ? FBA_PHASE_INIT_FC : FBA_PHASE_INIT, (uint32_t)i);
         rec_set_state(recs + (size_t)i * P.Cs, P.C, domain_start(P, g));
+        if (fc && P.cheat) continue;  // CheatingReinvigoration::initiate: sampleCorrectGraphState = the base prior record
         if (fc) {  // sampleFullyConnectedState: FactoredTigerPriors.cpp:324-337, CollisionAvoidancePriors.cpp:429-440, SysAdminFactoredPrior.cpp:57-69
             if (dom_is_sys(P.domain)) {
                 sys_fill_fully_connected(P, recs + (size_t)i * P.Cs);
@@ -1122,7 +1163,7 @@ __global__ void __launch_bounds__(256) reset_kernel(Problem P, DeviceState D, in
     const size_t sb = pbase(P, e, cur), db = pbase(P, e, cur ^ 1);
     Rng g = slot_rng(P, D, e);
     g.position((uint32_t)D.run[e], (uint32_t)D.episode[e], 0);
-    if (P.belief == FBA_BELIEF_REJECTION) {
+    if (P.belief == FBA_BELIEF_REJECTION || fc || P.cheat) {  // (the cheating belief resets its weighted filter in place too, CheatingReinvigoration.cpp:48-62)
         float* recs = (fc ? D.p_rec_fc : D.p_rec) + sb * (size_t)P.Cs;
         for (int i = i_lo + tid; i < i_hi; i += 256) {
             g.stream(fc ? FBA_PHASE_RESET_FC : FBA_PHASE_RESET, (uint32_t)i);
@@ -1158,7 +1199,7 @@ __global__ void post_reset_kernel(Problem P, DeviceState D)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= P.E || D.need_reset[e] != 1) return;
-    if (P.belief == FBA_BELIEF_IMPORTANCE) D.bufsel[e] ^= 1;
+    if (P.belief == FBA_BELIEF_IMPORTANCE && !P.cheat) D.bufsel[e] ^= 1;
     D.need_reset[e] = 0;
 }
 
@@ -1262,12 +1303,17 @@ void launch_belief_update(const Problem& P, const DeviceState& D, hipStream_t st
         }
         return;
     }
+    if (P.cheat) {  // rejectSample on the correct-graph filter first (CheatingReinvigoration.cpp:111)
+        if (P.dirichlet_regular) hipLaunchKernelGGL((reject_kernel<true, false>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, 1);
+        else hipLaunchKernelGGL((reject_kernel<false, false>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, 1);
+    }
     if (!D.is_multi) {
         const bool tiger_table = P.model == FBA_MODEL_BA_TABLE && !P.dirichlet_regular &&
                                  (P.domain == FBA_DOM_TIGER_EPISODIC || P.domain == FBA_DOM_TIGER_CONTINUOUS);
         if (P.dirichlet_regular) hipLaunchKernelGGL((importance_kernel<true, false>), dim3(P.E), dim3(IS_BLOCK), 0, st, P, D);
         else if (tiger_table) hipLaunchKernelGGL((importance_kernel<false, true>), dim3(P.E), dim3(IS_BLOCK), 0, st, P, D);
         else hipLaunchKernelGGL((importance_kernel<false, false>), dim3(P.E), dim3(IS_BLOCK), 0, st, P, D);
+        if (P.cheat) hipLaunchKernelGGL(cheat_kernel, dim3(P.E), dim3(256), 0, st, P, D);
         return;
     }
     const int nchunks = (P.N + 255) / 256;
@@ -1284,13 +1330,13 @@ void launch_belief_update(const Problem& P, const DeviceState& D, hipStream_t st
 void launch_init(const Problem& P, const DeviceState& D, hipStream_t st)
 {
     hipLaunchKernelGGL(init_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), P.E), dim3(256), 0, st, P, D, 0);
-    if (P.reinvig) hipLaunchKernelGGL(init_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), P.E), dim3(256), 0, st, P, D, 1);
+    if (P.reinvig || P.cheat) hipLaunchKernelGGL(init_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), P.E), dim3(256), 0, st, P, D, 1);
     hipLaunchKernelGGL(post_init_kernel, dim3(ceil_div(P.E, 256)), dim3(256), 0, st, P, D);
 }
 void launch_reset(const Problem& P, const DeviceState& D, hipStream_t st)
 {
     hipLaunchKernelGGL(reset_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), P.E), dim3(256), 0, st, P, D, 0);
-    if (P.reinvig) hipLaunchKernelGGL(reset_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), P.E), dim3(256), 0, st, P, D, 1);
+    if (P.reinvig || P.cheat) hipLaunchKernelGGL(reset_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), P.E), dim3(256), 0, st, P, D, 1);
     hipLaunchKernelGGL(post_reset_kernel, dim3(ceil_div(P.E, 256)), dim3(256), 0, st, P, D);
 }
 void launch_flush(const Problem& P, const DeviceState& D, hipStream_t st)

@@ -49,8 +49,10 @@ struct DeviceState {
     uint8_t* bufsel;    // [E]
     double* p_weight;   // [2][E][N]
     float* p_rec;       // [2][E][N][Cs] particle records (counts | state | pad)
-    float* p_rec_fc;    // same shape: the reinvigoration belief's fully connected filter (else null)
+    float* p_rec_fc;    // same shape: the second filter of the reinvigoration (fully connected) / cheating (correct graph) belief
     uint8_t* bufsel_fc; // [E]
+    double* lik;        // [E] cheating belief: CheatingReinvigoration::_likelihood; [E] holds the threshold
+    uint8_t* cheat_pending;  // [E] the update of this tick pushed log(likelihood) below the threshold
     double* wscan;      // [E][N] scratch: inclusive device-order prefix sums of normalised weights
     double* ctot;       // [E][N/256 + 2] scratch: chunk totals / carries of the multi-workgroup filter
     double* is_tot;     // [E][2] total weight before normalisation, total of the normalised weights

@@ -34,7 +34,7 @@ struct Options {
                                 dirichlet = "expected", id;
     int verbose = 0, runs = 1, horizon = 10, sims = 1000, max_depth = -1, particles = 100, size = 0, height = 0, width = 0,
         episodes = 1, slots = 0, device = 0, resample_amount = 0;
-    double discount = .95, exploration = 100;
+    double discount = .95, exploration = 100, threshold = 0;
     float noise = 0, counts_total = 10000;
     bool help = false;
 };
@@ -50,14 +50,16 @@ void usage()
         "  -H, --horizon N                Horizon, number of steps per episode (10)\n"
         "  -d, --discount X               Discount for future rewards (0.95)\n"
         "  -P, --planner NAME             random or po-uct (po-uct)\n"
-        "  -B, --belief NAME              rejection_sampling, importance_sampling or (fbapomdp) reinvigoration\n"
+        "  -B, --belief NAME              rejection_sampling, importance_sampling or (fbapomdp) reinvigoration,\n"
+        "                                 cheating-reinvigoration\n"
         "      --seed STR                 Global seed for all random samples\n"
         "      --id STR                   The id to give this process\n"
         "  -s, --simulation-amount N      simulations per search (1000)\n"
         "      --mcts-max-depth N         max search depth, horizon if negative (-1)\n"
         "  -u, --exploration-constant X   UCB exploration constant (100)\n"
         "      --particle-amount N        particles in the filter (100)\n"
-        "      --resample-amount N        particles reinvigorated per belief update (reinvigoration belief)\n"
+        "      --resample-amount N        particles reinvigorated per belief update (reinvigoration beliefs)\n"
+        "      --threshold X              cheating-reinvigoration: log likelihood before cheating (< 0)\n"
         "  -D, --domain NAME              episodic-tiger, continuous-tiger, episodic-factored-tiger,\n"
         "                                 continuous-factored-tiger, gridworld, random-collision-avoidance,\n"
         "                                 centered-collision-avoidance, independent-sysadmin, linear-sysadmin\n"
@@ -107,6 +109,7 @@ bool parse(int argc, char** argv, Options& o, std::string& err)
             else if (k == "--exploration-constant") o.exploration = std::stod(v);
             else if (k == "--particle-amount") o.particles = std::stoi(v);
             else if (k == "--resample-amount") o.resample_amount = std::stoi(v);
+            else if (k == "--threshold") o.threshold = std::stod(v);
             else if (k == "--domain") o.domain = v;
             else if (k == "--size") o.size = std::stoi(v);
             else if (k == "--height") o.height = std::stoi(v);
@@ -153,13 +156,15 @@ bool to_config(Options const& o, fba_config& c, std::string& err)
     if (o.belief == "rejection_sampling" || o.belief == "hip-rejection_sampling") c.belief = FBA_BELIEF_REJECTION;
     else if (o.belief == "importance_sampling" || o.belief == "hip-importance_sampling") c.belief = FBA_BELIEF_IMPORTANCE;
     else if (o.belief == "reinvigoration" && o.mode == "fbapomdp") c.belief = FBA_BELIEF_REINVIGORATION;  // BABelief.cpp:28-31
+    else if (o.belief == "cheating-reinvigoration" && o.mode == "fbapomdp") c.belief = FBA_BELIEF_CHEATING;  // BABelief.cpp:60-65
     else { err = "please enter a legit state stimator: rejection_sampling, importance_sampling or (fbapomdp) reinvigoration, provided: " + o.belief; return false; }
-    if ((o.resample_amount == 0) ^ (o.belief != "reinvigoration")) {  // BeliefConf.cpp:40-49
+    if ((o.resample_amount == 0) ^ (o.belief != "reinvigoration" && o.belief != "cheating-reinvigoration")) {  // BeliefConf.cpp:40-49
         err = "You have set the resample amount (" + std::to_string(o.resample_amount) + "), but are not using one of the beliefs (" + o.belief +
               ") that use it: reinvigoration, cheating-reinvigoration and incubator";
         return false;
     }
     c.resample_amount = o.resample_amount;
+    c.threshold = o.threshold;
     if (o.dirichlet == "expected" || o.dirichlet == "1") c.dirichlet_regular = 0;
     else if (o.dirichlet == "regular" || o.dirichlet == "0") c.dirichlet_regular = 1;
     else { err = "please enter either 'regular' or 'expected' for dirichlet_sampling_method, given: " + o.dirichlet; return false; }

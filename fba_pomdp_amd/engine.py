@@ -158,7 +158,7 @@ class Engine:
     def belief_get(self, slot=0, weights=None):
         n = self.cfg.particles
         s = np.zeros(n, np.int32)
-        want_w = self.cfg.belief == N.BELIEF_IMPORTANCE if weights is None else weights
+        want_w = self.cfg.belief in (N.BELIEF_IMPORTANCE, N.BELIEF_CHEATING) if weights is None else weights
         w = np.zeros(n, np.float64)
         cnt = np.zeros((n, self.ncnt), np.float32)
         self._chk(self.L.fba_belief_get(self.h, slot, s.ctypes.data, w.ctypes.data if want_w else None,
@@ -166,7 +166,7 @@ class Engine:
         return s, w, cnt
 
     def belief_get_fully_connected(self, slot=0):
-        """The second filter of the reinvigoration belief (ReinvigoratingRejectionSampling.hpp)."""
+        """The second filter of the reinvigoration (fully connected) / cheating (correct graph) belief."""
         n = self.cfg.particles
         s = np.zeros(n, np.int32)
         cnt = np.zeros((n, self.ncnt), np.float32)

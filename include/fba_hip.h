@@ -44,7 +44,8 @@ enum {
 enum { FBA_MODEL_POMDP = 0, FBA_MODEL_BA_TABLE = 1, FBA_MODEL_BA_FACTORED = 2 };
 /* -B rejection_sampling | importance_sampling (BeliefConf.hpp, Belief.cpp:13-24) | reinvigoration
  * (BABelief.cpp:28-31: ReinvigoratingRejectionSampling, factored models only) */
-enum { FBA_BELIEF_REJECTION = 0, FBA_BELIEF_IMPORTANCE = 1, FBA_BELIEF_REINVIGORATION = 2 };
+enum { FBA_BELIEF_REJECTION = 0, FBA_BELIEF_IMPORTANCE = 1, FBA_BELIEF_REINVIGORATION = 2,
+       FBA_BELIEF_CHEATING = 3 /* cheating-reinvigoration (BABelief.cpp:60-65: prototypes::CheatingReinvigoration) */ };
 /* -P po-uct | random (Planner.cpp:12-19) */
 enum { FBA_PLANNER_POUCT = 0, FBA_PLANNER_RANDOM = 1 };
 /* --structure-prior (FBAConf.hpp) */
@@ -104,7 +105,8 @@ typedef struct fba_config {
                                 * bug-compatible with the reference's biased sampler (BAConf.hpp:22,
                                 * random.cpp:146-242) */
     int32_t resample_amount; /* --resample-amount: particles bred per update by the reinvigoration
-                              * belief (BeliefConf.cpp:17-21) */
+                              * belief / copied per cheat by the cheating belief (BeliefConf.cpp:17-21) */
+    double threshold;        /* --threshold: log likelihood below which the cheating belief cheats (< 0) */
 } fba_config;
 
 /* One record per real time-step: the information the reference prints at -v 2 / -v 3
@@ -192,7 +194,8 @@ int fba_belief_update(fba_ctx* ctx, const int32_t* action, const int32_t* obs, c
 int fba_belief_get(fba_ctx* ctx, int32_t slot, int32_t* state, double* weight, float* counts);
 int fba_belief_set(fba_ctx* ctx, int32_t slot, const int32_t* state, const double* weight, const float* counts);
 /* the second filter of the reinvigoration belief (ReinvigoratingRejectionSampling.hpp:
- * _fully_connected_belief), for tests */
+ * _fully_connected_belief) or of the cheating belief (CheatingReinvigoration.hpp:
+ * _correct_structured_belief), for tests */
 int fba_belief_get_fully_connected(fba_ctx* ctx, int32_t slot, int32_t* state, float* counts);
 /* per-slot record of the last select_action / belief_update (root statistics, rejection count,
  * belief checksum) */

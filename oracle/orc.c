@@ -99,6 +99,7 @@ struct orc_ctx {
     float* fpool;
     float* fpool_new;
     float* breed_tmp;
+    double likelihood; /* CheatingReinvigoration::_likelihood */
     double total_w; /* WeightedFilter::_total_weight */
     double* wscratch;
     double* wscan;
@@ -203,6 +204,7 @@ static int is_episodic(int d)
 }
 static int is_grid(int d) { return d == ORC_DOM_GRIDWORLD; }
 static int is_ca(int d) { return d == ORC_DOM_COLLISION_AVOID; }
+static int is_weighted(const orc_ctx* c);
 static int is_sys(int d) { return d == ORC_DOM_SYSADMIN_INDEPENDENT || d == ORC_DOM_SYSADMIN_LINEAR; }
 
 /* ---- collision avoidance.  ref: src/domains/collision-avoidance/CollisionAvoidance.cpp
@@ -1851,9 +1853,12 @@ static void weighted_refresh_scan(orc_ctx* c)
     c->total_w = dev_scan(c->wscratch, n, c->wscan);
 }
 
+/* the main filter is a WeightedFilter (importance sampling; the cheating belief's _belief) */
+static int is_weighted(const orc_ctx* c) { return c->cfg.belief == ORC_BELIEF_IMPORTANCE || c->cfg.belief == ORC_BELIEF_CHEATING; }
+
 static int32_t belief_sample(orc_ctx* c)
 {
-    return c->cfg.belief != ORC_BELIEF_IMPORTANCE ? flat_sample(c) : weighted_sample(c);
+    return is_weighted(c) ? weighted_sample(c) : flat_sample(c);
 }
 
 static void swap_pools(orc_ctx* c)
@@ -1888,7 +1893,18 @@ static void belief_initiate(orc_ctx* c)
         c->P[i].w = w;
         c->total_w += w; /* WeightedFilter::add(T, w) WeightedFilter.cpp:60-66 */
     }
-    if (c->cfg.belief == ORC_BELIEF_IMPORTANCE) weighted_refresh_scan(c);
+    if (is_weighted(c)) weighted_refresh_scan(c);
+    if (c->cfg.belief == ORC_BELIEF_CHEATING) {
+        /* CheatingReinvigoration::initiate (CheatingReinvigoration.cpp:64-90): a second FlatFilter of
+         * fbapomdp.sampleCorrectGraphState() particles (the prior's own structure: the base record) */
+        for (i = 0; i < n; ++i) {
+            orc_rng_stream(&c->rng, ORC_PH_INIT_FC, (uint32_t)i);
+            c->F[i].s = domain_start(c);
+            c->F[i].w = 0;
+            memcpy(c->F[i].cnt, c->prior, sizeof(float) * (size_t)c->ncnt);
+        }
+        c->likelihood = 1;
+    }
     if (c->cfg.belief == ORC_BELIEF_REINVIGORATION) {
         /* ReinvigoratingRejectionSampling::initiate (ReinvigoratingRejectionSampling.cpp:55-76):
          * after the n start states, n x FBAPOMDP::sampleFullyConnectedState (FBAPOMDP.cpp:63-67 ->
@@ -2098,6 +2114,29 @@ static void belief_update(orc_ctx* c, int32_t a, int32_t o)
         reject_sample(c, a, o, ORC_PH_REJECT_FC);
         swap_main_fc(c);
         c->last_update_count = count;
+    } else if (c->cfg.belief == ORC_BELIEF_CHEATING) {
+        /* CheatingReinvigoration::updateEstimation (CheatingReinvigoration.cpp:105-128) */
+        double l;
+        swap_main_fc(c);
+        reject_sample(c, a, o, ORC_PH_REJECT_FC);
+        swap_main_fc(c);
+        l = is_update(c, a, o);
+        is_resample(c);
+        c->likelihood *= l;
+        if (m_log(c, c->likelihood) < c->cfg.threshold) {
+            /* cheat (:130-143): g++ evaluates replace's arguments right to left, so the correct filter is
+             * sampled before slowRandomInt picks the victim; the victim keeps its weight */
+            int n = c->cfg.particles, k;
+            for (k = 0; k < c->cfg.resample_amount; ++k) {
+                int32_t src, victim;
+                orc_rng_stream(&c->rng, ORC_PH_REINVIG, (uint32_t)k);
+                src    = orc_int(&c->rng, n);
+                victim = orc_slow_int(&c->rng, 0, n);
+                c->P[victim].s = c->F[src].s;
+                memcpy(c->P[victim].cnt, c->F[src].cnt, sizeof(float) * (size_t)c->ncnt);
+            }
+            c->likelihood = 1;
+        }
     } else {
         is_update(c, a, o);
         is_resample(c);
@@ -2110,12 +2149,12 @@ static void belief_update(orc_ctx* c, int32_t a, int32_t o)
 static void belief_reset_domain_state(orc_ctx* c)
 {
     int i, n = c->cfg.particles;
-    if (c->cfg.belief != ORC_BELIEF_IMPORTANCE) {
+    if (c->cfg.belief != ORC_BELIEF_IMPORTANCE) { /* (the cheating belief resets its weighted filter in place too, CheatingReinvigoration.cpp:48-62) */
         for (i = 0; i < n; ++i) {
             orc_rng_stream(&c->rng, ORC_PH_RESET, (uint32_t)i);
             c->P[i].s = domain_start(c);
         }
-        if (c->cfg.belief == ORC_BELIEF_REINVIGORATION) /* ReinvigoratingRejectionSampling.cpp:109-119 */
+        if (c->cfg.belief == ORC_BELIEF_REINVIGORATION || c->cfg.belief == ORC_BELIEF_CHEATING) /* ReinvigoratingRejectionSampling.cpp:109-119 */
             for (i = 0; i < n; ++i) {
                 orc_rng_stream(&c->rng, ORC_PH_RESET_FC, (uint32_t)i);
                 c->F[i].s = domain_start(c);
@@ -2141,7 +2180,7 @@ static uint64_t belief_hash(orc_ctx* c)
 {
     uint64_t h = 0;
     int i, n = c->cfg.particles;
-    int weighted = c->cfg.belief == ORC_BELIEF_IMPORTANCE;
+    int weighted = is_weighted(c);
     for (i = 0; i < n; ++i)
         h += particle_hash((uint64_t)i, c->P[i].s, weighted ? c->P[i].w : 0.0, c->P[i].cnt,
                            c->ncnt);
@@ -2387,8 +2426,23 @@ orc_ctx* orc_create(const orc_config* cfg)
             c->Pnew[i].cnt = c->pool_new + (size_t)i * c->ncnt;
         }
     }
-    if (cfg->belief == ORC_BELIEF_REINVIGORATION) {
-        if (cfg->model != ORC_MODEL_BA_FACTORED || !(is_ftiger(cfg->domain) || is_ca(cfg->domain) || is_sys(cfg->domain)) ||
+    if (cfg->belief == ORC_BELIEF_CHEATING) {
+        if (cfg->model != ORC_MODEL_BA_FACTORED) {
+            snprintf(c->err, sizeof c->err, "cheating-reinvigoration belief: needs a factored model (fbapomdp)");
+            return c;
+        }
+        if (cfg->resample_amount < 1) { /* CheatingReinvigoration.cpp:30-34 */
+            snprintf(c->err, sizeof c->err, "CheatingReinvigoration::cannot initiate belief of size < 1 (%d), or resample size of < 1 (%d)", n, cfg->resample_amount);
+            return c;
+        }
+        if (cfg->threshold >= 0) { /* :36-40 */
+            snprintf(c->err, sizeof c->err, "CheatingReinvigoration::cannot initiate with resample_threshold >= 0 (is:%f)", cfg->threshold);
+            return c;
+        }
+    }
+    if (cfg->belief == ORC_BELIEF_REINVIGORATION || cfg->belief == ORC_BELIEF_CHEATING) {
+        if (cfg->belief == ORC_BELIEF_CHEATING) { /* checked above */
+        } else if (cfg->model != ORC_MODEL_BA_FACTORED || !(is_ftiger(cfg->domain) || is_ca(cfg->domain) || is_sys(cfg->domain)) ||
             (is_ca(cfg->domain) && cfg->structure_prior == ORC_SP_FULLY_CONNECTED)) {
             /* the reference has fully connected priors for factored tiger, collision avoidance and
              * sysadmin; GridWorldFactBAPrior::sampleFullyConnectedState throws "nyi" */

@@ -39,7 +39,8 @@ enum {
 enum { ORC_MODEL_POMDP = 0, ORC_MODEL_BA_TABLE = 1, ORC_MODEL_BA_FACTORED = 2 };
 /* belief */
 /* REINVIGORATION = beliefs::bayes_adaptive::factored::ReinvigoratingRejectionSampling (-B reinvigoration) */
-enum { ORC_BELIEF_REJECTION = 0, ORC_BELIEF_IMPORTANCE = 1, ORC_BELIEF_REINVIGORATION = 2 };
+/* CHEATING = beliefs::bayes_adaptive::prototypes::CheatingReinvigoration (-B cheating-reinvigoration) */
+enum { ORC_BELIEF_REJECTION = 0, ORC_BELIEF_IMPORTANCE = 1, ORC_BELIEF_REINVIGORATION = 2, ORC_BELIEF_CHEATING = 3 };
 /* floating-point summation order of the importance-sampling filter:
  * REF = the reference's sequential loops; DEV = the HIP engine's fixed reduction tree */
 enum { ORC_ARITH_REF = 0, ORC_ARITH_DEV = 1 };
@@ -77,7 +78,8 @@ typedef struct orc_config {
     int32_t planner;       /* ORC_PLANNER_* */
     int32_t ca_centered;   /* collision avoidance: 1 = centered-collision-avoidance, 0 = random-collision-avoidance */
     int32_t dirichlet_regular; /* --dirichlet_sampling_method regular (0 = expected, the default) */
-    int32_t resample_amount;   /* --resample-amount: particles bred per update (reinvigoration belief) */
+    int32_t resample_amount;   /* --resample-amount: particles bred per update (reinvigoration belief) / copied per cheat */
+    double threshold;          /* --threshold: log-likelihood below which the cheating belief cheats (< 0) */
 } orc_config;
 
 /* One record per real time-step; the HIP engine emits the same layout (fba_trace_rec). */

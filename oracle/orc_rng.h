@@ -47,7 +47,7 @@ enum {
     ORC_PH_REJECT    = 5, /* rejection sampling: unit = attempt index                  */
     ORC_PH_IS_UPDATE = 6, /* importance update: unit = particle index                  */
     ORC_PH_RESAMPLE  = 7, /* importance resample: unit = output particle index         */
-    ORC_PH_REINVIG   = 8, /* reinvigoration: unit = index of the bred particle          */
+    ORC_PH_REINVIG   = 8, /* reinvigoration / cheating: unit = index of the bred (copied) particle */
     ORC_PH_INIT_FC   = 9, /* fully connected filter, initiate: unit = particle index    */
     ORC_PH_RESET_FC  = 10,/* fully connected filter, reset: unit = particle index       */
     ORC_PH_REJECT_FC = 11 /* fully connected filter, rejection: unit = attempt index    */

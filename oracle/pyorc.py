@@ -16,7 +16,7 @@ _LIB = os.path.join(_HERE, "liborc.so")
 DOM_TIGER_EPISODIC, DOM_TIGER_CONTINUOUS, DOM_FTIGER_EPISODIC, DOM_FTIGER_CONTINUOUS, DOM_GRIDWORLD, DOM_COLLISION_AVOID = range(6)
 DOM_SYSADMIN_INDEPENDENT, DOM_SYSADMIN_LINEAR = 7, 8
 MODEL_POMDP, MODEL_BA_TABLE, MODEL_BA_FACTORED = range(3)
-BELIEF_REJECTION, BELIEF_IMPORTANCE, BELIEF_REINVIGORATION = range(3)
+BELIEF_REJECTION, BELIEF_IMPORTANCE, BELIEF_REINVIGORATION, BELIEF_CHEATING = range(4)
 ARITH_REF, ARITH_DEV = range(2)
 RNG_MT, RNG_PHILOX = range(2)
 PLANNER_POUCT, PLANNER_RANDOM = range(2)
@@ -36,7 +36,7 @@ class Config(C.Structure):
         ("structure_prior", C.c_int32), ("rng_mode", C.c_int32), ("arith", C.c_int32),
         ("philox_seed", C.c_uint64), ("seed_str", C.c_char * 64),
         ("run_offset", C.c_int32), ("trace", C.c_int32), ("planner", C.c_int32), ("ca_centered", C.c_int32), ("dirichlet_regular", C.c_int32),
-        ("resample_amount", C.c_int32),
+        ("resample_amount", C.c_int32), ("threshold", C.c_double),
     ]
 
 

@@ -22,7 +22,7 @@ def test_cli_help_and_argument_errors(cli):
     assert r.returncode == 0
     for flag in ("--runs", "--horizon", "--discount", "--planner", "--belief", "--seed", "--simulation-amount",
                  "--mcts-max-depth", "--exploration-constant", "--particle-amount", "--domain", "--size", "--episodes",
-                 "--resample-amount", "--dirichlet_sampling_method", "--noise", "--counts-total", "--structure-prior", "--output-file"):
+                 "--resample-amount", "--threshold", "--dirichlet_sampling_method", "--noise", "--counts-total", "--structure-prior", "--output-file"):
         assert flag in r.stdout                                  # the reference's flag names (Conf.cpp, BAConf.cpp, ...)
     for args, msg in ((["planning", "-D", "nope"], "legit domain"), (["planning", "-D", "episodic-tiger", "--bogus", "1"], "unrecognised"),
                       (["planning", "-D", "episodic-tiger", "--runs"], "missing"), (["frobnicate"], "unknown mode"),
@@ -76,5 +76,14 @@ def test_cli_bapomdp_and_fbapomdp_write_one_line_per_episode(cli, tmp_path):
                         "-f", str(out3)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert len([l for l in out3.read_text().splitlines() if l and not l.startswith("#")]) == 3
+    out4 = tmp_path / "cheat.res"
+    r = subprocess.run([cli, "fbapomdp", "-D", "linear-sysadmin", "--size", "3", "-B", "cheating-reinvigoration", "--resample-amount", "4",
+                        "--threshold", "-1.5", "-s", "48", "--particle-amount", "40", "--runs", "4", "--episodes", "2", "-H", "6",
+                        "-f", str(out4)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert len([l for l in out4.read_text().splitlines() if l and not l.startswith("#")]) == 2
+    r = subprocess.run([cli, "fbapomdp", "-D", "linear-sysadmin", "--size", "3", "-B", "cheating-reinvigoration", "--resample-amount", "4"],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "resample_threshold >= 0" in r.stderr       # CheatingReinvigoration.cpp:36-40
     r = subprocess.run([cli, "bapomdp", "-D", "episodic-tiger", "--noise", "0.9"], capture_output=True, text=True)
     assert r.returncode == 1 and "noise has to be between" in r.stderr      # TigerPriors.cpp:22-25

@@ -199,6 +199,55 @@ def test_reinvigoration_belief_both_filters_equal_oracle_step_by_step():
     assert seen_unforced
 
 
+@pytest.mark.parametrize("domain,kw", [
+    ("episodic-factored-tiger", dict(size=3, structure_prior=1, threshold=-1.5, resample_amount=7)),
+    ("gridworld", dict(size=3, structure_prior=2, threshold=-3.0, resample_amount=4, horizon=8)),
+    ("random-collision-avoidance", dict(size=1, width=4, height=3, structure_prior=1, threshold=-2.0, resample_amount=3)),
+    ("linear-sysadmin", dict(size=3, threshold=-1.0, resample_amount=5, horizon=6)),
+])
+def test_fbapomdp_cheating_reinvigoration_belief(domain, kw):
+    """-B cheating-reinvigoration (prototypes/CheatingReinvigoration.cpp): importance sampling on the
+    belief, rejection sampling on a second filter of correct-graph particles; when the accumulated log
+    likelihood drops below --threshold, --resample-amount particles are copied across."""
+    eng, o = _pair(domain, N.MODEL_BA_FACTORED, "cheating-reinvigoration", 291, particles=48, sims=64, runs=5, episodes=3, slots=3, **kw)
+    _assert_same_experiment(eng, o, ba=True)
+    fs, fcnt = eng.belief_get_fully_connected(0)
+    assert fcnt.shape == (48, eng.ncnt)
+
+
+def test_cheating_belief_cheats_and_keeps_both_filters_equal_to_the_oracle():
+    kw = dict(size=2, particles=64, sims=16, structure_prior=1, resample_amount=10, threshold=-0.5)
+    eng = fba.Engine("episodic-factored-tiger", model=N.MODEL_BA_FACTORED, belief="cheating-reinvigoration", seed=37, slots=1, **kw)
+    o = orc.Oracle(domain=orc.DOM_FTIGER_EPISODIC, model=orc.MODEL_BA_FACTORED, belief=orc.BELIEF_CHEATING,
+                   rng_mode=orc.RNG_PHILOX, arith=orc.ARITH_DEV, philox_seed=37, **kw)
+    L = orc.lib()
+    L.orc_rng_episode(o.rng, 0, 0, 0)
+    o.belief_initiate()
+    eng.belief_init()
+    o.belief_reset_domain_state()
+    eng.belief_reset_domain_state()
+    correct_mask_seen = False
+    for t, ob in enumerate([0, 1, 1, 0, 1, 0]):
+        L.orc_rng_episode(o.rng, 0, 0, t)
+        eng.set_position(run=0, episode=0, t=t)
+        o.belief_update(2, ob)
+        eng.belief_update(2, ob)
+        s, w, cnt = eng.belief_get(0)
+        os_, ow, ocnt = o.belief_get()
+        assert np.array_equal(s, os_) and np.array_equal(w, ow) and np.array_equal(cnt.view(np.uint32), ocnt.view(np.uint32))
+        fs, fcnt = eng.belief_get_fully_connected(0)
+        ofs, ofcnt = o.belief_get_fc()
+        assert np.array_equal(fs, ofs) and np.array_equal(fcnt.view(np.uint32), ofcnt.view(np.uint32))
+        assert np.all(fcnt.view(np.uint32)[:, -1] == 1)                  # the second filter keeps the correct graph {tiger location}
+        assert eng.last_step_info()[0]["weight_total"] > 0
+    with pytest.raises(ValueError, match="resample_threshold >= 0"):
+        fba.Engine("episodic-factored-tiger", model=N.MODEL_BA_FACTORED, belief="cheating-reinvigoration", size=2, particles=8,
+                   sims=4, resample_amount=2, threshold=0.0)
+    with pytest.raises(ValueError, match="needs a factored model"):
+        fba.Engine("episodic-tiger", model=N.MODEL_BA_TABLE, belief="cheating-reinvigoration", particles=8, sims=4,
+                   resample_amount=2, threshold=-1.0)
+
+
 def test_reinvigoration_belief_argument_checks():
     with pytest.raises(ValueError, match="needs a factored model"):
         fba.Engine("episodic-tiger", model=N.MODEL_BA_TABLE, belief="reinvigoration", resample_amount=4, particles=8, sims=4)
@@ -206,7 +255,7 @@ def test_reinvigoration_belief_argument_checks():
         fba.Engine("episodic-factored-tiger", model=N.MODEL_BA_FACTORED, belief="reinvigoration", size=2, particles=8, sims=4)
     eng = fba.Engine("episodic-factored-tiger", model=N.MODEL_BA_FACTORED, size=2, particles=8, sims=4, slots=1)
     eng.belief_init()
-    with pytest.raises(ValueError, match="fully connected"):
+    with pytest.raises(ValueError, match="second filter"):
         eng.belief_get_fully_connected(0)
 
 
