@@ -73,13 +73,24 @@ struct Rng {
 // Views of a particle's count blob: straight from HBM, or staged in LDS as [word][lane]
 // (stride = workgroup size, so lane l only ever touches bank l mod 32: conflict-free).
 // ---------------------------------------------------------------------------------------------
+// `row_regs`: read a Dirichlet row into registers before using it (sample_expected_mult).  Pays off where
+// few waves are in flight and every element would otherwise be a separate wait on HBM / L2 -- the
+// search over records too big to stage; costs instructions where occupancy already hides the latency
+// (belief kernels) or the row sits in LDS.
 struct GlobalView {
     const float* p;
+    static constexpr bool row_regs = false;
+    __device__ __forceinline__ float at(int k) const { return p[k]; }
+};
+struct GlobalSearchView {
+    const float* p;
+    static constexpr bool row_regs = true;
     __device__ __forceinline__ float at(int k) const { return p[k]; }
 };
 template <int STRIDE>
 struct LdsView {
     const float* p;
+    static constexpr bool row_regs = false;
     __device__ __forceinline__ float at(int k) const { return p[k * STRIDE]; }
 };
 
@@ -100,10 +111,41 @@ __device__ __forceinline__ int sample_from_mult_f(Rng& g, const View& row, int o
     return n - 1;
 }
 
-// sampleFromExpectedMult: total accumulated in double
+// sampleFromExpectedMult: total accumulated in double.
+// Views with `row_regs` read rows of up to ROWREG entries into registers first, all loads issued
+// together: the two passes (total, CDF) then wait for memory once instead of once per element.
+// Same operations, same order, same result.
+constexpr int ROWREG = 16;
+template <int K, class View>
+__device__ __forceinline__ int sample_expected_mult_regs(Rng& g, const View& row, int off, int n)
+{
+    float r[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) r[i] = i < n ? row.at(off + i) : 0.f;
+    double total = (double)r[0];
+#pragma unroll
+    for (int i = 1; i < K; ++i)
+        if (i < n) total += (double)r[i];
+    const double p = g.u01() * total;
+    float sum = r[0];
+    int pick  = n - 1;
+    bool done = false;
+#pragma unroll
+    for (int i = 1; i < K; ++i)
+        if (i < n && !done) {
+            if (p < (double)sum) { pick = i - 1; done = true; }
+            else sum += r[i];
+        }
+    return pick;
+}
 template <class View>
 __device__ __forceinline__ int sample_expected_mult(Rng& g, const View& row, int off, int n)
 {
+    if (View::row_regs && n <= ROWREG) {  // (rows of one node have one length: the branch is as good as uniform)
+        if (n <= 2) return sample_expected_mult_regs<2>(g, row, off, n);
+        if (n <= 8) return sample_expected_mult_regs<8>(g, row, off, n);
+        return sample_expected_mult_regs<ROWREG>(g, row, off, n);
+    }
     double total = (double)row.at(off);
     for (int i = 1; i < n; ++i) total += (double)row.at(off + i);
     return sample_from_mult_f(g, row, off, n, total);
@@ -131,13 +173,14 @@ __device__ __forceinline__ double expected_mult_at(const View& row, int off, int
 constexpr int MAXF     = 8;   // state / observation features
 constexpr int MAXNODES = 160; // A * (FS + FO)
 constexpr int MAXINC   = 9;   // count increments of one UpdateCounts step (FS + FO)
-struct alignas(16) FNode {  // 48 bytes: three 16-byte loads bring a whole node description
+struct alignas(16) FNode {  // 48 bytes: three 16-byte loads bring a whole node description (load_node)
     int32_t off, out, nmax, var;
     uint32_t fixed_mask;
     uint8_t maxp[MAXF];  // candidate parents (state features), in order
     uint8_t psz[MAXF];   // psz[j] = number of values of parent maxp[j] (filled by the engine after the build)
     uint32_t pad[3];
 };
+static_assert(sizeof(FNode) == 48, "load_node reads an FNode as three 16-byte words");
 struct FDesc {
     int32_t FS, FO, nvar, ncounts;
     int32_t Ssz[MAXF], Osz[MAXF], Sstep[MAXF], Ostep[MAXF];
@@ -595,6 +638,37 @@ __device__ __forceinline__ uint64_t pack_features(int v, const int32_t* step, in
 }
 __device__ __forceinline__ int feat(uint64_t p, int i) { return (int)((p >> (8 * i)) & 0xffu); }
 
+// One node description into registers with three 16-byte loads (LDS or global); its byte arrays are
+// then read with compile-time shifts instead of one byte load per parent.
+struct NodeRegs {
+    int32_t off, out, nmax, var;
+    uint32_t fixed_mask;
+    uint32_t maxp_lo, maxp_hi, psz_lo, psz_hi;
+    __device__ __forceinline__ int parent(int j) const { return (int)(((j < 4 ? maxp_lo : maxp_hi) >> (8 * (j & 3))) & 0xffu); }
+    __device__ __forceinline__ int psize(int j) const { return (int)(((j < 4 ? psz_lo : psz_hi) >> (8 * (j & 3))) & 0xffu); }
+};
+__device__ __forceinline__ NodeRegs load_node(const FNode* p)
+{
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    const uint4 a = q[0], b = q[1], c = q[2];
+    NodeRegs r;
+    r.off = (int32_t)a.x; r.out = (int32_t)a.y; r.nmax = (int32_t)a.z; r.var = (int32_t)a.w;
+    r.fixed_mask = b.x; r.maxp_lo = b.y; r.maxp_hi = b.z; r.psz_lo = b.w; r.psz_hi = c.x;
+    return r;
+}
+template <class View>
+__device__ __forceinline__ uint32_t node_mask(const FDesc* fd, const NodeRegs& nd, const View& cnt)
+{
+    return nd.var >= 0 ? __float_as_uint(cnt.at(fd->ncounts + nd.var)) : nd.fixed_mask;
+}
+__device__ __forceinline__ int node_row(const FDesc*, const NodeRegs& nd, uint32_t mask, uint64_t fv)
+{
+    int idx = 0;
+#pragma unroll
+    for (int j = 0; j < MAXF; ++j)
+        if (j < nd.nmax && ((mask >> j) & 1u)) idx = idx * nd.psize(j) + feat(fv, nd.parent(j));
+    return nd.off + idx * nd.out;
+}
 template <class View>
 __device__ __forceinline__ uint32_t node_mask(const FDesc* fd, const FNode& nd, const View& cnt)
 {
@@ -624,7 +698,7 @@ __device__ __forceinline__ bool fact_step(const Problem& P, Rng& g, const View& 
 #pragma unroll
     for (int f = 0; f < MAXF; ++f)
         if (f < FS) {
-            const FNode& nd = fd->nodes[a * FS + f];
+            const NodeRegs nd = load_node(&fd->nodes[a * FS + f]);
             const int row   = node_row(fd, nd, node_mask(fd, nd, cnt), fv);
             const int v     = sample_row<REG>(P, g, cnt, row, nd.out);
             inc.add(f, row + v);
@@ -635,7 +709,7 @@ __device__ __forceinline__ bool fact_step(const Problem& P, Rng& g, const View& 
 #pragma unroll
     for (int f = 0; f < MAXF; ++f)
         if (f < FO) {
-            const FNode& nd     = fd->nodes[P.A * FS + a * FO + f];
+            const NodeRegs nd   = load_node(&fd->nodes[P.A * FS + a * FO + f]);
             const uint32_t mask = node_mask(fd, nd, cnt);
             const int v         = sample_row<REG>(P, g, cnt, node_row(fd, nd, mask, nf), nd.out);
             ob = ob * fd->Osz[f] + v;
@@ -659,7 +733,7 @@ __device__ __forceinline__ double fact_obs_prob(const Problem& P, Rng& g, const 
 #pragma unroll
     for (int f = 0; f < MAXF; ++f)
         if (f < fd->FO) {
-            const FNode& nd = fd->nodes[P.A * fd->FS + a * fd->FO + f];
+            const NodeRegs nd = load_node(&fd->nodes[P.A * fd->FS + a * fd->FO + f]);
             const int row   = node_row(fd, nd, node_mask(fd, nd, cnt), fv);
             if (REG) {  // sampleMultinominal = sampleMult: a fresh Dirichlet draw per observation feature
                 prob *= (float)sample_mult_at(P.zig, g, cnt, row, nd.out, feat(of, f));

@@ -8,7 +8,7 @@
 namespace fba {
 
 constexpr int SEARCH_BLOCK  = 64;    // one wave per workgroup, one tree per lane
-constexpr int SEARCH_STAGE_WORDS = 64;  // particle records up to this many words are staged in LDS by the search
+constexpr int SEARCH_STAGE_WORDS = 128; // particle records up to this many words are staged in LDS by the search
 constexpr int ROOT_CHILDREN = 8;        // root child pointers are kept in LDS when A*O is at most this
 constexpr int REJECT_BLOCK  = 256;   // attempts per chunk of the rejection filter
 constexpr int IS_BLOCK      = 1024;  // one workgroup per slot in the importance filter
