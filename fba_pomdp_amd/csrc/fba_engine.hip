@@ -799,6 +799,17 @@ int tick(fba_ctx* c)
     return FBA_OK;
 }
 
+// after a synchronisation point: did a rejection update give up (fba_kernels.h REJECT_MAX_ATTEMPTS)?
+int check_fault(fba_ctx* c)
+{
+    int32_t f = 0;
+    HIPCHK(c, hipMemcpy(&f, c->D.fault, sizeof f, hipMemcpyDeviceToHost));
+    if (!f) return FBA_OK;
+    HIPCHK(c, hipMemset(c->D.fault, 0, sizeof f));
+    return fail(c, FBA_ESTATE, "rejection sampling in slot %d accepted fewer than %d particles in %d attempts: no particle of the filter "
+                "can produce the observation (the reference loops forever in RejectionSampling.hpp:26-72 here)", f - 1, c->P.N, REJECT_MAX_ATTEMPTS);
+}
+
 int set_flags(fba_ctx* c, uint8_t* dev, const uint8_t* mask, uint8_t value)
 {
     std::vector<uint8_t> h((size_t)c->P.E, value);
@@ -863,6 +874,7 @@ int run_experiment(fba_ctx* c, fba_stat* stats)
         int32_t n_active = 0;
         HIPCHK(c, hipMemcpyAsync(&n_active, c->d_n_active, sizeof n_active, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        if ((rc = check_fault(c))) return rc;
         if (n_active <= 0) break;
     }
     std::vector<double> ret((size_t)runs * eps);
@@ -1216,6 +1228,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     CHK(dev_alloc(c, &D.cur, E));
     CHK(dev_alloc(c, &D.trace_count, 1));
     CHK(dev_alloc(c, &c->d_n_active, 1));
+    CHK(dev_alloc(c, &D.fault, 1));
     CHK(dev_alloc(c, &c->d_prior, P.Cs));
     CHK(dev_alloc(c, &c->d_uni_scan, (size_t)P.N + 1));
     CHK(dev_alloc(c, &c->d_log1p, (size_t)P.sims + 2));
@@ -1399,7 +1412,7 @@ int fba_belief_update(fba_ctx* c, const int32_t* action, const int32_t* obs, con
     if ((rc = timed(c, k_update_kind(c), [&] { launch_belief_update(c->P, c->D, c->stream); }))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
-    return FBA_OK;
+    return check_fault(c);
 }
 
 int fba_belief_get(fba_ctx* c, int32_t slot, int32_t* state, double* weight, float* counts)
@@ -1501,7 +1514,7 @@ int fba_run_ticks(fba_ctx* c, int32_t ticks)
     for (int k = 0; k < ticks; ++k)
         if ((rc = tick(c))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return FBA_OK;
+    return check_fault(c);
 }
 
 int fba_get_returns(const fba_ctx* cc, double* returns, int32_t* lengths)

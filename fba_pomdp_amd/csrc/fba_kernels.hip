@@ -564,6 +564,16 @@ __global__ void __launch_bounds__(REJECT_BLOCK) reject_kernel(Problem P, DeviceS
 
     int acc = 0, base = 0;
     while (acc < N) {
+        if (base >= REJECT_MAX_ATTEMPTS) {
+            // The reference would spin forever here (no particle can produce the observation); a GPU must
+            // not.  Park the slot and tell the host, which turns it into an error.
+            if (tid == 0) {
+                atomicCAS(D.fault, 0, 1 + e);
+                D.need_update[e] = 0;
+                D.active[e]      = 0;
+            }
+            return;
+        }
         const int k = base + tid;
         g.stream(phase, (uint32_t)k);
         const int src = g.uniform_int(N);                       // FlatFilter::sample

@@ -1,0 +1,123 @@
+"""Randomised differential test: engine (HIP) against the oracle (Philox, device arithmetic) over random
+valid configurations -- domains x simulators x beliefs x sizes x modes.  python scripts/fuzz_parity.py [n] [seed]"""
+import os, sys, random, traceback
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import fba_pomdp_amd as fba
+from fba_pomdp_amd import _native as N
+from oracle import pyorc as orc
+
+DOM = {"random-collision-avoidance": orc.DOM_COLLISION_AVOID, "centered-collision-avoidance": orc.DOM_COLLISION_AVOID,
+       "gridworld": orc.DOM_GRIDWORLD, "episodic-tiger": orc.DOM_TIGER_EPISODIC, "continuous-tiger": orc.DOM_TIGER_CONTINUOUS,
+       "episodic-factored-tiger": orc.DOM_FTIGER_EPISODIC, "continuous-factored-tiger": orc.DOM_FTIGER_CONTINUOUS,
+       "independent-sysadmin": orc.DOM_SYSADMIN_INDEPENDENT, "linear-sysadmin": orc.DOM_SYSADMIN_LINEAR}
+
+
+def draw(rng):
+    domain = rng.choice(list(DOM))
+    model = rng.choice([N.MODEL_POMDP, N.MODEL_BA_TABLE, N.MODEL_BA_FACTORED])
+    kw = dict(particles=rng.choice([1, 7, 33, 64, 130]), sims=rng.choice([1, 5, 40, 96]), horizon=rng.choice([1, 3, 7, 12]),
+              runs=rng.choice([1, 3, 6]), discount=rng.choice([0.5, 0.95, 1.0]), exploration=rng.choice([0.0, 1.0, 100.0]))
+    kw["max_depth"] = rng.choice([-1, 0, 1, 4, kw["horizon"]])
+    slots = rng.choice([1, 2, kw["runs"]])
+    if "tiger" in domain and "factored" not in domain:
+        pass
+    elif "factored-tiger" in domain:
+        kw["size"] = rng.choice([1, 2, 3])
+    elif domain == "gridworld":
+        kw["size"] = rng.choice([3, 4])
+        kw["particles"] = rng.choice([64, 130])   # a filter without the true goal can never be updated
+    elif "sysadmin" in domain:
+        kw["size"] = rng.choice([1, 2, 3, 4])
+    else:
+        kw["width"], kw["height"], kw["size"] = rng.choice([(3, 3, 1), (4, 3, 2), (3, 5, 1)])
+    belief = rng.choice(["rejection_sampling", "importance_sampling"])
+    if model != N.MODEL_POMDP:
+        kw["episodes"] = rng.choice([1, 2, 3])
+        kw["counts_total"] = rng.choice([10.0, 777.0, 10000.0])
+        if "tiger" in domain:
+            kw["noise"] = rng.choice([0.0, 0.1, -0.1])
+        elif domain == "gridworld" or "collision" in domain:
+            kw["noise"] = rng.choice([0.0, 0.1])
+    if model == N.MODEL_BA_FACTORED:
+        if "factored-tiger" in domain:
+            kw["structure_prior"] = rng.choice([0, 1, 2, 3])
+        elif domain == "gridworld":
+            kw["structure_prior"] = rng.choice([0, 2])
+        elif "collision" in domain:
+            kw["structure_prior"] = rng.choice([0, 1, 2, 3])
+        b = rng.random()
+        if b < 0.2 and domain != "gridworld" and not ("collision" in domain and kw.get("structure_prior") == 3):
+            belief = "reinvigoration"
+            kw["resample_amount"] = rng.choice([1, 4, 20])
+        elif b < 0.4:
+            belief = "cheating-reinvigoration"
+            kw["resample_amount"] = rng.choice([1, 5])
+            kw["threshold"] = rng.choice([-0.3, -2.0, -50.0])
+    if model != N.MODEL_POMDP and rng.random() < 0.2:
+        longest = {"gridworld": 99, "random-collision-avoidance": kw.get("height", 0), "centered-collision-avoidance": kw.get("height", 0)}.get(domain, 2)
+        if model == N.MODEL_BA_FACTORED and longest <= 16 or model == N.MODEL_BA_TABLE and "tiger" in domain and "factored" not in domain:
+            kw["dirichlet_regular"] = 1
+    if rng.random() < 0.15:
+        kw["planner"] = "random"
+    return domain, model, belief, slots, kw
+
+
+def one(domain, model, belief, slots, kw, seed):
+    kw = dict(kw)
+    planner = kw.pop("planner", "po-uct")
+    eng = fba.Engine(domain, model=model, belief=belief, planner=planner, seed=seed, slots=slots, trace=1, **kw)
+    okw = dict(kw)
+    if domain == "centered-collision-avoidance":
+        okw["ca_centered"] = 1
+    o = orc.Oracle(domain=DOM[domain], model=model, belief=N.BELIEF_NAMES[belief], planner=N.PLANNER_NAMES[planner],
+                   rng_mode=orc.RNG_PHILOX, arith=orc.ARITH_DEV, philox_seed=seed, trace=1, **okw)
+    ba = model != N.MODEL_POMDP
+    try:
+        stats = eng.run_bapomdp() if ba else [eng.run_planning()]
+    except fba.FbaError as e:
+        if "accepted fewer than" in str(e):   # the reference (and the oracle) would never return from this update
+            print("   degenerate filter, skipped:", str(e)[:70], flush=True)
+            eng.close()
+            return
+        raise
+    ostats, res = o.run_bapomdp() if ba else (lambda r: ([r[0]], r[1]))(o.run_planning())
+    tr, otr = eng.trace(), o.trace(res.n_trace)
+    assert len(tr) == len(otr), (len(tr), len(otr))
+    for name in tr.dtype.names:
+        same = np.all((tr[name] == otr[name]).reshape(len(tr), -1), axis=1)
+        assert same.all(), f"{name}: first mismatch at record {np.nonzero(~same)[0][0]}"
+    for a, b in zip(stats, ostats):
+        assert (a.count, a.mean, a.m2) == (b.count, b.mean, b.m2)
+    c = eng.counters()
+    assert (c.sim_steps, c.belief_steps, c.env_steps) == (res.sim_steps, res.belief_steps, res.env_steps)
+    eng.close()
+
+
+def run(n, seed, verbose=True):
+    """(mismatches, refused) over n random configurations"""
+    rng = random.Random(seed)
+    bad = skipped = 0
+    for i in range(n):
+        cfg = draw(rng)
+        if verbose:
+            print(i, cfg[0], cfg[1], cfg[2], cfg[3], cfg[4], flush=True)
+        try:
+            one(*cfg, seed=1000 + i)
+        except ValueError as e:          # both sides must refuse the same configurations
+            skipped += 1
+            if verbose and skipped <= 8:
+                print("refused:", cfg[0], cfg[1], cfg[2], str(e)[:90], flush=True)
+        except Exception as e:
+            bad += 1
+            print("MISMATCH", i, cfg, "\n   ", str(e)[:300], flush=True)
+            if not isinstance(e, AssertionError):
+                traceback.print_exc()
+    return bad, skipped
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    bad, skipped = run(n, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    print(f"{n} configurations: {bad} mismatches, {skipped} refused", flush=True)
+    sys.exit(1 if bad else 0)

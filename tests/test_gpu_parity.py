@@ -539,6 +539,21 @@ def test_per_step_interface_matches_oracle_calls():
         assert eng.last_step_info()[0]["update_count"] == L.orc_last_update_count(o.h)
 
 
+def test_rejection_update_with_an_impossible_observation_fails_instead_of_spinning():
+    """beliefs::rejectSample loops until N particles reproduce the observation (RejectionSampling.hpp:26-72);
+    when none can, the reference never returns.  The device gives up after 2^28 attempts and the call fails."""
+    eng = fba.Engine("episodic-tiger", model=N.MODEL_BA_TABLE, particles=4, sims=4, slots=2, seed=3)
+    eng.belief_init()
+    eng.belief_reset_domain_state()
+    s, _, cnt = eng.belief_get(1)
+    cnt[:, 12 + 2 * 4 + 0 * 2 + 1] = 0      # psi(listen, left, hear right) = 0
+    cnt[:, 12 + 2 * 4 + 1 * 2 + 1] = 0      # psi(listen, right, hear right) = 0: "hear right" cannot happen
+    eng.belief_set(1, state=s, counts=cnt)
+    with pytest.raises(fba.FbaError, match="accepted fewer than 4 particles"):
+        eng.belief_update(2, 1, active=[0, 1])
+    eng.belief_update(2, 0, active=[1, 1])   # the ctx stays usable
+
+
 def test_belief_update_rejects_out_of_range_arguments():
     eng = fba.Engine("episodic-tiger", particles=8, sims=4, slots=2)
     eng.belief_init()
