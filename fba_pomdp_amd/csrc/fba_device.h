@@ -722,6 +722,49 @@ __device__ __forceinline__ bool fact_step(const Problem& P, Rng& g, const View& 
     return t;
 }
 
+// fact_step for the factored-tiger FBA-POMDP with FS = K + 1 binary state features, everything the
+// generic code reads from the model description restated from build_ftiger_factored_prior's layout:
+//   T(open a, f)   no parents   at (a*FS + f)*2          T(listen, f)  parent f   at 4*FS + 4*f + 2*value
+//   O(open a)      no parents   at 8*FS + 2*a            O(listen)     parents = the particle's mask over the
+//   features (feature 0 first), rows at 8*FS + 4 + 2*row;  mask word at 8*FS + 4 + (2 << FS).
+// Feature f of state s is bit FS-1-f.  Same draws, same order, same increments as fact_step.
+template <int FS, class View, class Sink>
+__device__ __forceinline__ bool ftiger_step(const Problem& P, Rng& g, const View& cnt, int& s, int a, int& o, double& r, const Sink& inc)
+{
+    constexpr int OBS = 8 * FS, MASKW = 8 * FS + 4 + (2 << FS);
+    const int loc = (s >> (FS - 1)) & 1;  // feature 0: the tiger's door
+    int ns = 0;
+#pragma unroll
+    for (int f = 0; f < FS; ++f) {
+        const int v   = (s >> (FS - 1 - f)) & 1;
+        const int row = a == 2 ? 4 * FS + 4 * f + 2 * v : (a * FS + f) * 2;
+        const int nv  = sample_expected_mult(g, cnt, row, 2);
+        inc.add(f, row + nv);
+        ns = ns * 2 + nv;
+    }
+    int row_new, row_old;  // the observation row of the new state (sampled) and of the old one (incremented: App. A #6)
+    if (a == 2) {
+        const uint32_t mask = __float_as_uint(cnt.at(MASKW));
+        int in = 0, io = 0;
+#pragma unroll
+        for (int f = 0; f < FS; ++f)
+            if ((mask >> f) & 1u) {
+                in = in * 2 + ((ns >> (FS - 1 - f)) & 1);
+                io = io * 2 + ((s >> (FS - 1 - f)) & 1);
+            }
+        row_new = OBS + 4 + 2 * in;
+        row_old = OBS + 4 + 2 * io;
+    } else {
+        row_new = row_old = OBS + 2 * a;
+    }
+    o = sample_expected_mult(g, cnt, row_new, 2);
+    inc.add(FS, row_old + o);
+    const bool t = dom_is_episodic(P.domain) && a != 2;
+    r = a == 2 ? -1.0 : (a == loc ? 10.0 : -100.0);
+    s = ns;
+    return t;
+}
+
 // BABNModel::computeObservationProbability (BABNModel.cpp:328-352)
 template <bool REG, class View>
 __device__ __forceinline__ double fact_obs_prob(const Problem& P, Rng& g, const View& cnt, int new_s, int a, int o)

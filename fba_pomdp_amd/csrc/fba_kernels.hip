@@ -165,13 +165,19 @@ __device__ __forceinline__ int ucb_select(const Problem& P, const DeviceState& D
 // record fits SEARCH_STAGE_WORDS (STAGE) -- the root particle's whole count blob, [word][lane], fetched with
 // one burst of 16-byte loads per simulation so that no step waits on HBM for its Dirichlet rows.
 // ---------------------------------------------------------------------------------------------
-template <bool STAGE, int AMAX, bool REG, bool TIGER_TABLE, int MODEL>
+// FTIGER > 0: the simulator is the factored-tiger FBA-POMDP with FTIGER binary state features (expected
+// Dirichlet mode); its step is ftiger_step<FTIGER>, the layout restated as literals.
+template <bool STAGE, int AMAX, bool REG, bool TIGER_TABLE, int MODEL, int FTIGER = 0>
 __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceState D)
 {
     // one instantiation per simulator: the launcher passes the model it read from P, so restating it
     // here drops the other simulators' code (a plain-POMDP search carries every domain's step(),
     // the Bayes-adaptive ones none of them) from this instantiation
     P.model = MODEL;
+    if (FTIGER > 0) {  // sizes of factored tiger with FTIGER - 1 irrelevant features
+        P.S = 1 << FTIGER; P.A = 3; P.O = 2;
+        if (P.domain != FBA_DOM_FTIGER_CONTINUOUS) P.domain = FBA_DOM_FTIGER_EPISODIC;
+    }
     // TIGER_TABLE: the launcher has checked that this is the tabular BA-POMDP over (episodic or
     // continuous) tiger; restating its sizes as literals lets the compiler unroll the two-entry
     // Dirichlet rows and fold every model / domain branch.  Same code, same results.
@@ -287,7 +293,9 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
             int o;
             double r;
             bool term;
-            if (STAGE) term = sim_step<REG>(P, g, LdsView<SEARCH_BLOCK>{stage}, s, a, o, r, NoInc{});
+            if (FTIGER > 0 && STAGE) term = ftiger_step<(FTIGER > 0 ? FTIGER : 1)>(P, g, LdsView<SEARCH_BLOCK>{stage}, s, a, o, r, NoInc{});
+            else if (FTIGER > 0) term = ftiger_step<(FTIGER > 0 ? FTIGER : 1)>(P, g, GlobalSearchView{cnt}, s, a, o, r, NoInc{});
+            else if (STAGE) term = sim_step<REG>(P, g, LdsView<SEARCH_BLOCK>{stage}, s, a, o, r, NoInc{});
             else term = sim_step<REG>(P, g, GlobalSearchView{cnt}, s, a, o, r, NoInc{});
             ++steps;
             if (mode == 1) {  // traverseChanceNode
@@ -1281,6 +1289,20 @@ void launch_search(const Problem& P, const DeviceState& D, hipStream_t st)
     if (tiger_table) {
         hipLaunchKernelGGL((search_kernel<true, 4, false, true, FBA_MODEL_BA_TABLE>), grid, block, lds, st, P, D);
         return;
+    }
+    if (P.model == FBA_MODEL_BA_FACTORED && (P.domain == FBA_DOM_FTIGER_EPISODIC || P.domain == FBA_DOM_FTIGER_CONTINUOUS) &&
+        !P.dirichlet_regular && P.planner == FBA_PLANNER_POUCT && !D.hash) {
+        const int FS = 31 - __builtin_clz((unsigned)P.S);  // S = 2^FS
+#define FBA_LAUNCH_FTIGER(FSV)                                                                                                    \
+    do {                                                                                                                          \
+        if (stage) hipLaunchKernelGGL((search_kernel<true, 4, false, false, FBA_MODEL_BA_FACTORED, FSV>), grid, block, lds, st, P, D); \
+        else hipLaunchKernelGGL((search_kernel<false, 4, false, false, FBA_MODEL_BA_FACTORED, FSV>), grid, block, lds, st, P, D);      \
+        return;                                                                                                                   \
+    } while (0)
+        if (FS == 2) FBA_LAUNCH_FTIGER(2);
+        if (FS == 3) FBA_LAUNCH_FTIGER(3);
+        if (FS == 4) FBA_LAUNCH_FTIGER(4);
+#undef FBA_LAUNCH_FTIGER
     }
     if (P.A <= 4) { if (stage) FBA_LAUNCH_SEARCH(true, 4); else FBA_LAUNCH_SEARCH(false, 4); }
     else if (P.A <= 8) { if (stage) FBA_LAUNCH_SEARCH(true, 8); else FBA_LAUNCH_SEARCH(false, 8); }
