@@ -852,6 +852,7 @@ int start_experiment(fba_ctx* c, int runs_total)
     const int32_t n_active = runs_total < 0 ? c->P.E : std::min(c->P.E, runs_total);
     HIPCHK(c, hipMemcpyAsync(c->d_n_active, &n_active, sizeof n_active, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->D.bufsel, 0, (size_t)c->P.E, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->D.lazy_reset, 0, (size_t)c->P.E, c->stream));
     if (c->D.bufsel_fc) HIPCHK(c, hipMemsetAsync(c->D.bufsel_fc, 0, (size_t)c->P.E, c->stream));
     launch_start(c->P, c->D, c->stream);
     if ((rc = timed(c, FBA_K_BELIEF_INIT, [&] { launch_init(c->P, c->D, c->stream); }))) return rc;
@@ -1229,6 +1230,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     CHK(dev_alloc(c, &D.trace_count, 1));
     CHK(dev_alloc(c, &c->d_n_active, 1));
     CHK(dev_alloc(c, &D.fault, 1));
+    CHK(dev_alloc(c, &D.lazy_reset, E));
     CHK(dev_alloc(c, &c->d_prior, P.Cs));
     CHK(dev_alloc(c, &c->d_uni_scan, (size_t)P.N + 1));
     CHK(dev_alloc(c, &c->d_log1p, (size_t)P.sims + 2));
@@ -1419,6 +1421,8 @@ int fba_belief_get(fba_ctx* c, int32_t slot, int32_t* state, double* weight, flo
 {
     if (!c || slot < 0 || slot >= c->P.E) return FBA_EINVAL;
     const Problem& P = c->P;
+    launch_materialize_reset(c->P, c->D, c->stream);  // a lazily reset rejection filter: write the states out first
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     uint8_t sel = 0;
     HIPCHK(c, hipMemcpy(&sel, c->D.bufsel + slot, 1, hipMemcpyDeviceToHost));
     const size_t pb = ((size_t)sel * P.E + slot) * (size_t)P.N;
@@ -1460,6 +1464,8 @@ int fba_belief_set(fba_ctx* c, int32_t slot, const int32_t* state, const double*
 {
     if (!c || slot < 0 || slot >= c->P.E) return FBA_EINVAL;
     const Problem& P = c->P;
+    launch_materialize_reset(c->P, c->D, c->stream);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     uint8_t sel = 0;
     HIPCHK(c, hipMemcpy(&sel, c->D.bufsel + slot, 1, hipMemcpyDeviceToHost));
     const size_t pb = ((size_t)sel * P.E + slot) * (size_t)P.N;

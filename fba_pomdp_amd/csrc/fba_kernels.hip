@@ -37,6 +37,20 @@ __device__ __forceinline__ size_t pbase(const Problem& P, int e, int buf) { retu
 __device__ __forceinline__ int rec_state(const float* rec, int C) { return __float_as_int(rec[C]); }
 __device__ __forceinline__ void rec_set_state(float* rec, int C, int s) { rec[C] = __int_as_float(s); }
 
+// resetDomainStateDistribution of the plain rejection filter (BARejectionSampling.cpp:49-60) gives particle i
+// the start state drawn from stream (run, episode, 0, RESET, i).  Writing 4 bytes into each of N records is a
+// poor use of HBM, so the reset is only flagged (lazy_reset_kernel) and the state is derived where it is
+// read -- the search's root sampling, the rejection attempts, the checksum -- until the first rejection
+// update of the episode rewrites every record anyway.
+__device__ __forceinline__ bool slot_lazy(const DeviceState& D, int e) { return D.lazy_reset[e] != 0; }
+__device__ __forceinline__ int lazy_state(const Problem& P, const DeviceState& D, int e, int i)
+{
+    Rng g = slot_rng(P, D, e);
+    g.position((uint32_t)D.run[e], (uint32_t)D.episode[e], 0);
+    g.stream(FBA_PHASE_RESET, (uint32_t)i);
+    return domain_start(P, g);
+}
+
 // WeightedFilter::sample (WeightedFilter.cpp:163-191) in device order: the largest i >= 1 whose
 // exclusive prefix sum is below the threshold, else 0.  `incl` holds inclusive prefix sums.
 __device__ __forceinline__ int weighted_pick(const double* __restrict__ incl, int n, double threshold)
@@ -225,7 +239,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
     if (P.planner == FBA_PLANNER_RANDOM) {  // RandomPlanner::selectAction RandomPlanner.cpp:14-24
         g.stream(FBA_PHASE_SEARCH, (uint32_t)P.sims);
         const int src = belief_sample_uniform(P, D, g);
-        D.action[e]   = domain_random_action(P, g, rec_state(prec + (size_t)src * P.Cs, P.C));
+        D.action[e]   = domain_random_action(P, g, slot_lazy(D, e) ? lazy_state(P, D, e, src) : rec_state(prec + (size_t)src * P.Cs, P.C));
         return;
     }
 
@@ -252,6 +266,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
         D.epoch[e] = epoch;
     }
 
+    const bool lazy = slot_lazy(D, e);  // particle states are still the episode's start-state draws (lazy_state)
     int sim = 0, mode = 0;  // 0 = start a simulation, 1 = in the tree, 2 = rollout
     int s = 0, node = 0, dtg = 0, plen = 0, rdepth = 0;
     const float* cnt = prec;
@@ -276,6 +291,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
             } else {
                 s = rec_state(cnt, P.C);
             }
+            if (lazy) s = lazy_state(P, D, e, src);
             node = 0; dtg = max_tree_depth; plen = 0; mode = 1;
         }
         bool finish = false, do_step = true;
@@ -568,6 +584,7 @@ __global__ void __launch_bounds__(REJECT_BLOCK) reject_kernel(Problem P, DeviceS
     const int C4 = P.Cs / 4, group = record_group(C4);
     const int ninc = model_ninc(P);
     const uint32_t phase = fc ? FBA_PHASE_REJECT_FC : FBA_PHASE_REJECT;
+    const bool lazy = slot_lazy(D, e);
     Rng g = slot_rng(P, D, e);
 
     int acc = 0, base = 0;
@@ -586,7 +603,7 @@ __global__ void __launch_bounds__(REJECT_BLOCK) reject_kernel(Problem P, DeviceS
         g.stream(phase, (uint32_t)k);
         const int src = g.uniform_int(N);                       // FlatFilter::sample
         const float* rec = scn + (size_t)src * P.Cs;
-        int s = rec_state(rec, P.C), so;
+        int s = (!fc && lazy) ? lazy_state(P, D, e, src) : rec_state(rec, P.C), so;
         double r;
         sim_step<REG>(P, g, GlobalView{rec}, s, a, so, r, LdsInc<REJECT_BLOCK>{s_inc + tid});  // UpdateCounts: the +1s land in the copy
         s_src[tid] = src;
@@ -620,6 +637,7 @@ __global__ void __launch_bounds__(REJECT_BLOCK) reject_kernel(Problem P, DeviceS
         D.upd_particles[e] += (unsigned long long)N;
         if (!fc) {
             D.need_update[e]      = 0;
+            D.lazy_reset[e]       = 0;  // every record of the new buffer carries its real state
             D.cur[e].update_count = s_count;
         }
     }
@@ -1207,6 +1225,29 @@ __global__ void __launch_bounds__(256) reset_kernel(Problem P, DeviceState D, in
     }
 }
 
+// Plain rejection filter: flag the reset instead of performing it (lazy_state).
+__global__ void lazy_reset_kernel(Problem P, DeviceState D)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= P.E || D.need_reset[e] != 1) return;
+    D.lazy_reset[e] = 1;
+    D.need_reset[e] = 0;
+}
+// ... and perform it after all, for a caller that wants to see the records (fba_belief_get / _set).
+__global__ void __launch_bounds__(256) materialize_reset_kernel(Problem P, DeviceState D)
+{
+    const int e = blockIdx.y, tid = threadIdx.x;
+    if (!D.lazy_reset[e]) return;
+    const int i_lo = blockIdx.x * PARTICLE_TILE, i_hi = min(P.N, i_lo + PARTICLE_TILE);
+    float* recs = D.p_rec + pbase(P, e, D.bufsel[e]) * (size_t)P.Cs;
+    for (int i = i_lo + tid; i < i_hi; i += 256) rec_set_state(recs + (size_t)i * P.Cs, P.C, lazy_state(P, D, e, i));
+}
+__global__ void post_materialize_kernel(Problem P, DeviceState D)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < P.E) D.lazy_reset[e] = 0;
+}
+
 // clears the request flags after init_kernel / reset_kernel (several workgroups serve one slot)
 __global__ void post_init_kernel(Problem P, DeviceState D)
 {
@@ -1233,10 +1274,12 @@ __global__ void __launch_bounds__(256) flush_kernel(Problem P, DeviceState D)
     if (tid == 0) s_sum = 0;
     __syncthreads();
     const size_t pb = pbase(P, e, D.bufsel[e]);
+    const bool lazy = slot_lazy(D, e);
     unsigned long long local = 0;
     for (int i = tid; i < P.N; i += 256) {
         const float* cnt = D.p_rec + (pb + i) * (size_t)P.Cs;
-        uint64_t h = mix64((uint64_t)i * 0x9E3779B97F4A7C15ull + (uint64_t)(uint32_t)rec_state(cnt, P.C));
+        const int st = lazy ? lazy_state(P, D, e, i) : rec_state(cnt, P.C);
+        uint64_t h = mix64((uint64_t)i * 0x9E3779B97F4A7C15ull + (uint64_t)(uint32_t)st);
         const double w = (P.belief == FBA_BELIEF_IMPORTANCE) ? D.p_weight[pb + i] : 0.0;
         h = mix64(h ^ (uint64_t)__double_as_longlong(w));
         for (int k = 0; k < P.C; ++k) h = mix64(h ^ ((uint64_t)__float_as_uint(cnt[k]) + ((uint64_t)k << 32)));
@@ -1365,8 +1408,17 @@ void launch_init(const Problem& P, const DeviceState& D, hipStream_t st)
     if (P.reinvig || P.cheat) hipLaunchKernelGGL(init_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), P.E), dim3(256), 0, st, P, D, 1);
     hipLaunchKernelGGL(post_init_kernel, dim3(ceil_div(P.E, 256)), dim3(256), 0, st, P, D);
 }
+void launch_materialize_reset(const Problem& P, const DeviceState& D, hipStream_t st)
+{
+    hipLaunchKernelGGL(materialize_reset_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), P.E), dim3(256), 0, st, P, D);
+    hipLaunchKernelGGL(post_materialize_kernel, dim3(ceil_div(P.E, 256)), dim3(256), 0, st, P, D);
+}
 void launch_reset(const Problem& P, const DeviceState& D, hipStream_t st)
 {
+    if (P.belief == FBA_BELIEF_REJECTION && !P.reinvig && !P.cheat) {  // the plain rejection filter resets lazily
+        hipLaunchKernelGGL(lazy_reset_kernel, dim3(ceil_div(P.E, 256)), dim3(256), 0, st, P, D);
+        return;
+    }
     hipLaunchKernelGGL(reset_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), P.E), dim3(256), 0, st, P, D, 0);
     if (P.reinvig || P.cheat) hipLaunchKernelGGL(reset_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), P.E), dim3(256), 0, st, P, D, 1);
     hipLaunchKernelGGL(post_reset_kernel, dim3(ceil_div(P.E, 256)), dim3(256), 0, st, P, D);

@@ -52,6 +52,7 @@ struct DeviceState {
     float* p_rec_fc;    // same shape: the second filter of the reinvigoration (fully connected) / cheating (correct graph) belief
     uint8_t* bufsel_fc; // [E]
     double* lik;        // [E] cheating belief: CheatingReinvigoration::_likelihood; [E] holds the threshold
+    uint8_t* lazy_reset;  // [E] rejection filter: resetDomainStateDistribution is pending -- particle i's state is the RESET-stream draw, not the record's word
     int32_t* fault;     // [1] 0, or 1 + the slot whose rejection update exceeded REJECT_MAX_ATTEMPTS (host reports it)
     uint8_t* cheat_pending;  // [E] the update of this tick pushed log(likelihood) below the threshold
     double* wscan;      // [E][N] scratch: inclusive device-order prefix sums of normalised weights
