@@ -1355,6 +1355,7 @@ int fba_set_position(fba_ctx* c, const int32_t* run, const int32_t* episode, con
 {
     if (!c) return FBA_EINVAL;
     const size_t n = (size_t)c->P.E * 4;
+    if (run || episode) launch_materialize_reset(c->P, c->D, c->stream);  // a pending lazy reset belongs to the old (run, episode)
     if (run) HIPCHK(c, hipMemcpyAsync(c->D.run, run, n, hipMemcpyHostToDevice, c->stream));
     if (episode) HIPCHK(c, hipMemcpyAsync(c->D.episode, episode, n, hipMemcpyHostToDevice, c->stream));
     if (t) HIPCHK(c, hipMemcpyAsync(c->D.t, t, n, hipMemcpyHostToDevice, c->stream));
