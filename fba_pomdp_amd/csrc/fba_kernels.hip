@@ -181,9 +181,16 @@ __device__ __forceinline__ int ucb_select(const Problem& P, const DeviceState& D
 // ---------------------------------------------------------------------------------------------
 // FTIGER > 0: the simulator is the factored-tiger FBA-POMDP with FTIGER binary state features (expected
 // Dirichlet mode); its step is ftiger_step<FTIGER>, the layout restated as literals.
-template <bool STAGE, int AMAX, bool REG, bool TIGER_TABLE, int MODEL, int FTIGER = 0>
+// TIGER_POMDP: planning on the tiger POMDP itself (BASELINE configs[0]); the sizes and the domain are literals.
+template <bool STAGE, int AMAX, bool REG, bool TIGER_TABLE, int MODEL, int FTIGER = 0, bool TIGER_POMDP = false>
 __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceState D)
 {
+    if (TIGER_POMDP) {
+        P.S = 2; P.A = 3; P.O = 2; P.C = 0; P.Cs = 4; P.planner = FBA_PLANNER_POUCT;
+        if (P.domain != FBA_DOM_TIGER_CONTINUOUS) P.domain = FBA_DOM_TIGER_EPISODIC;
+        P.belief = P.belief == FBA_BELIEF_IMPORTANCE ? FBA_BELIEF_IMPORTANCE : FBA_BELIEF_REJECTION;
+        D.cq_off = 4; D.child_off = 10; D.node_words = 16; D.hash = nullptr;  // node layout of A = 3, O = 2 (fba_engine.hip)
+    }
     // one instantiation per simulator: the launcher passes the model it read from P, so restating it
     // here drops the other simulators' code (a plain-POMDP search carries every domain's step(),
     // the Bayes-adaptive ones none of them) from this instantiation
@@ -1331,6 +1338,11 @@ void launch_search(const Problem& P, const DeviceState& D, hipStream_t st)
                              (P.domain == FBA_DOM_TIGER_EPISODIC || P.domain == FBA_DOM_TIGER_CONTINUOUS) && !D.hash;
     if (tiger_table) {
         hipLaunchKernelGGL((search_kernel<true, 4, false, true, FBA_MODEL_BA_TABLE>), grid, block, lds, st, P, D);
+        return;
+    }
+    if (P.model == FBA_MODEL_POMDP && P.planner == FBA_PLANNER_POUCT && !D.hash &&
+        (P.domain == FBA_DOM_TIGER_EPISODIC || P.domain == FBA_DOM_TIGER_CONTINUOUS)) {
+        hipLaunchKernelGGL((search_kernel<false, 4, false, false, FBA_MODEL_POMDP, 0, true>), grid, block, lds, st, P, D);
         return;
     }
     if (P.model == FBA_MODEL_BA_FACTORED && (P.domain == FBA_DOM_FTIGER_EPISODIC || P.domain == FBA_DOM_FTIGER_CONTINUOUS) &&
