@@ -567,9 +567,14 @@ __device__ __forceinline__ int record_group(int C4)
 // ---------------------------------------------------------------------------------------------
 // `fc` = 1 runs the update on the reinvigoration belief's fully connected filter (launched before
 // the main filter's update, which is the one that clears the request flag).
-template <bool REG, bool TIGER_TABLE>
+template <bool REG, bool TIGER_TABLE, int FTIGER = 0>
 __global__ void __launch_bounds__(REJECT_BLOCK) reject_kernel(Problem P, DeviceState D, int fc)
 {
+    if (FTIGER > 0) {  // factored tiger with FTIGER binary state features (see search_kernel)
+        P.model = FBA_MODEL_BA_FACTORED;
+        P.S = 1 << FTIGER; P.A = 3; P.O = 2;
+        if (P.domain != FBA_DOM_FTIGER_CONTINUOUS) P.domain = FBA_DOM_FTIGER_EPISODIC;
+    }
     if (TIGER_TABLE) {  // sizes restated as literals (see search_kernel)
         fc = 0;
         P.model = FBA_MODEL_BA_TABLE;
@@ -612,7 +617,9 @@ __global__ void __launch_bounds__(REJECT_BLOCK) reject_kernel(Problem P, DeviceS
         const float* rec = scn + (size_t)src * P.Cs;
         int s = (!fc && lazy) ? lazy_state(P, D, e, src) : rec_state(rec, P.C), so;
         double r;
-        sim_step<REG>(P, g, GlobalView{rec}, s, a, so, r, LdsInc<REJECT_BLOCK>{s_inc + tid});  // UpdateCounts: the +1s land in the copy
+        // UpdateCounts: the +1s land in the copy
+        if (FTIGER > 0) ftiger_step<(FTIGER > 0 ? FTIGER : 1)>(P, g, GlobalView{rec}, s, a, so, r, LdsInc<REJECT_BLOCK>{s_inc + tid});
+        else sim_step<REG>(P, g, GlobalView{rec}, s, a, so, r, LdsInc<REJECT_BLOCK>{s_inc + tid});
         s_src[tid] = src;
         s_ns[tid]  = s;
         const bool ok = (so == o);
@@ -1383,8 +1390,14 @@ void launch_belief_update(const Problem& P, const DeviceState& D, hipStream_t st
         const bool tiger_table = P.model == FBA_MODEL_BA_TABLE && !P.dirichlet_regular &&
                                  (P.domain == FBA_DOM_TIGER_EPISODIC || P.domain == FBA_DOM_TIGER_CONTINUOUS);
         if (P.reinvig) hipLaunchKernelGGL(reinvigorate_kernel, dim3(P.E), dim3(256), 0, st, P, D);
+        const int ft = (P.model == FBA_MODEL_BA_FACTORED && !P.dirichlet_regular &&
+                        (P.domain == FBA_DOM_FTIGER_EPISODIC || P.domain == FBA_DOM_FTIGER_CONTINUOUS))
+                           ? 31 - __builtin_clz((unsigned)P.S) : 0;  // S = 2^FS
         for (int fc = P.reinvig ? 1 : 0; fc >= 0; --fc) {  // the main filter's launch clears the request flag: last
-            if (P.dirichlet_regular) hipLaunchKernelGGL((reject_kernel<true, false>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
+            if (ft == 2) hipLaunchKernelGGL((reject_kernel<false, false, 2>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
+            else if (ft == 3) hipLaunchKernelGGL((reject_kernel<false, false, 3>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
+            else if (ft == 4) hipLaunchKernelGGL((reject_kernel<false, false, 4>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
+            else if (P.dirichlet_regular) hipLaunchKernelGGL((reject_kernel<true, false>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
             else if (tiger_table) hipLaunchKernelGGL((reject_kernel<false, true>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
             else hipLaunchKernelGGL((reject_kernel<false, false>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
         }
