@@ -765,6 +765,46 @@ __device__ __forceinline__ bool ftiger_step(const Problem& P, Rng& g, const View
     return t;
 }
 
+// fact_step for the gridworld FBA-POMDP, with what the generic code reads from the model description
+// restated from build_gridworld_factored_prior's layout (features x, y, goal; XY = N*N*G*N, GG = N*N*G*G):
+//   T(a, x) at a*(2XY+GG), T(a, y) at +XY: parents {x, y} (mask 3: row (x*N+y)) or {x, y, goal} (mask 7: row
+//   ((x*N+y)*G+goal)), N entries; T(a, goal) at +2XY: row ((x*N+y)*G+goal), G entries;
+//   O(a, f) after all T nodes, per action N*N + N*N + G*G: row = value of feature f; masks at ncounts + 2a + f.
+// Same draws, same order, same increments as fact_step (observation rows incremented at the OLD state's values).
+template <class View, class Sink>
+__device__ __forceinline__ bool gridworld_fact_step(const Problem& P, Rng& g, const View& cnt, int& s, int a, int& o, double& r, const Sink& inc)
+{
+    const GridDesc* gw = P.gw;
+    const int N = gw->N, G = gw->G, A = P.A;
+    const int XY = N * N * G * N, GG = N * N * G * G, NN = N * N;
+    const int x = s / (N * G), y = (s / G) % N, gl = s % G;
+    const int tbase = a * (2 * XY + GG), obase = A * (2 * XY + GG) + a * (2 * NN + G * G);
+    const int ncounts = A * (2 * XY + GG) + A * (2 * NN + G * G);
+    const int cell = x * N + y;
+    const uint32_t mx = __float_as_uint(cnt.at(ncounts + 2 * a)), my = __float_as_uint(cnt.at(ncounts + 2 * a + 1));
+    const int rx = tbase + ((mx & 4u) ? cell * G + gl : cell) * N;
+    const int ry = tbase + XY + ((my & 4u) ? cell * G + gl : cell) * N;
+    const int rg = tbase + 2 * XY + (cell * G + gl) * G;
+    const int nx = sample_expected_mult(g, cnt, rx, N);
+    inc.add(0, rx + nx);
+    const int ny = sample_expected_mult(g, cnt, ry, N);
+    inc.add(1, ry + ny);
+    const int ng = sample_expected_mult(g, cnt, rg, G);
+    inc.add(2, rg + ng);
+    const int ns = (nx * N + ny) * G + ng;
+    const int ox = sample_expected_mult(g, cnt, obase + nx * N, N);
+    inc.add(3, obase + x * N + ox);
+    const int oy = sample_expected_mult(g, cnt, obase + NN + ny * N, N);
+    inc.add(4, obase + NN + y * N + oy);
+    const int og = sample_expected_mult(g, cnt, obase + 2 * NN + ng * G, G);
+    inc.add(5, obase + 2 * NN + gl * G + og);
+    o = (ox * N + oy) * G + og;
+    const bool t = ext_terminal(P, s, a, ns);
+    r            = ext_reward(P, s, a, ns);
+    s            = ns;
+    return t;
+}
+
 // BABNModel::computeObservationProbability (BABNModel.cpp:328-352)
 template <bool REG, class View>
 __device__ __forceinline__ double fact_obs_prob(const Problem& P, Rng& g, const View& cnt, int new_s, int a, int o)
@@ -799,7 +839,10 @@ template <bool REG, class View, class Sink>
 __device__ __forceinline__ bool sim_step(const Problem& P, Rng& g, const View& cnt, int& s, int a, int& o, double& r, const Sink& inc)
 {
     if (P.model == FBA_MODEL_POMDP) return domain_step(P, g, s, a, o, r);
-    if (P.model == FBA_MODEL_BA_FACTORED) return fact_step<REG>(P, g, cnt, s, a, o, r, inc);
+    if (P.model == FBA_MODEL_BA_FACTORED) {
+        if (!REG && dom_is_grid(P.domain)) return gridworld_fact_step(P, g, cnt, s, a, o, r, inc);
+        return fact_step<REG>(P, g, cnt, s, a, o, r, inc);
+    }
     const int S = P.S, A = P.A, O = P.O;
     const int t_off = s * A * S + a * S;
     const int ns    = sample_row<REG>(P, g, cnt, t_off, S);
