@@ -237,6 +237,7 @@ struct Problem {
     float noise, counts_total;
     int32_t structure_prior;
     int32_t domain, model, belief, planner;
+    int32_t ca_plain;   // collision avoidance, factored model with the correct-graph layout (one parent per node, no masks): ca_fact_step applies
     int32_t fd_bytes;   // bytes of *fd in use (header + A*(FS+FO) nodes): what a kernel stages in LDS
     int32_t cheat;      // cheating belief: particles copied from the correct-graph filter per cheat (belief = IMPORTANCE then); 0 = off
     int32_t reinvig;    // reinvigoration belief: particles bred per update (belief = REJECTION then); 0 = off
@@ -805,6 +806,51 @@ __device__ __forceinline__ bool gridworld_fact_step(const Problem& P, Rng& g, co
     return t;
 }
 
+// fact_step for the collision-avoidance FBA-POMDP with the correct-graph prior (no per-particle masks:
+// fd->nvar == 0, every node has the one parent it should), layout of build_ca_factored_prior restated:
+//   per action  T(x) W*W at +0, T(y) H*H at +W*W, T(obstacle k) H*H at +W*W + H*H*(1+k);  row = own value
+//   O(a, k) H*H after all T nodes at a*n*H*H + k*H*H;  row = the obstacle's (new) position.
+// Same draws, same order, same increments as fact_step.
+template <class View, class Sink>
+__device__ __forceinline__ bool ca_fact_step(const Problem& P, Rng& g, const View& cnt, int& s, int a, int& o, double& r, const Sink& inc)
+{
+    const CADesc* ca = P.ca;
+    const int W = ca->W, H = ca->H, n = ca->n, Hn = ca->Hn, A = P.A;
+    const int tsize = W * W + H * H * (1 + n), tbase = a * tsize, obase = A * tsize + a * n * H * H;
+    const int x = s / (H * Hn), y = (s / Hn) % H, packed = s % Hn;
+    const int rx = tbase + x * W;
+    const int nx = sample_expected_mult(g, cnt, rx, W);
+    inc.add(0, rx + nx);
+    const int ry = tbase + W * W + y * H;
+    const int ny = sample_expected_mult(g, cnt, ry, H);
+    inc.add(1, ry + ny);
+    int nobs = 0;
+#pragma unroll
+    for (int k = 0; k < MAXF - 2; ++k)
+        if (k < n) {
+            const int b   = ca_obstacle(ca, packed, k);
+            const int row = tbase + W * W + H * H * (1 + k) + b * H;
+            const int nb  = sample_expected_mult(g, cnt, row, H);
+            inc.add(2 + k, row + nb);
+            nobs = nobs * H + nb;
+        }
+    const int ns = (nx * H + ny) * Hn + nobs;
+    int oobs = 0;
+#pragma unroll
+    for (int k = 0; k < MAXF - 2; ++k)
+        if (k < n) {
+            const int nb = ca_obstacle(ca, nobs, k), b = ca_obstacle(ca, packed, k);
+            const int ob = sample_expected_mult(g, cnt, obase + k * H * H + nb * H, H);
+            inc.add(2 + n + k, obase + k * H * H + b * H + ob);  // incremented at the OLD position (App. A #6)
+            oobs = oobs * H + ob;
+        }
+    o = oobs;
+    const bool t = ext_terminal(P, s, a, ns);
+    r            = ext_reward(P, s, a, ns);
+    s            = ns;
+    return t;
+}
+
 // BABNModel::computeObservationProbability (BABNModel.cpp:328-352)
 template <bool REG, class View>
 __device__ __forceinline__ double fact_obs_prob(const Problem& P, Rng& g, const View& cnt, int new_s, int a, int o)
@@ -841,6 +887,7 @@ __device__ __forceinline__ bool sim_step(const Problem& P, Rng& g, const View& c
     if (P.model == FBA_MODEL_POMDP) return domain_step(P, g, s, a, o, r);
     if (P.model == FBA_MODEL_BA_FACTORED) {
         if (!REG && dom_is_grid(P.domain)) return gridworld_fact_step(P, g, cnt, s, a, o, r, inc);
+        if (!REG && dom_is_ca(P.domain) && P.ca_plain) return ca_fact_step(P, g, cnt, s, a, o, r, inc);
         return fact_step<REG>(P, g, cnt, s, a, o, r, inc);
     }
     const int S = P.S, A = P.A, O = P.O;

@@ -1082,6 +1082,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     P.ca = nullptr;
     P.sys = nullptr;
     P.fd_bytes = 0;
+    P.ca_plain = 0;
     P.zig = nullptr;
     P.dirichlet_regular = cfg->dirichlet_regular ? 1 : 0;
     if (cfg->model == FBA_MODEL_BA_TABLE) {
@@ -1305,6 +1306,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         for (int k = 0; k < nnodes; ++k)
             for (int j = 0; j < fdh.nodes[k].nmax; ++j) fdh.nodes[k].psz[j] = (uint8_t)fdh.Ssz[fdh.nodes[k].maxp[j]];
         P.fd_bytes = (int32_t)(offsetof(FDesc, nodes) + (size_t)nnodes * sizeof(FNode));
+        P.ca_plain = is_ca(cfg->domain) && fdh.nvar == 0 && fdh.nodes[2].nmax == 1;  // correct graph, no masks (not fully-connected)
         CHK(dev_alloc(c, &c->d_fdesc, 1));
         HIPC(hipMemcpyAsync(c->d_fdesc, &c->fdesc, sizeof(FDesc), hipMemcpyHostToDevice, c->stream));
         P.fd = c->d_fdesc;
