@@ -87,6 +87,23 @@ struct GlobalSearchView {
     static constexpr bool row_regs = true;
     __device__ __forceinline__ float at(int k) const { return p[k]; }
 };
+// A record seen through increments that have not been written yet: at(k) = base.at(k) + 1.0f for every
+// pending increment of cell k, added one at a time as incrementCountsOf would (importance update:
+// the observation probability is read from the counts AFTER the step's increments).
+template <class Base>
+struct PendingIncView {
+    Base base;
+    const int32_t* col;  // pending cell indices col[q * stride], q < ninc
+    int stride, ninc;
+    static constexpr bool row_regs = Base::row_regs;
+    __device__ __forceinline__ float at(int k) const
+    {
+        float v = base.at(k);
+        for (int q = 0; q < ninc; ++q)
+            if (col[q * stride] == k) v += 1.0f;
+        return v;
+    }
+};
 template <int STRIDE>
 struct LdsView {
     const float* p;

@@ -1161,7 +1161,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     }
 
     // slots
-    const size_t per_slot = (size_t)P.N * (2 * 8 + 8 + ((P.reinvig || P.cheat) ? 4 : 2) * (size_t)P.Cs * 4) + (size_t)D.max_nodes * D.node_words * 4 + (size_t)hcap * 16 + 1024;
+    const size_t per_slot = (size_t)P.N * (2 * 8 + 8 + 4 * (MAXINC + 1) + ((P.reinvig || P.cheat) ? 4 : 2) * (size_t)P.Cs * 4) + (size_t)D.max_nodes * D.node_words * 4 + (size_t)hcap * 16 + 1024;
     int E = cfg->slots;
     if (E <= 0) {
         size_t free_b = 0, total_b = 0;
@@ -1194,6 +1194,8 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         CHK(dev_alloc(c, &D.bufsel_fc, E));
     }
     CHK(dev_alloc(c, &D.wscan, is ? (size_t)E * P.N : 1, false));
+    D.side_w = 1 + (P.model == FBA_MODEL_BA_FACTORED ? c->fdesc.FS + c->fdesc.FO : (P.model == FBA_MODEL_BA_TABLE ? 2 : 0));
+    CHK(dev_alloc(c, &D.p_side, is ? (size_t)E * P.N * D.side_w : 1, false));
     {
         // one workgroup per slot up to IS_MAX_CHUNKS*256 particles, several launches beyond
         // (FBA_IS_MULTI_MIN lowers the switch-over so tests can exercise the large-filter path)

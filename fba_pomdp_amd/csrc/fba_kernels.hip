@@ -563,6 +563,37 @@ __device__ __forceinline__ void gather_records(float* __restrict__ dst, const fl
     }
 }
 
+// The importance filters' gather: output record j is source record s_src[j] with that SOURCE particle's
+// pending update applied -- new state and +1s from its row of the side array (written by the update
+// pass, which leaves the source buffer untouched: no partial-line write-backs).
+__device__ __forceinline__ void gather_records_side(float* __restrict__ dst, const float* __restrict__ src, const int32_t* s_src,
+                                                    const int32_t* __restrict__ side, int side_w, int m, int C4, int C, int group,
+                                                    int nthreads)
+{
+    const int gid = threadIdx.x / group, part0 = threadIdx.x % group, ngroups = nthreads / group;
+    const int ninc = side_w - 1;
+    for (int j = gid; j < m; j += ngroups) {
+        const int p      = s_src[j];
+        const float4* sp = reinterpret_cast<const float4*>(src) + (size_t)p * C4;
+        float4* dp       = reinterpret_cast<float4*>(dst) + (size_t)j * C4;
+        const int32_t* sd = side + (size_t)p * side_w;
+        const float nstate = __int_as_float(sd[0]);
+        for (int part = part0; part < C4; part += group) {
+            float4 v = sp[part];
+            const int lo = part * 4;
+            for (int k = 0; k < ninc; ++k) bump(v, sd[1 + k] - lo, 1.0f);
+            const int d = C - lo;
+            if (d == 0) v.x = nstate; else if (d == 1) v.y = nstate; else if (d == 2) v.z = nstate; else if (d == 3) v.w = nstate;
+            dp[part] = v;
+        }
+    }
+}
+
+// Deferring the increments to the gather pays when a record is a line or two (the update pass then dirties
+// nothing); for records of many lines the in-place update touches only the FS + FO lines it increments and the
+// gather stays a plain copy, which is cheaper than testing every 16-byte piece against every pending cell.
+__device__ __forceinline__ bool defer_increments(const Problem& P) { return P.Cs <= 64; }
+
 __device__ __forceinline__ int record_group(int C4)
 {
     int g = 1;
@@ -897,6 +928,8 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
     double* dw      = D.p_weight + db;
     float* dcn      = D.p_rec + db * (size_t)P.Cs;
     double* wscan   = D.wscan + (size_t)e * N;
+    int32_t* side   = D.p_side + (size_t)e * N * D.side_w;
+    const bool defer = defer_increments(P);
     const int C4 = P.Cs / 4, group = record_group(C4);
     const int ninc = model_ninc(P);
     Rng g = slot_rng(P, D, e);
@@ -907,9 +940,19 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
         int s = rec_state(cnt, P.C), so;
         double r;
         sim_step<REG>(P, g, GlobalView{cnt}, s, a, so, r, LdsInc<IS_BLOCK>{s_inc + tid});
-        for (int q = 0; q < ninc; ++q) cnt[s_inc[q * IS_BLOCK + tid]] += 1.0f;  // incrementCountsOf (BAFlatModel.cpp:126-139, BABNModel.cpp:354-382)
-        rec_set_state(cnt, P.C, s);
-        sw[i] *= sim_obs_prob<REG>(P, g, GlobalView{cnt}, s, a, o);  // probability from the updated counts
+        // incrementCountsOf (BAFlatModel.cpp:126-139, BABNModel.cpp:354-382) is deferred to the gather: the new
+        // state and the cells go to the side array, the record is only read
+        if (defer) {
+            int32_t* sd = side + (size_t)i * D.side_w;
+            sd[0] = s;
+            for (int q = 0; q < ninc; ++q) sd[1 + q] = s_inc[q * IS_BLOCK + tid];
+            // probability from the updated counts
+            sw[i] *= sim_obs_prob<REG>(P, g, PendingIncView<GlobalView>{GlobalView{cnt}, s_inc + tid, IS_BLOCK, ninc}, s, a, o);
+        } else {
+            for (int q = 0; q < ninc; ++q) cnt[s_inc[q * IS_BLOCK + tid]] += 1.0f;
+            rec_set_state(cnt, P.C, s);
+            sw[i] *= sim_obs_prob<REG>(P, g, GlobalView{cnt}, s, a, o);
+        }
     }
     __syncthreads();
     const double total = block_device_scan(sw, N, nullptr, s_carry);
@@ -927,7 +970,8 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
         }
         __syncthreads();
         const int m = min(IS_BLOCK, N - j0);
-        gather_records(dcn + (size_t)j0 * P.Cs, scn, nullptr, s_src, nullptr, 0, 0, nullptr, m, C4, P.C, group, IS_BLOCK);
+        if (defer) gather_records_side(dcn + (size_t)j0 * P.Cs, scn, s_src, side, D.side_w, m, C4, P.C, group, IS_BLOCK);
+        else gather_records(dcn + (size_t)j0 * P.Cs, scn, nullptr, s_src, nullptr, 0, 0, nullptr, m, C4, P.C, group, IS_BLOCK);
         __syncthreads();
     }
     if (tid == 0) {
@@ -1069,9 +1113,16 @@ __global__ void __launch_bounds__(256) is_multi_step_kernel(Problem P, DeviceSta
             int s = rec_state(cnt, P.C), so;
             double r;
             sim_step<REG>(P, g, GlobalView{cnt}, s, a, so, r, LdsInc<256>{s_inc + tid});
-            for (int q = 0; q < ninc; ++q) cnt[s_inc[q * 256 + tid]] += 1.0f;
-            rec_set_state(cnt, P.C, s);
-            v     = sw[i] * sim_obs_prob<REG>(P, g, GlobalView{cnt}, s, a, o);
+            if (defer_increments(P)) {  // see importance_kernel
+                int32_t* sd = D.p_side + ((size_t)e * N + i) * D.side_w;
+                sd[0] = s;
+                for (int q = 0; q < ninc; ++q) sd[1 + q] = s_inc[q * 256 + tid];
+                v = sw[i] * sim_obs_prob<REG>(P, g, PendingIncView<GlobalView>{GlobalView{cnt}, s_inc + tid, 256, ninc}, s, a, o);
+            } else {
+                for (int q = 0; q < ninc; ++q) cnt[s_inc[q * 256 + tid]] += 1.0f;
+                rec_set_state(cnt, P.C, s);
+                v = sw[i] * sim_obs_prob<REG>(P, g, GlobalView{cnt}, s, a, o);
+            }
             sw[i] = v;
         }
         sum = (k == 0) ? v : sum + v;
@@ -1120,8 +1171,12 @@ __global__ void __launch_bounds__(256) is_multi_resample_kernel(Problem P, Devic
         D.p_weight[db + j] = 1.0 / (double)N;
     }
     __syncthreads();
-    gather_records(D.p_rec + (db + j0) * (size_t)P.Cs, D.p_rec + sb * (size_t)P.Cs, nullptr, s_src, nullptr, 0, 0, nullptr,
-                   min(256, N - j0), C4, P.C, group, 256);
+    if (defer_increments(P))
+        gather_records_side(D.p_rec + (db + j0) * (size_t)P.Cs, D.p_rec + sb * (size_t)P.Cs, s_src, D.p_side + (size_t)e * N * D.side_w, D.side_w,
+                            min(256, N - j0), C4, P.C, group, 256);
+    else
+        gather_records(D.p_rec + (db + j0) * (size_t)P.Cs, D.p_rec + sb * (size_t)P.Cs, nullptr, s_src, nullptr, 0, 0, nullptr,
+                       min(256, N - j0), C4, P.C, group, 256);
 }
 
 __global__ void __launch_bounds__(256) is_multi_scan_kernel(Problem P, DeviceState D)
