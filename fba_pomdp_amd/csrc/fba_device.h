@@ -43,8 +43,8 @@ struct Rng {
             uint32_t a = k0, b = k1;
 #pragma unroll
             for (int i = 0; i < 10; ++i) {
-                uint32_t hi0 = __umulhi(0xD2511F53u, x0), lo0 = 0xD2511F53u * x0;
-                uint32_t hi1 = __umulhi(0xCD9E8D57u, x2), lo1 = 0xCD9E8D57u * x2;
+                const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)x0, p1 = (uint64_t)0xCD9E8D57u * (uint64_t)x2;  // one 32x32->64 multiply each
+                const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
                 uint32_t n0 = hi1 ^ x1 ^ a, n2 = hi0 ^ x3 ^ b;
                 x0 = n0; x1 = lo1; x2 = n2; x3 = lo0;
                 a += 0x9E3779B9u;
