@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
             cnt = prec + (size_t)src * P.Cs;
             if (STAGE) {
                 const float4* rp = reinterpret_cast<const float4*>(cnt);
-                const int n4 = P.Cs >> 2;
+                const int n4 = (P.C + 4) >> 2;  // counts and the state word; the padding behind them is not needed
                 for (int k = 0; k < n4; ++k) {
                     const float4 v = rp[k];
                     stage[(4 * k + 0) * SEARCH_BLOCK] = v.x;
