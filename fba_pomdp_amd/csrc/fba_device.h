@@ -254,7 +254,7 @@ struct Problem {
     float noise, counts_total;
     int32_t structure_prior;
     int32_t domain, model, belief, planner;
-    int32_t ca_plain;   // collision avoidance, factored model with the correct-graph layout (one parent per node, no masks): ca_fact_step applies
+    int32_t ca_plain;   // collision avoidance / sysadmin, factored model in the prior's own fixed graph (no masks): ca_fact_step / sysadmin_fact_step apply
     int32_t fd_bytes;   // bytes of *fd in use (header + A*(FS+FO) nodes): what a kernel stages in LDS
     int32_t cheat;      // cheating belief: particles copied from the correct-graph filter per cheat (belief = IMPORTANCE then); 0 = off
     int32_t reinvig;    // reinvigoration belief: particles bred per update (belief = REJECTION then); 0 = off
@@ -868,6 +868,47 @@ __device__ __forceinline__ bool ca_fact_step(const Problem& P, Rng& g, const Vie
     return t;
 }
 
+// fact_step for the sysadmin FBA-POMDP with the prior's own graph (no per-particle masks: fd->nvar == 0),
+// layout of build_sysadmin_factored_prior restated.  Feature c (the model's computer c) is bit N-1-c of s.
+//   independent: T(a, c) parent {c}: 4 floats at a*4N + 4c, row = value of c
+//   linear:      T(a, c) parents {c-1, c, c+1} clipped: c = 0 -> 8 floats at +0 (N = 1: 4), 0 < c < N-1 -> 16
+//                floats at 8 + 16(c-1), c = N-1 -> 8 floats at 8 + 16(N-2); row = parent values, last fastest
+//   O(a) parent {a mod N}: 4 floats after all T nodes at 4a
+// Same draws, same order, same increments as fact_step.
+template <class View, class Sink>
+__device__ __forceinline__ bool sysadmin_fact_step(const Problem& P, Rng& g, const View& cnt, int& s, int a, int& o, double& r, const Sink& inc)
+{
+    const int N = P.sys->N, A = P.A;
+    const bool linear = P.domain == FBA_DOM_SYSADMIN_LINEAR;
+    const int tsize = !linear ? 4 * N : (N == 1 ? 4 : 16 * N - 16);
+    const int tbase = a * tsize, obase = A * tsize + 4 * a;
+    int ns = 0;
+#pragma unroll
+    for (int c = 0; c < MAXF; ++c)
+        if (c < N) {
+            const int v = (s >> (N - 1 - c)) & 1;
+            int off, row;
+            if (!linear || N == 1) { off = 4 * c; row = v; }
+            else {
+                const int vl = c > 0 ? (s >> (N - c)) & 1 : 0, vr = c < N - 1 ? (s >> (N - 2 - c)) & 1 : 0;
+                if (c == 0) { off = 0; row = v * 2 + vr; }
+                else if (c == N - 1) { off = 8 + 16 * (N - 2); row = vl * 2 + v; }
+                else { off = 8 + 16 * (c - 1); row = (vl * 2 + v) * 2 + vr; }
+            }
+            const int cell = tbase + off + 2 * row;
+            const int nv   = sample_expected_mult(g, cnt, cell, 2);
+            inc.add(c, cell + nv);
+            ns = ns * 2 + nv;
+        }
+    const int f = a % N;  // the operated computer's feature
+    o = sample_expected_mult(g, cnt, obase + 2 * ((ns >> (N - 1 - f)) & 1), 2);
+    inc.add(N, obase + 2 * ((s >> (N - 1 - f)) & 1) + o);  // incremented at the OLD state's value (App. A #6)
+    const bool t = ext_terminal(P, s, a, ns);
+    r            = ext_reward(P, s, a, ns);
+    s            = ns;
+    return t;
+}
+
 // BABNModel::computeObservationProbability (BABNModel.cpp:328-352)
 template <bool REG, class View>
 __device__ __forceinline__ double fact_obs_prob(const Problem& P, Rng& g, const View& cnt, int new_s, int a, int o)
@@ -905,6 +946,7 @@ __device__ __forceinline__ bool sim_step(const Problem& P, Rng& g, const View& c
     if (P.model == FBA_MODEL_BA_FACTORED) {
         if (!REG && dom_is_grid(P.domain)) return gridworld_fact_step(P, g, cnt, s, a, o, r, inc);
         if (!REG && dom_is_ca(P.domain) && P.ca_plain) return ca_fact_step(P, g, cnt, s, a, o, r, inc);
+        if (!REG && dom_is_sys(P.domain) && P.ca_plain) return sysadmin_fact_step(P, g, cnt, s, a, o, r, inc);
         return fact_step<REG>(P, g, cnt, s, a, o, r, inc);
     }
     const int S = P.S, A = P.A, O = P.O;

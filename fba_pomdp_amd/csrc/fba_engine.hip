@@ -1308,7 +1308,8 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         for (int k = 0; k < nnodes; ++k)
             for (int j = 0; j < fdh.nodes[k].nmax; ++j) fdh.nodes[k].psz[j] = (uint8_t)fdh.Ssz[fdh.nodes[k].maxp[j]];
         P.fd_bytes = (int32_t)(offsetof(FDesc, nodes) + (size_t)nnodes * sizeof(FNode));
-        P.ca_plain = is_ca(cfg->domain) && fdh.nvar == 0 && fdh.nodes[2].nmax == 1;  // correct graph, no masks (not fully-connected)
+        P.ca_plain = (is_ca(cfg->domain) && fdh.nvar == 0 && fdh.nodes[2].nmax == 1) ||  // correct graph, no masks (not fully-connected)
+                     (is_sys(cfg->domain) && fdh.nvar == 0);
         CHK(dev_alloc(c, &c->d_fdesc, 1));
         HIPC(hipMemcpyAsync(c->d_fdesc, &c->fdesc, sizeof(FDesc), hipMemcpyHostToDevice, c->stream));
         P.fd = c->d_fdesc;
