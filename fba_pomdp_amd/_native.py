@@ -31,7 +31,7 @@ DOM_TIGER_EPISODIC, DOM_TIGER_CONTINUOUS, DOM_FTIGER_EPISODIC, DOM_FTIGER_CONTIN
 DOM_SYSADMIN_INDEPENDENT, DOM_SYSADMIN_LINEAR = 7, 8
 MODEL_POMDP, MODEL_BA_TABLE, MODEL_BA_FACTORED = range(3)
 BELIEF_REJECTION, BELIEF_IMPORTANCE, BELIEF_REINVIGORATION, BELIEF_CHEATING = range(4)
-PLANNER_POUCT, PLANNER_RANDOM = range(2)
+PLANNER_POUCT, PLANNER_RANDOM, PLANNER_TS = range(3)
 OK, EINVAL, EHIP, ENODEVICE, ESTATE = 0, -1, -2, -3, -4
 
 DOMAIN_NAMES = {  # reference -D strings (DomainConf.cpp)
@@ -43,7 +43,7 @@ DOMAIN_NAMES = {  # reference -D strings (DomainConf.cpp)
 }
 BELIEF_NAMES = {"rejection_sampling": BELIEF_REJECTION, "importance_sampling": BELIEF_IMPORTANCE,
                 "reinvigoration": BELIEF_REINVIGORATION, "cheating-reinvigoration": BELIEF_CHEATING}
-PLANNER_NAMES = {"po-uct": PLANNER_POUCT, "random": PLANNER_RANDOM}
+PLANNER_NAMES = {"po-uct": PLANNER_POUCT, "random": PLANNER_RANDOM, "ts": PLANNER_TS}
 
 
 class Config(C.Structure):

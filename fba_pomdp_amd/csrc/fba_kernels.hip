@@ -286,6 +286,14 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
     }
 
     const bool lazy = slot_lazy(D, e);  // particle states are still the episode's start-state draws (lazy_state)
+    // -P ts: TSPlanner / BATSPlanner (src/planners/ts/TSPlanner.cpp:16-29, bayes-adaptive/BATSPlanner.cpp:19-34) sample
+    // the belief once and plan on that point estimate, whose sample() draws nothing: every simulation starts
+    // from the same particle and its stream begins with the UCB tie-break.
+    int ts_src = -1;
+    if (P.planner == FBA_PLANNER_TS) {
+        g.stream(FBA_PHASE_SEARCH, (uint32_t)P.sims + 2u);
+        ts_src = belief_sample_uniform(P, D, g);
+    }
     int sim = 0, mode = 0;  // 0 = start a simulation, 1 = in the tree, 2 = rollout
     int s = 0, node = 0, dtg = 0, plen = 0, rdepth = 0;
     const float* cnt = prec;
@@ -294,7 +302,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
         if (mode == 0) {
             if (sim >= P.sims) break;
             g.stream(FBA_PHASE_SEARCH, (uint32_t)sim);
-            const int src = belief_sample_uniform(P, D, g);
+            const int src = ts_src >= 0 ? ts_src : belief_sample_uniform(P, D, g);
             cnt = prec + (size_t)src * P.Cs;
             if (STAGE) {
                 const float4* rp = reinterpret_cast<const float4*>(cnt);

@@ -49,7 +49,7 @@ void usage()
         "      --runs N                   Number of runs (1)\n"
         "  -H, --horizon N                Horizon, number of steps per episode (10)\n"
         "  -d, --discount X               Discount for future rewards (0.95)\n"
-        "  -P, --planner NAME             random or po-uct (po-uct)\n"
+        "  -P, --planner NAME             random, ts (Thompson sampling) or po-uct (po-uct)\n"
         "  -B, --belief NAME              rejection_sampling, importance_sampling or (fbapomdp) reinvigoration,\n"
         "                                 cheating-reinvigoration\n"
         "      --seed STR                 Global seed for all random samples\n"
@@ -152,7 +152,8 @@ bool to_config(Options const& o, fba_config& c, std::string& err)
     c.domain = domains.at(o.domain);
     if (o.planner == "po-uct" || o.planner == "hip-po-uct") c.planner = FBA_PLANNER_POUCT;
     else if (o.planner == "random") c.planner = FBA_PLANNER_RANDOM;
-    else { err = "please enter a legit planner: random or po-uct, provided: " + o.planner; return false; }
+    else if (o.planner == "ts") c.planner = FBA_PLANNER_TS;
+    else { err = "please enter a legit planner: random, ts or po-uct, provided: " + o.planner; return false; }
     if (o.belief == "rejection_sampling" || o.belief == "hip-rejection_sampling") c.belief = FBA_BELIEF_REJECTION;
     else if (o.belief == "importance_sampling" || o.belief == "hip-importance_sampling") c.belief = FBA_BELIEF_IMPORTANCE;
     else if (o.belief == "reinvigoration" && o.mode == "fbapomdp") c.belief = FBA_BELIEF_REINVIGORATION;  // BABelief.cpp:28-31

@@ -46,8 +46,8 @@ enum { FBA_MODEL_POMDP = 0, FBA_MODEL_BA_TABLE = 1, FBA_MODEL_BA_FACTORED = 2 };
  * (BABelief.cpp:28-31: ReinvigoratingRejectionSampling, factored models only) */
 enum { FBA_BELIEF_REJECTION = 0, FBA_BELIEF_IMPORTANCE = 1, FBA_BELIEF_REINVIGORATION = 2,
        FBA_BELIEF_CHEATING = 3 /* cheating-reinvigoration (BABelief.cpp:60-65: prototypes::CheatingReinvigoration) */ };
-/* -P po-uct | random (Planner.cpp:12-19) */
-enum { FBA_PLANNER_POUCT = 0, FBA_PLANNER_RANDOM = 1 };
+/* -P po-uct | random | ts (Planner.cpp:12-19, BAPlanner.cpp:13-20; ts = Thompson sampling: TSPlanner / BATSPlanner) */
+enum { FBA_PLANNER_POUCT = 0, FBA_PLANNER_RANDOM = 1, FBA_PLANNER_TS = 2 };
 /* --structure-prior (FBAConf.hpp) */
 enum { FBA_SP_NONE = 0, FBA_SP_UNIFORM = 1, FBA_SP_MATCH_UNIFORM = 2, FBA_SP_FULLY_CONNECTED = 3 };
 

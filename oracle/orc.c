@@ -2194,18 +2194,24 @@ static uint64_t belief_hash(orc_ctx* c)
 static int32_t select_action(orc_ctx* c, int hist_len, orc_trace_rec* rec)
 {
     int i, n = c->cfg.sims, a;
-    int32_t root, best;
+    int32_t root, best, ts_src = -1;
     c->step_counter = &c->sim_steps;
     if (c->cfg.planner == ORC_PLANNER_RANDOM) {
         /* ref: RandomPlanner::selectAction src/planners/random/RandomPlanner.cpp:14-24 */
         orc_rng_stream(&c->rng, ORC_PH_SEARCH, (uint32_t)n);
         return domain_random_action(c, c->P[belief_sample(c)].s);
     }
+    if (c->cfg.planner == ORC_PLANNER_TS) {
+        /* TSPlanner::selectAction (src/planners/ts/TSPlanner.cpp:16-29) / BATSPlanner (BATSPlanner.cpp:19-34):
+         * one belief.sample(), then PO-UCT on a point-estimate belief whose sample() draws nothing */
+        orc_rng_stream(&c->rng, ORC_PH_SEARCH, (uint32_t)n + 2);
+        ts_src = belief_sample(c);
+    }
     tree_reset(c);
     /* simulator.addLegalActions(belief.sample(), ...) : one belief draw, result unused here
      * because every supported domain has state-independent legal actions */
     orc_rng_stream(&c->rng, ORC_PH_SEARCH, (uint32_t)n);
-    (void)belief_sample(c);
+    if (ts_src < 0) (void)belief_sample(c);
     root = tree_new_node(c);
     {
         int d = c->cfg.horizon - hist_len;
@@ -2215,7 +2221,7 @@ static int32_t select_action(orc_ctx* c, int hist_len, orc_trace_rec* rec)
         simstate st;
         int32_t src;
         orc_rng_stream(&c->rng, ORC_PH_SEARCH, (uint32_t)i);
-        src    = belief_sample(c);
+        src    = ts_src >= 0 ? ts_src : belief_sample(c);
         st.s   = c->P[src].s;
         st.cnt = c->P[src].cnt;
         traverse_action(c, root, &st, c->tr.max_tree_depth);

@@ -45,7 +45,7 @@ enum { ORC_BELIEF_REJECTION = 0, ORC_BELIEF_IMPORTANCE = 1, ORC_BELIEF_REINVIGOR
  * REF = the reference's sequential loops; DEV = the HIP engine's fixed reduction tree */
 enum { ORC_ARITH_REF = 0, ORC_ARITH_DEV = 1 };
 /* planner (reference -P) */
-enum { ORC_PLANNER_POUCT = 0, ORC_PLANNER_RANDOM = 1 };
+enum { ORC_PLANNER_POUCT = 0, ORC_PLANNER_RANDOM = 1, ORC_PLANNER_TS = 2 /* -P ts: TSPlanner / BATSPlanner */ };
 /* FBA structure prior (reference FBAConf::structure_prior) */
 enum { ORC_SP_NONE = 0, ORC_SP_UNIFORM = 1, ORC_SP_MATCH_UNIFORM = 2, ORC_SP_FULLY_CONNECTED = 3 };
 

@@ -19,7 +19,7 @@ MODEL_POMDP, MODEL_BA_TABLE, MODEL_BA_FACTORED = range(3)
 BELIEF_REJECTION, BELIEF_IMPORTANCE, BELIEF_REINVIGORATION, BELIEF_CHEATING = range(4)
 ARITH_REF, ARITH_DEV = range(2)
 RNG_MT, RNG_PHILOX = range(2)
-PLANNER_POUCT, PLANNER_RANDOM = range(2)
+PLANNER_POUCT, PLANNER_RANDOM, PLANNER_TS = range(3)
 SP_NONE, SP_UNIFORM, SP_MATCH_UNIFORM, SP_FULLY_CONNECTED = range(4)
 PH_INIT, PH_RESET, PH_START, PH_SEARCH, PH_ENV, PH_REJECT, PH_IS_UPDATE, PH_RESAMPLE = range(8)
 MAX_ACTIONS = 16

@@ -59,7 +59,7 @@ def draw(rng):
         if model == N.MODEL_BA_FACTORED and longest <= 16 or model == N.MODEL_BA_TABLE and "tiger" in domain and "factored" not in domain:
             kw["dirichlet_regular"] = 1
     if rng.random() < 0.15:
-        kw["planner"] = "random"
+        kw["planner"] = rng.choice(["random", "ts"])
     return domain, model, belief, slots, kw
 
 

@@ -85,5 +85,8 @@ def test_cli_bapomdp_and_fbapomdp_write_one_line_per_episode(cli, tmp_path):
     r = subprocess.run([cli, "fbapomdp", "-D", "linear-sysadmin", "--size", "3", "-B", "cheating-reinvigoration", "--resample-amount", "4"],
                        capture_output=True, text=True)
     assert r.returncode == 1 and "resample_threshold >= 0" in r.stderr       # CheatingReinvigoration.cpp:36-40
+    r = subprocess.run([cli, "planning", "-D", "episodic-tiger", "-P", "ts", "-s", "64", "--particle-amount", "32", "--runs", "20",
+                        "-f", str(tmp_path / "ts.res")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
     r = subprocess.run([cli, "bapomdp", "-D", "episodic-tiger", "--noise", "0.9"], capture_output=True, text=True)
     assert r.returncode == 1 and "noise has to be between" in r.stderr      # TigerPriors.cpp:22-25

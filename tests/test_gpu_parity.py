@@ -25,6 +25,8 @@ def _pair(domain, model, belief, seed, slots=None, size=0, **kw):
     okw = dict(kw)
     if domain == "centered-collision-avoidance":
         okw["ca_centered"] = 1
+    if isinstance(okw.get("planner"), str):
+        okw["planner"] = N.PLANNER_NAMES[okw["planner"]]
     o = orc.Oracle(domain=DOM[domain], model=model, belief=N.BELIEF_NAMES[belief], rng_mode=orc.RNG_PHILOX,
                    arith=orc.ARITH_DEV, philox_seed=seed, trace=1, size=size, **okw)
     return eng, o
@@ -492,6 +494,19 @@ def test_bapomdp_slots_fewer_than_runs():
     eng, o = _pair("episodic-tiger", N.MODEL_BA_TABLE, "rejection_sampling", 24, slots=3, particles=64, sims=64,
                    runs=8, episodes=2)
     _assert_same_experiment(eng, o, ba=True)
+
+
+@pytest.mark.parametrize("domain,model,belief,kw", [
+    ("episodic-tiger", N.MODEL_POMDP, "rejection_sampling", {}),
+    ("episodic-tiger", N.MODEL_BA_TABLE, "importance_sampling", dict(episodes=3)),
+    ("gridworld", N.MODEL_BA_FACTORED, "importance_sampling", dict(episodes=2, size=3, structure_prior=2, horizon=8)),
+    ("linear-sysadmin", N.MODEL_BA_FACTORED, "rejection_sampling", dict(episodes=2, size=3, horizon=6)),
+])
+def test_thompson_sampling_planner(domain, model, belief, kw):
+    """-P ts: TSPlanner / BATSPlanner -- one belief sample, then PO-UCT from that single particle."""
+    kw = dict(kw)
+    eng, o = _pair(domain, model, belief, 311, size=kw.pop("size", 0), planner="ts", particles=64, sims=96, runs=6, slots=3, **kw)
+    _assert_same_experiment(eng, o, ba=model != N.MODEL_POMDP)
 
 
 def test_random_planner():
