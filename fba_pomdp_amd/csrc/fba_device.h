@@ -274,6 +274,7 @@ __device__ __forceinline__ bool dom_is_ftiger(int d) { return d == FBA_DOM_FTIGE
 __device__ __forceinline__ bool dom_is_episodic(int d) { return d == FBA_DOM_TIGER_EPISODIC || d == FBA_DOM_FTIGER_EPISODIC; }
 __device__ __forceinline__ bool dom_is_grid(int d) { return d == FBA_DOM_GRIDWORLD; }
 __device__ __forceinline__ bool dom_is_ca(int d) { return d == FBA_DOM_COLLISION_AVOID || d == FBA_DOM_COLLISION_AVOID_CENTERED; }
+__device__ __forceinline__ bool dom_is_coffee(int d) { return d == FBA_DOM_COFFEE || d == FBA_DOM_COFFEE_BOUTILIER; }
 __device__ __forceinline__ bool dom_is_sys(int d) { return d == FBA_DOM_SYSADMIN_INDEPENDENT || d == FBA_DOM_SYSADMIN_LINEAR; }
 
 // SysAdmin::numFailingNeighbours (SysAdmin.cpp:221-246): linear topology, neighbours c-1 and c+1
@@ -357,6 +358,7 @@ __device__ __forceinline__ int domain_start(const Problem& P, Rng& g)
 __device__ __forceinline__ int domain_random_action(const Problem& P, Rng& g, int /*s*/)
 {
     if (dom_is_grid(P.domain)) return g.slow_int(0, 4);  // GridWorld::generateRandomAction :220-226
+    if (dom_is_coffee(P.domain)) return g.boolean() ? 1 : 0;  // CoffeeProblem::generateRandomAction :27-34
     return g.uniform_int(P.A);
 }
 
@@ -365,6 +367,23 @@ __device__ __forceinline__ int domain_random_action(const Problem& P, Rng& g, in
 __device__ __forceinline__ bool domain_step(const Problem& P, Rng& g, int& s, int a, int& o, double& r)
 {
     const int d = P.domain;
+    if (dom_is_coffee(d)) {  // CoffeeProblem::step :67-148; bits: rains 1, umbrella 2, wet 4, has coffee 8, wants coffee 16
+        const bool boutilier = d == FBA_DOM_COFFEE_BOUTILIER;
+        const int st = s;
+        r = (st & 4) ? -1 : -.5;
+        if (st & 16) r += (st & 8) ? 2 : -2;
+        if (a == 0) {  // GetCoffee: two draws whatever the version; always hears Want_Coffee
+            if ((st & 1) && !(st & 2)) s |= 4;
+            if (g.u01() < .9) s |= 8;
+            if (g.u01() < (boutilier ? 0 : .9)) s &= ~16;
+            o = 0;
+        } else {  // CheckCoffee
+            if (g.u01() < (boutilier ? 0 : .3)) s &= ~8;
+            if (g.u01() < (boutilier ? 0 : .3)) s |= 16;
+            o = (s & 16) ? ((g.u01() < .8) ? 0 : 1) : ((g.u01() < .9) ? 1 : 0);
+        }
+        return false;
+    }
     if (dom_is_sys(d)) {  // SysAdmin::step :107-152
         const int N = P.sys->N, op = a >= N ? a - N : a;
         int index = s;
@@ -450,6 +469,11 @@ __device__ __forceinline__ bool domain_step(const Problem& P, Rng& g, int& s, in
 // Tiger / FactoredTiger::computeObservationProbability (Tiger.cpp:27-38)
 __device__ __forceinline__ double domain_obs_prob(const Problem& P, int o, int a, int new_s)
 {
+    if (dom_is_coffee(P.domain)) {  // CoffeeProblem::computeObservationProbability :44-60
+        if (a == 0) return o == 0 ? 1 : 0;
+        if (new_s & 16) return o == 0 ? .8 : 1 - .8;
+        return o == 1 ? .9 : 1 - .9;
+    }
     if (dom_is_sys(P.domain)) {  // SysAdmin::computeObservationProbability :154-165 (float results)
         const int op = a >= P.sys->N ? a - P.sys->N : a;
         return (o == ((new_s >> op) & 1)) ? (double).95f : (double)(1 - .95f);

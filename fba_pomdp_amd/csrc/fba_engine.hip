@@ -1024,6 +1024,15 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
             }
             P.S = 2 << cfg->size; P.A = 3; P.O = 2;
             break;
+        case FBA_DOM_COFFEE:
+        case FBA_DOM_COFFEE_BOUTILIER:  // CoffeeProblem.hpp: 5 binary features, {GetCoffee, CheckCoffee}, {Want, NotWant}
+            if (cfg->model != FBA_MODEL_POMDP) {  // factory::makeBADomainExtension has no coffee entry
+                fail(nullptr, FBA_EINVAL, "the coffee problem has no Bayes-adaptive extension: planning only");
+                delete c;
+                return FBA_EINVAL;
+            }
+            P.S = 32; P.A = 2; P.O = 2;
+            break;
         case FBA_DOM_SYSADMIN_INDEPENDENT:
         case FBA_DOM_SYSADMIN_LINEAR:
             if (cfg->size < 1 || cfg->size > 8) {  // SysAdmin.cpp:17-21; 2N actions <= FBA_MAX_ACTIONS

@@ -38,7 +38,9 @@ enum {
     FBA_DOM_COLLISION_AVOID   = 5, /* random-collision-avoidance src/domains/collision-avoidance/CollisionAvoidance.cpp */
     FBA_DOM_COLLISION_AVOID_CENTERED = 6, /* centered-collision-avoidance (VERSION INITIALIZE_CENTRE) */
     FBA_DOM_SYSADMIN_INDEPENDENT = 7, /* independent-sysadmin --size N  src/domains/sysadmin/SysAdmin.cpp */
-    FBA_DOM_SYSADMIN_LINEAR      = 8  /* linear-sysadmin --size N                                         */
+    FBA_DOM_SYSADMIN_LINEAR      = 8, /* linear-sysadmin --size N                                         */
+    FBA_DOM_COFFEE               = 9, /* coffee            src/domains/coffee/CoffeeProblem.cpp (planning only) */
+    FBA_DOM_COFFEE_BOUTILIER     = 10 /* boutilier-coffee  (the version with acquiring / losing coffee switched off) */
 };
 /* simulator: plain POMDP (planning), tabular BA-POMDP (bapomdp), factored (fbapomdp) */
 enum { FBA_MODEL_POMDP = 0, FBA_MODEL_BA_TABLE = 1, FBA_MODEL_BA_FACTORED = 2 };

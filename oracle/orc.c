@@ -205,6 +205,7 @@ static int is_episodic(int d)
 static int is_grid(int d) { return d == ORC_DOM_GRIDWORLD; }
 static int is_ca(int d) { return d == ORC_DOM_COLLISION_AVOID; }
 static int is_weighted(const orc_ctx* c);
+static int is_coffee(int d) { return d == ORC_DOM_COFFEE || d == ORC_DOM_COFFEE_BOUTILIER; }
 static int is_sys(int d) { return d == ORC_DOM_SYSADMIN_INDEPENDENT || d == ORC_DOM_SYSADMIN_LINEAR; }
 
 /* ---- collision avoidance.  ref: src/domains/collision-avoidance/CollisionAvoidance.cpp
@@ -370,6 +371,7 @@ static int32_t domain_start(orc_ctx* c)
     if (is_tiger(c->cfg.domain)) return orc_bool(&c->rng) ? 0 : 1;
     if (is_ftiger(c->cfg.domain)) return orc_int(&c->rng, c->S);
     if (is_sys(c->cfg.domain)) return c->S - 1; /* SysAdmin::sampleStartState :102-105: all computers on, no draw */
+    if (is_coffee(c->cfg.domain)) return orc_int(&c->rng, 32); /* CoffeeProblem::sampleStartState :62-65: integerDistribution(0, 32) */
     if (is_ca(c->cfg.domain)) { /* sampleStartState :270-273 -> categoricalDistr::sample -> sampleFromMult<float>(values, S, _total) */
         double p  = orc_u01(&c->rng) * c->ca_start_total;
         float sum = 0;
@@ -399,6 +401,7 @@ static int32_t domain_random_action(orc_ctx* c, int32_t s)
     if (is_grid(c->cfg.domain)) return orc_slow_int(&c->rng, 0, 4); /* GridWorld::generateRandomAction :220-226 */
     if (is_ca(c->cfg.domain)) return orc_int(&c->rng, 3); /* integerDistribution(0, NUM_ACTIONS) */
     if (is_sys(c->cfg.domain)) return orc_int(&c->rng, c->A); /* SysAdmin.cpp:167-170: integerDistribution(0, A) */
+    if (is_coffee(c->cfg.domain)) return orc_bool(&c->rng) ? 1 : 0; /* CoffeeProblem.cpp:27-34: _actions.get((int)boolean()) */
     return 0;
 }
 
@@ -431,6 +434,27 @@ static int domain_step(orc_ctx* c, int32_t* s, int32_t a, int32_t* o, double* r)
             *s = orc_int(&c->rng, c->S);    /* sampleStartState() */
         }
         return is_episodic(d) && a != 2;
+    }
+    if (is_coffee(d)) { /* CoffeeProblem::step :67-148; masks CoffeeProblemIndices.hpp: rains 1, umbrella 2, wet 4, has coffee 8, wants coffee 16 */
+        int boutilier = d == ORC_DOM_COFFEE_BOUTILIER;
+        int32_t st = *s, ns = st;
+        double reward = -.5;
+        if (st & 4) reward = -1;
+        if (st & 16) reward += (st & 8) ? 2 : -2;
+        if (a == 0) { /* GetCoffee */
+            if ((st & 1) && !(st & 2)) ns |= 4;
+            if (orc_u01(&c->rng) < .9) ns |= 8;
+            if (orc_u01(&c->rng) < (boutilier ? 0 : .9)) ns &= ~16;
+            *o = 0; /* Want_Coffee */
+        } else { /* CheckCoffee */
+            if (orc_u01(&c->rng) < (boutilier ? 0 : .3)) ns &= ~8;
+            if (orc_u01(&c->rng) < (boutilier ? 0 : .3)) ns |= 16;
+            if (ns & 16) *o = (orc_u01(&c->rng) < .8) ? 0 : 1;
+            else *o = (orc_u01(&c->rng) < .9) ? 1 : 0;
+        }
+        *s = ns;
+        *r = reward;
+        return 0;
     }
     if (is_sys(d)) { /* SysAdmin::step :107-152 */
         int N = c->sys_N, rebooting = a >= N, op = rebooting ? a - N : a, k;
@@ -495,6 +519,11 @@ static double domain_obs_prob(orc_ctx* c, int32_t o, int32_t a, int32_t new_s)
         int loc = (new_s < c->S / 2) ? 0 : 1;
         if (a != 2) return .5;
         return (loc == o) ? .85 : .15;
+    }
+    if (is_coffee(d)) { /* CoffeeProblem::computeObservationProbability :44-60 */
+        if (a == 0) return o == 0 ? 1 : 0;
+        if (new_s & 16) return o == 0 ? .8 : 1 - .8;
+        return o == 1 ? .9 : 1 - .9;
     }
     if (is_sys(d)) { /* SysAdmin::computeObservationProbability :154-165: float results */
         int op = a >= c->sys_N ? a - c->sys_N : a;
@@ -2392,6 +2421,8 @@ orc_ctx* orc_create(const orc_config* cfg)
             sys_setup(c, cfg->size);
             c->S = 1 << cfg->size; c->A = 2 * cfg->size; c->O = 2;
             break;
+        case ORC_DOM_COFFEE:
+        case ORC_DOM_COFFEE_BOUTILIER: c->S = 32; c->A = 2; c->O = 2; break;
         case ORC_DOM_GRIDWORLD:
             if (cfg->size < 3 || cfg->size > 15) {
                 snprintf(c->err, sizeof c->err, "please enter a size larger than 3 to be able to run gridworld (you entered %d)", cfg->size);

@@ -33,7 +33,9 @@ enum {
     ORC_DOM_COLLISION_AVOID   = 5,
     /* 6 is the HIP engine's centered-collision-avoidance (here: ca_centered) */
     ORC_DOM_SYSADMIN_INDEPENDENT = 7, /* -D independent-sysadmin --size N */
-    ORC_DOM_SYSADMIN_LINEAR      = 8  /* -D linear-sysadmin --size N      */
+    ORC_DOM_SYSADMIN_LINEAR      = 8, /* -D linear-sysadmin --size N      */
+    ORC_DOM_COFFEE               = 9, /* -D coffee            (planning only) src/domains/coffee/CoffeeProblem.cpp */
+    ORC_DOM_COFFEE_BOUTILIER     = 10 /* -D boutilier-coffee                                                      */
 };
 /* simulator model */
 enum { ORC_MODEL_POMDP = 0, ORC_MODEL_BA_TABLE = 1, ORC_MODEL_BA_FACTORED = 2 };

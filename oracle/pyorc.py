@@ -15,6 +15,7 @@ _LIB = os.path.join(_HERE, "liborc.so")
 # enums (oracle/orc.h)
 DOM_TIGER_EPISODIC, DOM_TIGER_CONTINUOUS, DOM_FTIGER_EPISODIC, DOM_FTIGER_CONTINUOUS, DOM_GRIDWORLD, DOM_COLLISION_AVOID = range(6)
 DOM_SYSADMIN_INDEPENDENT, DOM_SYSADMIN_LINEAR = 7, 8
+DOM_COFFEE, DOM_COFFEE_BOUTILIER = 9, 10
 MODEL_POMDP, MODEL_BA_TABLE, MODEL_BA_FACTORED = range(3)
 BELIEF_REJECTION, BELIEF_IMPORTANCE, BELIEF_REINVIGORATION, BELIEF_CHEATING = range(4)
 ARITH_REF, ARITH_DEV = range(2)

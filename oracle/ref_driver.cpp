@@ -27,6 +27,7 @@
 #include "beliefs/particle_filters/RejectionSampling.hpp"
 #include "beliefs/particle_filters/WeightedFilter.hpp"
 #include "domains/collision-avoidance/CollisionAvoidance.hpp"
+#include "domains/coffee/CoffeeProblem.hpp"
 #include "domains/gridworld/GridWorld.hpp"
 #include "domains/sysadmin/SysAdmin.hpp"
 #include "domains/sysadmin/SysAdminBAExtension.hpp"
@@ -108,6 +109,7 @@ static void rng_vectors(char const* s)
 static void walk(POMDP const& d, char const* s, int n)
 {
     std::vector<int> rec; /* a, s', o, r, term, flattened */
+    std::vector<double> rew; /* the rewards again, not truncated */
     seed(s);
     State const* st = d.sampleStartState();
     int start       = st->index();
@@ -120,6 +122,7 @@ static void walk(POMDP const& d, char const* s, int n)
         rec.push_back(st->index());
         rec.push_back(o->index());
         rec.push_back((int)r.toDouble());
+        rew.push_back(r.toDouble());
         rec.push_back(t.terminated() ? 1 : 0);
         d.releaseAction(a);
         d.releaseObservation(o);
@@ -131,6 +134,8 @@ static void walk(POMDP const& d, char const* s, int n)
     }
     printf("{\"seed\": \"%s\", \"start\": %d, \"rec\": ", s, start);
     arr(rec, pi);
+    printf(", \"rew\": ");
+    arr(rew, pd);
     printf("}");
 }
 
@@ -677,6 +682,11 @@ int main(int argc, char** argv)
     { domains::SysAdmin d(8, "linear"); walk(d, "52", 400); }
     key("sysadmin4_linear_tables");
     sysadmin_tables(4, "linear");
+
+    key("coffee");
+    { domains::CoffeeProblem d(""); walk(d, "60", 400); }
+    key("coffee_boutilier");
+    { domains::CoffeeProblem d("boutilier"); walk(d, "61", 400); }
 
     key("tiger_obs_prob");
     { domains::Tiger d(domains::Tiger::EPISODIC); obs_table(d, 2, 3, 2); }

@@ -10,17 +10,20 @@ from oracle import pyorc as orc
 DOM = {"random-collision-avoidance": orc.DOM_COLLISION_AVOID, "centered-collision-avoidance": orc.DOM_COLLISION_AVOID,
        "gridworld": orc.DOM_GRIDWORLD, "episodic-tiger": orc.DOM_TIGER_EPISODIC, "continuous-tiger": orc.DOM_TIGER_CONTINUOUS,
        "episodic-factored-tiger": orc.DOM_FTIGER_EPISODIC, "continuous-factored-tiger": orc.DOM_FTIGER_CONTINUOUS,
-       "independent-sysadmin": orc.DOM_SYSADMIN_INDEPENDENT, "linear-sysadmin": orc.DOM_SYSADMIN_LINEAR}
+       "independent-sysadmin": orc.DOM_SYSADMIN_INDEPENDENT, "linear-sysadmin": orc.DOM_SYSADMIN_LINEAR,
+       "coffee": orc.DOM_COFFEE, "boutilier-coffee": orc.DOM_COFFEE_BOUTILIER}
 
 
 def draw(rng):
     domain = rng.choice(list(DOM))
     model = rng.choice([N.MODEL_POMDP, N.MODEL_BA_TABLE, N.MODEL_BA_FACTORED])
+    if "coffee" in domain:
+        model = N.MODEL_POMDP   # planning only
     kw = dict(particles=rng.choice([1, 7, 33, 64, 130]), sims=rng.choice([1, 5, 40, 96]), horizon=rng.choice([1, 3, 7, 12]),
               runs=rng.choice([1, 3, 6]), discount=rng.choice([0.5, 0.95, 1.0]), exploration=rng.choice([0.0, 1.0, 100.0]))
     kw["max_depth"] = rng.choice([-1, 0, 1, 4, kw["horizon"]])
     slots = rng.choice([1, 2, kw["runs"]])
-    if "tiger" in domain and "factored" not in domain:
+    if "tiger" in domain and "factored" not in domain or "coffee" in domain:
         pass
     elif "factored-tiger" in domain:
         kw["size"] = rng.choice([1, 2, 3])

@@ -88,5 +88,10 @@ def test_cli_bapomdp_and_fbapomdp_write_one_line_per_episode(cli, tmp_path):
     r = subprocess.run([cli, "planning", "-D", "episodic-tiger", "-P", "ts", "-s", "64", "--particle-amount", "32", "--runs", "20",
                         "-f", str(tmp_path / "ts.res")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+    r = subprocess.run([cli, "planning", "-D", "boutilier-coffee", "-s", "64", "--particle-amount", "32", "--runs", "12", "-H", "6",
+                        "-f", str(tmp_path / "coffee.res")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([cli, "bapomdp", "-D", "coffee"], capture_output=True, text=True)
+    assert r.returncode == 1 and "planning only" in r.stderr
     r = subprocess.run([cli, "bapomdp", "-D", "episodic-tiger", "--noise", "0.9"], capture_output=True, text=True)
     assert r.returncode == 1 and "noise has to be between" in r.stderr      # TigerPriors.cpp:22-25

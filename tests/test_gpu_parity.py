@@ -16,7 +16,8 @@ pytestmark = pytest.mark.gpu
 DOM = {"random-collision-avoidance": orc.DOM_COLLISION_AVOID, "centered-collision-avoidance": orc.DOM_COLLISION_AVOID,
        "gridworld": orc.DOM_GRIDWORLD, "episodic-tiger": orc.DOM_TIGER_EPISODIC, "continuous-tiger": orc.DOM_TIGER_CONTINUOUS,
        "episodic-factored-tiger": orc.DOM_FTIGER_EPISODIC, "continuous-factored-tiger": orc.DOM_FTIGER_CONTINUOUS,
-       "independent-sysadmin": orc.DOM_SYSADMIN_INDEPENDENT, "linear-sysadmin": orc.DOM_SYSADMIN_LINEAR}
+       "independent-sysadmin": orc.DOM_SYSADMIN_INDEPENDENT, "linear-sysadmin": orc.DOM_SYSADMIN_LINEAR,
+       "coffee": orc.DOM_COFFEE, "boutilier-coffee": orc.DOM_COFFEE_BOUTILIER}
 
 
 def _pair(domain, model, belief, seed, slots=None, size=0, **kw):
@@ -464,6 +465,21 @@ def test_planning_sysadmin(domain, size, belief):
     """planning -D *-sysadmin: 2N actions (ucb_pick<16> at N = 8), never terminal."""
     eng, o = _pair(domain, N.MODEL_POMDP, belief, 151 + size, size=size, particles=100, sims=160, runs=9, horizon=7, slots=4)
     _assert_same_experiment(eng, o, ba=False)
+
+
+@pytest.mark.parametrize("domain,belief,planner", [
+    ("coffee", "rejection_sampling", "po-uct"), ("coffee", "importance_sampling", "po-uct"),
+    ("boutilier-coffee", "rejection_sampling", "po-uct"), ("boutilier-coffee", "importance_sampling", "ts")])
+def test_planning_coffee(domain, belief, planner):
+    """planning -D coffee | boutilier-coffee (CoffeeProblem.cpp): 32 states, 2 actions, fractional rewards,
+    never terminal; both versions spend the same draws per step."""
+    eng, o = _pair(domain, N.MODEL_POMDP, belief, 171, particles=150, sims=200, runs=10, horizon=8, slots=5, planner=planner)
+    _assert_same_experiment(eng, o, ba=False)
+
+
+def test_coffee_has_no_bayes_adaptive_model():
+    with pytest.raises(ValueError, match="planning only"):
+        fba.Engine("coffee", model=N.MODEL_BA_TABLE, particles=4, sims=4)
 
 
 @pytest.mark.parametrize("domain,size,model,belief", [
