@@ -23,13 +23,14 @@ HIPCC_FLAGS = [
     "-Wall", "-Wno-unused-function",
 ]
 
-MAX_ACTIONS = 16
+MAX_ACTIONS = 24
 K_SEARCH, K_ENV, K_BELIEF_RS, K_BELIEF_IS, K_BELIEF_RESET, K_BELIEF_INIT, K_COUNT = range(7)
 KERNEL_NAMES = ["search_kernel", "env_kernel", "reject_kernel", "importance_kernel", "reset_kernel", "init_kernel"]
 
 DOM_TIGER_EPISODIC, DOM_TIGER_CONTINUOUS, DOM_FTIGER_EPISODIC, DOM_FTIGER_CONTINUOUS, DOM_GRIDWORLD, DOM_COLLISION_AVOID, DOM_COLLISION_AVOID_CENTERED = range(7)
 DOM_SYSADMIN_INDEPENDENT, DOM_SYSADMIN_LINEAR = 7, 8
 DOM_COFFEE, DOM_COFFEE_BOUTILIER = 9, 10
+DOM_AGR = 11
 MODEL_POMDP, MODEL_BA_TABLE, MODEL_BA_FACTORED = range(3)
 BELIEF_REJECTION, BELIEF_IMPORTANCE, BELIEF_REINVIGORATION, BELIEF_CHEATING = range(4)
 PLANNER_POUCT, PLANNER_RANDOM, PLANNER_TS = range(3)
@@ -41,7 +42,7 @@ DOMAIN_NAMES = {  # reference -D strings (DomainConf.cpp)
     "gridworld": DOM_GRIDWORLD,
     "random-collision-avoidance": DOM_COLLISION_AVOID, "centered-collision-avoidance": DOM_COLLISION_AVOID_CENTERED,
     "independent-sysadmin": DOM_SYSADMIN_INDEPENDENT, "linear-sysadmin": DOM_SYSADMIN_LINEAR,
-    "coffee": DOM_COFFEE, "boutilier-coffee": DOM_COFFEE_BOUTILIER,
+    "coffee": DOM_COFFEE, "boutilier-coffee": DOM_COFFEE_BOUTILIER, "agr": DOM_AGR,
 }
 BELIEF_NAMES = {"rejection_sampling": BELIEF_REJECTION, "importance_sampling": BELIEF_IMPORTANCE,
                 "reinvigoration": BELIEF_REINVIGORATION, "cheating-reinvigoration": BELIEF_CHEATING}

@@ -274,6 +274,8 @@ __device__ __forceinline__ bool dom_is_ftiger(int d) { return d == FBA_DOM_FTIGE
 __device__ __forceinline__ bool dom_is_episodic(int d) { return d == FBA_DOM_TIGER_EPISODIC || d == FBA_DOM_FTIGER_EPISODIC; }
 __device__ __forceinline__ bool dom_is_grid(int d) { return d == FBA_DOM_GRIDWORLD; }
 __device__ __forceinline__ bool dom_is_ca(int d) { return d == FBA_DOM_COLLISION_AVOID || d == FBA_DOM_COLLISION_AVOID_CENTERED; }
+__device__ __forceinline__ bool dom_is_agr(int d) { return d == FBA_DOM_AGR; }
+constexpr int AGR_N = 10;  // factory::makeEnvironment builds AGR(10) (Environment.cpp:32-33)
 __device__ __forceinline__ bool dom_is_coffee(int d) { return d == FBA_DOM_COFFEE || d == FBA_DOM_COFFEE_BOUTILIER; }
 __device__ __forceinline__ bool dom_is_sys(int d) { return d == FBA_DOM_SYSADMIN_INDEPENDENT || d == FBA_DOM_SYSADMIN_LINEAR; }
 
@@ -336,6 +338,7 @@ __device__ __forceinline__ float gw_obs_displ_prob(const GridDesc* gw, int loc, 
 __device__ __forceinline__ int domain_start(const Problem& P, Rng& g)
 {
     if (dom_is_tiger(P.domain)) return g.boolean() ? 0 : 1;
+    if (dom_is_agr(P.domain)) return (2 * AGR_N + 1) * g.uniform_int(2 * AGR_N + 1) + AGR_N;  // AGR::sampleStartState :236-239: target at 0, goal uniform
     if (dom_is_sys(P.domain)) return P.S - 1;  // SysAdmin::sampleStartState :102-105: all computers on, no draw
     if (dom_is_ca(P.domain)) {  // sampleStartState :270-273 -> categoricalDistr::sample -> sampleFromMult<float>
         const CADesc* ca = P.ca;
@@ -367,6 +370,20 @@ __device__ __forceinline__ int domain_random_action(const Problem& P, Rng& g, in
 __device__ __forceinline__ bool domain_step(const Problem& P, Rng& g, int& s, int a, int& o, double& r)
 {
     const int d = P.domain;
+    if (dom_is_agr(d)) {  // AGR::step :247-305, no draws: state = (2n+1)(goal+n) + pos+n; help(-n..n) = 0..2n, work, observe
+        constexpr int n = AGR_N;
+        const int goal = s / (2 * n + 1) - n;
+        int pos = s % (2 * n + 1) - n;
+        bool helped = false;
+        if (a <= 2 * n) {
+            helped = a - n == goal && pos == goal;
+            r = helped ? 100 : -100;
+        } else r = (a == 2 * n + 1) ? -5 : -10;
+        pos += max(-1, min(1, goal - pos));
+        s = (2 * n + 1) * (goal + n) + pos + n;
+        o = (a == 2 * n + 2) ? pos + n : 2 * n + 1;  // observe sees the NEW position, the rest "none"
+        return helped;
+    }
     if (dom_is_coffee(d)) {  // CoffeeProblem::step :67-148; bits: rains 1, umbrella 2, wet 4, has coffee 8, wants coffee 16
         const bool boutilier = d == FBA_DOM_COFFEE_BOUTILIER;
         const int st = s;

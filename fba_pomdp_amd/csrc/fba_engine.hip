@@ -1024,6 +1024,14 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
             }
             P.S = 2 << cfg->size; P.A = 3; P.O = 2;
             break;
+        case FBA_DOM_AGR:  // AGR(10): 21 x 21 (goal, position) states, 21 help actions + work + observe, 21 positions + "none"
+            if (cfg->model != FBA_MODEL_POMDP || cfg->belief != FBA_BELIEF_REJECTION) {  // AGR.cpp:307-310 (thrown by the first weighted update)
+                fail(nullptr, FBA_EINVAL, "AGR::computeObservationProbability nyi");
+                delete c;
+                return FBA_EINVAL;
+            }
+            P.S = 21 * 21; P.A = 23; P.O = 22;
+            break;
         case FBA_DOM_COFFEE:
         case FBA_DOM_COFFEE_BOUTILIER:  // CoffeeProblem.hpp: 5 binary features, {GetCoffee, CheckCoffee}, {Want, NotWant}
             if (cfg->model != FBA_MODEL_POMDP) {  // factory::makeBADomainExtension has no coffee entry

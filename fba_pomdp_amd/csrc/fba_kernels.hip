@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
             ++steps;
             if (mode == 1) {  // traverseChanceNode
                 path_r[(size_t)plen * SEARCH_BLOCK]  = r;
-                path_na[(size_t)plen * SEARCH_BLOCK] = (node << 4) | a;
+                path_na[(size_t)plen * SEARCH_BLOCK] = (node << 5) | a  /* a < FBA_MAX_ACTIONS <= 32 */;
                 ++plen;
                 if (term) finish = true;
                 else {
@@ -373,8 +373,8 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
             for (int k = plen - 1; k >= 0; --k) {
                 const int na     = path_na[(size_t)k * SEARCH_BLOCK];
                 const double ret = path_r[(size_t)k * SEARCH_BLOCK] + P.gamma * del;
-                const int act    = na & 15;
-                if ((na >> 4) == 0) {
+                const int act    = na & 31;
+                if ((na >> 5) == 0) {
                     // register-array element `act`: select, ONE division, write back
                     int n = 0;
                     double q = 0.0;
@@ -389,7 +389,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
                     ++r_vis;
                     root_L = D.log1p_tab[r_vis];
                 } else {
-                    int32_t* rec = tree + (size_t)(na >> 4) * W;
+                    int32_t* rec = tree + (size_t)(na >> 5) * W;
                     double* q    = reinterpret_cast<double*>(rec + D.cq_off) + act;
                     int n;
                     if (P.A == 3) {  // {visits, n0, n1, n2} is one 16-byte word: one load, one store
@@ -1443,7 +1443,8 @@ void launch_search(const Problem& P, const DeviceState& D, hipStream_t st)
     }
     if (P.A <= 4) { if (stage) FBA_LAUNCH_SEARCH(true, 4); else FBA_LAUNCH_SEARCH(false, 4); }
     else if (P.A <= 8) { if (stage) FBA_LAUNCH_SEARCH(true, 8); else FBA_LAUNCH_SEARCH(false, 8); }
-    else { if (stage) FBA_LAUNCH_SEARCH(true, 16); else FBA_LAUNCH_SEARCH(false, 16); }
+    else if (P.A <= 16) { if (stage) FBA_LAUNCH_SEARCH(true, 16); else FBA_LAUNCH_SEARCH(false, 16); }
+    else FBA_LAUNCH_SEARCH_M(false, 24, FBA_MODEL_POMDP);  // agr (23 actions) is a POMDP-only domain
 #undef FBA_LAUNCH_SEARCH_M
 #undef FBA_LAUNCH_SEARCH
 }

@@ -63,7 +63,7 @@ void usage()
         "  -D, --domain NAME              episodic-tiger, continuous-tiger, episodic-factored-tiger,\n"
         "                                 continuous-factored-tiger, gridworld, random-collision-avoidance,\n"
         "                                 centered-collision-avoidance, independent-sysadmin, linear-sysadmin,\n"
-        "                                 coffee, boutilier-coffee (planning only)\n"
+        "                                 coffee, boutilier-coffee, agr (planning only)\n"
         "      --size N  --height N  --width N\n"
         "      --episodes N               (bapomdp, fbapomdp) episodes per run (1)\n"
         "      --dirichlet_sampling_method regular|expected (expected)\n"
@@ -149,7 +149,7 @@ bool to_config(Options const& o, fba_config& c, std::string& err)
         {"gridworld", FBA_DOM_GRIDWORLD}, {"random-collision-avoidance", FBA_DOM_COLLISION_AVOID},
         {"centered-collision-avoidance", FBA_DOM_COLLISION_AVOID_CENTERED},
         {"independent-sysadmin", FBA_DOM_SYSADMIN_INDEPENDENT}, {"linear-sysadmin", FBA_DOM_SYSADMIN_LINEAR},
-        {"coffee", FBA_DOM_COFFEE}, {"boutilier-coffee", FBA_DOM_COFFEE_BOUTILIER}};
+        {"coffee", FBA_DOM_COFFEE}, {"boutilier-coffee", FBA_DOM_COFFEE_BOUTILIER}, {"agr", FBA_DOM_AGR}};
     if (!domains.count(o.domain)) { err = "please enter a legit domain, provided: " + o.domain; return false; }  // DomainConf.cpp:52-58
     c.domain = domains.at(o.domain);
     if (o.planner == "po-uct" || o.planner == "hip-po-uct") c.planner = FBA_PLANNER_POUCT;

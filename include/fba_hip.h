@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define FBA_ABI_VERSION 1
-#define FBA_MAX_ACTIONS 16
+#define FBA_MAX_ACTIONS 24
 
 /* domains: reference src/domains, selected by -D (DomainConf.hpp) */
 enum {
@@ -40,7 +40,8 @@ enum {
     FBA_DOM_SYSADMIN_INDEPENDENT = 7, /* independent-sysadmin --size N  src/domains/sysadmin/SysAdmin.cpp */
     FBA_DOM_SYSADMIN_LINEAR      = 8, /* linear-sysadmin --size N                                         */
     FBA_DOM_COFFEE               = 9, /* coffee            src/domains/coffee/CoffeeProblem.cpp (planning only) */
-    FBA_DOM_COFFEE_BOUTILIER     = 10 /* boutilier-coffee  (the version with acquiring / losing coffee switched off) */
+    FBA_DOM_COFFEE_BOUTILIER     = 10, /* boutilier-coffee  (the version with acquiring / losing coffee switched off) */
+    FBA_DOM_AGR                  = 11  /* agr               src/domains/agr/AGR.cpp, AGR(10): planning with rejection sampling only */
 };
 /* simulator: plain POMDP (planning), tabular BA-POMDP (bapomdp), factored (fbapomdp) */
 enum { FBA_MODEL_POMDP = 0, FBA_MODEL_BA_TABLE = 1, FBA_MODEL_BA_FACTORED = 2 };

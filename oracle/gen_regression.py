@@ -3,6 +3,7 @@ paths whose orchestration cannot be pinned through oracle/_ref (their reference 
 Boost) -- the structure beliefs, the sysadmin / gridworld / collision-avoidance tabular priors.  They only
 detect accidental changes of the restatement.  Writes tests/golden/oracle_regression.json."""
 import hashlib
+import numpy as np
 import json
 import os
 import sys
@@ -30,10 +31,20 @@ CASES = {
 COMMON = dict(particles=48, sims=64, horizon=6, max_depth=6, runs=3, episodes=3, rng_mode=orc.RNG_MT, arith=orc.ARITH_REF, trace=1)
 
 
+def _legacy_layout(tr):
+    """The hashes were taken when a trace record held 16 root entries; every case here has <= 16 actions, so
+    cut the two root arrays back to 16 columns and the committed hashes keep their meaning."""
+    fields = [(n, tr.dtype[n].base.str, (16,)) if tr.dtype[n].shape else (n, tr.dtype[n].str) for n in tr.dtype.names]
+    old = np.zeros(len(tr), dtype=np.dtype(fields, align=tr.dtype.isalignedstruct))
+    for n in tr.dtype.names:
+        old[n] = tr[n][:, :16] if tr.dtype[n].shape else tr[n]
+    return old
+
+
 def run(name):
     o = orc.Oracle(seed_str="7", **COMMON, **CASES[name])
     stats, res = o.run_bapomdp()
-    tr = o.trace(res.n_trace)
+    tr = _legacy_layout(o.trace(res.n_trace))
     return {"means": [s.mean for s in stats], "sim_steps": res.sim_steps, "belief_steps": res.belief_steps,
             "trace_sha256": hashlib.sha256(tr.tobytes()).hexdigest(), "records": int(res.n_trace)}
 

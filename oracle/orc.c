@@ -206,6 +206,8 @@ static int is_grid(int d) { return d == ORC_DOM_GRIDWORLD; }
 static int is_ca(int d) { return d == ORC_DOM_COLLISION_AVOID; }
 static int is_weighted(const orc_ctx* c);
 static int is_coffee(int d) { return d == ORC_DOM_COFFEE || d == ORC_DOM_COFFEE_BOUTILIER; }
+static int is_agr(int d) { return d == ORC_DOM_AGR; }
+#define AGR_N 10 /* factory::makeEnvironment: new domains::AGR(10), Environment.cpp:32-33 */
 static int is_sys(int d) { return d == ORC_DOM_SYSADMIN_INDEPENDENT || d == ORC_DOM_SYSADMIN_LINEAR; }
 
 /* ---- collision avoidance.  ref: src/domains/collision-avoidance/CollisionAvoidance.cpp
@@ -371,6 +373,8 @@ static int32_t domain_start(orc_ctx* c)
     if (is_tiger(c->cfg.domain)) return orc_bool(&c->rng) ? 0 : 1;
     if (is_ftiger(c->cfg.domain)) return orc_int(&c->rng, c->S);
     if (is_sys(c->cfg.domain)) return c->S - 1; /* SysAdmin::sampleStartState :102-105: all computers on, no draw */
+    if (is_agr(c->cfg.domain)) /* AGR::sampleStartState :236-239: the j-th state with target_pos == 0 is goal -n + j */
+        return (2 * AGR_N + 1) * orc_int(&c->rng, 2 * AGR_N + 1) + AGR_N;
     if (is_coffee(c->cfg.domain)) return orc_int(&c->rng, 32); /* CoffeeProblem::sampleStartState :62-65: integerDistribution(0, 32) */
     if (is_ca(c->cfg.domain)) { /* sampleStartState :270-273 -> categoricalDistr::sample -> sampleFromMult<float>(values, S, _total) */
         double p  = orc_u01(&c->rng) * c->ca_start_total;
@@ -401,6 +405,7 @@ static int32_t domain_random_action(orc_ctx* c, int32_t s)
     if (is_grid(c->cfg.domain)) return orc_slow_int(&c->rng, 0, 4); /* GridWorld::generateRandomAction :220-226 */
     if (is_ca(c->cfg.domain)) return orc_int(&c->rng, 3); /* integerDistribution(0, NUM_ACTIONS) */
     if (is_sys(c->cfg.domain)) return orc_int(&c->rng, c->A); /* SysAdmin.cpp:167-170: integerDistribution(0, A) */
+    if (is_agr(c->cfg.domain)) return orc_int(&c->rng, c->A); /* AGR.cpp:241-245: integerDistribution(0, 2n + 3) */
     if (is_coffee(c->cfg.domain)) return orc_bool(&c->rng) ? 1 : 0; /* CoffeeProblem.cpp:27-34: _actions.get((int)boolean()) */
     return 0;
 }
@@ -434,6 +439,21 @@ static int domain_step(orc_ctx* c, int32_t* s, int32_t a, int32_t* o, double* r)
             *s = orc_int(&c->rng, c->S);    /* sampleStartState() */
         }
         return is_episodic(d) && a != 2;
+    }
+    if (is_agr(d)) { /* AGR::step :247-305: no draws.  state = (2n+1)(goal+n) + pos+n; actions help(-n..n) = 0..2n, work 2n+1, observe 2n+2 */
+        int n = AGR_N, goal = *s / (2 * n + 1) - n, pos = *s % (2 * n + 1) - n, helped = 0, diff, stp;
+        if (a <= 2 * n) {
+            helped = (a - n == goal && pos == goal);
+            *r     = helped ? 100 : -100;
+        } else
+            *r = (a == 2 * n + 1) ? -5 : -10;
+        diff = goal - pos;
+        stp  = diff > 1 ? 1 : diff;
+        stp  = stp < -1 ? -1 : stp;
+        pos += stp;
+        *s = (2 * n + 1) * (goal + n) + pos + n;
+        *o = (a == 2 * n + 2) ? pos + n : 2 * n + 1; /* observe sees the NEW position, everything else sees "none" */
+        return helped;
     }
     if (is_coffee(d)) { /* CoffeeProblem::step :67-148; masks CoffeeProblemIndices.hpp: rains 1, umbrella 2, wet 4, has coffee 8, wants coffee 16 */
         int boutilier = d == ORC_DOM_COFFEE_BOUTILIER;
@@ -2420,6 +2440,13 @@ orc_ctx* orc_create(const orc_config* cfg)
             if (cfg->size > 8) { snprintf(c->err, sizeof c->err, "sysadmin: at most 8 computers (2N <= %d actions)", ORC_MAX_ACTIONS); return c; }
             sys_setup(c, cfg->size);
             c->S = 1 << cfg->size; c->A = 2 * cfg->size; c->O = 2;
+            break;
+        case ORC_DOM_AGR:
+            if (cfg->model != ORC_MODEL_POMDP || cfg->belief != ORC_BELIEF_REJECTION) { /* AGR.cpp:307-310 throws on the first weighted update */
+                snprintf(c->err, sizeof c->err, "AGR::computeObservationProbability nyi");
+                return c;
+            }
+            c->S = (2 * AGR_N + 1) * (2 * AGR_N + 1); c->A = 2 * AGR_N + 3; c->O = 2 * AGR_N + 2;
             break;
         case ORC_DOM_COFFEE:
         case ORC_DOM_COFFEE_BOUTILIER: c->S = 32; c->A = 2; c->O = 2; break;

@@ -35,7 +35,8 @@ enum {
     ORC_DOM_SYSADMIN_INDEPENDENT = 7, /* -D independent-sysadmin --size N */
     ORC_DOM_SYSADMIN_LINEAR      = 8, /* -D linear-sysadmin --size N      */
     ORC_DOM_COFFEE               = 9, /* -D coffee            (planning only) src/domains/coffee/CoffeeProblem.cpp */
-    ORC_DOM_COFFEE_BOUTILIER     = 10 /* -D boutilier-coffee                                                      */
+    ORC_DOM_COFFEE_BOUTILIER     = 10, /* -D boutilier-coffee                                                     */
+    ORC_DOM_AGR                  = 11  /* -D agr (AGR(10), planning with rejection sampling only) src/domains/agr/AGR.cpp */
 };
 /* simulator model */
 enum { ORC_MODEL_POMDP = 0, ORC_MODEL_BA_TABLE = 1, ORC_MODEL_BA_FACTORED = 2 };
@@ -51,7 +52,7 @@ enum { ORC_PLANNER_POUCT = 0, ORC_PLANNER_RANDOM = 1, ORC_PLANNER_TS = 2 /* -P t
 /* FBA structure prior (reference FBAConf::structure_prior) */
 enum { ORC_SP_NONE = 0, ORC_SP_UNIFORM = 1, ORC_SP_MATCH_UNIFORM = 2, ORC_SP_FULLY_CONNECTED = 3 };
 
-#define ORC_MAX_ACTIONS 16
+#define ORC_MAX_ACTIONS 24
 
 typedef struct orc_config {
     int32_t domain;

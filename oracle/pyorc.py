@@ -16,6 +16,7 @@ _LIB = os.path.join(_HERE, "liborc.so")
 DOM_TIGER_EPISODIC, DOM_TIGER_CONTINUOUS, DOM_FTIGER_EPISODIC, DOM_FTIGER_CONTINUOUS, DOM_GRIDWORLD, DOM_COLLISION_AVOID = range(6)
 DOM_SYSADMIN_INDEPENDENT, DOM_SYSADMIN_LINEAR = 7, 8
 DOM_COFFEE, DOM_COFFEE_BOUTILIER = 9, 10
+DOM_AGR = 11
 MODEL_POMDP, MODEL_BA_TABLE, MODEL_BA_FACTORED = range(3)
 BELIEF_REJECTION, BELIEF_IMPORTANCE, BELIEF_REINVIGORATION, BELIEF_CHEATING = range(4)
 ARITH_REF, ARITH_DEV = range(2)
@@ -23,7 +24,7 @@ RNG_MT, RNG_PHILOX = range(2)
 PLANNER_POUCT, PLANNER_RANDOM, PLANNER_TS = range(3)
 SP_NONE, SP_UNIFORM, SP_MATCH_UNIFORM, SP_FULLY_CONNECTED = range(4)
 PH_INIT, PH_RESET, PH_START, PH_SEARCH, PH_ENV, PH_REJECT, PH_IS_UPDATE, PH_RESAMPLE = range(8)
-MAX_ACTIONS = 16
+MAX_ACTIONS = 24
 
 
 class Config(C.Structure):

@@ -27,6 +27,7 @@
 #include "beliefs/particle_filters/RejectionSampling.hpp"
 #include "beliefs/particle_filters/WeightedFilter.hpp"
 #include "domains/collision-avoidance/CollisionAvoidance.hpp"
+#include "domains/agr/AGR.hpp"
 #include "domains/coffee/CoffeeProblem.hpp"
 #include "domains/gridworld/GridWorld.hpp"
 #include "domains/sysadmin/SysAdmin.hpp"
@@ -687,6 +688,9 @@ int main(int argc, char** argv)
     { domains::CoffeeProblem d(""); walk(d, "60", 400); }
     key("coffee_boutilier");
     { domains::CoffeeProblem d("boutilier"); walk(d, "61", 400); }
+
+    key("agr");
+    { domains::AGR d(10); walk(d, "62", 600); }
 
     key("tiger_obs_prob");
     { domains::Tiger d(domains::Tiger::EPISODIC); obs_table(d, 2, 3, 2); }

@@ -11,13 +11,13 @@ DOM = {"random-collision-avoidance": orc.DOM_COLLISION_AVOID, "centered-collisio
        "gridworld": orc.DOM_GRIDWORLD, "episodic-tiger": orc.DOM_TIGER_EPISODIC, "continuous-tiger": orc.DOM_TIGER_CONTINUOUS,
        "episodic-factored-tiger": orc.DOM_FTIGER_EPISODIC, "continuous-factored-tiger": orc.DOM_FTIGER_CONTINUOUS,
        "independent-sysadmin": orc.DOM_SYSADMIN_INDEPENDENT, "linear-sysadmin": orc.DOM_SYSADMIN_LINEAR,
-       "coffee": orc.DOM_COFFEE, "boutilier-coffee": orc.DOM_COFFEE_BOUTILIER}
+       "coffee": orc.DOM_COFFEE, "boutilier-coffee": orc.DOM_COFFEE_BOUTILIER, "agr": orc.DOM_AGR}
 
 
 def draw(rng):
     domain = rng.choice(list(DOM))
     model = rng.choice([N.MODEL_POMDP, N.MODEL_BA_TABLE, N.MODEL_BA_FACTORED])
-    if "coffee" in domain:
+    if "coffee" in domain or domain == "agr":
         model = N.MODEL_POMDP   # planning only
     kw = dict(particles=rng.choice([1, 7, 33, 64, 130]), sims=rng.choice([1, 5, 40, 96]), horizon=rng.choice([1, 3, 7, 12]),
               runs=rng.choice([1, 3, 6]), discount=rng.choice([0.5, 0.95, 1.0]), exploration=rng.choice([0.0, 1.0, 100.0]))
@@ -25,6 +25,8 @@ def draw(rng):
     slots = rng.choice([1, 2, kw["runs"]])
     if "tiger" in domain and "factored" not in domain or "coffee" in domain:
         pass
+    elif domain == "agr":
+        kw["particles"] = rng.choice([256, 400])   # 21 goals: a filter without the true one can never be updated
     elif "factored-tiger" in domain:
         kw["size"] = rng.choice([1, 2, 3])
     elif domain == "gridworld":
@@ -34,7 +36,7 @@ def draw(rng):
         kw["size"] = rng.choice([1, 2, 3, 4])
     else:
         kw["width"], kw["height"], kw["size"] = rng.choice([(3, 3, 1), (4, 3, 2), (3, 5, 1)])
-    belief = rng.choice(["rejection_sampling", "importance_sampling"])
+    belief = rng.choice(["rejection_sampling", "importance_sampling"]) if domain != "agr" else "rejection_sampling"
     if model != N.MODEL_POMDP:
         kw["episodes"] = rng.choice([1, 2, 3])
         kw["counts_total"] = rng.choice([10.0, 777.0, 10000.0])

@@ -41,7 +41,7 @@ def test_default_config_matches_reference_cli_defaults(lib):
 def test_struct_layouts_match_between_engine_and_oracle():
     from oracle import pyorc as orc
     assert N.TRACE_DTYPE == orc.TRACE_DTYPE
-    assert N.TRACE_DTYPE.itemsize == 256  # sizeof(fba_trace_rec) = sizeof(orc_trace_rec)
+    assert N.TRACE_DTYPE.itemsize == 352  # sizeof(fba_trace_rec) = sizeof(orc_trace_rec)
 
 
 def test_statistic_matches_reference_known_answers(lib, golden):

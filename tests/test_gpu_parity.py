@@ -17,7 +17,7 @@ DOM = {"random-collision-avoidance": orc.DOM_COLLISION_AVOID, "centered-collisio
        "gridworld": orc.DOM_GRIDWORLD, "episodic-tiger": orc.DOM_TIGER_EPISODIC, "continuous-tiger": orc.DOM_TIGER_CONTINUOUS,
        "episodic-factored-tiger": orc.DOM_FTIGER_EPISODIC, "continuous-factored-tiger": orc.DOM_FTIGER_CONTINUOUS,
        "independent-sysadmin": orc.DOM_SYSADMIN_INDEPENDENT, "linear-sysadmin": orc.DOM_SYSADMIN_LINEAR,
-       "coffee": orc.DOM_COFFEE, "boutilier-coffee": orc.DOM_COFFEE_BOUTILIER}
+       "coffee": orc.DOM_COFFEE, "boutilier-coffee": orc.DOM_COFFEE_BOUTILIER, "agr": orc.DOM_AGR}
 
 
 def _pair(domain, model, belief, seed, slots=None, size=0, **kw):
@@ -475,6 +475,19 @@ def test_planning_coffee(domain, belief, planner):
     never terminal; both versions spend the same draws per step."""
     eng, o = _pair(domain, N.MODEL_POMDP, belief, 171, particles=150, sims=200, runs=10, horizon=8, slots=5, planner=planner)
     _assert_same_experiment(eng, o, ba=False)
+
+
+@pytest.mark.parametrize("planner,sims", [("po-uct", 300), ("ts", 120)])
+def test_planning_agr(planner, sims):
+    """planning -D agr (AGR.cpp, AGR(10)): 441 states, 23 actions (search_kernel<.., 24, ..>), 22 observations,
+    deterministic dynamics; the first 23 simulations each open a new root action."""
+    eng, o = _pair("agr", N.MODEL_POMDP, "rejection_sampling", 181, particles=300, sims=sims, runs=8, horizon=9, slots=4, planner=planner)
+    _assert_same_experiment(eng, o, ba=False)
+
+
+def test_agr_refuses_weighted_beliefs():
+    with pytest.raises(ValueError, match="computeObservationProbability nyi"):    # AGR.cpp:307-310
+        fba.Engine("agr", belief="importance_sampling", particles=4, sims=4)
 
 
 def test_coffee_has_no_bayes_adaptive_model():
