@@ -257,6 +257,7 @@ struct Problem {
     int32_t ca_plain;   // collision avoidance / sysadmin, factored model in the prior's own fixed graph (no masks): ca_fact_step / sysadmin_fact_step apply
     int32_t fd_bytes;   // bytes of *fd in use (header + A*(FS+FO) nodes): what a kernel stages in LDS
     int32_t cheat;      // cheating belief: particles copied from the correct-graph filter per cheat (belief = IMPORTANCE then); 0 = off
+    int32_t point;      // point-estimate belief: N = 1 and Belief::sample() returns the state without a draw
     int32_t reinvig;    // reinvigoration belief: particles bred per update (belief = REJECTION then); 0 = off
     int32_t S, A, O;
     int32_t N;          // particles per slot

@@ -964,12 +964,20 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         return fail(nullptr, FBA_ENODEVICE, "no HIP device visible: libfba_hip has no CPU path");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, FBA_EINVAL, "device %d out of range (%d visible)", cfg->device, ndev);
 
+    fba_config eff = *cfg;
+    const bool point = eff.belief == FBA_BELIEF_POINT;
+    if (point) {  // PointEstimation.cpp:36-76 / BAPointEstimation.cpp: the rejection update of a single state
+        eff.belief    = FBA_BELIEF_REJECTION;
+        eff.particles = 1;
+    }
+    cfg = &eff;
     fba_ctx* c = new fba_ctx();
     c->cfg     = *cfg;
     Problem& P = c->P;
     P.domain = cfg->domain; P.model = cfg->model; P.belief = cfg->belief; P.planner = cfg->planner;
     P.reinvig = 0;
     P.cheat   = 0;
+    P.point   = point ? 1 : 0;
     if (cfg->belief == FBA_BELIEF_CHEATING) {
         // a weighted (importance) filter + a rejection filter of correct-graph particles it copies from when
         // its log likelihood drops below --threshold (prototypes/CheatingReinvigoration.cpp)

@@ -78,7 +78,7 @@ __device__ __forceinline__ int uniform_weight_pick(const double* __restrict__ in
 // Belief::sample() of a freshly initiated / resampled filter (all weights 1/N)
 __device__ __forceinline__ int belief_sample_uniform(const Problem& P, const DeviceState& D, Rng& g)
 {
-    if (P.belief == FBA_BELIEF_REJECTION) return g.uniform_int(P.N);          // FlatFilter.cpp:97-102
+    if (P.belief == FBA_BELIEF_REJECTION) return P.point ? 0 : g.uniform_int(P.N);  // FlatFilter.cpp:97-102; PointEstimation::sample :30-34
     return uniform_weight_pick(D.uni_scan, P.N, g.u01() * D.uni_total, D.uni_total);
 }
 
@@ -664,7 +664,7 @@ __global__ void __launch_bounds__(REJECT_BLOCK) reject_kernel(Problem P, DeviceS
         }
         const int k = base + tid;
         g.stream(phase, (uint32_t)k);
-        const int src = g.uniform_int(N);                       // FlatFilter::sample
+        const int src = P.point ? 0 : g.uniform_int(N);         // FlatFilter::sample; the point estimate copies its one state
         const float* rec = scn + (size_t)src * P.Cs;
         int s = (!fc && lazy) ? lazy_state(P, D, e, src) : rec_state(rec, P.C), so;
         double r;

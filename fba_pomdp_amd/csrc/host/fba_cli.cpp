@@ -50,7 +50,7 @@ void usage()
         "  -H, --horizon N                Horizon, number of steps per episode (10)\n"
         "  -d, --discount X               Discount for future rewards (0.95)\n"
         "  -P, --planner NAME             random, ts (Thompson sampling) or po-uct (po-uct)\n"
-        "  -B, --belief NAME              rejection_sampling, importance_sampling or (fbapomdp) reinvigoration,\n"
+        "  -B, --belief NAME              point_estimate, rejection_sampling, importance_sampling or (fbapomdp) reinvigoration,\n"
         "                                 cheating-reinvigoration\n"
         "      --seed STR                 Global seed for all random samples\n"
         "      --id STR                   The id to give this process\n"
@@ -158,9 +158,10 @@ bool to_config(Options const& o, fba_config& c, std::string& err)
     else { err = "please enter a legit planner: random, ts or po-uct, provided: " + o.planner; return false; }
     if (o.belief == "rejection_sampling" || o.belief == "hip-rejection_sampling") c.belief = FBA_BELIEF_REJECTION;
     else if (o.belief == "importance_sampling" || o.belief == "hip-importance_sampling") c.belief = FBA_BELIEF_IMPORTANCE;
+    else if (o.belief == "point_estimate") c.belief = FBA_BELIEF_POINT;  // Belief.cpp:13-14, BABelief.cpp:19-20
     else if (o.belief == "reinvigoration" && o.mode == "fbapomdp") c.belief = FBA_BELIEF_REINVIGORATION;  // BABelief.cpp:28-31
     else if (o.belief == "cheating-reinvigoration" && o.mode == "fbapomdp") c.belief = FBA_BELIEF_CHEATING;  // BABelief.cpp:60-65
-    else { err = "please enter a legit state stimator: rejection_sampling, importance_sampling or (fbapomdp) reinvigoration, provided: " + o.belief; return false; }
+    else { err = "please enter a legit state stimator: point_estimate, rejection_sampling, importance_sampling or (fbapomdp) reinvigoration, provided: " + o.belief; return false; }
     if ((o.resample_amount == 0) ^ (o.belief != "reinvigoration" && o.belief != "cheating-reinvigoration")) {  // BeliefConf.cpp:40-49
         err = "You have set the resample amount (" + std::to_string(o.resample_amount) + "), but are not using one of the beliefs (" + o.belief +
               ") that use it: reinvigoration, cheating-reinvigoration and incubator";

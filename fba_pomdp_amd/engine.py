@@ -41,6 +41,8 @@ class Engine:
             if not hasattr(cfg, k):
                 raise AttributeError(f"fba_config has no field '{k}'")
             setattr(cfg, k, v)
+        if cfg.belief == N.BELIEF_POINT:
+            cfg.particles = 1   # what fba_create does with it; keeps the array sizes of this wrapper right
         self.cfg = cfg
         h = C.c_void_p()
         rc = self.L.fba_create(C.byref(cfg), C.byref(h))

@@ -48,7 +48,9 @@ enum { FBA_MODEL_POMDP = 0, FBA_MODEL_BA_TABLE = 1, FBA_MODEL_BA_FACTORED = 2 };
 /* -B rejection_sampling | importance_sampling (BeliefConf.hpp, Belief.cpp:13-24) | reinvigoration
  * (BABelief.cpp:28-31: ReinvigoratingRejectionSampling, factored models only) */
 enum { FBA_BELIEF_REJECTION = 0, FBA_BELIEF_IMPORTANCE = 1, FBA_BELIEF_REINVIGORATION = 2,
-       FBA_BELIEF_CHEATING = 3 /* cheating-reinvigoration (BABelief.cpp:60-65: prototypes::CheatingReinvigoration) */ };
+       FBA_BELIEF_CHEATING = 3, /* cheating-reinvigoration (BABelief.cpp:60-65: prototypes::CheatingReinvigoration) */
+       FBA_BELIEF_POINT = 4 /* point_estimate (Belief.cpp:13-14 PointEstimation, BABelief.cpp:19-20 BAPointEstimation): one state,
+                             * updated by rejection; `particles` is ignored (1) and sample() draws nothing */ };
 /* -P po-uct | random | ts (Planner.cpp:12-19, BAPlanner.cpp:13-20; ts = Thompson sampling: TSPlanner / BATSPlanner) */
 enum { FBA_PLANNER_POUCT = 0, FBA_PLANNER_RANDOM = 1, FBA_PLANNER_TS = 2 };
 /* --structure-prior (FBAConf.hpp) */

@@ -111,6 +111,7 @@ struct orc_ctx {
     int32_t n_trace, cap_trace;
     /* per-selectAction outputs */
     int32_t last_update_count;
+    int32_t point; /* belief = point estimate (run as a rejection filter of one particle) */
     double last_weight_total;
 };
 
@@ -1866,7 +1867,7 @@ static double dev_scan(const double* w, int n, double* incl)
 }
 
 /* FlatFilter::sample.  ref: src/beliefs/particle_filters/FlatFilter.cpp:97-102 */
-static int32_t flat_sample(orc_ctx* c) { return orc_int(&c->rng, c->cfg.particles); }
+static int32_t flat_sample(orc_ctx* c) { return c->point ? 0 : orc_int(&c->rng, c->cfg.particles); }
 
 /* WeightedFilter::sample.  ref: src/beliefs/particle_filters/WeightedFilter.cpp:163-191
  * (scan from the back, strict >, index 0 is the fall-through).
@@ -2403,6 +2404,14 @@ orc_ctx* orc_create(const orc_config* cfg)
 {
     orc_ctx* c = (orc_ctx*)calloc(1, sizeof(orc_ctx));
     int i, n;
+    orc_config eff = *cfg;
+    if (eff.belief == ORC_BELIEF_POINT) { /* PointEstimation.cpp / BAPointEstimation.cpp: one state, updated by rejection,
+                                           * and sample() returns it without touching the RNG */
+        eff.belief    = ORC_BELIEF_REJECTION;
+        eff.particles = 1;
+        c->point      = 1;
+    }
+    cfg    = &eff;
     c->cfg = *cfg;
     if (c->cfg.max_depth < 0) c->cfg.max_depth = c->cfg.horizon; /* ArgumentParser.cpp:37-40 */
     if (cfg->rng_mode == ORC_RNG_MT) {

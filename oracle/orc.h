@@ -43,7 +43,8 @@ enum { ORC_MODEL_POMDP = 0, ORC_MODEL_BA_TABLE = 1, ORC_MODEL_BA_FACTORED = 2 };
 /* belief */
 /* REINVIGORATION = beliefs::bayes_adaptive::factored::ReinvigoratingRejectionSampling (-B reinvigoration) */
 /* CHEATING = beliefs::bayes_adaptive::prototypes::CheatingReinvigoration (-B cheating-reinvigoration) */
-enum { ORC_BELIEF_REJECTION = 0, ORC_BELIEF_IMPORTANCE = 1, ORC_BELIEF_REINVIGORATION = 2, ORC_BELIEF_CHEATING = 3 };
+enum { ORC_BELIEF_REJECTION = 0, ORC_BELIEF_IMPORTANCE = 1, ORC_BELIEF_REINVIGORATION = 2, ORC_BELIEF_CHEATING = 3,
+       ORC_BELIEF_POINT = 4 /* -B point_estimate: src/beliefs/point_estimation/PointEstimation.cpp, bayes-adaptive/BAPointEstimation.cpp */ };
 /* floating-point summation order of the importance-sampling filter:
  * REF = the reference's sequential loops; DEV = the HIP engine's fixed reduction tree */
 enum { ORC_ARITH_REF = 0, ORC_ARITH_DEV = 1 };

@@ -18,7 +18,7 @@ DOM_SYSADMIN_INDEPENDENT, DOM_SYSADMIN_LINEAR = 7, 8
 DOM_COFFEE, DOM_COFFEE_BOUTILIER = 9, 10
 DOM_AGR = 11
 MODEL_POMDP, MODEL_BA_TABLE, MODEL_BA_FACTORED = range(3)
-BELIEF_REJECTION, BELIEF_IMPORTANCE, BELIEF_REINVIGORATION, BELIEF_CHEATING = range(4)
+BELIEF_REJECTION, BELIEF_IMPORTANCE, BELIEF_REINVIGORATION, BELIEF_CHEATING, BELIEF_POINT = range(5)
 ARITH_REF, ARITH_DEV = range(2)
 RNG_MT, RNG_PHILOX = range(2)
 PLANNER_POUCT, PLANNER_RANDOM, PLANNER_TS = range(3)
@@ -188,6 +188,8 @@ def make_config(**kw):
         if not hasattr(c, k):
             raise AttributeError(k)
         setattr(c, k, v)
+    if c.belief == BELIEF_POINT:
+        c.particles = 1   # what the library does with it; keeps the array sizes of this wrapper right
     return c
 
 

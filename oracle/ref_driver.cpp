@@ -26,6 +26,7 @@
 #include "beliefs/particle_filters/ImportanceSampler.hpp"
 #include "beliefs/particle_filters/RejectionSampling.hpp"
 #include "beliefs/particle_filters/WeightedFilter.hpp"
+#include "beliefs/point_estimation/PointEstimation.hpp"
 #include "domains/collision-avoidance/CollisionAvoidance.hpp"
 #include "domains/agr/AGR.hpp"
 #include "domains/coffee/CoffeeProblem.hpp"
@@ -587,12 +588,16 @@ static void regular_dirichlet(char const* s)
     printf(", \"next_u01\": %.17g}", rnd::uniform_rand01());
 }
 
-/* episode::run with the reference's RandomPlanner and RejectionSampling belief */
+/* episode::run with the reference's RandomPlanner and RejectionSampling belief (n > 0) or its
+ * PointEstimation belief (n == 0, on the continuous tiger so that episodes last the whole horizon) */
 static void random_planner_episodes(char const* s, int n, int episodes)
 {
-    domains::Tiger env(domains::Tiger::EPISODIC), sim(domains::Tiger::EPISODIC);
+    auto const type = n ? domains::Tiger::EPISODIC : domains::Tiger::CONTINUOUS;
+    domains::Tiger env(type), sim(type);
     planners::RandomPlanner planner;
-    beliefs::RejectionSampling belief((size_t)n);
+    beliefs::RejectionSampling rs((size_t)(n ? n : 1));
+    beliefs::PointEstimation point;
+    Belief& belief = n ? static_cast<Belief&>(rs) : static_cast<Belief&>(point);
     seed(s);
     std::vector<double> rets;
     std::vector<int> lens;
@@ -746,6 +751,9 @@ int main(int argc, char** argv)
 
     key("random_planner_episodes");
     random_planner_episodes("16", 32, 60);
+
+    key("random_planner_point_estimate");
+    random_planner_episodes("17", 0, 40);
 
     key("statistic");
     statistic();

@@ -477,6 +477,22 @@ def test_planning_coffee(domain, belief, planner):
     _assert_same_experiment(eng, o, ba=False)
 
 
+@pytest.mark.parametrize("domain,model,kw", [
+    ("continuous-tiger", N.MODEL_POMDP, dict(runs=40, horizon=10)),
+    ("boutilier-coffee", N.MODEL_POMDP, dict(runs=12, horizon=8)),
+    ("episodic-tiger", N.MODEL_BA_TABLE, dict(runs=12, episodes=4)),
+    ("episodic-factored-tiger", N.MODEL_BA_FACTORED, dict(runs=10, episodes=3, size=2, structure_prior=2)),
+    ("linear-sysadmin", N.MODEL_BA_FACTORED, dict(runs=6, episodes=2, size=3, horizon=6, planner="ts")),
+])
+def test_point_estimate_belief(domain, model, kw):
+    """-B point_estimate (PointEstimation.cpp / BAPointEstimation.cpp): one (BA) state per slot, updated by rejection,
+    sampled without a draw; `particles` is ignored."""
+    eng, o = _pair(domain, model, "point_estimate", 191, particles=50, sims=128, slots=4, **kw)
+    _assert_same_experiment(eng, o, ba=model != N.MODEL_POMDP)
+    s, _, cnt = eng.belief_get(0)
+    assert s.shape == (1,) and cnt.shape[0] == 1
+
+
 @pytest.mark.parametrize("planner,sims", [("po-uct", 300), ("ts", 120)])
 def test_planning_agr(planner, sims):
     """planning -D agr (AGR.cpp, AGR(10)): 441 states, 23 actions (search_kernel<.., 24, ..>), 22 observations,
