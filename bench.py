@@ -80,7 +80,7 @@ def measured_traffic(args, kname, slots):
     (FETCH_SIZE and WRITE_SIZE in separate runs of this same command; profiles/*.json says how
     they were collected and corrected).  None when the workload differs from the profiled one."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write.json")
-    if not os.path.exists(path) or slots != 131072 or args.sims != 4096 or args.particles != 4096:
+    if not os.path.exists(path) or slots != 163840 or args.sims != 4096 or args.particles != 4096:
         return None, None
     with open(path) as f:
         d = json.load(f)
@@ -94,7 +94,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--slots", type=int, default=131072, help="concurrent runs per GPU (1.3 MB of HBM each at the default workload)")
+    ap.add_argument("--slots", type=int, default=163840,
+                    help="concurrent runs per GPU (1.3 MB of HBM each at the default workload); 163840 = 10 search waves per CU, "
+                         "one below what the LDS of a CU holds, so that an uneven spread of workgroups over CUs leaves no tail")
     ap.add_argument("--sims", type=int, default=4096)
     ap.add_argument("--particles", type=int, default=4096)
     ap.add_argument("--horizon", type=int, default=10)
@@ -137,7 +139,7 @@ def main():
 
     import fba_pomdp_amd as fba
     slots = args.slots
-    while True:  # 1.3 MB of HBM per slot: halve if this GPU cannot give 170 GB right now
+    while True:  # 1.3 MB of HBM per slot: step down if this GPU cannot give 213 GB right now
         try:
             eng = fba.Engine("episodic-tiger", model=fba.MODEL_BA_TABLE, belief=args.belief,
                              sims=args.sims, particles=args.particles, horizon=args.horizon,
@@ -147,8 +149,9 @@ def main():
         except fba.FbaError as e:
             if "out of memory" not in str(e) or slots <= 1024:
                 raise
-            print(f"[bench] {slots} slots do not fit ({e}); retrying with {slots // 2}", file=sys.stderr)
-            slots //= 2
+            nxt = 131072 if slots > 131072 else slots // 2
+            print(f"[bench] {slots} slots do not fit ({e}); retrying with {nxt}", file=sys.stderr)
+            slots = nxt
 
     def barrier():
         torch.cuda.synchronize()

@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
         // consulted several times per sampled feature: keep the part in use in LDS, at the end of
         // this workgroup's allocation, instead of chasing it through global memory
         const int depth_cap0 = P.max_depth > 0 ? P.max_depth : 1;
-        size_t words = (size_t)depth_cap0 * SEARCH_BLOCK * 3 + (STAGE ? (size_t)P.Cs * SEARCH_BLOCK : 0) +
+        size_t words = (size_t)depth_cap0 * SEARCH_BLOCK * 2 + (STAGE ? (size_t)P.Cs * SEARCH_BLOCK : 0) +
                        (P.A * P.O <= ROOT_CHILDREN ? (size_t)P.A * P.O * SEARCH_BLOCK : 0);
         words = (words + 3) & ~(size_t)3;  // 16-byte aligned
         uint4* dst       = reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(lds) + words);
@@ -241,8 +241,11 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
     if (e >= P.E || !D.active[e]) return;
 
     const int depth_cap = P.max_depth > 0 ? P.max_depth : 1;
-    double* path_r      = lds + lane;                                                   // [depth][block]
-    int32_t* path_na    = reinterpret_cast<int32_t*>(lds + (size_t)depth_cap * SEARCH_BLOCK) + lane;
+    // Rewards on the path are kept as fp32: every reward of every domain here (and of the BA extensions) is a
+    // small integer or a multiple of 1/2, so the round trip through float is exact and the back-up still
+    // computes in fp64 -- and 4 bytes x depth x 64 lanes of LDS per wave buy one more resident wave per CU.
+    float* path_r       = reinterpret_cast<float*>(lds) + lane;                         // [depth][block]
+    int32_t* path_na    = reinterpret_cast<int32_t*>(path_r - lane + (size_t)depth_cap * SEARCH_BLOCK) + lane;
     float* stage        = reinterpret_cast<float*>(path_na - lane + (size_t)depth_cap * SEARCH_BLOCK) + lane;  // [Cs][block]
     // children of the root, [a*O + o][block], when there are at most ROOT_CHILDREN of them
     const bool root_lds = P.A * P.O <= ROOT_CHILDREN;
@@ -342,7 +345,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
             else term = sim_step<REG>(P, g, GlobalSearchView{cnt}, s, a, o, r, NoInc{});
             ++steps;
             if (mode == 1) {  // traverseChanceNode
-                path_r[(size_t)plen * SEARCH_BLOCK]  = r;
+                path_r[(size_t)plen * SEARCH_BLOCK]  = (float)r;
                 path_na[(size_t)plen * SEARCH_BLOCK] = (node << 5) | a  /* a < FBA_MAX_ACTIONS <= 32 */;
                 ++plen;
                 if (term) finish = true;
@@ -372,7 +375,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
             double del = delayed;
             for (int k = plen - 1; k >= 0; --k) {
                 const int na     = path_na[(size_t)k * SEARCH_BLOCK];
-                const double ret = path_r[(size_t)k * SEARCH_BLOCK] + P.gamma * del;
+                const double ret = (double)path_r[(size_t)k * SEARCH_BLOCK] + P.gamma * del;
                 const int act    = na & 31;
                 if ((na >> 5) == 0) {
                     // register-array element `act`: select, ONE division, write back
@@ -616,10 +619,13 @@ __device__ __forceinline__ int record_group(int C4)
 // reference's result: the new filter is the first N accepted attempts, in order, and the
 // reported loop count is the index of the N-th accepted attempt + 1.
 // ---------------------------------------------------------------------------------------------
+// BLK = attempts per chunk = workgroup size.  Measured on the bench workload: 256 and 512 give the same time,
+// 1024 is 10 % slower (a larger last chunk runs attempts nobody needs), and halving the resident workgroups
+// per CU changes nothing -- the kernel is bound by the memory system's rate for random 128-byte lines.
 // `fc` = 1 runs the update on the reinvigoration belief's fully connected filter (launched before
 // the main filter's update, which is the one that clears the request flag).
-template <bool REG, bool TIGER_TABLE, int FTIGER = 0>
-__global__ void __launch_bounds__(REJECT_BLOCK) reject_kernel(Problem P, DeviceState D, int fc)
+template <bool REG, bool TIGER_TABLE, int FTIGER = 0, int BLK = REJECT_BLOCK>
+__global__ void __launch_bounds__(BLK) reject_kernel(Problem P, DeviceState D, int fc)
 {
     if (FTIGER > 0) {  // factored tiger with FTIGER binary state features (see search_kernel)
         P.model = FBA_MODEL_BA_FACTORED;
@@ -632,8 +638,8 @@ __global__ void __launch_bounds__(REJECT_BLOCK) reject_kernel(Problem P, DeviceS
         P.S = 2; P.A = 3; P.O = 2; P.phi_len = 12; P.C = 24; P.Cs = 32;
         if (P.domain != FBA_DOM_TIGER_CONTINUOUS) P.domain = FBA_DOM_TIGER_EPISODIC;
     }
-    __shared__ int32_t s_src[REJECT_BLOCK], s_ns[REJECT_BLOCK], s_owner[REJECT_BLOCK], s_inc[MAXINC * REJECT_BLOCK];
-    __shared__ int32_t s_wave[REJECT_BLOCK / 64];
+    __shared__ int32_t s_src[BLK], s_ns[BLK], s_owner[BLK], s_inc[MAXINC * BLK];
+    __shared__ int32_t s_wave[BLK / 64];
     __shared__ int32_t s_count;
     const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (!D.need_update[e]) return;
@@ -669,8 +675,8 @@ __global__ void __launch_bounds__(REJECT_BLOCK) reject_kernel(Problem P, DeviceS
         int s = (!fc && lazy) ? lazy_state(P, D, e, src) : rec_state(rec, P.C), so;
         double r;
         // UpdateCounts: the +1s land in the copy
-        if (FTIGER > 0) ftiger_step<(FTIGER > 0 ? FTIGER : 1)>(P, g, GlobalView{rec}, s, a, so, r, LdsInc<REJECT_BLOCK>{s_inc + tid});
-        else sim_step<REG>(P, g, GlobalView{rec}, s, a, so, r, LdsInc<REJECT_BLOCK>{s_inc + tid});
+        if (FTIGER > 0) ftiger_step<(FTIGER > 0 ? FTIGER : 1)>(P, g, GlobalView{rec}, s, a, so, r, LdsInc<BLK>{s_inc + tid});
+        else sim_step<REG>(P, g, GlobalView{rec}, s, a, so, r, LdsInc<BLK>{s_inc + tid});
         s_src[tid] = src;
         s_ns[tid]  = s;
         const bool ok = (so == o);
@@ -679,7 +685,7 @@ __global__ void __launch_bounds__(REJECT_BLOCK) reject_kernel(Problem P, DeviceS
         if (lane == 0) s_wave[wave] = __popcll(ballot);
         __syncthreads();
         int woff = 0, chunk = 0;
-        for (int w = 0; w < REJECT_BLOCK / 64; ++w) {
+        for (int w = 0; w < BLK / 64; ++w) {
             if (w < wave) woff += s_wave[w];
             chunk += s_wave[w];
         }
@@ -690,9 +696,9 @@ __global__ void __launch_bounds__(REJECT_BLOCK) reject_kernel(Problem P, DeviceS
         }
         __syncthreads();
         const int m = min(chunk, N - acc);
-        gather_records(dcn + (size_t)acc * P.Cs, scn, s_owner, s_src, s_inc, ninc, REJECT_BLOCK, s_ns, m, C4, P.C, group, REJECT_BLOCK);
+        gather_records(dcn + (size_t)acc * P.Cs, scn, s_owner, s_src, s_inc, ninc, BLK, s_ns, m, C4, P.C, group, BLK);
         acc += m;
-        base += REJECT_BLOCK;
+        base += BLK;
         __syncthreads();
     }
     if (tid == 0) {
@@ -1399,7 +1405,7 @@ void launch_search(const Problem& P, const DeviceState& D, hipStream_t st)
 {
     const int depth_cap = P.max_depth > 0 ? P.max_depth : 1;
     const bool stage = P.model != FBA_MODEL_POMDP && P.Cs <= SEARCH_STAGE_WORDS;
-    size_t lds = (size_t)depth_cap * SEARCH_BLOCK * (sizeof(double) + sizeof(int32_t)) +
+    size_t lds = (size_t)depth_cap * SEARCH_BLOCK * (sizeof(float) + sizeof(int32_t)) +
                  (stage ? (size_t)P.Cs * SEARCH_BLOCK * sizeof(float) : 0) +
                  (P.A * P.O <= ROOT_CHILDREN ? (size_t)P.A * P.O * SEARCH_BLOCK * sizeof(int32_t) : 0);
     if (P.model == FBA_MODEL_BA_FACTORED) lds = ((lds + 15) & ~(size_t)15) + (((size_t)P.fd_bytes + 15) & ~(size_t)15);  // + the model description

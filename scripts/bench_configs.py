@@ -31,6 +31,8 @@ CONFIGS = {
 
 for name in (sys.argv[1:] or ["c1", "c3", "c4small"]):
     cfg = dict(CONFIGS[name])
+    if os.environ.get("FBA_SLOTS"):   # try another number of concurrent runs
+        cfg["slots"] = int(os.environ["FBA_SLOTS"])
     ticks = cfg.pop("ticks")
     domain = cfg.pop("domain")
     t0 = time.perf_counter()
