@@ -89,6 +89,20 @@ class Counters(C.Structure):
     _fields_ = [("sim_steps", C.c_uint64), ("belief_steps", C.c_uint64), ("env_steps", C.c_uint64)]
 
 
+MAX_FEATURES, MAX_NODES = 8, 160
+
+
+class FactoredNode(C.Structure):
+    _fields_ = [("offset", C.c_int32), ("out", C.c_int32), ("n_candidates", C.c_int32), ("mask_word", C.c_int32),
+                ("fixed_mask", C.c_uint32), ("candidate", C.c_uint8 * MAX_FEATURES), ("candidate_size", C.c_uint8 * MAX_FEATURES)]
+
+
+class FactoredLayout(C.Structure):
+    _fields_ = [("n_state_features", C.c_int32), ("n_obs_features", C.c_int32), ("n_nodes", C.c_int32), ("n_counts", C.c_int32),
+                ("n_mask_words", C.c_int32), ("state_feature_size", C.c_int32 * MAX_FEATURES),
+                ("obs_feature_size", C.c_int32 * MAX_FEATURES), ("node", FactoredNode * MAX_NODES)]
+
+
 class KernelTime(C.Structure):
     _fields_ = [("ms", C.c_double), ("launches", C.c_uint64), ("units", C.c_uint64), ("bytes", C.c_uint64)]
 
@@ -96,7 +110,7 @@ class KernelTime(C.Structure):
 # every symbol include/fba_hip.h declares
 EXPORTS = [
     "fba_abi_version", "fba_default_config", "fba_create", "fba_destroy", "fba_last_error",
-    "fba_domain_sizes", "fba_counts_len", "fba_slots", "fba_set_model_tabular", "fba_get_prior",
+    "fba_domain_sizes", "fba_counts_len", "fba_slots", "fba_set_model_tabular", "fba_get_prior", "fba_get_factored_layout",
     "fba_set_position", "fba_belief_init", "fba_belief_reset_domain_state", "fba_select_action",
     "fba_belief_update", "fba_belief_get", "fba_belief_set", "fba_belief_get_fully_connected", "fba_last_step_info",
     "fba_run_planning", "fba_run_bapomdp", "fba_run_ticks", "fba_get_returns", "fba_get_counters", "fba_get_return_sums",
@@ -158,6 +172,7 @@ def load():
     L.fba_slots.argtypes = [vp]
     L.fba_set_model_tabular.argtypes = [vp, vp, vp]
     L.fba_get_prior.argtypes = [vp, vp]
+    L.fba_get_factored_layout.argtypes = [vp, vp]
     L.fba_set_position.argtypes = [vp, vp, vp, vp]
     L.fba_belief_init.argtypes = [vp]
     L.fba_belief_reset_domain_state.argtypes = [vp]

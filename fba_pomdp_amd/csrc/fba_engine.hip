@@ -1374,6 +1374,29 @@ int fba_set_model_tabular(fba_ctx* c, const float* phi, const float* psi)
     return upload_prior(c);
 }
 
+int fba_get_factored_layout(const fba_ctx* c, fba_factored_layout* out)
+{
+    if (!c || !out) return FBA_EINVAL;
+    if (c->P.model != FBA_MODEL_BA_FACTORED) return fail(const_cast<fba_ctx*>(c), FBA_EINVAL, "fba_get_factored_layout: not a factored model");
+    static_assert(FBA_MAX_FEATURES == MAXF && FBA_MAX_NODES == MAXNODES, "public layout struct mirrors FDesc");
+    const FDesc& d = c->fdesc;
+    memset(out, 0, sizeof *out);
+    out->n_state_features = d.FS;
+    out->n_obs_features   = d.FO;
+    out->n_nodes          = c->P.A * (d.FS + d.FO);
+    out->n_counts         = d.ncounts;
+    out->n_mask_words     = d.nvar;
+    for (int f = 0; f < d.FS; ++f) out->state_feature_size[f] = d.Ssz[f];
+    for (int f = 0; f < d.FO; ++f) out->obs_feature_size[f] = d.Osz[f];
+    for (int k = 0; k < out->n_nodes; ++k) {
+        const FNode& nd       = d.nodes[k];
+        fba_factored_node& o  = out->node[k];
+        o.offset = nd.off; o.out = nd.out; o.n_candidates = nd.nmax; o.mask_word = nd.var; o.fixed_mask = nd.fixed_mask;
+        for (int j = 0; j < nd.nmax; ++j) { o.candidate[j] = nd.maxp[j]; o.candidate_size[j] = (uint8_t)d.Ssz[nd.maxp[j]]; }
+    }
+    return FBA_OK;
+}
+
 int fba_get_prior(const fba_ctx* c, float* counts)
 {
     if (!c || !counts) return FBA_EINVAL;

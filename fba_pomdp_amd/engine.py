@@ -122,6 +122,12 @@ class Engine:
         self._chk(self.L.fba_get_prior(self.h, out.ctypes.data))
         return out
 
+    def factored_layout(self):
+        """How a factored particle's count blob is laid out (include/fba_hip.h, fba_factored_layout)."""
+        out = N.FactoredLayout()
+        self._chk(self.L.fba_get_factored_layout(self.h, C.byref(out)))
+        return out
+
     def set_model_tabular(self, phi, psi):
         phi = np.ascontiguousarray(phi, np.float32)
         psi = np.ascontiguousarray(psi, np.float32)

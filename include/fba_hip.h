@@ -179,6 +179,32 @@ int fba_slots(const fba_ctx* ctx);      /* slots actually resident (cfg.slots, o
 int fba_set_model_tabular(fba_ctx* ctx, const float* phi, const float* psi);
 int fba_get_prior(const fba_ctx* ctx, float* counts);
 
+/* Layout of a factored particle's count blob (model = FBA_MODEL_BA_FACTORED), for hosts that read or
+ * write particles with fba_belief_get / fba_belief_set -- what BABNModel + DBNNode hold per state
+ * (BABNModel.hpp:30-200, DBNNode.hpp:20-120), flattened:
+ *   blob = n_counts floats of CPTs, then n_mask_words words (uint32 bit patterns stored in float slots).
+ *   node k: T(a, f) = node[a * n_state_features + f], O(a, f) = node[A * n_state_features + a * n_obs_features + f].
+ *   A node owns room for EVERY candidate parent set ("max layout"); the parents in use are the candidates j
+ *   whose bit j is set in the particle's mask word `mask_word` (or in `fixed_mask` when mask_word < 0).
+ *   Row of parent values v: idx = 0; for j in candidate order, if bit j set: idx = idx * candidate_size[j] + v[candidate[j]];
+ *   the row starts at blob[offset + idx * out] and has `out` counts (DBNNode::cptIndex, last parent fastest).
+ *   Parent values are features of the PREVIOUS state for T nodes and of the NEW state for O nodes; a state index
+ *   is its features in mixed radix, last feature fastest (indexing::project, utils/index.cpp:51-83). */
+#define FBA_MAX_FEATURES 8
+#define FBA_MAX_NODES 160
+typedef struct fba_factored_node {
+    int32_t offset, out, n_candidates, mask_word;
+    uint32_t fixed_mask;
+    uint8_t candidate[FBA_MAX_FEATURES];      /* state-feature ids, in order */
+    uint8_t candidate_size[FBA_MAX_FEATURES]; /* number of values of each candidate */
+} fba_factored_node;
+typedef struct fba_factored_layout {
+    int32_t n_state_features, n_obs_features, n_nodes, n_counts, n_mask_words;
+    int32_t state_feature_size[FBA_MAX_FEATURES], obs_feature_size[FBA_MAX_FEATURES];
+    fba_factored_node node[FBA_MAX_NODES];
+} fba_factored_layout;
+int fba_get_factored_layout(const fba_ctx* ctx, fba_factored_layout* out);
+
 /* ---- per-step interface: one call per reference virtual call -------------------------- */
 
 /* Where each slot is in its experiment; addresses the Philox streams of the calls below. */

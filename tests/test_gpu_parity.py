@@ -493,6 +493,61 @@ def test_point_estimate_belief(domain, model, kw):
     assert s.shape == (1,) and cnt.shape[0] == 1
 
 
+@pytest.mark.parametrize("domain,kw", [
+    ("episodic-factored-tiger", dict(size=3, structure_prior=2)),
+    ("gridworld", dict(size=3, structure_prior=2)),
+    ("random-collision-avoidance", dict(width=4, height=3, size=2, structure_prior=1)),
+    ("linear-sysadmin", dict(size=3)),
+])
+def test_factored_layout_decodes_particles(domain, kw):
+    """fba_get_factored_layout: a host that only knows the published layout rule (include/fba_hip.h) reproduces the
+    model's observation probabilities P(o | a, s') = prod_f row_f[o_f] / sum(row_f) from a particle's raw blob."""
+    eng = fba.Engine(domain, model=N.MODEL_BA_FACTORED, belief="importance_sampling", particles=16, sims=4, slots=1, seed=5, **kw)
+    o = orc.Oracle(domain=DOM[domain], model=N.MODEL_BA_FACTORED, belief=orc.BELIEF_IMPORTANCE, particles=16, sims=4,
+                   rng_mode=orc.RNG_PHILOX, arith=orc.ARITH_DEV, philox_seed=5, **kw)
+    eng.belief_init()
+    lay = eng.factored_layout()
+    FS, FO = lay.n_state_features, lay.n_obs_features
+    assert lay.n_nodes == eng.A * (FS + FO) and lay.n_counts + lay.n_mask_words == eng.ncnt
+    ssz = list(lay.state_feature_size[:FS]); osz = list(lay.obs_feature_size[:FO])
+    assert int(np.prod(ssz)) == eng.S and int(np.prod(osz)) == eng.O
+    # node tables tile the count part of the blob, in node order, each with room for every candidate parent
+    off = 0
+    for k in range(lay.n_nodes):
+        nd = lay.node[k]
+        assert nd.offset == off
+        off += nd.out * int(np.prod([nd.candidate_size[j] for j in range(nd.n_candidates)] or [1]))
+        assert -1 <= nd.mask_word < lay.n_mask_words
+    assert off == lay.n_counts
+    _, _, cnt = eng.belief_get(0)
+
+    def features(idx, sizes):   # last feature fastest
+        out = []
+        for z in reversed(sizes):
+            out.append(idx % z); idx //= z
+        return out[::-1]
+
+    rng = np.random.default_rng(1)
+    for _ in range(40):
+        blob = cnt[rng.integers(len(cnt))]
+        a, ns, ob = int(rng.integers(eng.A)), int(rng.integers(eng.S)), int(rng.integers(eng.O))
+        v, of = features(ns, ssz), features(ob, osz)
+        p = 1.0
+        for f in range(FO):
+            nd = lay.node[eng.A * FS + a * FO + f]
+            mask = int(blob[lay.n_counts + nd.mask_word:][:1].view(np.uint32)[0]) if nd.mask_word >= 0 else nd.fixed_mask
+            idx = 0
+            for j in range(nd.n_candidates):
+                if (mask >> j) & 1:
+                    idx = idx * nd.candidate_size[j] + v[nd.candidate[j]]
+            row = blob[nd.offset + idx * nd.out:][:nd.out].astype(np.float64)
+            p *= row[of[f]] / row.sum() if row.sum() > 0 else 0.0
+        want = o.model_obs_prob(np.ascontiguousarray(blob), ns, a, ob)
+        assert abs(p - want) <= 1e-6 * max(want, 1e-12), (a, ns, ob, p, want)
+    with pytest.raises(ValueError, match="not a factored model"):
+        fba.Engine("episodic-tiger", model=N.MODEL_BA_TABLE, particles=4, sims=4).factored_layout()
+
+
 @pytest.mark.parametrize("planner,sims", [("po-uct", 300), ("ts", 120)])
 def test_planning_agr(planner, sims):
     """planning -D agr (AGR.cpp, AGR(10)): 441 states, 23 actions (search_kernel<.., 24, ..>), 22 observations,
