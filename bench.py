@@ -8,6 +8,7 @@ One "step" = one real time-step of every resident slot: RBAPOUCT search (`sims` 
 true-environment step, and the particle-filter belief update.  Workload (N = 1 and per GPU for
 N > 1) is BASELINE.json configs[1]: episodic-tiger BA-POMCP, 4096 sims/step, 4096 particles,
 tabular BA-POMDP, expected-Dirichlet sampling, rejection-sampling belief (the reference default).
+Particles are stored packed (24 uint16 increment counts over the shared prior + state: 64 B).
 Runs are independent, so N GPUs run N disjoint sets of runs (weak scaling); the only collective is
 one all-reduce of {episodes, sum of returns, sum of squares} + the step counters at the end.
 
@@ -80,7 +81,7 @@ def measured_traffic(args, kname, slots):
     (FETCH_SIZE and WRITE_SIZE in separate runs of this same command; profiles/*.json says how
     they were collected and corrected).  None when the workload differs from the profiled one."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write.json")
-    if not os.path.exists(path) or slots != 163840 or args.sims != 4096 or args.particles != 4096:
+    if not os.path.exists(path) or slots != 229376 or args.sims != 4096 or args.particles != 4096:
         return None, None
     with open(path) as f:
         d = json.load(f)
@@ -94,9 +95,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--slots", type=int, default=163840,
-                    help="concurrent runs per GPU (1.3 MB of HBM each at the default workload); 163840 = 10 search waves per CU, "
-                         "one below what the LDS of a CU holds, so that an uneven spread of workgroups over CUs leaves no tail")
+    ap.add_argument("--slots", type=int, default=229376,
+                    help="concurrent runs per GPU (0.79 MB of HBM each at the default workload, packed particles); "
+                         "229376 = 14 search waves per CU, what the LDS of a CU holds at 10.8 KB per wave")
     ap.add_argument("--sims", type=int, default=4096)
     ap.add_argument("--particles", type=int, default=4096)
     ap.add_argument("--horizon", type=int, default=10)
@@ -139,7 +140,7 @@ def main():
 
     import fba_pomdp_amd as fba
     slots = args.slots
-    while True:  # 1.3 MB of HBM per slot: step down if this GPU cannot give 213 GB right now
+    while True:  # 0.79 MB of HBM per slot: step down if this GPU cannot give 180 GB right now
         try:
             eng = fba.Engine("episodic-tiger", model=fba.MODEL_BA_TABLE, belief=args.belief,
                              sims=args.sims, particles=args.particles, horizon=args.horizon,
@@ -149,7 +150,7 @@ def main():
         except fba.FbaError as e:
             if "out of memory" not in str(e) or slots <= 1024:
                 raise
-            nxt = 131072 if slots > 131072 else slots // 2
+            nxt = 163840 if slots > 163840 else (131072 if slots > 131072 else slots // 2)
             print(f"[bench] {slots} slots do not fit ({e}); retrying with {nxt}", file=sys.stderr)
             slots = nxt
 
@@ -186,6 +187,11 @@ def main():
         kname = "reject_kernel" if args.belief == "rejection_sampling" else "importance_kernel"
         k = kt[kname]
         achieved = (k.bytes / 1e9) / (k.ms / 1e3) if k.ms > 0 else 0.0
+        # the same bytes formula with the sizes of the format actually stored (packed: 2 bytes per count)
+        stored = achieved
+        if eng.particle_bytes == 64 and kname == "reject_kernel" and k.ms > 0:
+            attempts = (k.bytes - k.units * 100) / 116.0
+            stored = (attempts * (52 + 4 + 4) + k.units * 52) / 1e9 / (k.ms / 1e3)
         search = kt["search_kernel"]
         n_ep = tot[2]
         traffic, traffic_src = measured_traffic(args, kname, eng.slots)
@@ -212,6 +218,8 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "launches": int(k.launches), "avg_ms": k.ms / max(int(k.launches), 1),
                 "algorithmic_bytes_per_launch": k.bytes / max(int(k.launches), 1),
+                "algorithmic_basis": "SURVEY.md 8(d): dense fp32 particle, Pb = 100 B, Rt = Ro = 8 B",
+                "particle_bytes_in_hbm": eng.particle_bytes, "stored_format_GBs": stored,
             },
             "search_kernel": {"avg_ms": search.ms / max(int(search.launches), 1),
                               "steps_per_s": search.units / (search.ms / 1e3) if search.ms > 0 else 0.0},

@@ -110,6 +110,21 @@ struct LdsView {
     static constexpr bool row_regs = false;
     __device__ __forceinline__ float at(int k) const { return p[k * STRIDE]; }
 };
+// Packed tabular particle (Problem::packed): the record holds, per cell of the count table, how many "+1"s the
+// cell has received (uint16, two per 32-bit word, even cell in the low half); count = prior[k] + that number.
+// The engine only packs when prior[k] + 65535 is exactly representable in fp32 for every k, so the sum below
+// is the very float the reference reaches by adding 1.0f that many times.  `words.at(w)` = word w of the record.
+template <class Base>
+struct PackedView {
+    Base words;
+    const float* prior;  // the dense prior table (LDS copy)
+    static constexpr bool row_regs = false;
+    __device__ __forceinline__ float at(int k) const
+    {
+        const uint32_t w = __float_as_uint(words.at(k >> 1));
+        return prior[k] + (float)((k & 1) ? (w >> 16) : (w & 0xffffu));
+    }
+};
 
 // ---------------------------------------------------------------------------------------------
 // Sampling primitives (reference src/utils/random.hpp:93-115, random.cpp:244-279)
@@ -257,6 +272,7 @@ struct Problem {
     int32_t ca_plain;   // collision avoidance / sysadmin, factored model in the prior's own fixed graph (no masks): ca_fact_step / sysadmin_fact_step apply
     int32_t fd_bytes;   // bytes of *fd in use (header + A*(FS+FO) nodes): what a kernel stages in LDS
     int32_t cheat;      // cheating belief: particles copied from the correct-graph filter per cheat (belief = IMPORTANCE then); 0 = off
+    int32_t packed;     // tabular tiger particles stored as uint16 increment counts over the shared prior (PackedView); C, Cs are then in words of that record
     int32_t point;      // point-estimate belief: N = 1 and Belief::sample() returns the state without a draw
     int32_t reinvig;    // reinvigoration belief: particles bred per update (belief = REJECTION then); 0 = off
     int32_t S, A, O;

@@ -35,8 +35,10 @@ struct fba_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     std::vector<void*> allocs;
-    std::vector<float> prior;  // host copy, C floats
+    std::vector<float> prior;  // host copy, dense_C floats
+    int dense_C          = 0;   // length of a particle's count table as the API sees it (= P.C unless P.packed)
     float* d_prior       = nullptr;
+    float* d_prior_dense = nullptr;  // packed particles: the dense prior table on the device
     FDesc fdesc{};          // host copy of the factored model description
     FDesc* d_fdesc       = nullptr;
     GridDesc gdesc{};
@@ -283,7 +285,7 @@ int build_tabular_prior(fba_ctx* c)
     const int S = P.S, A = P.A, O = P.O;
     const float noise = c->cfg.noise, total = c->cfg.counts_total;
     if (is_sys(P.domain)) {  // SysAdminFlatPrior: zero-initialised BAFlatModel, --noise / -C unused
-        c->prior.assign((size_t)P.C, 0.f);
+        c->prior.assign((size_t)c->dense_C, 0.f);
         SysFlat flat{P, c->sysdesc, c->prior.data()};
         for (int s = 0; s < S; ++s) flat.recur(s, S - 1, c->sysdesc.N - 1, 1);
         float* psi = c->prior.data() + P.phi_len;  // :60-90: the observation tells the operated computer's bit
@@ -304,7 +306,7 @@ int build_tabular_prior(fba_ctx* c)
         const CADesc& ca = c->cadesc;
         const int W = ca.W, H = ca.H, n = ca.n, Hn = ca.Hn;
         if (!(noise < .5 && noise > -.5)) return fail(c, FBA_EINVAL, "CollisionAvoidanceTablePrior needs -.5 < noise < .5 (is: %f)", noise);
-        c->prior.assign((size_t)P.C, 0.f);
+        c->prior.assign((size_t)c->dense_C, 0.f);
         float* phi = c->prior.data();
         float* psi = c->prior.data() + P.phi_len;
         auto trans = [&](int y, int ny) -> double {  // obstacleTransProb :136-170
@@ -348,7 +350,7 @@ int build_tabular_prior(fba_ctx* c)
         const int N = g.N, G = g.G;
         if (noise < 0 || noise > (1 - .15))
             return fail(c, FBA_EINVAL, "Gridworld expects noise in between 0 and %f (received %f)", 1 - .15, noise);
-        c->prior.assign((size_t)P.C, 0.f);
+        c->prior.assign((size_t)c->dense_C, 0.f);
         float* phi = c->prior.data();
         float* psi = c->prior.data() + P.phi_len;
         for (int a = 0; a < A; ++a)
@@ -379,7 +381,7 @@ int build_tabular_prior(fba_ctx* c)
     }
     if (noise <= -.15 || noise > .3) return fail(c, FBA_EINVAL, "noise has to be between -.15 and .3");
     const float acc = (.85f - noise) * total, inacc = (.15f + noise) * total;
-    c->prior.assign((size_t)P.C, 5000.f);
+    c->prior.assign((size_t)c->dense_C, 5000.f);
     float* phi = c->prior.data();
     float* psi = c->prior.data() + P.phi_len;
     const int listen = 2;
@@ -729,10 +731,26 @@ int build_ftiger_factored_prior(fba_ctx* c)
     return FBA_OK;
 }
 
+// prior[k] + j is the float the reference reaches by j additions of 1.0f for every j a uint16 holds
+bool packable_prior(const std::vector<float>& prior)
+{
+    for (float p : prior) {
+        const double top = (double)p + 65535.0;
+        if (!(p >= 0.f) || (double)(float)top != top) return false;
+    }
+    return true;
+}
+
 int upload_prior(fba_ctx* c)
 {
     std::vector<float> padded((size_t)c->P.Cs, 0.f);
-    std::copy(c->prior.begin(), c->prior.end(), padded.begin());
+    if (c->P.packed) {  // records start as "no increments yet"; the table itself goes beside them
+        if (!packable_prior(c->prior))
+            return fail(c, FBA_EINVAL, "this context stores particles packed (uint16 increments over the prior), which needs prior counts c with "
+                                       "c + 65535 exact in fp32; create it with FBA_DENSE_PARTICLES=1 in the environment for other tables");
+        HIPCHK(c, hipMemcpyAsync(c->d_prior_dense, c->prior.data(), c->prior.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    } else
+        std::copy(c->prior.begin(), c->prior.end(), padded.begin());
     HIPCHK(c, hipMemcpyAsync(c->d_prior, padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return FBA_OK;
@@ -1110,6 +1128,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     P.ca_plain = 0;
     P.zig = nullptr;
     P.dirichlet_regular = cfg->dirichlet_regular ? 1 : 0;
+    P.packed = 0;
     if (cfg->model == FBA_MODEL_BA_TABLE) {
         P.phi_len = P.S * P.A * P.S;
         P.C       = P.phi_len + P.A * P.S * P.O;
@@ -1132,6 +1151,22 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     }
     // record stride (fba_state.h): counts + state word, padded to a power of two up to 64 words
     // (so small particles are whole cache lines), to a multiple of 4 words beyond that
+    c->dense_C = P.C;
+    // Packed particles (PackedView, fba_device.h): the tabular tiger particle as 24 uint16 increment counts over
+    // the shared prior -- 64 bytes instead of 128 in every belief update and every root sample.  Only where every
+    // kernel that touches the records is a tiger-table instantiation (launch_search / launch_belief_update), the
+    // prior is exact under "+ 65535" (TigerBAPrior: 5000, 0 and the two listen counts below) and one run cannot
+    // add more than 65535 to a cell (one T and one O increment per real step).
+    if (cfg->model == FBA_MODEL_BA_TABLE && is_tiger(cfg->domain) && !cfg->dirichlet_regular && cfg->planner == FBA_PLANNER_POUCT &&
+        (cfg->belief == FBA_BELIEF_REJECTION || cfg->belief == FBA_BELIEF_IMPORTANCE) && cfg->particles <= IS_MAX_CHUNKS * 256 &&
+        !std::getenv("FBA_IS_MULTI_MIN") && !std::getenv("FBA_DENSE_PARTICLES") && (long long)cfg->episodes * cfg->horizon <= 65535 &&
+        cfg->noise > -.15 && cfg->noise <= .3) {
+        const std::vector<float> listen = {(.85f - cfg->noise) * cfg->counts_total, (.15f + cfg->noise) * cfg->counts_total, 5000.f, 0.f};
+        if (packable_prior(listen)) {
+            P.packed = 1;
+            P.C      = (c->dense_C + 1) / 2;  // words holding the uint16 pairs; the state word follows
+        }
+    }
     {
         int need = P.C + 1, cs = 4;
         if (need <= 64) { while (cs < need) cs <<= 1; }
@@ -1260,9 +1295,11 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     CHK(dev_alloc(c, &D.fault, 1));
     CHK(dev_alloc(c, &D.lazy_reset, E));
     CHK(dev_alloc(c, &c->d_prior, P.Cs));
+    CHK(dev_alloc(c, &c->d_prior_dense, std::max(c->dense_C, 1)));
     CHK(dev_alloc(c, &c->d_uni_scan, (size_t)P.N + 1));
     CHK(dev_alloc(c, &c->d_log1p, (size_t)P.sims + 2));
     D.prior     = c->d_prior;
+    D.prior_dense = c->d_prior_dense;
     D.uni_scan  = c->d_uni_scan;
     D.log1p_tab = c->d_log1p;
     D.trace_on  = cfg->trace ? 1 : 0;
@@ -1361,17 +1398,21 @@ int fba_domain_sizes(const fba_ctx* c, int32_t* S, int32_t* A, int32_t* O)
     *S = c->P.S; *A = c->P.A; *O = c->P.O;
     return FBA_OK;
 }
-int fba_counts_len(const fba_ctx* c) { return c ? c->P.C : FBA_EINVAL; }
+int fba_counts_len(const fba_ctx* c) { return c ? c->dense_C : FBA_EINVAL; }
 int fba_slots(const fba_ctx* c) { return c ? c->P.E : FBA_EINVAL; }
+int fba_particle_bytes(const fba_ctx* c) { return c ? c->P.Cs * 4 : FBA_EINVAL; }
 
 int fba_set_model_tabular(fba_ctx* c, const float* phi, const float* psi)
 {
     if (!c || !phi || !psi) return FBA_EINVAL;
     if (c->P.model != FBA_MODEL_BA_TABLE) return fail(c, FBA_EINVAL, "fba_set_model_tabular needs model = BA_TABLE");
-    c->prior.assign((size_t)c->P.C, 0.f);
+    std::vector<float> keep = c->prior;
+    c->prior.assign((size_t)c->dense_C, 0.f);
     std::copy(phi, phi + c->P.phi_len, c->prior.begin());
-    std::copy(psi, psi + (c->P.C - c->P.phi_len), c->prior.begin() + c->P.phi_len);
-    return upload_prior(c);
+    std::copy(psi, psi + (c->dense_C - c->P.phi_len), c->prior.begin() + c->P.phi_len);
+    const int rc = upload_prior(c);
+    if (rc) c->prior = keep;
+    return rc;
 }
 
 int fba_get_factored_layout(const fba_ctx* c, fba_factored_layout* out)
@@ -1490,7 +1531,11 @@ int fba_belief_get(fba_ctx* c, int32_t slot, int32_t* state, double* weight, flo
         for (int i = 0; i < P.N; ++i) {
             const float* rec = tmp.data() + (size_t)i * P.Cs;
             if (state) std::memcpy(&state[i], &rec[P.C], 4);
-            if (counts && P.C) std::copy(rec, rec + P.C, counts + (size_t)i * P.C);
+            if (counts && P.packed) {  // count = prior + number of increments (PackedView)
+                const uint32_t* w = reinterpret_cast<const uint32_t*>(rec);
+                for (int k = 0; k < c->dense_C; ++k)
+                    counts[(size_t)i * c->dense_C + k] = c->prior[k] + (float)((k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffffu));
+            } else if (counts && P.C) std::copy(rec, rec + P.C, counts + (size_t)i * P.C);
         }
     }
     return FBA_OK;
@@ -1533,7 +1578,18 @@ int fba_belief_set(fba_ctx* c, int32_t slot, const int32_t* state, const double*
         for (int i = 0; i < P.N; ++i) {
             float* rec = tmp.data() + (size_t)i * P.Cs;
             if (state) std::memcpy(&rec[P.C], &state[i], 4);
-            if (counts && P.C) std::copy(counts + (size_t)i * P.C, counts + (size_t)(i + 1) * P.C, rec);
+            if (counts && P.packed) {
+                uint32_t* w = reinterpret_cast<uint32_t*>(rec);
+                for (int k = 0; k < P.C; ++k) w[k] = 0;
+                for (int k = 0; k < c->dense_C; ++k) {
+                    const double inc = (double)counts[(size_t)i * c->dense_C + k] - (double)c->prior[k];
+                    if (inc < 0 || inc > 65535 || inc != std::floor(inc))
+                        return fail(c, FBA_EINVAL, "particle %d, count %d: %g is not the prior (%g) plus 0..65535 increments, which packed particles "
+                                                   "need; create the context with FBA_DENSE_PARTICLES=1 in the environment for arbitrary counts",
+                                    i, k, (double)counts[(size_t)i * c->dense_C + k], (double)c->prior[k]);
+                    w[k >> 1] |= (uint32_t)inc << (16 * (k & 1));
+                }
+            } else if (counts && P.C) std::copy(counts + (size_t)i * P.C, counts + (size_t)(i + 1) * P.C, rec);
         }
         HIPCHK(c, hipMemcpy(c->D.p_rec + pb * P.Cs, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
     }
@@ -1623,9 +1679,11 @@ int fba_get_kernel_times(fba_ctx* c, fba_kernel_time* out)
     if (rc) return rc;
     // algorithmic bytes, SURVEY.md section 8(d): Pb = particle payload, Rt / Ro = bytes of the
     // transition / observation rows one step consults
-    const uint64_t Pb = 4 + 4 * (uint64_t)P.C;
+    // (always SURVEY's dense figure, 4 bytes per count, also when the particles are stored packed: DESIGN.md section 5)
+    const uint64_t cell = 4;
+    const uint64_t Pb = 4 + cell * (uint64_t)c->dense_C;
     uint64_t Rt = 0, Ro = 0;
-    if (P.model == FBA_MODEL_BA_TABLE) { Rt = 4 * (uint64_t)P.S; Ro = 4 * (uint64_t)P.O; }
+    if (P.model == FBA_MODEL_BA_TABLE) { Rt = cell * (uint64_t)P.S; Ro = cell * (uint64_t)P.O; }
     if (P.model == FBA_MODEL_BA_FACTORED) {
         for (int f = 0; f < c->fdesc.FS; ++f) Rt += 4 * (uint64_t)c->fdesc.Ssz[f];
         for (int f = 0; f < c->fdesc.FO; ++f) Ro += 4 * (uint64_t)c->fdesc.Osz[f];

@@ -194,7 +194,7 @@ __device__ __forceinline__ int ucb_select(const Problem& P, const DeviceState& D
 // FTIGER > 0: the simulator is the factored-tiger FBA-POMDP with FTIGER binary state features (expected
 // Dirichlet mode); its step is ftiger_step<FTIGER>, the layout restated as literals.
 // TIGER_POMDP: planning on the tiger POMDP itself (BASELINE configs[0]); the sizes and the domain are literals.
-template <bool STAGE, int AMAX, bool REG, bool TIGER_TABLE, int MODEL, int FTIGER = 0, bool TIGER_POMDP = false>
+template <bool STAGE, int AMAX, bool REG, int TIGER_TABLE, int MODEL, int FTIGER = 0, bool TIGER_POMDP = false>
 __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceState D)
 {
     if (TIGER_POMDP) {
@@ -220,10 +220,16 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
         if (P.domain != FBA_DOM_TIGER_CONTINUOUS) P.domain = FBA_DOM_TIGER_EPISODIC;
         P.belief = P.belief == FBA_BELIEF_IMPORTANCE ? FBA_BELIEF_IMPORTANCE : FBA_BELIEF_REJECTION;
         D.cq_off = 4; D.child_off = 10; D.node_words = 16; D.hash = nullptr;  // node layout of A = 3, O = 2 (fba_engine.hip)
+        if (TIGER_TABLE == 2) { P.C = 12; P.Cs = 16; }  // packed particles (PackedView): 24 uint16 + state in 64 bytes
     }
     extern __shared__ double lds[];
+    __shared__ float s_prior[TIGER_TABLE == 2 ? 24 : 1];
     const int lane = threadIdx.x;
     const int e    = blockIdx.x * SEARCH_BLOCK + lane;
+    if (TIGER_TABLE == 2) {
+        if (lane < 24) s_prior[lane] = D.prior_dense[lane];
+        __syncthreads();
+    }
     if (MODEL == FBA_MODEL_BA_FACTORED) {
         // the factored model's description (which parents, how many values, where the rows start) is
         // consulted several times per sampled feature: keep the part in use in LDS, at the end of
@@ -341,6 +347,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
             bool term;
             if (FTIGER > 0 && STAGE) term = ftiger_step<(FTIGER > 0 ? FTIGER : 1)>(P, g, LdsView<SEARCH_BLOCK>{stage}, s, a, o, r, NoInc{});
             else if (FTIGER > 0) term = ftiger_step<(FTIGER > 0 ? FTIGER : 1)>(P, g, GlobalSearchView{cnt}, s, a, o, r, NoInc{});
+            else if (TIGER_TABLE == 2) term = sim_step<REG>(P, g, PackedView<LdsView<SEARCH_BLOCK>>{LdsView<SEARCH_BLOCK>{stage}, s_prior}, s, a, o, r, NoInc{});
             else if (STAGE) term = sim_step<REG>(P, g, LdsView<SEARCH_BLOCK>{stage}, s, a, o, r, NoInc{});
             else term = sim_step<REG>(P, g, GlobalSearchView{cnt}, s, a, o, r, NoInc{});
             ++steps;
@@ -550,10 +557,23 @@ __device__ __forceinline__ void bump(float4& v, int d, float add)
     v.z += (d == 2) ? add : 0.f;
     v.w += (d == 3) ? add : 0.f;
 }
+// the same "+1" on a packed record (PackedView): cell c lives in half (c & 1) of word c >> 1
+__device__ __forceinline__ void bump_cell(float4& v, int cell, int lo, bool packed)
+{
+    if (!packed) { bump(v, cell - lo, 1.0f); return; }
+    const int d = (cell >> 1) - lo;
+    const uint32_t add = (cell & 1) ? 0x10000u : 1u;
+    v.x = __uint_as_float(__float_as_uint(v.x) + ((d == 0) ? add : 0u));
+    v.y = __uint_as_float(__float_as_uint(v.y) + ((d == 1) ? add : 0u));
+    v.z = __uint_as_float(__float_as_uint(v.z) + ((d == 2) ? add : 0u));
+    v.w = __uint_as_float(__float_as_uint(v.w) + ((d == 3) ? add : 0u));
+}
+
 // s_owner[j] (nullable) = the thread whose LDS columns (s_src, s_state, s_inc) describe output record j
 __device__ __forceinline__ void gather_records(float* __restrict__ dst, const float* __restrict__ src, const int32_t* s_owner,
                                                const int32_t* s_src, const int32_t* s_inc, int ninc, int inc_stride,
-                                               const int32_t* s_state, int m, int C4, int C, int group, int nthreads)
+                                               const int32_t* s_state, int m, int C4, int C, int group, int nthreads,
+                                               bool packed = false)
 {
     const int gid = threadIdx.x / group, part0 = threadIdx.x % group, ngroups = nthreads / group;
     for (int j = gid; j < m; j += ngroups) {
@@ -563,7 +583,7 @@ __device__ __forceinline__ void gather_records(float* __restrict__ dst, const fl
         for (int part = part0; part < C4; part += group) {
             float4 v = sp[part];
             const int lo = part * 4;
-            for (int k = 0; k < ninc; ++k) bump(v, s_inc[k * inc_stride + t] - lo, 1.0f);
+            for (int k = 0; k < ninc; ++k) bump_cell(v, s_inc[k * inc_stride + t], lo, packed);
             if (s_state) {  // new domain state in word C
                 const int d = C - lo;
                 const float f = __int_as_float(s_state[t]);
@@ -579,7 +599,7 @@ __device__ __forceinline__ void gather_records(float* __restrict__ dst, const fl
 // pass, which leaves the source buffer untouched: no partial-line write-backs).
 __device__ __forceinline__ void gather_records_side(float* __restrict__ dst, const float* __restrict__ src, const int32_t* s_src,
                                                     const int32_t* __restrict__ side, int side_w, int m, int C4, int C, int group,
-                                                    int nthreads)
+                                                    int nthreads, bool packed = false)
 {
     const int gid = threadIdx.x / group, part0 = threadIdx.x % group, ngroups = nthreads / group;
     const int ninc = side_w - 1;
@@ -592,7 +612,7 @@ __device__ __forceinline__ void gather_records_side(float* __restrict__ dst, con
         for (int part = part0; part < C4; part += group) {
             float4 v = sp[part];
             const int lo = part * 4;
-            for (int k = 0; k < ninc; ++k) bump(v, sd[1 + k] - lo, 1.0f);
+            for (int k = 0; k < ninc; ++k) bump_cell(v, sd[1 + k], lo, packed);
             const int d = C - lo;
             if (d == 0) v.x = nstate; else if (d == 1) v.y = nstate; else if (d == 2) v.z = nstate; else if (d == 3) v.w = nstate;
             dp[part] = v;
@@ -624,7 +644,7 @@ __device__ __forceinline__ int record_group(int C4)
 // per CU changes nothing -- the kernel is bound by the memory system's rate for random 128-byte lines.
 // `fc` = 1 runs the update on the reinvigoration belief's fully connected filter (launched before
 // the main filter's update, which is the one that clears the request flag).
-template <bool REG, bool TIGER_TABLE, int FTIGER = 0, int BLK = REJECT_BLOCK>
+template <bool REG, int TIGER_TABLE, int FTIGER = 0, int BLK = REJECT_BLOCK>
 __global__ void __launch_bounds__(BLK) reject_kernel(Problem P, DeviceState D, int fc)
 {
     if (FTIGER > 0) {  // factored tiger with FTIGER binary state features (see search_kernel)
@@ -636,13 +656,19 @@ __global__ void __launch_bounds__(BLK) reject_kernel(Problem P, DeviceState D, i
         fc = 0;
         P.model = FBA_MODEL_BA_TABLE;
         P.S = 2; P.A = 3; P.O = 2; P.phi_len = 12; P.C = 24; P.Cs = 32;
+        if (TIGER_TABLE == 2) { P.C = 12; P.Cs = 16; }  // packed particles (PackedView)
         if (P.domain != FBA_DOM_TIGER_CONTINUOUS) P.domain = FBA_DOM_TIGER_EPISODIC;
     }
+    __shared__ float s_prior[TIGER_TABLE == 2 ? 24 : 1];
     __shared__ int32_t s_src[BLK], s_ns[BLK], s_owner[BLK], s_inc[MAXINC * BLK];
     __shared__ int32_t s_wave[BLK / 64];
     __shared__ int32_t s_count;
     const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (!D.need_update[e]) return;
+    if (TIGER_TABLE == 2) {
+        if (tid < 24) s_prior[tid] = D.prior_dense[tid];
+        __syncthreads();
+    }
     const int a = D.action[e], o = D.obs[e], N = P.N;
     uint8_t* bufsel = fc ? D.bufsel_fc : D.bufsel;
     float* recs     = fc ? D.p_rec_fc : D.p_rec;
@@ -676,6 +702,7 @@ __global__ void __launch_bounds__(BLK) reject_kernel(Problem P, DeviceState D, i
         double r;
         // UpdateCounts: the +1s land in the copy
         if (FTIGER > 0) ftiger_step<(FTIGER > 0 ? FTIGER : 1)>(P, g, GlobalView{rec}, s, a, so, r, LdsInc<BLK>{s_inc + tid});
+        else if (TIGER_TABLE == 2) sim_step<REG>(P, g, PackedView<GlobalView>{GlobalView{rec}, s_prior}, s, a, so, r, LdsInc<BLK>{s_inc + tid});
         else sim_step<REG>(P, g, GlobalView{rec}, s, a, so, r, LdsInc<BLK>{s_inc + tid});
         s_src[tid] = src;
         s_ns[tid]  = s;
@@ -696,7 +723,7 @@ __global__ void __launch_bounds__(BLK) reject_kernel(Problem P, DeviceState D, i
         }
         __syncthreads();
         const int m = min(chunk, N - acc);
-        gather_records(dcn + (size_t)acc * P.Cs, scn, s_owner, s_src, s_inc, ninc, BLK, s_ns, m, C4, P.C, group, BLK);
+        gather_records(dcn + (size_t)acc * P.Cs, scn, s_owner, s_src, s_inc, ninc, BLK, s_ns, m, C4, P.C, group, BLK, TIGER_TABLE == 2);
         acc += m;
         base += BLK;
         __syncthreads();
@@ -922,18 +949,24 @@ __global__ void __launch_bounds__(IS_BLOCK) uniform_scan_kernel(int n, double* w
 //   3. N multinomial draws by binary search on the prefix sums
 //   4. whole-record gather into the other buffer, weights reset to 1/N
 // ---------------------------------------------------------------------------------------------
-template <bool REG, bool TIGER_TABLE>
+template <bool REG, int TIGER_TABLE>
 __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceState D)
 {
     if (TIGER_TABLE) {  // sizes restated as literals (see search_kernel)
         P.model = FBA_MODEL_BA_TABLE;
         P.S = 2; P.A = 3; P.O = 2; P.phi_len = 12; P.C = 24; P.Cs = 32;
+        if (TIGER_TABLE == 2) { P.C = 12; P.Cs = 16; }  // packed particles (PackedView)
         if (P.domain != FBA_DOM_TIGER_CONTINUOUS) P.domain = FBA_DOM_TIGER_EPISODIC;
     }
+    __shared__ float s_prior[TIGER_TABLE == 2 ? 24 : 1];
     __shared__ double s_carry[IS_MAX_CHUNKS + 2];
     __shared__ int32_t s_src[IS_BLOCK], s_inc[MAXINC * IS_BLOCK];
     const int e = blockIdx.x, tid = threadIdx.x;
     if (!D.need_update[e]) return;
+    if (TIGER_TABLE == 2) {
+        if (tid < 24) s_prior[tid] = D.prior_dense[tid];
+        __syncthreads();
+    }
     const int a = D.action[e], o = D.obs[e], N = P.N;
     const int cur = D.bufsel[e];
     const size_t sb = pbase(P, e, cur), db = pbase(P, e, cur ^ 1);
@@ -953,7 +986,8 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
         float* cnt = scn + (size_t)i * P.Cs;
         int s = rec_state(cnt, P.C), so;
         double r;
-        sim_step<REG>(P, g, GlobalView{cnt}, s, a, so, r, LdsInc<IS_BLOCK>{s_inc + tid});
+        if (TIGER_TABLE == 2) sim_step<REG>(P, g, PackedView<GlobalView>{GlobalView{cnt}, s_prior}, s, a, so, r, LdsInc<IS_BLOCK>{s_inc + tid});
+        else sim_step<REG>(P, g, GlobalView{cnt}, s, a, so, r, LdsInc<IS_BLOCK>{s_inc + tid});
         // incrementCountsOf (BAFlatModel.cpp:126-139, BABNModel.cpp:354-382) is deferred to the gather: the new
         // state and the cells go to the side array, the record is only read
         if (defer) {
@@ -961,7 +995,9 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
             sd[0] = s;
             for (int q = 0; q < ninc; ++q) sd[1 + q] = s_inc[q * IS_BLOCK + tid];
             // probability from the updated counts
-            sw[i] *= sim_obs_prob<REG>(P, g, PendingIncView<GlobalView>{GlobalView{cnt}, s_inc + tid, IS_BLOCK, ninc}, s, a, o);
+            if (TIGER_TABLE == 2)
+                sw[i] *= sim_obs_prob<REG>(P, g, PendingIncView<PackedView<GlobalView>>{PackedView<GlobalView>{GlobalView{cnt}, s_prior}, s_inc + tid, IS_BLOCK, ninc}, s, a, o);
+            else sw[i] *= sim_obs_prob<REG>(P, g, PendingIncView<GlobalView>{GlobalView{cnt}, s_inc + tid, IS_BLOCK, ninc}, s, a, o);
         } else {
             for (int q = 0; q < ninc; ++q) cnt[s_inc[q * IS_BLOCK + tid]] += 1.0f;
             rec_set_state(cnt, P.C, s);
@@ -984,7 +1020,7 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
         }
         __syncthreads();
         const int m = min(IS_BLOCK, N - j0);
-        if (defer) gather_records_side(dcn + (size_t)j0 * P.Cs, scn, s_src, side, D.side_w, m, C4, P.C, group, IS_BLOCK);
+        if (defer) gather_records_side(dcn + (size_t)j0 * P.Cs, scn, s_src, side, D.side_w, m, C4, P.C, group, IS_BLOCK, TIGER_TABLE == 2);
         else gather_records(dcn + (size_t)j0 * P.Cs, scn, nullptr, s_src, nullptr, 0, 0, nullptr, m, C4, P.C, group, IS_BLOCK);
         __syncthreads();
     }
@@ -1377,7 +1413,12 @@ __global__ void __launch_bounds__(256) flush_kernel(Problem P, DeviceState D)
         uint64_t h = mix64((uint64_t)i * 0x9E3779B97F4A7C15ull + (uint64_t)(uint32_t)st);
         const double w = (P.belief == FBA_BELIEF_IMPORTANCE) ? D.p_weight[pb + i] : 0.0;
         h = mix64(h ^ (uint64_t)__double_as_longlong(w));
-        for (int k = 0; k < P.C; ++k) h = mix64(h ^ ((uint64_t)__float_as_uint(cnt[k]) + ((uint64_t)k << 32)));
+        if (P.packed) {  // the checksum is over the counts themselves, whatever the storage (PackedView)
+            const PackedView<GlobalView> pv{GlobalView{cnt}, D.prior_dense};
+            const int dense = P.phi_len + P.A * P.S * P.O;
+            for (int k = 0; k < dense; ++k) h = mix64(h ^ ((uint64_t)__float_as_uint(pv.at(k)) + ((uint64_t)k << 32)));
+        } else
+            for (int k = 0; k < P.C; ++k) h = mix64(h ^ ((uint64_t)__float_as_uint(cnt[k]) + ((uint64_t)k << 32)));
         local += h;
     }
     atomicAdd(&s_sum, local);
@@ -1413,8 +1454,8 @@ void launch_search(const Problem& P, const DeviceState& D, hipStream_t st)
 #define FBA_LAUNCH_SEARCH_M(STG, AM, MODEL)                                                                              \
     do {                                                                                                                 \
         if (P.dirichlet_regular && MODEL != FBA_MODEL_POMDP)                                                             \
-            hipLaunchKernelGGL((search_kernel<STG, AM, (MODEL != FBA_MODEL_POMDP), false, MODEL>), grid, block, lds, st, P, D); \
-        else hipLaunchKernelGGL((search_kernel<STG, AM, false, false, MODEL>), grid, block, lds, st, P, D);             \
+            hipLaunchKernelGGL((search_kernel<STG, AM, (MODEL != FBA_MODEL_POMDP), 0, MODEL>), grid, block, lds, st, P, D); \
+        else hipLaunchKernelGGL((search_kernel<STG, AM, false, 0, MODEL>), grid, block, lds, st, P, D);             \
     } while (0)
 #define FBA_LAUNCH_SEARCH(STG, AM)                                                                  \
     do {                                                                                            \
@@ -1425,12 +1466,13 @@ void launch_search(const Problem& P, const DeviceState& D, hipStream_t st)
     const bool tiger_table = P.model == FBA_MODEL_BA_TABLE && P.planner == FBA_PLANNER_POUCT && !P.dirichlet_regular && stage &&
                              (P.domain == FBA_DOM_TIGER_EPISODIC || P.domain == FBA_DOM_TIGER_CONTINUOUS) && !D.hash;
     if (tiger_table) {
-        hipLaunchKernelGGL((search_kernel<true, 4, false, true, FBA_MODEL_BA_TABLE>), grid, block, lds, st, P, D);
+        if (P.packed) hipLaunchKernelGGL((search_kernel<true, 4, false, 2, FBA_MODEL_BA_TABLE>), grid, block, lds, st, P, D);
+        else hipLaunchKernelGGL((search_kernel<true, 4, false, 1, FBA_MODEL_BA_TABLE>), grid, block, lds, st, P, D);
         return;
     }
     if (P.model == FBA_MODEL_POMDP && P.planner == FBA_PLANNER_POUCT && !D.hash &&
         (P.domain == FBA_DOM_TIGER_EPISODIC || P.domain == FBA_DOM_TIGER_CONTINUOUS)) {
-        hipLaunchKernelGGL((search_kernel<false, 4, false, false, FBA_MODEL_POMDP, 0, true>), grid, block, lds, st, P, D);
+        hipLaunchKernelGGL((search_kernel<false, 4, false, 0, FBA_MODEL_POMDP, 0, true>), grid, block, lds, st, P, D);
         return;
     }
     if (P.model == FBA_MODEL_BA_FACTORED && (P.domain == FBA_DOM_FTIGER_EPISODIC || P.domain == FBA_DOM_FTIGER_CONTINUOUS) &&
@@ -1438,8 +1480,8 @@ void launch_search(const Problem& P, const DeviceState& D, hipStream_t st)
         const int FS = 31 - __builtin_clz((unsigned)P.S);  // S = 2^FS
 #define FBA_LAUNCH_FTIGER(FSV)                                                                                                    \
     do {                                                                                                                          \
-        if (stage) hipLaunchKernelGGL((search_kernel<true, 4, false, false, FBA_MODEL_BA_FACTORED, FSV>), grid, block, lds, st, P, D); \
-        else hipLaunchKernelGGL((search_kernel<false, 4, false, false, FBA_MODEL_BA_FACTORED, FSV>), grid, block, lds, st, P, D);      \
+        if (stage) hipLaunchKernelGGL((search_kernel<true, 4, false, 0, FBA_MODEL_BA_FACTORED, FSV>), grid, block, lds, st, P, D); \
+        else hipLaunchKernelGGL((search_kernel<false, 4, false, 0, FBA_MODEL_BA_FACTORED, FSV>), grid, block, lds, st, P, D);      \
         return;                                                                                                                   \
     } while (0)
         if (FS == 2) FBA_LAUNCH_FTIGER(2);
@@ -1476,25 +1518,28 @@ void launch_belief_update(const Problem& P, const DeviceState& D, hipStream_t st
                         (P.domain == FBA_DOM_FTIGER_EPISODIC || P.domain == FBA_DOM_FTIGER_CONTINUOUS))
                            ? 31 - __builtin_clz((unsigned)P.S) : 0;  // S = 2^FS
         for (int fc = P.reinvig ? 1 : 0; fc >= 0; --fc) {  // the main filter's launch clears the request flag: last
-            if (ft == 2) hipLaunchKernelGGL((reject_kernel<false, false, 2>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
-            else if (ft == 3) hipLaunchKernelGGL((reject_kernel<false, false, 3>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
-            else if (ft == 4) hipLaunchKernelGGL((reject_kernel<false, false, 4>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
-            else if (P.dirichlet_regular) hipLaunchKernelGGL((reject_kernel<true, false>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
-            else if (tiger_table) hipLaunchKernelGGL((reject_kernel<false, true>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
-            else hipLaunchKernelGGL((reject_kernel<false, false>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
+            if (ft == 2) hipLaunchKernelGGL((reject_kernel<false, 0, 2>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
+            else if (ft == 3) hipLaunchKernelGGL((reject_kernel<false, 0, 3>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
+            else if (ft == 4) hipLaunchKernelGGL((reject_kernel<false, 0, 4>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
+            else if (P.dirichlet_regular) hipLaunchKernelGGL((reject_kernel<true, 0>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
+            else if (tiger_table && P.packed)  // (packed records: no longer bound by the memory system; chunks of 512 are 4 % faster than 256 / 1024)
+                hipLaunchKernelGGL((reject_kernel<false, 2, 0, 512>), dim3(P.E), dim3(512), 0, st, P, D, fc);
+            else if (tiger_table) hipLaunchKernelGGL((reject_kernel<false, 1>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
+            else hipLaunchKernelGGL((reject_kernel<false, 0>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
         }
         return;
     }
     if (P.cheat) {  // rejectSample on the correct-graph filter first (CheatingReinvigoration.cpp:111)
-        if (P.dirichlet_regular) hipLaunchKernelGGL((reject_kernel<true, false>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, 1);
-        else hipLaunchKernelGGL((reject_kernel<false, false>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, 1);
+        if (P.dirichlet_regular) hipLaunchKernelGGL((reject_kernel<true, 0>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, 1);
+        else hipLaunchKernelGGL((reject_kernel<false, 0>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, 1);
     }
     if (!D.is_multi) {
         const bool tiger_table = P.model == FBA_MODEL_BA_TABLE && !P.dirichlet_regular &&
                                  (P.domain == FBA_DOM_TIGER_EPISODIC || P.domain == FBA_DOM_TIGER_CONTINUOUS);
-        if (P.dirichlet_regular) hipLaunchKernelGGL((importance_kernel<true, false>), dim3(P.E), dim3(IS_BLOCK), 0, st, P, D);
-        else if (tiger_table) hipLaunchKernelGGL((importance_kernel<false, true>), dim3(P.E), dim3(IS_BLOCK), 0, st, P, D);
-        else hipLaunchKernelGGL((importance_kernel<false, false>), dim3(P.E), dim3(IS_BLOCK), 0, st, P, D);
+        if (P.dirichlet_regular) hipLaunchKernelGGL((importance_kernel<true, 0>), dim3(P.E), dim3(IS_BLOCK), 0, st, P, D);
+        else if (tiger_table && P.packed) hipLaunchKernelGGL((importance_kernel<false, 2>), dim3(P.E), dim3(IS_BLOCK), 0, st, P, D);
+        else if (tiger_table) hipLaunchKernelGGL((importance_kernel<false, 1>), dim3(P.E), dim3(IS_BLOCK), 0, st, P, D);
+        else hipLaunchKernelGGL((importance_kernel<false, 0>), dim3(P.E), dim3(IS_BLOCK), 0, st, P, D);
         if (P.cheat) hipLaunchKernelGGL(cheat_kernel, dim3(P.E), dim3(256), 0, st, P, D);
         return;
     }

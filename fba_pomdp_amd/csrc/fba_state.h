@@ -62,7 +62,8 @@ struct DeviceState {
     double* is_tot;     // [E][2] total weight before normalisation, total of the normalised weights
     int32_t ctot_stride;
     int32_t is_multi;   // importance filter runs as several launches (N too large for one workgroup)
-    const float* prior; // [Cs] prior record (state word unset)
+    const float* prior; // [Cs] prior record (state word unset); all zero increments when Problem::packed
+    const float* prior_dense;  // packed particles: the prior count table itself
     const double* uni_scan; // [N] prefix sums of N uniform weights 1/N (device order)
     double uni_total;
     // --- tree ---

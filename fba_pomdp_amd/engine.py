@@ -55,6 +55,7 @@ class Engine:
         self.S, self.A, self.O = S.value, A.value, O.value
         self.ncnt = self.L.fba_counts_len(h)
         self.slots = self.L.fba_slots(h)
+        self.particle_bytes = self.L.fba_particle_bytes(h)
 
     def close(self):
         if getattr(self, "h", None):

@@ -171,6 +171,10 @@ const char* fba_last_error(const fba_ctx* ctx); /* ctx may be NULL: last create 
 
 int fba_domain_sizes(const fba_ctx* ctx, int32_t* S, int32_t* A, int32_t* O);
 int fba_counts_len(const fba_ctx* ctx); /* floats per particle count blob (0 for plain POMDP) */
+int fba_particle_bytes(const fba_ctx* ctx); /* HBM bytes of one particle record.  Tabular tiger particles are stored packed
+                                             * (uint16 increment counts over the shared prior, 64 B instead of 128 B) when the
+                                             * prior allows it exactly; FBA_DENSE_PARTICLES=1 in the environment forces fp32 counts.
+                                             * fba_belief_get / fba_belief_set always speak fp32 counts. */
 int fba_slots(const fba_ctx* ctx);      /* slots actually resident (cfg.slots, or the library's choice) */
 
 /* Prior count tables.  fba_create builds the domain's own prior (TigerPriors.cpp:14-43,

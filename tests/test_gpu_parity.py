@@ -548,6 +548,41 @@ def test_factored_layout_decodes_particles(domain, kw):
         fba.Engine("episodic-tiger", model=N.MODEL_BA_TABLE, particles=4, sims=4).factored_layout()
 
 
+@pytest.mark.parametrize("belief", ["rejection_sampling", "importance_sampling", "point_estimate"])
+def test_packed_tiger_particles_equal_dense_ones(belief, monkeypatch):
+    """Tabular tiger particles are stored as uint16 increment counts over the prior (64 B) when that is exact;
+    FBA_DENSE_PARTICLES=1 keeps fp32 counts (128 B).  Same experiment, same trace, same particles, and both equal
+    the oracle (the packed one through every other tiger test here)."""
+    kw = dict(particles=300, sims=256, runs=12, episodes=5, slots=4, seed=77, trace=1)
+    out = []
+    for dense in (False, True):
+        if dense:
+            monkeypatch.setenv("FBA_DENSE_PARTICLES", "1")
+        eng = fba.Engine("episodic-tiger", model=N.MODEL_BA_TABLE, belief=belief, **kw)
+        monkeypatch.delenv("FBA_DENSE_PARTICLES", raising=False)
+        assert eng.particle_bytes == (128 if dense else 64) and eng.ncnt == 24
+        stats = eng.run_bapomdp()
+        out.append(([(s.count, s.mean, s.m2) for s in stats], eng.trace(), [eng.belief_get(k) for k in range(4)], eng))
+    assert out[0][0] == out[1][0]
+    assert out[0][1].tobytes() == out[1][1].tobytes()
+    for a, b in zip(out[0][2], out[1][2]):
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    # fba_belief_set speaks fp32 counts in both formats: move a filter from the dense engine into the packed one
+    packed, dense = out[0][3], out[1][3]
+    s, w, cnt = dense.belief_get(2)
+    packed.belief_set(0, state=s, weight=w if belief == "importance_sampling" else None, counts=cnt)
+    s2, _, cnt2 = packed.belief_get(0)
+    assert np.array_equal(s, s2) and np.array_equal(cnt, cnt2)
+    with pytest.raises(ValueError, match="plus 0..65535 increments"):
+        packed.belief_set(0, counts=cnt + 0.5)
+    with pytest.raises(ValueError, match="FBA_DENSE_PARTICLES"):
+        packed.set_model_tabular(np.full(12, 0.3, np.float32), np.full(12, 0.7, np.float32))
+    packed.set_model_tabular(np.full(12, 7.0, np.float32), np.full(12, 2.5, np.float32))   # exact under + 65535: accepted
+    # priors that are not exact under "+ 65535" are never packed
+    eng = fba.Engine("episodic-tiger", model=N.MODEL_BA_TABLE, counts_total=777.0, particles=8, sims=8)
+    assert eng.particle_bytes == 128
+
+
 @pytest.mark.parametrize("planner,sims", [("po-uct", 300), ("ts", 120)])
 def test_planning_agr(planner, sims):
     """planning -D agr (AGR.cpp, AGR(10)): 441 states, 23 actions (search_kernel<.., 24, ..>), 22 observations,
@@ -658,12 +693,12 @@ def test_rejection_update_with_an_impossible_observation_fails_instead_of_spinni
     """beliefs::rejectSample loops until N particles reproduce the observation (RejectionSampling.hpp:26-72);
     when none can, the reference never returns.  The device gives up after 2^28 attempts and the call fails."""
     eng = fba.Engine("episodic-tiger", model=N.MODEL_BA_TABLE, particles=4, sims=4, slots=2, seed=3)
+    prior = eng.prior()
+    prior[12 + 2 * 4 + 0 * 2 + 1] = 0      # psi(listen, left, hear right) = 0
+    prior[12 + 2 * 4 + 1 * 2 + 1] = 0      # psi(listen, right, hear right) = 0: "hear right" cannot happen
+    eng.set_model_tabular(prior[:12], prior[12:])
     eng.belief_init()
     eng.belief_reset_domain_state()
-    s, _, cnt = eng.belief_get(1)
-    cnt[:, 12 + 2 * 4 + 0 * 2 + 1] = 0      # psi(listen, left, hear right) = 0
-    cnt[:, 12 + 2 * 4 + 1 * 2 + 1] = 0      # psi(listen, right, hear right) = 0: "hear right" cannot happen
-    eng.belief_set(1, state=s, counts=cnt)
     with pytest.raises(fba.FbaError, match="accepted fewer than 4 particles"):
         eng.belief_update(2, 1, active=[0, 1])
     eng.belief_update(2, 0, active=[1, 1])   # the ctx stays usable
