@@ -81,7 +81,7 @@ def measured_traffic(args, kname, slots):
     (FETCH_SIZE and WRITE_SIZE in separate runs of this same command; profiles/*.json says how
     they were collected and corrected).  None when the workload differs from the profiled one."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write.json")
-    if not os.path.exists(path) or slots != 229376 or args.sims != 4096 or args.particles != 4096:
+    if not os.path.exists(path) or slots != 245760 or args.sims != 4096 or args.particles != 4096:
         return None, None
     with open(path) as f:
         d = json.load(f)
@@ -95,9 +95,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--slots", type=int, default=229376,
+    ap.add_argument("--slots", type=int, default=245760,
                     help="concurrent runs per GPU (0.79 MB of HBM each at the default workload, packed particles); "
-                         "229376 = 14 search waves per CU, what the LDS of a CU holds at 10.8 KB per wave")
+                         "245760 = 15 search waves per CU, one below what a CU holds (16: 116 VGPRs, 10.1 KB of LDS per wave)")
     ap.add_argument("--sims", type=int, default=4096)
     ap.add_argument("--particles", type=int, default=4096)
     ap.add_argument("--horizon", type=int, default=10)
@@ -140,7 +140,7 @@ def main():
 
     import fba_pomdp_amd as fba
     slots = args.slots
-    while True:  # 0.79 MB of HBM per slot: step down if this GPU cannot give 180 GB right now
+    while True:  # 0.79 MB of HBM per slot: step down if this GPU cannot give 194 GB right now
         try:
             eng = fba.Engine("episodic-tiger", model=fba.MODEL_BA_TABLE, belief=args.belief,
                              sims=args.sims, particles=args.particles, horizon=args.horizon,
@@ -150,7 +150,7 @@ def main():
         except fba.FbaError as e:
             if "out of memory" not in str(e) or slots <= 1024:
                 raise
-            nxt = 163840 if slots > 163840 else (131072 if slots > 131072 else slots // 2)
+            nxt = 196608 if slots > 196608 else (163840 if slots > 163840 else (131072 if slots > 131072 else slots // 2))
             print(f"[bench] {slots} slots do not fit ({e}); retrying with {nxt}", file=sys.stderr)
             slots = nxt
 

@@ -194,6 +194,11 @@ __device__ __forceinline__ int ucb_select(const Problem& P, const DeviceState& D
 // FTIGER > 0: the simulator is the factored-tiger FBA-POMDP with FTIGER binary state features (expected
 // Dirichlet mode); its step is ftiger_step<FTIGER>, the layout restated as literals.
 // TIGER_POMDP: planning on the tiger POMDP itself (BASELINE configs[0]); the sizes and the domain are literals.
+__host__ __device__ __forceinline__ bool root_children_in_lds(const Problem& P, const DeviceState& D)
+{
+    return P.A * P.O <= ROOT_CHILDREN && D.max_nodes <= 32767;
+}
+
 template <bool STAGE, int AMAX, bool REG, int TIGER_TABLE, int MODEL, int FTIGER = 0, bool TIGER_POMDP = false>
 __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceState D)
 {
@@ -236,7 +241,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
         // this workgroup's allocation, instead of chasing it through global memory
         const int depth_cap0 = P.max_depth > 0 ? P.max_depth : 1;
         size_t words = (size_t)depth_cap0 * SEARCH_BLOCK * 2 + (STAGE ? (size_t)P.Cs * SEARCH_BLOCK : 0) +
-                       (P.A * P.O <= ROOT_CHILDREN ? (size_t)P.A * P.O * SEARCH_BLOCK : 0);
+                       (root_children_in_lds(P, D) ? (size_t)P.A * P.O * SEARCH_BLOCK / 2 : 0);
         words = (words + 3) & ~(size_t)3;  // 16-byte aligned
         uint4* dst       = reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(lds) + words);
         const uint4* src = reinterpret_cast<const uint4*>(P.fd);
@@ -254,8 +259,9 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
     int32_t* path_na    = reinterpret_cast<int32_t*>(path_r - lane + (size_t)depth_cap * SEARCH_BLOCK) + lane;
     float* stage        = reinterpret_cast<float*>(path_na - lane + (size_t)depth_cap * SEARCH_BLOCK) + lane;  // [Cs][block]
     // children of the root, [a*O + o][block], when there are at most ROOT_CHILDREN of them
-    const bool root_lds = P.A * P.O <= ROOT_CHILDREN;
-    int32_t* rootch     = reinterpret_cast<int32_t*>(stage - lane + (STAGE ? (size_t)P.Cs * SEARCH_BLOCK : 0)) + lane;
+    // (node indices fit 16 bits up to 32 766 simulations; beyond that the root's children stay in its record)
+    const bool root_lds = root_children_in_lds(P, D);
+    int16_t* rootch     = reinterpret_cast<int16_t*>(stage - lane + (STAGE ? (size_t)P.Cs * SEARCH_BLOCK : 0)) + lane;
 
     Rng g               = slot_rng(P, D, e);
     const int hist_len  = D.t[e];
@@ -363,7 +369,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
                     else {  // expand: new leaf, then rollout(depth_to_go - 1)
                         const int nn = n_nodes++;
                         node_init(D, tree + (size_t)nn * W, P.A, P.O);
-                        if (at_root_lds) rootch[(a * P.O + o) * SEARCH_BLOCK] = nn;
+                        if (at_root_lds) rootch[(a * P.O + o) * SEARCH_BLOCK] = (int16_t)nn;
                         else child_set(P, D, tree, tab, epoch, node, a, o, nn);
                         mode = 2; rdepth = dtg - 1; rret = 0; rdisc = 1;
                         if (rdepth == 0) finish = true;
@@ -1448,7 +1454,7 @@ void launch_search(const Problem& P, const DeviceState& D, hipStream_t st)
     const bool stage = P.model != FBA_MODEL_POMDP && P.Cs <= SEARCH_STAGE_WORDS;
     size_t lds = (size_t)depth_cap * SEARCH_BLOCK * (sizeof(float) + sizeof(int32_t)) +
                  (stage ? (size_t)P.Cs * SEARCH_BLOCK * sizeof(float) : 0) +
-                 (P.A * P.O <= ROOT_CHILDREN ? (size_t)P.A * P.O * SEARCH_BLOCK * sizeof(int32_t) : 0);
+                 (root_children_in_lds(P, D) ? (size_t)P.A * P.O * SEARCH_BLOCK * sizeof(int16_t) : 0);
     if (P.model == FBA_MODEL_BA_FACTORED) lds = ((lds + 15) & ~(size_t)15) + (((size_t)P.fd_bytes + 15) & ~(size_t)15);  // + the model description
     const dim3 grid(ceil_div(P.E, SEARCH_BLOCK)), block(SEARCH_BLOCK);
 #define FBA_LAUNCH_SEARCH_M(STG, AM, MODEL)                                                                              \
