@@ -1698,6 +1698,10 @@ int fba_get_kernel_times(fba_ctx* c, fba_kernel_time* out)
     if (P.belief == FBA_BELIEF_REJECTION) {
         out[FBA_K_BELIEF_RS].units = particles;
         out[FBA_K_BELIEF_RS].bytes = attempts * (Pb + Rt + Ro) + particles * Pb;
+        // reject_tiger_lds_kernel (packed particles, N <= TIGER_LDS_MAX_N): the alternative formula SURVEY 8(d) asks to be
+        // stated when the build does not move dense particles -- the attempts run from LDS, so an update reads the
+        // filter once to park it, reads the N accepted sources and writes N records, 64 bytes each
+        if (P.packed && P.N <= TIGER_LDS_MAX_N) out[FBA_K_BELIEF_RS].bytes = particles * 3 * (uint64_t)(P.Cs * 4);
     } else {
         out[FBA_K_BELIEF_IS].units = particles;
         out[FBA_K_BELIEF_IS].bytes = particles * (32 + Rt + Ro) + particles * (8 + 2 * Pb);

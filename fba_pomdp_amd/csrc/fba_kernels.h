@@ -11,6 +11,7 @@ constexpr int SEARCH_BLOCK  = 64;    // one wave per workgroup, one tree per lan
 constexpr int SEARCH_STAGE_WORDS = 128; // particle records up to this many words are staged in LDS by the search
 constexpr int ROOT_CHILDREN = 8;        // root child pointers are kept in LDS when A*O is at most this
 constexpr int REJECT_BLOCK  = 256;   // attempts per chunk of the rejection filter
+constexpr int TIGER_LDS_MAX_N = 4096;  // reject_tiger_lds_kernel: filters up to this many packed tiger particles are parked in LDS
 constexpr int REJECT_MAX_ATTEMPTS = 1 << 28;  // per update: beyond this the observation is taken to be impossible under the filter
 constexpr int IS_BLOCK      = 1024;  // one workgroup per slot in the importance filter
 constexpr int PARTICLE_TILE = 4096;  // particles one workgroup initialises / resets

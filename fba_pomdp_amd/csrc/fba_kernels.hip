@@ -748,6 +748,121 @@ __global__ void __launch_bounds__(BLK) reject_kernel(Problem P, DeviceState D, i
 }
 
 // ---------------------------------------------------------------------------------------------
+// reject_tiger_lds_kernel: the same rejectSample for packed tabular-tiger particles with N <= 4096, arranged so
+// that the attempts never touch HBM.  For the slot's action a, a step from particle i reads only three words
+// of its record -- the (s, a, .) transition pair, the (a, 0, .) and (a, 1, .) observation pairs -- and its state:
+//   1. one sequential pass parks those 12 bytes + the state of every particle in LDS (48 + 4 KB);
+//   2. attempt k = stream k, as in reject_kernel, samples its source from LDS; the accepted attempts are
+//      appended in attempt order to a 16-bit list (source, old state, new state), until N are accepted;
+//   3. one pass copies the listed source records to the new filter with their two "+1"s (cells
+//      T(s, a, s') and O(a, s', o)) and the new state -- N independent 64-byte copies, no synchronisation.
+// Same draws, same order, same result as reject_kernel<false, 2>; two thirds fewer random memory requests.
+// ---------------------------------------------------------------------------------------------
+struct TigerRowView {   // the counts one step of action a from state s can read, out of the three parked words
+    uint32_t wt, wo0, wo1;
+    int a;
+    const float* prior;
+    static constexpr bool row_regs = false;
+    __device__ __forceinline__ float at(int k) const
+    {
+        // (masks, not a chain of ?: -- the compiler turns that into an indexed private array, i.e. scratch)
+        const int q = k - 12 - a * 4;
+        const uint32_t mt = (uint32_t) - (int)(k < 12), m1 = ~mt & (uint32_t) - (int)(q >= 2), m0 = ~(mt | m1);
+        const uint32_t w = (wt & mt) | (wo0 & m0) | (wo1 & m1);
+        return prior[k] + (float)((k & 1) ? (w >> 16) : (w & 0xffffu));
+    }
+};
+template <int BLK>
+__global__ void __launch_bounds__(BLK) reject_tiger_lds_kernel(Problem P, DeviceState D)
+{
+    P.model = FBA_MODEL_BA_TABLE;
+    P.S = 2; P.A = 3; P.O = 2; P.phi_len = 12; P.C = 12; P.Cs = 16;
+    if (P.domain != FBA_DOM_TIGER_CONTINUOUS) P.domain = FBA_DOM_TIGER_EPISODIC;
+    extern __shared__ uint32_t s_tab[];  // [N][3] words, then [N] state bytes
+    __shared__ uint16_t s_acc[TIGER_LDS_MAX_N];
+    __shared__ float s_prior[24];
+    __shared__ int32_t s_wave[BLK / 64];
+    __shared__ int32_t s_count;
+    const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (!D.need_update[e]) return;
+    const int a = D.action[e], o = D.obs[e], N = P.N;
+    const int cur = D.bufsel[e];
+    const size_t sb = pbase(P, e, cur), db = pbase(P, e, cur ^ 1);
+    const float* scn = D.p_rec + sb * (size_t)P.Cs;
+    float* dcn       = D.p_rec + db * (size_t)P.Cs;
+    uint8_t* s_st    = reinterpret_cast<uint8_t*>(s_tab + 3 * (size_t)N);
+    if (tid < 24) s_prior[tid] = D.prior_dense[tid];
+    const bool lazy = slot_lazy(D, e);
+    for (int i = tid; i < N; i += BLK) {
+        const uint32_t* rec = reinterpret_cast<const uint32_t*>(scn) + (size_t)i * 16;
+        const uint32_t w0 = rec[a], w1 = rec[3 + a], wo0 = rec[6 + 2 * a], wo1 = rec[7 + 2 * a];  // cell pairs (0,a,.) (1,a,.) | (a,0,.) (a,1,.)
+        const int st = lazy ? lazy_state(P, D, e, i) : (int)rec[12];
+        s_tab[3 * i + 0] = st ? w1 : w0;
+        s_tab[3 * i + 1] = wo0;
+        s_tab[3 * i + 2] = wo1;
+        s_st[i]          = (uint8_t)st;
+    }
+    __syncthreads();
+    Rng g = slot_rng(P, D, e);
+    int acc = 0, base = 0;
+    while (acc < N) {
+        if (base >= REJECT_MAX_ATTEMPTS) {  // see reject_kernel
+            if (tid == 0) {
+                atomicCAS(D.fault, 0, 1 + e);
+                D.need_update[e] = 0;
+                D.active[e]      = 0;
+            }
+            return;
+        }
+        const int k = base + tid;
+        g.stream(FBA_PHASE_REJECT, (uint32_t)k);
+        const int src = P.point ? 0 : g.uniform_int(N);         // FlatFilter::sample
+        const int s0  = s_st[src];
+        int s = s0, so;
+        double r;
+        sim_step<false>(P, g, TigerRowView{s_tab[3 * src], s_tab[3 * src + 1], s_tab[3 * src + 2], a, s_prior}, s, a, so, r, NoInc{});
+        const bool ok = (so == o);
+        const unsigned long long ballot = __ballot(ok);
+        const int prefix = __popcll(ballot & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wave] = __popcll(ballot);
+        __syncthreads();
+        int woff = 0, chunk = 0;
+        for (int w = 0; w < BLK / 64; ++w) {
+            if (w < wave) woff += s_wave[w];
+            chunk += s_wave[w];
+        }
+        const int j = acc + woff + prefix;  // position among all accepted attempts
+        if (ok && j < N) {
+            s_acc[j] = (uint16_t)(src | (s0 << 12) | (s << 13));
+            if (j == N - 1) s_count = k + 1;
+        }
+        acc += min(chunk, N - acc);
+        base += BLK;
+        __syncthreads();
+    }
+    // the new filter: record j = source record with T(s, a, s') and O(a, s', o) bumped and the new state
+    const int part = tid & 3;
+    for (int j = tid >> 2; j < N; j += BLK / 4) {
+        const uint32_t en = s_acc[j];
+        const int src = en & 4095, s0 = (en >> 12) & 1, ns = (en >> 13) & 1;
+        float4 v = reinterpret_cast<const float4*>(scn)[(size_t)src * 4 + part];
+        bump_cell(v, s0 * 6 + a * 2 + ns, part * 4, true);
+        bump_cell(v, 12 + a * 4 + ns * 2 + o, part * 4, true);
+        if (part == 3) v.x = __int_as_float(ns);  // the state word (12)
+        reinterpret_cast<float4*>(dcn)[(size_t)j * 4 + part] = v;
+    }
+    if (tid == 0) {
+        D.bufsel[e] = cur ^ 1;
+        D.belief_steps[e] += (unsigned long long)s_count;
+        D.upd_attempts[e] += (unsigned long long)s_count;
+        D.upd_particles[e] += (unsigned long long)N;
+        D.need_update[e]      = 0;
+        D.lazy_reset[e]       = 0;  // every record of the new buffer carries its real state
+        D.cur[e].update_count = s_count;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // reinvigorate_kernel: ReinvigoratingRejectionSampling::reinvigorateParticles
 // (ReinvigoratingRejectionSampling.cpp:121-131), one workgroup per slot, before the two rejection
 // updates.  Iteration i breeds one particle (breed, :24-35): the structure of a random particle
@@ -1528,7 +1643,9 @@ void launch_belief_update(const Problem& P, const DeviceState& D, hipStream_t st
             else if (ft == 3) hipLaunchKernelGGL((reject_kernel<false, 0, 3>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
             else if (ft == 4) hipLaunchKernelGGL((reject_kernel<false, 0, 4>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
             else if (P.dirichlet_regular) hipLaunchKernelGGL((reject_kernel<true, 0>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
-            else if (tiger_table && P.packed)  // (packed records: no longer bound by the memory system; chunks of 512 are 4 % faster than 256 / 1024)
+            else if (tiger_table && P.packed && P.N <= TIGER_LDS_MAX_N)
+                hipLaunchKernelGGL((reject_tiger_lds_kernel<512>), dim3(P.E), dim3(512), (size_t)P.N * 13 + 16, st, P, D);
+            else if (tiger_table && P.packed)  // (chunks of 512 are 4 % faster than 256 / 1024 on packed records)
                 hipLaunchKernelGGL((reject_kernel<false, 2, 0, 512>), dim3(P.E), dim3(512), 0, st, P, D, fc);
             else if (tiger_table) hipLaunchKernelGGL((reject_kernel<false, 1>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
             else hipLaunchKernelGGL((reject_kernel<false, 0>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);

@@ -30,14 +30,14 @@ def per_kernel(path, counter):
 
 fetch = per_kernel(os.path.join(SRC, "fetch", "run_counter_collection.csv"), "FETCH_SIZE")
 write = per_kernel(os.path.join(SRC, "write", "run_counter_collection.csv"), "WRITE_SIZE")
-rk = [k for k in fetch if "reject_kernel" in k][0]
+rk = [k for k in fetch if "reject_tiger_lds_kernel" in k or "reject_kernel" in k][0]
 # full launches only (the warm-up tick and the last, partly idle one move fewer bytes)
 f_full = max(fetch[rk]) * 1024.0
 w_full = max(write[rk]) * 1024.0
 doc = {
     "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline",
     "config": "default bench workload, 245760 slots, packed particles (64 B records)",
-    "kernel": "reject_kernel",
+    "kernel": "reject_kernel",  # bench.py's name for the rejection update, whichever instantiation runs it
     "kernel_instantiation": rk,
     "fetch_bytes_per_launch_raw": f_full,
     "write_bytes_per_launch": w_full,
@@ -46,10 +46,10 @@ doc = {
     "notes": [
         "counter unit KiB (MI355X_MICROARCH.md, HBM / rocprofv3): values below are KiB per launch summed over instances; the per-launch figure used is the largest (a launch in which every slot updates)",
         "WRITE_SIZE is exact on gfx950: 245760 slots x 4096 particles x 64 B = 64.42 GB is the minimum this kernel can write",
-        "FETCH_SIZE is reported raw; the guide's x2 correction is calibrated for wide coalesced streaming reads. This kernel reads 4-8 B per lane scattered over 64-B particle records (the attempts) plus 16 B per lane record gathers (L2 hits on lines the attempts just fetched); x2 would put the kernel above the 8 TB/s peak, so raw is the better estimate here",
+        "FETCH_SIZE is reported raw (no x2): the kernel reads each 64-B record in 4-byte pieces (the pass that parks the filter in LDS) and in 16-byte pieces, four lanes per record (the gather); the guide's x2 correction is calibrated for wide coalesced streaming reads and would put the gather above what was written",
     ],
     "per_launch_KiB": {k: {"fetch_KiB_per_launch": fetch.get(k, []), "write_KiB_per_launch": write.get(k, [])}
-                       for k in fetch if "search_kernel" in k or "reject_kernel" in k},
+                       for k in fetch if "search_kernel" in k or "reject_kernel" in k or "reject_tiger_lds_kernel" in k},
 }
 with open(os.path.join(DST, f"{tag}_pmc_fetch_write.json"), "w") as f:
     json.dump(doc, f, indent=1)
