@@ -89,7 +89,13 @@ int dev_alloc(fba_ctx* c, T** p, size_t n, bool zero = true)
 {
     if (n == 0) n = 1;
     void* q = nullptr;
-    HIPCHK(c, hipMalloc(&q, n * sizeof(T)));
+    {
+        const hipError_t e = hipMalloc(&q, n * sizeof(T));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();  // the error is reported here; it must not stay behind for a later context's hipGetLastError()
+            return fail(c, FBA_EHIP, "hipMalloc(&q, n * sizeof(T)) failed: %s (%s:%d)", hipGetErrorString(e), __FILE__, __LINE__);
+        }
+    }
     c->allocs.push_back(q);
     if (zero) HIPCHK(c, hipMemsetAsync(q, 0, n * sizeof(T), c->stream));
     *p = static_cast<T*>(q);
@@ -965,6 +971,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
 {
     if (!cfg || !out) return fail(nullptr, FBA_EINVAL, "fba_create: null argument");
     *out = nullptr;
+    (void)hipGetLastError();  // a new context starts from a clean error state
     // ---- validation: the reference's constructor / validate() errors
     // (POUCT.cpp:34-50, RejectionSampling.cpp:7-13, FactoredTiger.cpp:13-17, TigerPriors.cpp:22-25)
     if (cfg->sims < 1 && cfg->planner == FBA_PLANNER_POUCT)

@@ -704,6 +704,15 @@ def test_rejection_update_with_an_impossible_observation_fails_instead_of_spinni
     eng.belief_update(2, 0, active=[1, 1])   # the ctx stays usable
 
 
+def test_a_failed_allocation_leaves_no_error_behind():
+    """fba_create that runs out of HBM reports it and cleans up; the next context must not trip over the stale
+    HIP error (bench.py steps down to fewer slots exactly this way)."""
+    with pytest.raises(fba.FbaError, match="out of memory"):
+        fba.Engine("episodic-tiger", model=N.MODEL_BA_TABLE, particles=4096, sims=4096, slots=600000)
+    eng, o = _pair("episodic-tiger", N.MODEL_BA_TABLE, "rejection_sampling", 5, particles=64, sims=64, runs=4, episodes=2)
+    _assert_same_experiment(eng, o, ba=True)
+
+
 def test_belief_update_rejects_out_of_range_arguments():
     eng = fba.Engine("episodic-tiger", particles=8, sims=4, slots=2)
     eng.belief_init()
