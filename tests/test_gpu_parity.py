@@ -704,6 +704,16 @@ def test_rejection_update_with_an_impossible_observation_fails_instead_of_spinni
     eng.belief_update(2, 0, active=[1, 1])   # the ctx stays usable
 
 
+def test_packed_tiger_rejection_beyond_the_lds_filter_size():
+    """Packed tiger filters of more than 4096 particles do not fit reject_tiger_lds_kernel's LDS copy and take
+    reject_kernel<packed>; the two agree with the oracle on either side of the limit."""
+    for particles in (4096, 4100):
+        eng, o = _pair("continuous-tiger", N.MODEL_BA_TABLE, "rejection_sampling", 23, particles=particles, sims=48, runs=2,
+                       episodes=2, horizon=4, slots=2)
+        assert eng.particle_bytes == 64
+        _assert_same_experiment(eng, o, ba=True)
+
+
 def test_a_failed_allocation_leaves_no_error_behind():
     """fba_create that runs out of HBM reports it and cleans up; the next context must not trip over the stale
     HIP error (bench.py steps down to fewer slots exactly this way)."""
