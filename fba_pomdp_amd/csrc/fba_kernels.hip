@@ -137,17 +137,56 @@ __device__ __forceinline__ int ucb_pick(const Problem& P, Rng& g, double L, cons
 {
     double best_q = -DBL_MAX;
     uint32_t mask = 0;
+    bool decided = false;
+    if (explore) {
+        // Fast paths that give the fp64 arg-max set exactly, without the fp64 divisions and square roots:
+        //  * unvisited actions: q + DBL_MAX rounds to DBL_MAX for every finite q here, so they tie exactly and
+        //    beat every visited action -- the candidate set is the set of unvisited actions;
+        //  * otherwise evaluate q + u sqrt(L / n) in fp32 (each operation within 1 ulp, so each value within
+        //    ~2^-21 of (|q| + bonus)); if one action leads by more than 1e-5 of the largest |q| + bonus -- twenty
+        //    times that error bound -- it is the unique fp64 maximum.  Anything closer falls through to fp64.
+        uint32_t unvisited = 0;
 #pragma unroll
-    for (int a = 0; a < AMAX; ++a)
-        if (a < P.A) {
-            double q = cq[a];
-            if (explore) q += (cn[a] == 0) ? DBL_MAX : P.exploration * sqrt(L / (double)cn[a]);
-            if (q >= best_q) {
-                if (q > best_q) mask = 0;
-                best_q = q;
-                mask |= 1u << a;
+        for (int a = 0; a < AMAX; ++a)
+            if (a < P.A && cn[a] == 0) unvisited |= 1u << a;
+        if (unvisited) {
+            mask    = unvisited;
+            decided = true;
+        } else {
+            const float Lf = (float)L, uf = (float)P.exploration;
+            float w[AMAX], top = -FLT_MAX, scale = 0.f;
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) {
+                const float qa = (float)cq[a];
+                const float b  = uf * __builtin_amdgcn_sqrtf(Lf * __builtin_amdgcn_rcpf((float)(a < P.A ? cn[a] : 1)));
+                w[a]  = (a < P.A) ? qa + b : -FLT_MAX;
+                top   = fmaxf(top, w[a]);
+                scale = fmaxf(scale, (a < P.A) ? fabsf(qa) + b : 0.f);
+            }
+            const float cut = top - 1.0e-5f * scale;
+            uint32_t near = 0;
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a)
+                if (w[a] >= cut) near |= 1u << a;
+            if (__popc(near) == 1 && scale < 1.0e30f) {
+                mask    = near;
+                decided = true;
             }
         }
+    }
+    if (!decided) {
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a)
+            if (a < P.A) {
+                double q = cq[a];
+                if (explore) q += (cn[a] == 0) ? DBL_MAX : P.exploration * sqrt(L / (double)cn[a]);
+                if (q >= best_q) {
+                    if (q > best_q) mask = 0;
+                    best_q = q;
+                    mask |= 1u << a;
+                }
+            }
+    }
     int k = g.slow_int(0, __popc(mask));
     while (k-- > 0) mask &= mask - 1;  // drop the k lowest candidates
     return __ffs(mask) - 1;
