@@ -1419,6 +1419,9 @@ int fba_set_model_tabular(fba_ctx* c, const float* phi, const float* psi)
     std::copy(psi, psi + (c->dense_C - c->P.phi_len), c->prior.begin() + c->P.phi_len);
     const int rc = upload_prior(c);
     if (rc) c->prior = keep;
+    // The prior is what Belief::initiate copies into every particle (BAPOMDPPrior::sample).  Packed particles hold
+    // increments over the table, so live particles would silently move to the new table: require a new initiate.
+    else if (c->P.packed) c->belief_ready = false;
     return rc;
 }
 

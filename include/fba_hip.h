@@ -179,7 +179,9 @@ int fba_slots(const fba_ctx* ctx);      /* slots actually resident (cfg.slots, o
 
 /* Prior count tables.  fba_create builds the domain's own prior (TigerPriors.cpp:14-43,
  * FactoredTigerPriors.cpp:18-88); this call overrides it with tables built by the caller
- * (BAFlatModel layout: phi[s*A*S + a*S + s'], psi[a*S*O + s'*O + o]). */
+ * (BAFlatModel layout: phi[s*A*S + a*S + s'], psi[a*S*O + s'*O + o]).  Takes effect at the next
+ * fba_belief_init (the prior is what initiate copies into the particles); where particles are stored packed
+ * (fba_particle_bytes) that call is required before the belief is used again. */
 int fba_set_model_tabular(fba_ctx* ctx, const float* phi, const float* psi);
 int fba_get_prior(const fba_ctx* ctx, float* counts);
 

@@ -578,6 +578,10 @@ def test_packed_tiger_particles_equal_dense_ones(belief, monkeypatch):
     with pytest.raises(ValueError, match="FBA_DENSE_PARTICLES"):
         packed.set_model_tabular(np.full(12, 0.3, np.float32), np.full(12, 0.7, np.float32))
     packed.set_model_tabular(np.full(12, 7.0, np.float32), np.full(12, 2.5, np.float32))   # exact under + 65535: accepted
+    with pytest.raises(fba.FbaError, match="belief not initiated"):    # packed particles are relative to the table: initiate again
+        packed.belief_update(2, 0)
+    packed.belief_init()
+    assert np.array_equal(packed.belief_get(0)[2][0], np.r_[np.full(12, 7.0, np.float32), np.full(12, 2.5, np.float32)])
     # priors that are not exact under "+ 65535" are never packed
     eng = fba.Engine("episodic-tiger", model=N.MODEL_BA_TABLE, counts_total=777.0, particles=8, sims=8)
     assert eng.particle_bytes == 128
