@@ -881,14 +881,26 @@ __global__ void __launch_bounds__(BLK) reject_tiger_lds_kernel(Problem P, Device
     }
     // the new filter: record j = source record with T(s, a, s') and O(a, s', o) bumped and the new state
     const int part = tid & 3;
-    for (int j = tid >> 2; j < N; j += BLK / 4) {
-        const uint32_t en = s_acc[j];
-        const int src = en & 4095, s0 = (en >> 12) & 1, ns = (en >> 13) & 1;
-        float4 v = reinterpret_cast<const float4*>(scn)[(size_t)src * 4 + part];
-        bump_cell(v, s0 * 6 + a * 2 + ns, part * 4, true);
-        bump_cell(v, 12 + a * 4 + ns * 2 + o, part * 4, true);
-        if (part == 3) v.x = __int_as_float(ns);  // the state word (12)
-        reinterpret_cast<float4*>(dcn)[(size_t)j * 4 + part] = v;
+    constexpr int GROUPS = BLK / 4, UNROLL = 4;  // four independent copies in flight per thread
+    for (int j0 = tid >> 2; j0 < N; j0 += GROUPS * UNROLL) {
+        uint32_t en[UNROLL];
+        float4 v[UNROLL];
+#pragma unroll
+        for (int q = 0; q < UNROLL; ++q) {
+            const int j = j0 + q * GROUPS;
+            en[q] = j < N ? s_acc[j] : 0u;
+            if (j < N) v[q] = reinterpret_cast<const float4*>(scn)[(size_t)(en[q] & 4095) * 4 + part];
+        }
+#pragma unroll
+        for (int q = 0; q < UNROLL; ++q) {
+            const int j = j0 + q * GROUPS;
+            if (j >= N) continue;
+            const int s0 = (en[q] >> 12) & 1, ns = (en[q] >> 13) & 1;
+            bump_cell(v[q], s0 * 6 + a * 2 + ns, part * 4, true);
+            bump_cell(v[q], 12 + a * 4 + ns * 2 + o, part * 4, true);
+            if (part == 3) v[q].x = __int_as_float(ns);  // the state word (12)
+            reinterpret_cast<float4*>(dcn)[(size_t)j * 4 + part] = v[q];
+        }
     }
     if (tid == 0) {
         D.bufsel[e] = cur ^ 1;
