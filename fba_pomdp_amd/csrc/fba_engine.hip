@@ -830,6 +830,7 @@ int check_fault(fba_ctx* c)
     HIPCHK(c, hipMemcpy(&f, c->D.fault, sizeof f, hipMemcpyDeviceToHost));
     if (!f) return FBA_OK;
     HIPCHK(c, hipMemset(c->D.fault, 0, sizeof f));
+    if (f < 0) return fail(c, FBA_ESTATE, "the search tree of slot %d needed more than the %d node records it has", -f - 1, c->D.max_nodes);
     return fail(c, FBA_ESTATE, "rejection sampling in slot %d accepted fewer than %d particles in %d attempts: no particle of the filter "
                 "can produce the observation (the reference loops forever in RejectionSampling.hpp:26-72 here)", f - 1, c->P.N, REJECT_MAX_ATTEMPTS);
 }
@@ -1219,7 +1220,15 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     D.cq_off     = (1 + P.A + 1) & ~1;
     D.child_off  = D.cq_off + 2 * P.A;
     D.node_words = hashed ? D.child_off : ((D.child_off + P.A * P.O + 1) & ~1);
-    D.max_nodes  = P.sims + 2;
+    D.max_nodes  = P.sims + 2;  // one new node per simulation at most
+    // Episodic (factored) tiger: only `listen` continues an episode and it has two observations, so a node has at most
+    // two children and the tree of a search of depth D is at most the complete binary tree with levels 0..D:
+    // 2^(D+1) - 1 nodes, whatever the number of simulations (2047 at the default depth 10 against 4098 / 16386
+    // records for 4096 / 16384 simulations).  search_kernel refuses to go past max_nodes (fault -> FBA_ESTATE).
+    if ((cfg->domain == FBA_DOM_TIGER_EPISODIC || cfg->domain == FBA_DOM_FTIGER_EPISODIC) && P.max_depth >= 0 && P.max_depth < 24)
+        D.max_nodes = std::min(D.max_nodes, (1 << (P.max_depth + 1)) + 1);  // (+1: odd, so that the slots' trees are not a power of two
+                                                                             // of bytes apart -- at exactly 128 KB the search ran 45 % slower)
+    if (const char* ev = std::getenv("FBA_NODE_BOUND")) D.max_nodes = std::max(2, std::atoi(ev));  // tests: exercise the overflow guard
     uint32_t hcap = 0;
     if (hashed) {
         hcap = 64;
@@ -1500,7 +1509,7 @@ int fba_select_action(fba_ctx* c, const int32_t* hist_len, const uint8_t* active
     if ((rc = timed(c, FBA_K_SEARCH, [&] { launch_search(c->P, c->D, c->stream); }))) return rc;
     HIPCHK(c, hipMemcpyAsync(action, c->D.action, (size_t)c->P.E * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return FBA_OK;
+    return check_fault(c);
 }
 
 int fba_belief_update(fba_ctx* c, const int32_t* action, const int32_t* obs, const uint8_t* active)

@@ -406,7 +406,11 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
                     const int c = at_root_lds ? rootch[(a * P.O + o) * SEARCH_BLOCK] : child_get(P, D, tree, tab, epoch, node, a, o);
                     if (c >= 0) { node = c; --dtg; }
                     else {  // expand: new leaf, then rollout(depth_to_go - 1)
-                        const int nn = n_nodes++;
+                        // never write past the slot's records: beyond the host's node bound (fba_engine.hip; cannot happen
+                        // while that bound holds) the last record is reused and the overflow reported after the loop.  (A
+                        // `break` here instead cost the whole kernel 45 %: the loop lost its shape.)
+                        const int nn = min(n_nodes, D.max_nodes - 1);
+                        ++n_nodes;
                         node_init(D, tree + (size_t)nn * W, P.A, P.O);
                         if (at_root_lds) rootch[(a * P.O + o) * SEARCH_BLOCK] = (int16_t)nn;
                         else child_set(P, D, tree, tab, epoch, node, a, o, nn);
@@ -466,6 +470,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
         }
     }
     g.stream(FBA_PHASE_SEARCH, (uint32_t)P.sims + 1u);
+    if (n_nodes > D.max_nodes) atomicCAS(D.fault, 0, -(1 + e));  // -> FBA_ESTATE on the host
     const int best = ucb_pick<AMAX>(P, g, 0.0, r_cn, r_cq, false);
     D.action[e]    = best;
     D.sim_steps[e] += steps;

@@ -718,6 +718,20 @@ def test_packed_tiger_rejection_beyond_the_lds_filter_size():
         _assert_same_experiment(eng, o, ba=True)
 
 
+def test_search_tree_node_bound_and_its_guard(monkeypatch):
+    """Episodic tiger trees are at most the complete binary tree of the search depth (only `listen` continues, two
+    observations), so a slot owns 2^(depth+1) node records instead of sims + 2.  Results are unchanged (every other
+    tiger test runs with the bound); a bound that is too small is caught by the kernel, not written past."""
+    eng, o = _pair("episodic-tiger", N.MODEL_POMDP, "rejection_sampling", 41, particles=64, sims=3000, runs=4, horizon=6, max_depth=3, slots=4)
+    _assert_same_experiment(eng, o, ba=False)          # 3000 simulations in 17 node records
+    assert int(eng.trace()["n_nodes"].max()) <= 15
+    monkeypatch.setenv("FBA_NODE_BOUND", "5")
+    small = fba.Engine("episodic-tiger", model=N.MODEL_BA_TABLE, particles=64, sims=400, runs=4, slots=4, seed=2)
+    monkeypatch.delenv("FBA_NODE_BOUND")
+    with pytest.raises(fba.FbaError, match="more than the 5 node records"):
+        small.run_bapomdp()
+
+
 def test_a_failed_allocation_leaves_no_error_behind():
     """fba_create that runs out of HBM reports it and cleans up; the next context must not trip over the stale
     HIP error (bench.py steps down to fewer slots exactly this way)."""
