@@ -96,7 +96,7 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--slots", type=int, default=245760,
-                    help="concurrent runs per GPU (0.79 MB of HBM each at the default workload, packed particles); "
+                    help="concurrent runs per GPU (0.66 MB of HBM each at the default workload, packed particles); "
                          "245760 = 15 search waves per CU, one below what a CU holds (16: 116 VGPRs, 10.1 KB of LDS per wave)")
     ap.add_argument("--sims", type=int, default=4096)
     ap.add_argument("--particles", type=int, default=4096)
@@ -140,7 +140,7 @@ def main():
 
     import fba_pomdp_amd as fba
     slots = args.slots
-    while True:  # 0.79 MB of HBM per slot: step down if this GPU cannot give 194 GB right now
+    while True:  # 0.66 MB of HBM per slot: step down if this GPU cannot give 161 GB right now
         try:
             eng = fba.Engine("episodic-tiger", model=fba.MODEL_BA_TABLE, belief=args.belief,
                              sims=args.sims, particles=args.particles, horizon=args.horizon,
