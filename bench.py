@@ -81,7 +81,7 @@ def measured_traffic(args, kname, slots):
     (FETCH_SIZE and WRITE_SIZE in separate runs of this same command; profiles/*.json says how
     they were collected and corrected).  None when the workload differs from the profiled one."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write.json")
-    if not os.path.exists(path) or slots != 245760 or args.sims != 4096 or args.particles != 4096:
+    if not os.path.exists(path) or slots != 262144 or args.sims != 4096 or args.particles != 4096:
         return None, None
     with open(path) as f:
         d = json.load(f)
@@ -95,9 +95,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--slots", type=int, default=245760,
-                    help="concurrent runs per GPU (0.66 MB of HBM each at the default workload, packed particles); "
-                         "245760 = 15 search waves per CU, one below what a CU holds (16: 116 VGPRs, 10.1 KB of LDS per wave)")
+    ap.add_argument("--slots", type=int, default=None,
+                    help="concurrent runs per GPU (0.66 MB of HBM each at the default workload, packed particles); default: 16 search "
+                         "waves per CU, what a CU holds at 116 VGPRs and 10.1 KB of LDS per wave = 262144 on the 256 CUs of an MI355X")
     ap.add_argument("--sims", type=int, default=4096)
     ap.add_argument("--particles", type=int, default=4096)
     ap.add_argument("--horizon", type=int, default=10)
@@ -139,8 +139,10 @@ def main():
             collective = "gloo"
 
     import fba_pomdp_amd as fba
+    if args.slots is None:   # one search wave (64 runs) per wave slot of the chip: 4 per SIMD, 16 per CU
+        args.slots = 64 * 16 * torch.cuda.get_device_properties(local_rank).multi_processor_count
     slots = args.slots
-    while True:  # 0.66 MB of HBM per slot: step down if this GPU cannot give 161 GB right now
+    while True:  # 0.66 MB of HBM per slot: step down if this GPU cannot give 172 GB right now
         try:
             eng = fba.Engine("episodic-tiger", model=fba.MODEL_BA_TABLE, belief=args.belief,
                              sims=args.sims, particles=args.particles, horizon=args.horizon,
@@ -150,7 +152,7 @@ def main():
         except fba.FbaError as e:
             if "out of memory" not in str(e) or slots <= 1024:
                 raise
-            nxt = 196608 if slots > 196608 else (163840 if slots > 163840 else (131072 if slots > 131072 else slots // 2))
+            nxt = next((v for v in (245760, 196608, 163840, 131072) if v < slots), slots // 2)
             print(f"[bench] {slots} slots do not fit ({e}); retrying with {nxt}", file=sys.stderr)
             slots = nxt
 

@@ -36,7 +36,7 @@ f_full = max(fetch[rk]) * 1024.0
 w_full = max(write[rk]) * 1024.0
 doc = {
     "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline",
-    "config": "default bench workload, 245760 slots, packed particles (64 B records)",
+    "config": "default bench workload, 262144 slots, packed particles (64 B records)",
     "kernel": "reject_kernel",  # bench.py's name for the rejection update, whichever instantiation runs it
     "kernel_instantiation": rk,
     "fetch_bytes_per_launch_raw": f_full,
@@ -45,7 +45,7 @@ doc = {
     "traffic_bytes_per_launch_fetch_x2": 2 * f_full + w_full,
     "notes": [
         "counter unit KiB (MI355X_MICROARCH.md, HBM / rocprofv3): values below are KiB per launch summed over instances; the per-launch figure used is the largest (a launch in which every slot updates)",
-        "WRITE_SIZE is exact on gfx950: 245760 slots x 4096 particles x 64 B = 64.42 GB is the minimum this kernel can write",
+        "WRITE_SIZE is exact on gfx950: 262144 slots x 4096 particles x 64 B = 68.72 GB is the minimum this kernel can write",
         "FETCH_SIZE is reported raw (no x2): the kernel reads each 64-B record in 4-byte pieces (the pass that parks the filter in LDS) and in 16-byte pieces, four lanes per record (the gather); the guide's x2 correction is calibrated for wide coalesced streaming reads and would put the gather above what was written",
     ],
     "per_launch_KiB": {k: {"fetch_KiB_per_launch": fetch.get(k, []), "write_KiB_per_launch": write.get(k, [])}
