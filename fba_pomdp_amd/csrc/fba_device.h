@@ -275,6 +275,11 @@ struct Problem {
     int32_t packed;     // tabular tiger particles stored as uint16 increment counts over the shared prior (PackedView); C, Cs are then in words of that record
     int32_t point;      // point-estimate belief: N = 1 and Belief::sample() returns the state without a draw
     int32_t reinvig;    // reinvigoration belief: particles bred per update (belief = REJECTION then); 0 = off
+    int32_t hist;       // history particles (gridworld FBA-POMDP, importance filter): a record holds the particle's increments as one
+                        // 4-byte entry per real step over the shared prior tables (HistView below); C = 0 then, hist_cap entries per record
+    int32_t hist_cap;
+    const float* hist_base;  // the prior count table every particle starts from (max layout, x / y nodes without the goal parent)
+    const float* hist_alt;   // [A][2][N*N*G*N]: the x / y transition nodes as a particle with the goal as their third parent starts them
     int32_t S, A, O;
     int32_t N;          // particles per slot
     int32_t C;          // floats per particle count blob
@@ -965,6 +970,186 @@ __device__ __forceinline__ bool sysadmin_fact_step(const Problem& P, Rng& g, con
     r            = ext_reward(P, s, a, ns);
     s            = ns;
     return t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// History particles (Problem::hist): the gridworld FBA-POMDP particle as "shared prior + what this particle
+// has added to it".  A Bayes-adaptive particle never changes a count except by the "+1"s of
+// BABNModel::incrementCountsOf (BABNModel.cpp:354-382) -- six per real step here, one per DBN node of the step's
+// action, at cells that (s, a, s', o') determine -- so instead of the 191 KB count table (N = 7) a record holds
+//   word 0   the domain state            word 1   bit 2a + f: node T(a, f), f in {x, y}, has the goal as third parent
+//   word 2 + t   entry t = the t-th real step of the run:   s' as (x, y, goal) 4 bits each | o' as (x, y, goal)
+//                4 bits each << 12 | a << 24, or bit 31 | start state (resetDomainStateDistribution: no increments)
+// and a count is prior[cell] + (number of entries that incremented the cell).  The reference's own copy-on-write
+// table (BAFlatModel.cpp:185-217) is the same idea at row granularity.  The engine only uses this form when
+// prior[k] + j, j <= hist_cap + 1, is for every k the float that j additions of 1.0f reach (checked on the host),
+// so a row read through the history is bit for bit the row of the dense table.
+// One simulated step = two passes over the entries (the three transition rows of (s, a), then the three
+// observation rows of (a, s')); an entry costs a few compares and adds, no memory beyond its own 4 bytes.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t HIST_START = 0x80000000u;
+constexpr int HIST_MAX_CAP    = 126;  // entries per record: 2 + cap words <= SEARCH_STAGE_WORDS, counts per cell fit 8 bits
+__host__ __device__ __forceinline__ uint32_t hist_pack(int x, int y, int g) { return (uint32_t)x | ((uint32_t)y << 4) | ((uint32_t)g << 8); }
+__host__ __device__ __forceinline__ uint32_t hist_entry(uint32_t ns, uint32_t o, int a) { return ns | (o << 12) | ((uint32_t)a << 24); }
+
+// increments per cell of one row (at most 16 cells), 8 bits each
+struct RowCount {
+    uint64_t lo, hi;
+    __device__ __forceinline__ void add(bool hit, int cell)
+    {
+        const uint64_t one = hit ? 1ull : 0ull;
+        lo += cell < 8 ? one << (8 * cell) : 0ull;
+        hi += cell < 8 ? 0ull : one << (8 * (cell - 8));
+    }
+    __device__ __forceinline__ float at(int i) const { return (float)(uint32_t)(((i < 8 ? lo >> (8 * i) : hi >> (8 * (i - 8)))) & 0xffull); }
+};
+
+struct GlobalEntries {
+    const uint32_t* p;
+    __device__ __forceinline__ uint32_t at(int t) const { return p[t]; }
+};
+template <int STRIDE>
+struct LdsEntries {
+    const uint32_t* p;
+    __device__ __forceinline__ uint32_t at(int t) const { return p[t * STRIDE]; }
+};
+
+// a Dirichlet row in registers: prior row + this particle's increments
+template <int K>
+struct HistRow {
+    float r[K];
+    __device__ __forceinline__ void load(const float* __restrict__ prior, int n, const RowCount& c)
+    {
+#pragma unroll
+        for (int i = 0; i < K; ++i) r[i] = i < n ? prior[i] + c.at(i) : 0.f;
+    }
+    // sampleFromExpectedMult (random.cpp:244-255): double total, float CDF against a double threshold
+    __device__ __forceinline__ int sample(Rng& g, int n) const
+    {
+        double total = (double)r[0];
+#pragma unroll
+        for (int i = 1; i < K; ++i)
+            if (i < n) total += (double)r[i];
+        const double p = g.u01() * total;
+        float sum = r[0];
+        int pick  = n - 1;
+        bool done = false;
+#pragma unroll
+        for (int i = 1; i < K; ++i)
+            if (i < n && !done) {
+                if (p < (double)sum) { pick = i - 1; done = true; }
+                else sum += r[i];
+            }
+        return pick;
+    }
+    // expectedMult(row)[o] as BABNModel::computeObservationProbability uses it: float sum, float division
+    __device__ __forceinline__ float prob(int n, int o) const
+    {
+        float sum = r[0], mine = r[0];
+#pragma unroll
+        for (int i = 1; i < K; ++i)
+            if (i < n) { sum += r[i]; mine = (i == o) ? r[i] : mine; }
+        return ((double)sum <= 1e-300) ? 0.0f : mine / sum;
+    }
+};
+
+// BAPOMDP::step (BAPOMDP.cpp:111-143) over BABNModel (BABNModel.cpp:292-325) for the gridworld FBA-POMDP on a
+// history particle: the draws, their order and every row value are those of gridworld_fact_step on the dense
+// table.  `sp` = the state as hist_pack(x, y, goal); returns the step's entry (what incrementCountsOf would
+// add, :354-382, App. A #6: observation rows at the OLD state's values) and, for the importance update,
+// P(real_o | a, s') from the counts after the step's own increments (BABNModel.cpp:328-352).
+template <int K, bool WANT_PROB, class Entries>
+__device__ __forceinline__ bool gridworld_hist_step_k(const Problem& P, Rng& g, const Entries& ent, int len, uint32_t mask, uint32_t& sp, int a,
+                                                      int& o, double& r, uint32_t& entry, int real_o, double& prob)
+{
+    const GridDesc* gw = P.gw;
+    const int N = gw->N, G = gw->G, A = P.A;
+    const int XY = N * N * G * N, GG = N * N * G * G, NN = N * N;
+    const int x = (int)(sp & 15u), y = (int)((sp >> 4) & 15u), gl = (int)(sp >> 8);
+    const int tbase = a * (2 * XY + GG), obase = A * (2 * XY + GG) + a * (2 * NN + G * G);
+    const int cell = x * N + y;
+    const bool mx = (mask >> (2 * a)) & 1u, my = (mask >> (2 * a + 1)) & 1u;
+    // pass 1: the increments this particle has made to the rows T(a, .)(x, y [, goal])
+    RowCount cx{0, 0}, cy{0, 0}, cg{0, 0};
+    {
+        uint32_t prev = 0;
+        const uint32_t want_xy = sp & 0xffu;
+        for (int t = 0; t < len; ++t) {
+            const uint32_t e = ent.at(t);
+            const bool hit_xy = (e >> 24) == (uint32_t)a && (prev & 0xffu) == want_xy;  // (a start entry has bit 31 set: never equal)
+            const bool hit_g  = hit_xy && (prev >> 8) == (uint32_t)gl;
+            cx.add(hit_xy && (!mx || hit_g), (int)(e & 15u));
+            cy.add(hit_xy && (!my || hit_g), (int)((e >> 4) & 15u));
+            cg.add(hit_g, (int)((e >> 8) & 15u));
+            prev = e & 0xfffu;
+        }
+    }
+    HistRow<K> row;
+    row.load(mx ? P.hist_alt + (size_t)(a * 2 + 0) * XY + (cell * G + gl) * N : P.hist_base + tbase + cell * N, N, cx);
+    const int nx = row.sample(g, N);
+    row.load(my ? P.hist_alt + (size_t)(a * 2 + 1) * XY + (cell * G + gl) * N : P.hist_base + tbase + XY + cell * N, N, cy);
+    const int ny = row.sample(g, N);
+    row.load(P.hist_base + tbase + 2 * XY + (cell * G + gl) * G, G, cg);
+    const int ng = row.sample(g, G);
+    // pass 2: the increments to the rows O(a, .)(value of the new state's feature); a step increments them at
+    // the row of the state it STARTED from
+    RowCount ox{0, 0}, oy{0, 0}, og{0, 0};
+    {
+        uint32_t prev = 0;
+        for (int t = 0; t < len; ++t) {
+            const uint32_t e = ent.at(t);
+            const bool hit_a = (e >> 24) == (uint32_t)a;
+            ox.add(hit_a && (prev & 15u) == (uint32_t)nx, (int)((e >> 12) & 15u));
+            oy.add(hit_a && ((prev >> 4) & 15u) == (uint32_t)ny, (int)((e >> 16) & 15u));
+            og.add(hit_a && (prev >> 8) == (uint32_t)ng, (int)((e >> 20) & 15u));
+            prev = e & 0xfffu;
+        }
+    }
+    HistRow<K> rox, roy, rog;
+    rox.load(P.hist_base + obase + nx * N, N, ox);
+    const int vx = rox.sample(g, N);
+    roy.load(P.hist_base + obase + NN + ny * N, N, oy);
+    const int vy = roy.sample(g, N);
+    rog.load(P.hist_base + obase + 2 * NN + ng * G, G, og);
+    const int vg = rog.sample(g, G);
+    o = (vx * N + vy) * G + vg;
+    if (WANT_PROB) {
+        // the step's own observation increments land at rows x, y, goal of the old state: they are part of the
+        // rows read here only where the feature kept its value
+        ox.add(x == nx, vx);
+        oy.add(y == ny, vy);
+        og.add(gl == ng, vg);
+        rox.load(P.hist_base + obase + nx * N, N, ox);
+        roy.load(P.hist_base + obase + NN + ny * N, N, oy);
+        rog.load(P.hist_base + obase + 2 * NN + ng * G, G, og);
+        const int qg = real_o % G, qy = (real_o / G) % N, qx = real_o / (N * G);
+        double pr = 1;
+        pr *= rox.prob(N, qx);
+        pr *= roy.prob(N, qy);
+        pr *= rog.prob(G, qg);
+        prob = pr;
+    }
+    const bool found = gw->goal[gl][0] == x && gw->goal[gl][1] == y;  // GridWorldBAExtension.cpp:74-99: terminal and reward from the OLD state
+    r     = found ? 1 : 0;
+    sp    = hist_pack(nx, ny, ng);
+    entry = hist_entry(sp, hist_pack(vx, vy, vg), a);
+    return found;
+}
+template <bool WANT_PROB, class Entries>
+__device__ __forceinline__ bool gridworld_hist_step(const Problem& P, Rng& g, const Entries& ent, int len, uint32_t mask, uint32_t& sp, int a, int& o,
+                                                    double& r, uint32_t& entry, int real_o, double& prob)
+{
+    if (P.gw->G <= 8) return gridworld_hist_step_k<8, WANT_PROB>(P, g, ent, len, mask, sp, a, o, r, entry, real_o, prob);
+    return gridworld_hist_step_k<16, WANT_PROB>(P, g, ent, len, mask, sp, a, o, r, entry, real_o, prob);
+}
+__device__ __forceinline__ uint32_t gridworld_pack_state(const GridDesc* gw, int s)
+{
+    const int N = gw->N, G = gw->G;
+    return hist_pack(s / (N * G), (s / G) % N, s % G);
+}
+__device__ __forceinline__ int gridworld_unpack_state(const GridDesc* gw, uint32_t sp)
+{
+    return ((int)(sp & 15u) * gw->N + (int)((sp >> 4) & 15u)) * gw->G + (int)(sp >> 8);
 }
 
 // BABNModel::computeObservationProbability (BABNModel.cpp:328-352)

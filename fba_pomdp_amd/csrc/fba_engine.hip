@@ -38,7 +38,9 @@ struct fba_ctx {
     std::vector<float> prior;  // host copy, dense_C floats
     int dense_C          = 0;   // length of a particle's count table as the API sees it (= P.C unless P.packed)
     float* d_prior       = nullptr;
-    float* d_prior_dense = nullptr;  // packed particles: the dense prior table on the device
+    float* d_prior_dense = nullptr;  // packed / history particles: the dense prior table on the device
+    std::vector<float> prior_alt;    // history particles: the x / y transition nodes with the goal as third parent, [A][2][N*N*G*N]
+    float* d_prior_alt   = nullptr;
     FDesc fdesc{};          // host copy of the factored model description
     FDesc* d_fdesc       = nullptr;
     GridDesc gdesc{};
@@ -747,10 +749,52 @@ bool packable_prior(const std::vector<float>& prior)
     return true;
 }
 
+// History particles (fba_device.h): GridWorldFactBAPrior::setNoisyTransitionNode (GridWorldBAPriors.cpp:255-295) for
+// every action and the x / y node -- what gw_fill_xy_node_with_goal writes into a dense record on the device.
+void build_gridworld_alt_prior(fba_ctx* c)
+{
+    const GridDesc& g = c->gdesc;
+    const int N = g.N, G = g.G, A = c->P.A, XY = N * N * G * N;
+    const float noise = c->cfg.noise, total = c->cfg.counts_total;
+    c->prior_alt.assign((size_t)A * 2 * XY, 0.f);
+    for (int a = 0; a < A; ++a)
+        for (int f = 0; f < 2; ++f) {
+            float* base = c->prior_alt.data() + (size_t)(a * 2 + f) * XY;
+            for (int x = 0; x < N; ++x)
+                for (int y = 0; y < N; ++y) {
+                    int nx = x, ny = y;
+                    const float trans_prob = gw_slow_at_h(g, x, y) ? (float)(.15 + (double)noise) : (float).95;
+                    gw_move_h(g, a, nx, ny);
+                    const int loc = f == 0 ? x : y, new_loc = f == 0 ? nx : ny;
+                    for (int gl = 0; gl < G; ++gl) {
+                        float* row = base + ((x * N + y) * G + gl) * N;
+                        row[loc] += (1 - trans_prob) * total;
+                        row[new_loc] += (trans_prob)*total;
+                    }
+                }
+        }
+}
+// v + (float)j is the float that j additions of 1.0f to v reach, for every j up to `most`
+bool increments_exact(const std::vector<float>& table, int most)
+{
+    for (float v : table) {
+        if (!(v >= 0.f)) return false;
+        float seq = v;
+        for (int j = 1; j <= most; ++j) {
+            seq += 1.0f;
+            if (seq != v + (float)j) return false;
+        }
+    }
+    return true;
+}
+
 int upload_prior(fba_ctx* c)
 {
     std::vector<float> padded((size_t)c->P.Cs, 0.f);
-    if (c->P.packed) {  // records start as "no increments yet"; the table itself goes beside them
+    if (c->P.hist) {  // records carry no counts: the tables sit beside them
+        HIPCHK(c, hipMemcpyAsync(c->d_prior_dense, c->prior.data(), c->prior.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_prior_alt, c->prior_alt.data(), c->prior_alt.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    } else if (c->P.packed) {  // records start as "no increments yet"; the table itself goes beside them
         if (!packable_prior(c->prior))
             return fail(c, FBA_EINVAL, "this context stores particles packed (uint16 increments over the prior), which needs prior counts c with "
                                        "c + 65535 exact in fp32; create it with FBA_DENSE_PARTICLES=1 in the environment for other tables");
@@ -830,6 +874,9 @@ int check_fault(fba_ctx* c)
     HIPCHK(c, hipMemcpy(&f, c->D.fault, sizeof f, hipMemcpyDeviceToHost));
     if (!f) return FBA_OK;
     HIPCHK(c, hipMemset(c->D.fault, 0, sizeof f));
+    if (f >= 0x40000000)
+        return fail(c, FBA_ESTATE, "slot %d: more belief updates and resets in one run than the %d (episodes * (horizon + 1)) a history particle was "
+                    "sized for; create the context with FBA_DENSE_PARTICLES=1 in the environment to drive it beyond that", f - 0x40000000, c->P.hist_cap);
     if (f < 0) return fail(c, FBA_ESTATE, "the search tree of slot %d needed more than the %d node records it has", -f - 1, c->D.max_nodes);
     return fail(c, FBA_ESTATE, "rejection sampling in slot %d accepted fewer than %d particles in %d attempts: no particle of the filter "
                 "can produce the observation (the reference loops forever in RejectionSampling.hpp:26-72 here)", f - 1, c->P.N, REJECT_MAX_ATTEMPTS);
@@ -1175,7 +1222,25 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
             P.C      = (c->dense_C + 1) / 2;  // words holding the uint16 pairs; the state word follows
         }
     }
-    {
+    // History particles (fba_device.h): the gridworld FBA-POMDP particle as one 4-byte entry per real step over the
+    // shared prior tables -- 100-500 bytes instead of 191 KB (N = 7) -- where the importance filter is the plain one,
+    // the run fits the record (one entry per update and per reset) and prior + j is exact in fp32 for every count a
+    // run can reach (so a row read through the entries is bit for bit the dense row).
+    P.hist = 0; P.hist_cap = 0; P.hist_base = nullptr; P.hist_alt = nullptr;
+    if (cfg->model == FBA_MODEL_BA_FACTORED && cfg->domain == FBA_DOM_GRIDWORLD && cfg->belief == FBA_BELIEF_IMPORTANCE &&
+        !cfg->dirichlet_regular && cfg->particles <= IS_MAX_CHUNKS * 256 && !std::getenv("FBA_IS_MULTI_MIN") &&
+        !std::getenv("FBA_DENSE_PARTICLES") && (long long)cfg->episodes * (cfg->horizon + 1) <= HIST_MAX_CAP) {
+        const int cap = cfg->episodes * (cfg->horizon + 1);
+        build_gridworld_alt_prior(c);
+        std::vector<float> counts(c->prior.begin(), c->prior.begin() + c->fdesc.ncounts);
+        if (increments_exact(counts, cap + 1) && increments_exact(c->prior_alt, cap + 1)) {
+            P.hist     = 1;
+            P.hist_cap = cap;
+            P.C        = 0;  // word 0 = state, word 1 = structure bits, words 2.. = entries
+        }
+    }
+    if (P.hist) P.Cs = (2 + P.hist_cap + 3) & ~3;
+    else {
         int need = P.C + 1, cs = 4;
         if (need <= 64) { while (cs < need) cs <<= 1; }
         else cs = (need + 3) & ~3;
@@ -1271,6 +1336,8 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     }
     CHK(dev_alloc(c, &D.wscan, is ? (size_t)E * P.N : 1, false));
     D.side_w = 1 + (P.model == FBA_MODEL_BA_FACTORED ? c->fdesc.FS + c->fdesc.FO : (P.model == FBA_MODEL_BA_TABLE ? 2 : 0));
+    if (P.hist) D.side_w = 2;  // {new state, the step's entry}
+    CHK(dev_alloc(c, &D.hist_len, E));
     CHK(dev_alloc(c, &D.p_side, is ? (size_t)E * P.N * D.side_w : 1, false));
     {
         // one workgroup per slot up to IS_MAX_CHUNKS*256 particles, several launches beyond
@@ -1312,6 +1379,11 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     CHK(dev_alloc(c, &D.lazy_reset, E));
     CHK(dev_alloc(c, &c->d_prior, P.Cs));
     CHK(dev_alloc(c, &c->d_prior_dense, std::max(c->dense_C, 1)));
+    if (P.hist) {
+        CHK(dev_alloc(c, &c->d_prior_alt, c->prior_alt.size()));
+        P.hist_base = c->d_prior_dense;
+        P.hist_alt  = c->d_prior_alt;
+    }
     CHK(dev_alloc(c, &c->d_uni_scan, (size_t)P.N + 1));
     CHK(dev_alloc(c, &c->d_log1p, (size_t)P.sims + 2));
     D.prior     = c->d_prior;
@@ -1531,6 +1603,42 @@ int fba_belief_update(fba_ctx* c, const int32_t* action, const int32_t* obs, con
     return check_fault(c);
 }
 
+// History particles: the dense count table of one record, as the API speaks of particles -- the prior (the goal-parent
+// form of the x / y nodes the structure bits name) plus 1.0f per entry and incremented cell, in entry order
+// (BABNModel::incrementCountsOf BABNModel.cpp:354-382 replayed).
+static void hist_materialize(const fba_ctx* c, const uint32_t* rec, int len, float* counts)
+{
+    const GridDesc& g = c->gdesc;
+    const int N = g.N, G = g.G, A = c->P.A;
+    const int XY = N * N * G * N, GG = N * N * G * G, NN = N * N, ncounts = c->fdesc.ncounts;
+    const uint32_t mask = rec[1];
+    std::copy(c->prior.begin(), c->prior.begin() + ncounts, counts);
+    for (int a = 0; a < A; ++a)
+        for (int f = 0; f < 2; ++f) {
+            const bool with_goal = (mask >> (2 * a + f)) & 1u;
+            if (with_goal) std::copy(c->prior_alt.begin() + (size_t)(a * 2 + f) * XY, c->prior_alt.begin() + (size_t)(a * 2 + f + 1) * XY,
+                                     counts + a * (2 * XY + GG) + f * XY);
+            const uint32_t m = with_goal ? 7u : 3u;
+            std::memcpy(&counts[ncounts + 2 * a + f], &m, 4);
+        }
+    uint32_t prev = 0;
+    for (int t = 0; t < len; ++t) {
+        const uint32_t en = rec[2 + t];
+        if (!(en >> 31)) {
+            const int a = (int)(en >> 24), x = (int)(prev & 15u), y = (int)((prev >> 4) & 15u), gl = (int)(prev >> 8);
+            const int tbase = a * (2 * XY + GG), obase = A * (2 * XY + GG) + a * (2 * NN + G * G), cell = x * N + y;
+            const bool mx = (mask >> (2 * a)) & 1u, my = (mask >> (2 * a + 1)) & 1u;
+            counts[tbase + (mx ? cell * G + gl : cell) * N + (int)(en & 15u)] += 1.0f;
+            counts[tbase + XY + (my ? cell * G + gl : cell) * N + (int)((en >> 4) & 15u)] += 1.0f;
+            counts[tbase + 2 * XY + (cell * G + gl) * G + (int)((en >> 8) & 15u)] += 1.0f;
+            counts[obase + x * N + (int)((en >> 12) & 15u)] += 1.0f;
+            counts[obase + NN + y * N + (int)((en >> 16) & 15u)] += 1.0f;
+            counts[obase + 2 * NN + gl * G + (int)((en >> 20) & 15u)] += 1.0f;
+        }
+        prev = en & 0xfffu;
+    }
+}
+
 int fba_belief_get(fba_ctx* c, int32_t slot, int32_t* state, double* weight, float* counts)
 {
     if (!c || slot < 0 || slot >= c->P.E) return FBA_EINVAL;
@@ -1544,13 +1652,16 @@ int fba_belief_get(fba_ctx* c, int32_t slot, int32_t* state, double* weight, flo
         if (P.belief != FBA_BELIEF_IMPORTANCE) return fail(c, FBA_EINVAL, "the rejection filter is unweighted");
         HIPCHK(c, hipMemcpy(weight, c->D.p_weight + pb, (size_t)P.N * 8, hipMemcpyDeviceToHost));
     }
-    if (state || (counts && P.C)) {
+    if (state || (counts && (P.C || P.hist))) {
         std::vector<float> tmp((size_t)P.N * P.Cs);
         HIPCHK(c, hipMemcpy(tmp.data(), c->D.p_rec + pb * P.Cs, tmp.size() * 4, hipMemcpyDeviceToHost));
+        int32_t hist_len = 0;
+        if (P.hist) HIPCHK(c, hipMemcpy(&hist_len, c->D.hist_len + slot, 4, hipMemcpyDeviceToHost));
         for (int i = 0; i < P.N; ++i) {
             const float* rec = tmp.data() + (size_t)i * P.Cs;
             if (state) std::memcpy(&state[i], &rec[P.C], 4);
-            if (counts && P.packed) {  // count = prior + number of increments (PackedView)
+            if (counts && P.hist) hist_materialize(c, reinterpret_cast<const uint32_t*>(rec), hist_len, counts + (size_t)i * c->dense_C);
+            else if (counts && P.packed) {  // count = prior + number of increments (PackedView)
                 const uint32_t* w = reinterpret_cast<const uint32_t*>(rec);
                 for (int k = 0; k < c->dense_C; ++k)
                     counts[(size_t)i * c->dense_C + k] = c->prior[k] + (float)((k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffffu));
@@ -1587,6 +1698,9 @@ int fba_belief_set(fba_ctx* c, int32_t slot, const int32_t* state, const double*
     uint8_t sel = 0;
     HIPCHK(c, hipMemcpy(&sel, c->D.bufsel + slot, 1, hipMemcpyDeviceToHost));
     const size_t pb = ((size_t)sel * P.E + slot) * (size_t)P.N;
+    if (P.hist && (state || counts))
+        return fail(c, FBA_EINVAL, "this context stores particles as histories of their own steps over the shared prior (gridworld FBA-POMDP), which "
+                                   "cannot take on arbitrary states or counts; create it with FBA_DENSE_PARTICLES=1 in the environment to set them");
     if (state)
         for (int i = 0; i < P.N; ++i)
             if (state[i] < 0 || state[i] >= P.S) return fail(c, FBA_EINVAL, "state %d out of range", state[i]);
@@ -1643,6 +1757,14 @@ int fba_run_ticks(fba_ctx* c, int32_t ticks)
     if (!c || ticks < 0) return FBA_EINVAL;
     int rc;
     if (!c->started) {
+        if (c->cfg.trace) {  // room for one run's worth of records per slot (later ones are counted, not kept)
+            const size_t cap = std::min<size_t>((size_t)c->P.E * c->P.episodes * c->P.horizon, (size_t)1 << 22);
+            if ((size_t)c->D.trace_cap < cap) {
+                if ((rc = dev_alloc(c, &c->D.trace, cap))) return rc;
+                c->D.trace_cap = (int32_t)cap;
+            }
+            HIPCHK(c, hipMemsetAsync(c->D.trace_count, 0, sizeof(int32_t), c->stream));
+        }
         if ((rc = start_experiment(c, -1))) return rc;
         c->started = true;
     }

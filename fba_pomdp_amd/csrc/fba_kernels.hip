@@ -238,7 +238,9 @@ __host__ __device__ __forceinline__ bool root_children_in_lds(const Problem& P, 
     return P.A * P.O <= ROOT_CHILDREN && D.max_nodes <= 32767;
 }
 
-template <bool STAGE, int AMAX, bool REG, int TIGER_TABLE, int MODEL, int FTIGER = 0, bool TIGER_POMDP = false>
+// HIST: the particles are history records (fba_device.h "History particles"): a simulation stages its root particle's
+// entries in LDS and every step reads its Dirichlet rows through them (gridworld_hist_step).
+template <bool STAGE, int AMAX, bool REG, int TIGER_TABLE, int MODEL, int FTIGER = 0, bool TIGER_POMDP = false, bool HIST = false>
 __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceState D)
 {
     if (TIGER_POMDP) {
@@ -274,7 +276,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
         if (lane < 24) s_prior[lane] = D.prior_dense[lane];
         __syncthreads();
     }
-    if (MODEL == FBA_MODEL_BA_FACTORED) {
+    if (MODEL == FBA_MODEL_BA_FACTORED && !HIST) {
         // the factored model's description (which parents, how many values, where the rows start) is
         // consulted several times per sampled feature: keep the part in use in LDS, at the end of
         // this workgroup's allocation, instead of chasing it through global memory
@@ -340,6 +342,8 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
     }
 
     const bool lazy = slot_lazy(D, e);  // particle states are still the episode's start-state draws (lazy_state)
+    const int hist_n = HIST ? D.hist_len[e] : 0;  // entries in every record of this slot
+    uint32_t sp = 0, hist_mask = 0;               // HIST: the simulated state as hist_pack(x, y, goal); the root particle's structure bits
     // -P ts: TSPlanner / BATSPlanner (src/planners/ts/TSPlanner.cpp:16-29, bayes-adaptive/BATSPlanner.cpp:19-34) sample
     // the belief once and plan on that point estimate, whose sample() draws nothing: every simulation starts
     // from the same particle and its stream begins with the UCB tie-break.
@@ -360,7 +364,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
             cnt = prec + (size_t)src * P.Cs;
             if (STAGE) {
                 const float4* rp = reinterpret_cast<const float4*>(cnt);
-                const int n4 = (P.C + 4) >> 2;  // counts and the state word; the padding behind them is not needed
+                const int n4 = HIST ? (hist_n + 5) >> 2 : (P.C + 4) >> 2;  // counts and the state word (HIST: state, structure bits, entries); the padding behind them is not needed
                 for (int k = 0; k < n4; ++k) {
                     const float4 v = rp[k];
                     stage[(4 * k + 0) * SEARCH_BLOCK] = v.x;
@@ -373,6 +377,10 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
                 s = rec_state(cnt, P.C);
             }
             if (lazy) s = lazy_state(P, D, e, src);
+            if (HIST) {
+                sp        = gridworld_pack_state(P.gw, s);
+                hist_mask = __float_as_uint(stage[1 * SEARCH_BLOCK]);
+            }
             node = 0; dtg = max_tree_depth; plen = 0; mode = 1;
         }
         bool finish = false, do_step = true;
@@ -390,7 +398,12 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
             int o;
             double r;
             bool term;
-            if (FTIGER > 0 && STAGE) term = ftiger_step<(FTIGER > 0 ? FTIGER : 1)>(P, g, LdsView<SEARCH_BLOCK>{stage}, s, a, o, r, NoInc{});
+            if (HIST) {
+                uint32_t entry;
+                double prob;
+                term = gridworld_hist_step<false>(P, g, LdsEntries<SEARCH_BLOCK>{reinterpret_cast<const uint32_t*>(stage) + 2 * SEARCH_BLOCK}, hist_n,
+                                                  hist_mask, sp, a, o, r, entry, 0, prob);
+            } else if (FTIGER > 0 && STAGE) term = ftiger_step<(FTIGER > 0 ? FTIGER : 1)>(P, g, LdsView<SEARCH_BLOCK>{stage}, s, a, o, r, NoInc{});
             else if (FTIGER > 0) term = ftiger_step<(FTIGER > 0 ? FTIGER : 1)>(P, g, GlobalSearchView{cnt}, s, a, o, r, NoInc{});
             else if (TIGER_TABLE == 2) term = sim_step<REG>(P, g, PackedView<LdsView<SEARCH_BLOCK>>{LdsView<SEARCH_BLOCK>{stage}, s_prior}, s, a, o, r, NoInc{});
             else if (STAGE) term = sim_step<REG>(P, g, LdsView<SEARCH_BLOCK>{stage}, s, a, o, r, NoInc{});
@@ -665,6 +678,31 @@ __device__ __forceinline__ void gather_records_side(float* __restrict__ dst, con
             for (int k = 0; k < ninc; ++k) bump_cell(v, sd[1 + k], lo, packed);
             const int d = C - lo;
             if (d == 0) v.x = nstate; else if (d == 1) v.y = nstate; else if (d == 2) v.z = nstate; else if (d == 3) v.w = nstate;
+            dp[part] = v;
+        }
+    }
+}
+
+// History particles (fba_device.h): output record j = source record s_src[j] -- its state word replaced, its structure
+// bits kept, its `len` entries copied -- with the source particle's pending entry (side row {new state, entry})
+// appended as entry `len`.  A power-of-two group of lanes moves one record in 16-byte pieces.
+__device__ __forceinline__ void gather_hist_records(float* __restrict__ dst, const float* __restrict__ src, const int32_t* s_src,
+                                                    const int32_t* __restrict__ side, int len, int m, int C4, int group, int nthreads)
+{
+    const int gid = threadIdx.x / group, part0 = threadIdx.x % group, ngroups = nthreads / group;
+    const int n4 = (len + 6) >> 2;  // pieces that hold words 0 .. 2 + len
+    const int at = 2 + len;         // the word the new entry goes to
+    for (int j = gid; j < m; j += ngroups) {
+        const int p      = s_src[j];
+        const float4* sp = reinterpret_cast<const float4*>(src) + (size_t)p * C4;
+        float4* dp       = reinterpret_cast<float4*>(dst) + (size_t)j * C4;
+        const int2 sd    = *reinterpret_cast<const int2*>(side + (size_t)p * 2);
+        for (int part = part0; part < n4; part += group) {
+            float4 v = sp[part];
+            if (part == 0) v.x = __int_as_float(sd.x);
+            const int d = at - part * 4;
+            const float f = __int_as_float(sd.y);
+            if (d == 0) v.x = f; else if (d == 1) v.y = f; else if (d == 2) v.z = f; else if (d == 3) v.w = f;
             dp[part] = v;
         }
     }
@@ -1126,7 +1164,9 @@ __global__ void __launch_bounds__(IS_BLOCK) uniform_scan_kernel(int n, double* w
 //   3. N multinomial draws by binary search on the prefix sums
 //   4. whole-record gather into the other buffer, weights reset to 1/N
 // ---------------------------------------------------------------------------------------------
-template <bool REG, int TIGER_TABLE>
+// HIST: history particles (gridworld FBA-POMDP): the step reads its rows through the particle's entries, the update
+// is one new entry per particle, appended by the gather.
+template <bool REG, int TIGER_TABLE, bool HIST = false>
 __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceState D)
 {
     if (TIGER_TABLE) {  // sizes restated as literals (see search_kernel)
@@ -1137,7 +1177,7 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
     }
     __shared__ float s_prior[TIGER_TABLE == 2 ? 24 : 1];
     __shared__ double s_carry[IS_MAX_CHUNKS + 2];
-    __shared__ int32_t s_src[IS_BLOCK], s_inc[MAXINC * IS_BLOCK];
+    __shared__ int32_t s_src[IS_BLOCK], s_inc[HIST ? 1 : MAXINC * IS_BLOCK];
     const int e = blockIdx.x, tid = threadIdx.x;
     if (!D.need_update[e]) return;
     if (TIGER_TABLE == 2) {
@@ -1145,6 +1185,15 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
         __syncthreads();
     }
     const int a = D.action[e], o = D.obs[e], N = P.N;
+    const int hist_n = HIST ? D.hist_len[e] : 0;
+    if (HIST && hist_n >= P.hist_cap) {  // more real steps than the records were sized for (episodes * (horizon + 1)): only the per-step interface can get here
+        if (tid == 0) {
+            atomicCAS(D.fault, 0, 0x40000000 + e);
+            D.need_update[e] = 0;
+            D.active[e]      = 0;
+        }
+        return;
+    }
     const int cur = D.bufsel[e];
     const size_t sb = pbase(P, e, cur), db = pbase(P, e, cur ^ 1);
     double* sw   = D.p_weight + sb;
@@ -1163,6 +1212,15 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
         float* cnt = scn + (size_t)i * P.Cs;
         int s = rec_state(cnt, P.C), so;
         double r;
+        if (HIST) {
+            const uint32_t* rec = reinterpret_cast<const uint32_t*>(cnt);
+            uint32_t sp = gridworld_pack_state(P.gw, s), entry;
+            double prob;
+            gridworld_hist_step<true>(P, g, GlobalEntries{rec + 2}, hist_n, rec[1], sp, a, so, r, entry, o, prob);
+            *reinterpret_cast<int2*>(side + (size_t)i * 2) = make_int2(gridworld_unpack_state(P.gw, sp), (int)entry);
+            sw[i] *= prob;
+            continue;
+        }
         if (TIGER_TABLE == 2) sim_step<REG>(P, g, PackedView<GlobalView>{GlobalView{cnt}, s_prior}, s, a, so, r, LdsInc<IS_BLOCK>{s_inc + tid});
         else sim_step<REG>(P, g, GlobalView{cnt}, s, a, so, r, LdsInc<IS_BLOCK>{s_inc + tid});
         // incrementCountsOf (BAFlatModel.cpp:126-139, BABNModel.cpp:354-382) is deferred to the gather: the new
@@ -1197,7 +1255,8 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
         }
         __syncthreads();
         const int m = min(IS_BLOCK, N - j0);
-        if (defer) gather_records_side(dcn + (size_t)j0 * P.Cs, scn, s_src, side, D.side_w, m, C4, P.C, group, IS_BLOCK, TIGER_TABLE == 2);
+        if (HIST) gather_hist_records(dcn + (size_t)j0 * P.Cs, scn, s_src, side, hist_n, m, C4, group, IS_BLOCK);
+        else if (defer) gather_records_side(dcn + (size_t)j0 * P.Cs, scn, s_src, side, D.side_w, m, C4, P.C, group, IS_BLOCK, TIGER_TABLE == 2);
         else gather_records(dcn + (size_t)j0 * P.Cs, scn, nullptr, s_src, nullptr, 0, 0, nullptr, m, C4, P.C, group, IS_BLOCK);
         __syncthreads();
     }
@@ -1209,6 +1268,7 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
         D.upd_particles[e] += (unsigned long long)N;
         D.cur[e].update_count = -1;
         D.cur[e].weight_total = total;
+        if (HIST) D.hist_len[e] = hist_n + 1;
         if (P.cheat) {  // CheatingReinvigoration::updateEstimation (CheatingReinvigoration.cpp:117-124)
             double lik = D.lik[e] * total;
             if (det_log(lik) < D.lik[P.E]) {
@@ -1459,6 +1519,23 @@ __global__ void __launch_bounds__(256) init_kernel(Problem P, DeviceState D, int
     float* recs     = (fc ? D.p_rec_fc : D.p_rec) + pb * (size_t)P.Cs;
     Rng g = slot_rng(P, D, e);
     g.position((uint32_t)D.run[e], 0, 0);
+    if (P.hist) {
+        // history particles: a fresh particle is its start state and its structure draws, no entries
+        // (GridWorldFactBAPrior::sampleFBAPOMDPState GridWorldBAPriors.cpp:415-441: one boolean per action and x / y node)
+        const double w1h = 1.0 / (double)P.N;
+        for (int i = i_lo + tid; i < i_hi; i += 256) {
+            g.stream(FBA_PHASE_INIT, (uint32_t)i);
+            uint32_t* rec = reinterpret_cast<uint32_t*>(recs + (size_t)i * P.Cs);
+            rec[0] = (uint32_t)domain_start(P, g);
+            uint32_t mask = 0;
+            if (P.structure_prior == FBA_SP_MATCH_UNIFORM)
+                for (int k = 0; k < 2 * P.A; ++k)
+                    if (g.boolean()) mask |= 1u << k;
+            rec[1] = mask;
+            D.p_weight[pb + i] = w1h;
+        }
+        return;
+    }
     // every particle starts from the prior record ...
     const int C4 = P.Cs / 4;
     const float4* pr = reinterpret_cast<const float4*>(D.prior);
@@ -1517,6 +1594,11 @@ __global__ void __launch_bounds__(256) reset_kernel(Problem P, DeviceState D, in
     }
     const int C4 = P.Cs / 4, group = record_group(C4);
     const double w1 = 1.0 / (double)P.N;
+    const int hist_n = P.hist ? D.hist_len[e] : 0;
+    if (P.hist && hist_n >= P.hist_cap) {  // see importance_kernel
+        if (tid == 0 && blockIdx.x == 0) atomicCAS(D.fault, 0, 0x40000000 + e);
+        return;
+    }
     for (int j0 = i_lo; j0 < i_hi; j0 += 256) {
         const int j = j0 + tid;
         if (j < i_hi) {
@@ -1527,6 +1609,24 @@ __global__ void __launch_bounds__(256) reset_kernel(Problem P, DeviceState D, in
         }
         __syncthreads();
         const int m = min(256, i_hi - j0);
+        if (P.hist) {
+            // the copy of the drawn particle with a "start" entry appended: the next step's rows are those of the new state
+            const int gid = tid / group, part0 = tid % group, ngroups = 256 / group, n4 = (hist_n + 6) >> 2, at = 2 + hist_n;
+            for (int q = gid; q < m; q += ngroups) {
+                const float4* sp4 = reinterpret_cast<const float4*>(D.p_rec + sb * (size_t)P.Cs) + (size_t)s_src[q] * C4;
+                float4* dp4       = reinterpret_cast<float4*>(D.p_rec + (db + j0) * (size_t)P.Cs) + (size_t)q * C4;
+                const float fs = __int_as_float(s_ns[q]), fe = __uint_as_float(HIST_START | gridworld_pack_state(P.gw, s_ns[q]));
+                for (int part = part0; part < n4; part += group) {
+                    float4 v = sp4[part];
+                    if (part == 0) v.x = fs;
+                    const int d = at - part * 4;
+                    if (d == 0) v.x = fe; else if (d == 1) v.y = fe; else if (d == 2) v.z = fe; else if (d == 3) v.w = fe;
+                    dp4[part] = v;
+                }
+            }
+            __syncthreads();
+            continue;
+        }
         gather_records(D.p_rec + (db + j0) * (size_t)P.Cs, D.p_rec + sb * (size_t)P.Cs, nullptr, s_src, nullptr, 0, 0, s_ns, m, C4,
                        P.C, group, 256);
         __syncthreads();
@@ -1560,13 +1660,16 @@ __global__ void post_materialize_kernel(Problem P, DeviceState D)
 __global__ void post_init_kernel(Problem P, DeviceState D)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < P.E) D.need_init[e] = 0;
+    if (e >= P.E) return;
+    if (P.hist && D.need_init[e]) D.hist_len[e] = 0;
+    D.need_init[e] = 0;
 }
 __global__ void post_reset_kernel(Problem P, DeviceState D)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= P.E || D.need_reset[e] != 1) return;
     if (P.belief == FBA_BELIEF_IMPORTANCE && !P.cheat) D.bufsel[e] ^= 1;
+    if (P.hist && D.hist_len[e] < P.hist_cap) D.hist_len[e] += 1;  // the start entry reset_kernel appended
     D.need_reset[e] = 0;
 }
 
@@ -1574,6 +1677,66 @@ __global__ void post_reset_kernel(Problem P, DeviceState D)
 // flush_kernel: belief checksum (sum over particles of a position-keyed hash, so the order of
 // the additions does not matter) and hand-over of the tick's trace record.
 // ---------------------------------------------------------------------------------------------
+// History particles: the same checksum over the particle's whole count table -- walked cell by cell in the dense
+// layout, prior value plus the number of entries that incremented the cell -- without ever building the table.
+// hist_next_cell: the smallest incremented cell index >= kmin and how many entries incremented it.
+__device__ void hist_next_cell(const Problem& P, const uint32_t* rec, int len, int kmin, int& nxt, int& mult)
+{
+    const int N = P.gw->N, G = P.gw->G, A = P.A;
+    const int XY = N * N * G * N, GG = N * N * G * G, NN = N * N;
+    const uint32_t mask = rec[1];
+    nxt = 0x7fffffff; mult = 0;
+    uint32_t prev = 0;
+    for (int t = 0; t < len; ++t) {
+        const uint32_t en = rec[2 + t];
+        if (!(en >> 31)) {
+            const int a = (int)(en >> 24), x = (int)(prev & 15u), y = (int)((prev >> 4) & 15u), gl = (int)(prev >> 8);
+            const int tbase = a * (2 * XY + GG), obase = A * (2 * XY + GG) + a * (2 * NN + G * G), cell = x * N + y;
+            const bool mx = (mask >> (2 * a)) & 1u, my = (mask >> (2 * a + 1)) & 1u;
+            const int c[6] = {tbase + (mx ? cell * G + gl : cell) * N + (int)(en & 15u),
+                              tbase + XY + (my ? cell * G + gl : cell) * N + (int)((en >> 4) & 15u),
+                              tbase + 2 * XY + (cell * G + gl) * G + (int)((en >> 8) & 15u),
+                              obase + x * N + (int)((en >> 12) & 15u),
+                              obase + NN + y * N + (int)((en >> 16) & 15u),
+                              obase + 2 * NN + gl * G + (int)((en >> 20) & 15u)};
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+                if (c[q] >= kmin) {
+                    if (c[q] < nxt) { nxt = c[q]; mult = 1; }
+                    else if (c[q] == nxt) ++mult;
+                }
+        }
+        prev = en & 0xfffu;
+    }
+}
+__device__ uint64_t hist_hash_counts(const Problem& P, const uint32_t* rec, int len, uint64_t h)
+{
+    const int N = P.gw->N, G = P.gw->G, A = P.A;
+    const int XY = N * N * G * N, GG = N * N * G * G, ncounts = A * (2 * XY + GG) + A * (2 * N * N + G * G);
+    const uint32_t mask = rec[1];
+    int k = 0, nxt, mult;
+    hist_next_cell(P, rec, len, 0, nxt, mult);
+    auto visit = [&](float prior) {
+        float v = prior;
+        if (k == nxt) {
+            v = prior + (float)mult;
+            hist_next_cell(P, rec, len, k + 1, nxt, mult);
+        }
+        h = mix64(h ^ ((uint64_t)__float_as_uint(v) + ((uint64_t)k << 32)));
+        ++k;
+    };
+    for (int a = 0; a < A; ++a) {
+        for (int f = 0; f < 2; ++f) {
+            const float* src = ((mask >> (2 * a + f)) & 1u) ? P.hist_alt + (size_t)(a * 2 + f) * XY : P.hist_base + k;
+            for (int i = 0; i < XY; ++i) visit(src[i]);
+        }
+        for (int i = 0; i < GG; ++i) visit(P.hist_base[k]);
+    }
+    while (k < ncounts) visit(P.hist_base[k]);
+    for (int w = 0; w < 2 * A; ++w, ++k) h = mix64(h ^ ((uint64_t)(((mask >> w) & 1u) ? 7u : 3u) + ((uint64_t)k << 32)));
+    return h;
+}
+
 __global__ void __launch_bounds__(256) flush_kernel(Problem P, DeviceState D)
 {
     __shared__ unsigned long long s_sum;
@@ -1590,7 +1753,8 @@ __global__ void __launch_bounds__(256) flush_kernel(Problem P, DeviceState D)
         uint64_t h = mix64((uint64_t)i * 0x9E3779B97F4A7C15ull + (uint64_t)(uint32_t)st);
         const double w = (P.belief == FBA_BELIEF_IMPORTANCE) ? D.p_weight[pb + i] : 0.0;
         h = mix64(h ^ (uint64_t)__double_as_longlong(w));
-        if (P.packed) {  // the checksum is over the counts themselves, whatever the storage (PackedView)
+        if (P.hist) h = hist_hash_counts(P, reinterpret_cast<const uint32_t*>(cnt), D.hist_len[e], h);
+        else if (P.packed) {  // the checksum is over the counts themselves, whatever the storage (PackedView)
             const PackedView<GlobalView> pv{GlobalView{cnt}, D.prior_dense};
             const int dense = P.phi_len + P.A * P.S * P.O;
             for (int k = 0; k < dense; ++k) h = mix64(h ^ ((uint64_t)__float_as_uint(pv.at(k)) + ((uint64_t)k << 32)));
@@ -1640,6 +1804,11 @@ void launch_search(const Problem& P, const DeviceState& D, hipStream_t st)
         else if (P.model == FBA_MODEL_BA_TABLE) FBA_LAUNCH_SEARCH_M(STG, AM, FBA_MODEL_BA_TABLE);   \
         else FBA_LAUNCH_SEARCH_M(false, AM, FBA_MODEL_POMDP);                                       \
     } while (0)
+    if (P.hist) {  // history particles (gridworld FBA-POMDP): the record is staged, the model description is not needed
+        lds = (size_t)depth_cap * SEARCH_BLOCK * (sizeof(float) + sizeof(int32_t)) + (size_t)P.Cs * SEARCH_BLOCK * sizeof(float);
+        hipLaunchKernelGGL((search_kernel<true, 4, false, 0, FBA_MODEL_BA_FACTORED, 0, false, true>), grid, block, lds, st, P, D);
+        return;
+    }
     const bool tiger_table = P.model == FBA_MODEL_BA_TABLE && P.planner == FBA_PLANNER_POUCT && !P.dirichlet_regular && stage &&
                              (P.domain == FBA_DOM_TIGER_EPISODIC || P.domain == FBA_DOM_TIGER_CONTINUOUS) && !D.hash;
     if (tiger_table) {
@@ -1715,7 +1884,8 @@ void launch_belief_update(const Problem& P, const DeviceState& D, hipStream_t st
     if (!D.is_multi) {
         const bool tiger_table = P.model == FBA_MODEL_BA_TABLE && !P.dirichlet_regular &&
                                  (P.domain == FBA_DOM_TIGER_EPISODIC || P.domain == FBA_DOM_TIGER_CONTINUOUS);
-        if (P.dirichlet_regular) hipLaunchKernelGGL((importance_kernel<true, 0>), dim3(P.E), dim3(IS_BLOCK), 0, st, P, D);
+        if (P.hist) hipLaunchKernelGGL((importance_kernel<false, 0, true>), dim3(P.E), dim3(IS_BLOCK), 0, st, P, D);
+        else if (P.dirichlet_regular) hipLaunchKernelGGL((importance_kernel<true, 0>), dim3(P.E), dim3(IS_BLOCK), 0, st, P, D);
         else if (tiger_table && P.packed) hipLaunchKernelGGL((importance_kernel<false, 2>), dim3(P.E), dim3(IS_BLOCK), 0, st, P, D);
         else if (tiger_table) hipLaunchKernelGGL((importance_kernel<false, 1>), dim3(P.E), dim3(IS_BLOCK), 0, st, P, D);
         else hipLaunchKernelGGL((importance_kernel<false, 0>), dim3(P.E), dim3(IS_BLOCK), 0, st, P, D);

@@ -55,7 +55,9 @@ struct DeviceState {
     uint8_t* lazy_reset;  // [E] rejection filter: resetDomainStateDistribution is pending -- particle i's state is the RESET-stream draw, not the record's word
     int32_t* fault;     // [1] 0, or 1 + the slot whose rejection update exceeded REJECT_MAX_ATTEMPTS (host reports it)
     uint8_t* cheat_pending;  // [E] the update of this tick pushed log(likelihood) below the threshold
-    int32_t* p_side;    // [E][N][side_w] importance filters: {new state, cells to increment} of the pending update (side_w = 1 + FS + FO)
+    int32_t* p_side;    // [E][N][side_w] importance filters: {new state, cells to increment} of the pending update (side_w = 1 + FS + FO;
+                        // history particles: {new state, the step's entry})
+    int32_t* hist_len;  // [E] history particles: entries every record of the slot holds (one per belief update and per reset of the run so far)
     int32_t side_w;
     double* wscan;      // [E][N] scratch: inclusive device-order prefix sums of normalised weights
     double* ctot;       // [E][N/256 + 2] scratch: chunk totals / carries of the multi-workgroup filter

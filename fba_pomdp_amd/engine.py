@@ -164,14 +164,16 @@ class Engine:
         act = None if active is None else np.ascontiguousarray(active, np.uint8)
         self._chk(self.L.fba_belief_update(self.h, a.ctypes.data, o.ctypes.data, None if act is None else act.ctypes.data))
 
-    def belief_get(self, slot=0, weights=None):
+    def belief_get(self, slot=0, weights=None, counts=True):
+        """States, weights and (counts=True) every particle's count table -- N x fba_counts_len floats, whatever the
+        storage on the device; ask for counts=False where that is gigabytes."""
         n = self.cfg.particles
         s = np.zeros(n, np.int32)
         want_w = self.cfg.belief in (N.BELIEF_IMPORTANCE, N.BELIEF_CHEATING) if weights is None else weights
         w = np.zeros(n, np.float64)
-        cnt = np.zeros((n, self.ncnt), np.float32)
+        cnt = np.zeros((n, self.ncnt), np.float32) if counts else None
         self._chk(self.L.fba_belief_get(self.h, slot, s.ctypes.data, w.ctypes.data if want_w else None,
-                                        cnt.ctypes.data if self.ncnt else None))
+                                        cnt.ctypes.data if counts and self.ncnt else None))
         return s, w, cnt
 
     def belief_get_fully_connected(self, slot=0):

@@ -22,8 +22,9 @@ CONFIGS = {
                  particles=4096, structure_prior=2, horizon=10, slots=81920, ticks=2),   # 5 search waves per CU: what LDS holds (22.5 KB staged record per wave)
     "c3half": dict(domain="episodic-factored-tiger", model=N.MODEL_BA_FACTORED, belief="rejection_sampling", size=3, sims=16384,
                    particles=4096, structure_prior=2, horizon=10, slots=16384, ticks=2),
+    # (two episodes per run: a history particle holds episodes * (horizon + 1) entries, fba_device.h)
     "c4": dict(domain="gridworld", model=N.MODEL_BA_FACTORED, belief="importance_sampling", size=7, sims=65536,
-               particles=16384, structure_prior=2, horizon=20, slots=32, ticks=2),
+               particles=16384, structure_prior=2, horizon=20, episodes=2, slots=16384, ticks=2),
     # the parity-sized variant of c4 (--size 5), fewer simulations so that a tick is short
     "c4small": dict(domain="gridworld", model=N.MODEL_BA_FACTORED, belief="importance_sampling", size=5, sims=8192,
                     particles=4096, structure_prior=2, horizon=20, slots=512, ticks=2),
@@ -34,9 +35,12 @@ for name in (sys.argv[1:] or ["c1", "c3", "c4small"]):
     if os.environ.get("FBA_SLOTS"):   # try another number of concurrent runs
         cfg["slots"] = int(os.environ["FBA_SLOTS"])
     ticks = cfg.pop("ticks")
+    if os.environ.get("FBA_TICKS"):
+        ticks = int(os.environ["FBA_TICKS"])
     domain = cfg.pop("domain")
+    cfg.setdefault("episodes", 1 if cfg['model'] == N.MODEL_POMDP else 64)
     t0 = time.perf_counter()
-    eng = fba.Engine(domain, episodes=1 if cfg['model'] == N.MODEL_POMDP else 64, runs=1 << 30, seed=7, **cfg)
+    eng = fba.Engine(domain, runs=1 << 30, seed=7, **cfg)
     eng.run_ticks(1)
     c0 = eng.counters()
     eng.reset_kernel_times()
@@ -47,6 +51,7 @@ for name in (sys.argv[1:] or ["c1", "c3", "c4small"]):
     kt = eng.kernel_times()
     steps = (c1.sim_steps - c0.sim_steps) + (c1.belief_steps - c0.belief_steps)
     out = {"config": name, "workload": {k: v for k, v in cfg.items()}, "domain": domain, "slots": eng.slots, "ticks": ticks,
+           "particle_bytes": eng.particle_bytes,
            "steps_per_s": steps / dt, "ms_per_tick": 1e3 * dt / ticks, "setup_s": t1 - t0,
            "kernels_ms_per_tick": {k: v.ms / ticks for k, v in kt.items() if v.ms > 0}}
     bel = kt["reject_kernel"] if cfg["belief"] == "rejection_sampling" else kt["importance_kernel"]

@@ -111,3 +111,52 @@ def test_throughput_driver_counts_steps_and_finishes_episodes():
     kt = eng.kernel_times()
     assert kt["search_kernel"].launches == 12 and kt["reject_kernel"].launches == 12
     assert kt["reject_kernel"].bytes > 0 and kt["search_kernel"].units == c.sim_steps
+
+
+def test_c4_full_size_history_particles_equal_dense_ones(monkeypatch):
+    """BASELINE configs[3] at its own size -- gridworld N = 7 (S = O = 490), 65 536 simulations per step, 16 384
+    particles, importance sampling, match-uniform structure prior -- one belief, two real steps: the engine on history
+    particles (176-byte records) against the engine on dense count tables (191 KB records, 3.1 GB per filter), whose
+    arithmetic the oracle pins at smaller particle counts: actions, root statistics, tree sizes, total weights and
+    the checksum over all 16 384 x 47 840 counts must agree bit for bit."""
+    kw = dict(model=N.MODEL_BA_FACTORED, belief="importance_sampling", size=7, sims=65536, particles=16384, structure_prior=2,
+              horizon=20, episodes=2, runs=1, slots=1, seed=401, trace=1)
+    out = []
+    for dense in (False, True):
+        if dense:
+            monkeypatch.setenv("FBA_DENSE_PARTICLES", "1")
+        eng = fba.Engine("gridworld", **kw)
+        if dense:
+            monkeypatch.delenv("FBA_DENSE_PARTICLES")
+        assert (eng.particle_bytes > 190000) == dense
+        eng.run_ticks(2)
+        info = eng.last_step_info()
+        out.append((eng.trace(), eng.counters().sim_steps, eng.counters().belief_steps))
+        assert info["root_n"][0, :4].sum() == 65536 and 2 <= info["n_nodes"][0] <= 65537
+        s, w, _ = eng.belief_get(0, counts=False)
+        assert np.all((s >= 0) & (s < 490)) and np.all(w == 1.0 / 16384)
+        eng.close()
+    (th, sh, bh), (td, sd, bd) = out
+    assert len(th) == len(td) == 2 and (sh, bh) == (sd, bd) and bh == 2 * 16384
+    for name in th.dtype.names:
+        assert np.array_equal(th[name], td[name]), name
+
+
+def test_c4_full_size_many_slots():
+    """The same configuration with as many beliefs in flight as a throughput run keeps per GPU-gigabyte: every slot's
+    search spends its 65 536 simulations, every filter is resampled to uniform weights, and a slot's results do not
+    depend on how many other slots run beside it."""
+    kw = dict(model=N.MODEL_BA_FACTORED, belief="importance_sampling", size=7, sims=65536, particles=16384, structure_prior=2,
+              horizon=20, episodes=2, runs=1 << 20, seed=402, trace=1)
+    many = fba.Engine("gridworld", slots=192, **kw)
+    many.run_ticks(1)
+    info = many.last_step_info()
+    assert np.all(info["root_n"][:, :4].sum(axis=1) == 65536)
+    assert np.all(info["weight_total"] > 0)
+    c = many.counters()
+    assert c.belief_steps == 192 * 16384 and c.sim_steps >= 192 * 65536
+    few = fba.Engine("gridworld", slots=3, **kw)
+    few.run_ticks(1)
+    tm, tf = many.trace(), few.trace()
+    for name in tm.dtype.names:
+        assert np.array_equal(tm[name][:3], tf[name]), name

@@ -371,6 +371,51 @@ def test_c3_size_one_search_and_update():
         assert np.array_equal(s, os_) and np.array_equal(cnt.view(np.uint32), ocnt.view(np.uint32))
 
 
+@pytest.mark.parametrize("size,sp,noise", [(3, 2, 0.0), (5, 2, 0.1), (7, 2, 0.0), (4, 0, 0.05)])
+def test_history_particles_equal_dense_ones(size, sp, noise, monkeypatch):
+    """The gridworld FBA-POMDP particle stored as its own history over the shared prior (Problem::hist, 4 bytes per
+    real step) against the same experiment on dense count tables (FBA_DENSE_PARTICLES=1): every trace field, the
+    checksum over every particle's whole count table included, every statistic, every counter."""
+    kw = dict(model=N.MODEL_BA_FACTORED, belief="importance_sampling", seed=131 + size, size=size, particles=96, sims=120, runs=6,
+              slots=6, episodes=3, horizon=9, structure_prior=sp, noise=noise, trace=1)
+    hist = fba.Engine("gridworld", **kw)
+    assert hist.particle_bytes == 4 * ((2 + 3 * 10 + 3) // 4 * 4)          # state, structure bits, episodes * (horizon + 1) entries
+    monkeypatch.setenv("FBA_DENSE_PARTICLES", "1")
+    dense = fba.Engine("gridworld", **kw)
+    monkeypatch.delenv("FBA_DENSE_PARTICLES")
+    assert dense.particle_bytes > 100 * hist.particle_bytes or size < 5
+    sh, sd = hist.run_bapomdp(), dense.run_bapomdp()
+    th, td = hist.trace(), dense.trace()
+    assert len(th) == len(td) > 0
+    for name in th.dtype.names:
+        assert np.array_equal(th[name], td[name]), name
+    assert [(s.count, s.mean, s.m2) for s in sh] == [(s.count, s.mean, s.m2) for s in sd]
+    ch, cd = hist.counters(), dense.counters()
+    assert (ch.sim_steps, ch.belief_steps, ch.env_steps) == (cd.sim_steps, cd.belief_steps, cd.env_steps)
+
+
+def test_fbapomdp_gridworld7_thousand_particles():
+    """BASELINE configs[3] domain (gridworld N = 7, match-uniform structure prior, importance sampling) with 1024
+    particles per belief against the oracle's dense 191 KB count tables: whole experiment, every trace field."""
+    eng, o = _pair("gridworld", N.MODEL_BA_FACTORED, "importance_sampling", 977, size=7, particles=1024, sims=400, runs=2,
+                   episodes=2, horizon=12, structure_prior=2)
+    assert eng.particle_bytes <= 128
+    _assert_same_experiment(eng, o, ba=True)
+
+
+def test_history_particles_refuse_more_steps_than_they_hold():
+    eng = fba.Engine("gridworld", model=N.MODEL_BA_FACTORED, belief="importance_sampling", size=3, particles=16, sims=8, horizon=2,
+                     structure_prior=2, slots=1, seed=5)
+    eng.belief_init()
+    eng.belief_reset_domain_state()
+    eng.belief_update(0, 0)
+    eng.belief_update(1, 0)                      # episodes * (horizon + 1) = 3 entries: full
+    with pytest.raises(fba.FbaError, match="FBA_DENSE_PARTICLES"):
+        eng.belief_update(0, 0)
+    with pytest.raises(ValueError, match="FBA_DENSE_PARTICLES"):
+        eng.belief_set(0, state=np.zeros(16, np.int32))
+
+
 def test_gridworld7_one_search_and_update():
     """BASELINE configs[3] domain size (N = 7: S = O = 490, hashed child table), parity-sized counts."""
     kw = dict(size=7, particles=48, sims=600, structure_prior=2, belief=1, horizon=20)
