@@ -278,6 +278,7 @@ struct Problem {
     int32_t hist;       // history particles (gridworld FBA-POMDP, importance filter): a record holds the particle's increments as one
                         // 4-byte entry per real step over the shared prior tables (HistView below); C = 0 then, hist_cap entries per record
     int32_t hist_cap;
+    int32_t hist_row;   // the longest Dirichlet row of the model (max(N, G)): picks the row width the kernels are instantiated for
     const float* hist_base;  // the prior count table every particle starts from (max layout, x / y nodes without the goal parent)
     const float* hist_alt;   // [A][2][N*N*G*N]: the x / y transition nodes as a particle with the goal as their third parent starts them
     int32_t S, A, O;
@@ -984,13 +985,41 @@ __device__ __forceinline__ bool sysadmin_fact_step(const Problem& P, Rng& g, con
 // table (BAFlatModel.cpp:185-217) is the same idea at row granularity.  The engine only uses this form when
 // prior[k] + j, j <= hist_cap + 1, is for every k the float that j additions of 1.0f reach (checked on the host),
 // so a row read through the history is bit for bit the row of the dense table.
-// One simulated step = two passes over the entries (the three transition rows of (s, a), then the three
-// observation rows of (a, s')); an entry costs a few compares and adds, no memory beyond its own 4 bytes.
+// One simulated step = two passes over the entries (the transition rows of (s, a), then the observation rows
+// of (a, s')); an entry costs a few compares and adds, no memory beyond its own 4 bytes.
+// The prior tables sit in HBM once per context (L2-resident), rows padded to a multiple of four floats so that
+// a row is two or three aligned 16-byte loads:
+//   hist_base: per action  T(x) [N*N*G rows of NS]  T(y) [same]  T(goal) [N*N*G rows of GS], then per action
+//              O(x) [N rows of NS]  O(y) [N rows of NS]  O(goal) [G rows of GS];   NS = N rounded up to 4, GS likewise
+//              (an x / y node without the goal parent uses its first N*N rows, as in the dense max layout)
+//   hist_alt:  per action and x / y node, the N*N*G rows of NS a particle with the goal parent starts from
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t HIST_START = 0x80000000u;
 constexpr int HIST_MAX_CAP    = 126;  // entries per record: 2 + cap words <= SEARCH_STAGE_WORDS, counts per cell fit 8 bits
+constexpr int HIST_QUAD       = 4;    // lanes that share one tree in search_hist_kernel
 __host__ __device__ __forceinline__ uint32_t hist_pack(int x, int y, int g) { return (uint32_t)x | ((uint32_t)y << 4) | ((uint32_t)g << 8); }
 __host__ __device__ __forceinline__ uint32_t hist_entry(uint32_t ns, uint32_t o, int a) { return ns | (o << 12) | ((uint32_t)a << 24); }
+
+// where the rows of the padded tables start (host and device)
+struct HistLayout {
+    int N, G, A, NS, GS, XY, GG, ON, OG, tstride, ostride, obase0, total, alt_total;
+    __host__ __device__ HistLayout(int n, int g, int a) : N(n), G(g), A(a)
+    {
+        NS = (N + 3) & ~3; GS = (G + 3) & ~3;
+        XY = N * N * G * NS; GG = N * N * G * GS; ON = N * NS; OG = G * GS;
+        tstride = 2 * XY + GG; ostride = 2 * ON + OG;
+        obase0 = A * tstride; total = obase0 + A * ostride; alt_total = A * 2 * XY;
+    }
+    // T(a, f) row of parent values (cell = x*N + y, goal); f = 0, 1: `with_goal` = the particle's structure bit
+    __host__ __device__ int t_row(int a, int f, bool with_goal, int cell, int gl) const
+    {
+        if (f == 2) return a * tstride + 2 * XY + (cell * G + gl) * GS;
+        return a * tstride + f * XY + (with_goal ? cell * G + gl : cell) * NS;
+    }
+    __host__ __device__ int alt_row(int a, int f, int cell, int gl) const { return (a * 2 + f) * XY + (cell * G + gl) * NS; }
+    // O(a, f) row of the feature's value v
+    __host__ __device__ int o_row(int a, int f, int v) const { return obase0 + a * ostride + (f == 2 ? 2 * ON + v * GS : f * ON + v * NS); }
+};
 
 // increments per cell of one row (at most 16 cells), 8 bits each
 struct RowCount {
@@ -1014,32 +1043,42 @@ struct LdsEntries {
     __device__ __forceinline__ uint32_t at(int t) const { return p[t * STRIDE]; }
 };
 
-// a Dirichlet row in registers: prior row + this particle's increments
+// a Dirichlet row in registers: prior row (K / 4 aligned 16-byte loads; the words past n belong to the next row
+// or the table's padding and are not used) + this particle's increments
 template <int K>
 struct HistRow {
     float r[K];
-    __device__ __forceinline__ void load(const float* __restrict__ prior, int n, const RowCount& c)
+    __device__ __forceinline__ void fetch(const float* __restrict__ prior)
+    {
+        const float4* p4 = reinterpret_cast<const float4*>(prior);
+#pragma unroll
+        for (int i = 0; i < K / 4; ++i) {
+            const float4 v = p4[i];
+            r[4 * i] = v.x; r[4 * i + 1] = v.y; r[4 * i + 2] = v.z; r[4 * i + 3] = v.w;
+        }
+    }
+    __device__ __forceinline__ void add(int n, const RowCount& c)
     {
 #pragma unroll
-        for (int i = 0; i < K; ++i) r[i] = i < n ? prior[i] + c.at(i) : 0.f;
+        for (int i = 0; i < K; ++i) r[i] = i < n ? r[i] + c.at(i) : 0.f;
     }
-    // sampleFromExpectedMult (random.cpp:244-255): double total, float CDF against a double threshold
-    __device__ __forceinline__ int sample(Rng& g, int n) const
+    // sampleFromExpectedMult (random.cpp:244-255) for the uniform draw u: double total, float CDF against a double
+    // threshold.  Counts are never negative, so the CDF does not decrease and "the first i with p < cdf(i), else
+    // n - 1" is the number of i <= n - 2 with p >= cdf(i): no branches.
+    __device__ __forceinline__ int sample(double u, int n) const
     {
         double total = (double)r[0];
 #pragma unroll
         for (int i = 1; i < K; ++i)
             if (i < n) total += (double)r[i];
-        const double p = g.u01() * total;
+        const double p = u * total;
         float sum = r[0];
-        int pick  = n - 1;
-        bool done = false;
+        int pick  = 0;
 #pragma unroll
-        for (int i = 1; i < K; ++i)
-            if (i < n && !done) {
-                if (p < (double)sum) { pick = i - 1; done = true; }
-                else sum += r[i];
-            }
+        for (int i = 1; i < K; ++i) {
+            pick += (i < n && !(p < (double)sum)) ? 1 : 0;
+            sum += r[i];
+        }
         return pick;
     }
     // expectedMult(row)[o] as BABNModel::computeObservationProbability uses it: float sum, float division
@@ -1052,23 +1091,28 @@ struct HistRow {
         return ((double)sum <= 1e-300) ? 0.0f : mine / sum;
     }
 };
+__device__ __forceinline__ double u01_of(uint64_t w) { return (double)(w >> 11) * (1.0 / 9007199254740992.0); }  // rnd::uniform_rand01 of one draw
 
 // BAPOMDP::step (BAPOMDP.cpp:111-143) over BABNModel (BABNModel.cpp:292-325) for the gridworld FBA-POMDP on a
-// history particle: the draws, their order and every row value are those of gridworld_fact_step on the dense
-// table.  `sp` = the state as hist_pack(x, y, goal); returns the step's entry (what incrementCountsOf would
-// add, :354-382, App. A #6: observation rows at the OLD state's values) and, for the importance update,
+// history particle, one lane per particle (the belief update): the draws, their order and every row value are those
+// of gridworld_fact_step on the dense table.  `sp` = the state as hist_pack(x, y, goal); returns the step's entry
+// (what incrementCountsOf would add, :354-382, App. A #6: observation rows at the OLD state's values) and
 // P(real_o | a, s') from the counts after the step's own increments (BABNModel.cpp:328-352).
-template <int K, bool WANT_PROB, class Entries>
+template <int KN, int KG, class Entries>
 __device__ __forceinline__ bool gridworld_hist_step_k(const Problem& P, Rng& g, const Entries& ent, int len, uint32_t mask, uint32_t& sp, int a,
                                                       int& o, double& r, uint32_t& entry, int real_o, double& prob)
 {
     const GridDesc* gw = P.gw;
-    const int N = gw->N, G = gw->G, A = P.A;
-    const int XY = N * N * G * N, GG = N * N * G * G, NN = N * N;
+    const HistLayout L(gw->N, gw->G, P.A);
+    const int N = L.N, G = L.G;
     const int x = (int)(sp & 15u), y = (int)((sp >> 4) & 15u), gl = (int)(sp >> 8);
-    const int tbase = a * (2 * XY + GG), obase = A * (2 * XY + GG) + a * (2 * NN + G * G);
     const int cell = x * N + y;
     const bool mx = (mask >> (2 * a)) & 1u, my = (mask >> (2 * a + 1)) & 1u;
+    HistRow<KN> rx, ry;
+    HistRow<KG> rg;
+    rx.fetch(mx ? P.hist_alt + L.alt_row(a, 0, cell, gl) : P.hist_base + L.t_row(a, 0, false, cell, gl));
+    ry.fetch(my ? P.hist_alt + L.alt_row(a, 1, cell, gl) : P.hist_base + L.t_row(a, 1, false, cell, gl));
+    rg.fetch(P.hist_base + L.t_row(a, 2, true, cell, gl));
     // pass 1: the increments this particle has made to the rows T(a, .)(x, y [, goal])
     RowCount cx{0, 0}, cy{0, 0}, cg{0, 0};
     {
@@ -1084,13 +1128,15 @@ __device__ __forceinline__ bool gridworld_hist_step_k(const Problem& P, Rng& g, 
             prev = e & 0xfffu;
         }
     }
-    HistRow<K> row;
-    row.load(mx ? P.hist_alt + (size_t)(a * 2 + 0) * XY + (cell * G + gl) * N : P.hist_base + tbase + cell * N, N, cx);
-    const int nx = row.sample(g, N);
-    row.load(my ? P.hist_alt + (size_t)(a * 2 + 1) * XY + (cell * G + gl) * N : P.hist_base + tbase + XY + cell * N, N, cy);
-    const int ny = row.sample(g, N);
-    row.load(P.hist_base + tbase + 2 * XY + (cell * G + gl) * G, G, cg);
-    const int ng = row.sample(g, G);
+    rx.add(N, cx);
+    const int nx = rx.sample(g.u01(), N);
+    ry.add(N, cy);
+    const int ny = ry.sample(g.u01(), N);
+    rg.add(G, cg);
+    const int ng = rg.sample(g.u01(), G);
+    rx.fetch(P.hist_base + L.o_row(a, 0, nx));
+    ry.fetch(P.hist_base + L.o_row(a, 1, ny));
+    rg.fetch(P.hist_base + L.o_row(a, 2, ng));
     // pass 2: the increments to the rows O(a, .)(value of the new state's feature); a step increments them at
     // the row of the state it STARTED from
     RowCount ox{0, 0}, oy{0, 0}, og{0, 0};
@@ -1105,28 +1151,29 @@ __device__ __forceinline__ bool gridworld_hist_step_k(const Problem& P, Rng& g, 
             prev = e & 0xfffu;
         }
     }
-    HistRow<K> rox, roy, rog;
-    rox.load(P.hist_base + obase + nx * N, N, ox);
-    const int vx = rox.sample(g, N);
-    roy.load(P.hist_base + obase + NN + ny * N, N, oy);
-    const int vy = roy.sample(g, N);
-    rog.load(P.hist_base + obase + 2 * NN + ng * G, G, og);
-    const int vg = rog.sample(g, G);
+    HistRow<KN> px = rx, py = ry;   // the prior rows, for the probability below
+    HistRow<KG> pg = rg;
+    rx.add(N, ox);
+    const int vx = rx.sample(g.u01(), N);
+    ry.add(N, oy);
+    const int vy = ry.sample(g.u01(), N);
+    rg.add(G, og);
+    const int vg = rg.sample(g.u01(), G);
     o = (vx * N + vy) * G + vg;
-    if (WANT_PROB) {
+    {
         // the step's own observation increments land at rows x, y, goal of the old state: they are part of the
         // rows read here only where the feature kept its value
         ox.add(x == nx, vx);
         oy.add(y == ny, vy);
         og.add(gl == ng, vg);
-        rox.load(P.hist_base + obase + nx * N, N, ox);
-        roy.load(P.hist_base + obase + NN + ny * N, N, oy);
-        rog.load(P.hist_base + obase + 2 * NN + ng * G, G, og);
+        px.add(N, ox);
+        py.add(N, oy);
+        pg.add(G, og);
         const int qg = real_o % G, qy = (real_o / G) % N, qx = real_o / (N * G);
         double pr = 1;
-        pr *= rox.prob(N, qx);
-        pr *= roy.prob(N, qy);
-        pr *= rog.prob(G, qg);
+        pr *= px.prob(N, qx);
+        pr *= py.prob(N, qy);
+        pr *= pg.prob(G, qg);
         prob = pr;
     }
     const bool found = gw->goal[gl][0] == x && gw->goal[gl][1] == y;  // GridWorldBAExtension.cpp:74-99: terminal and reward from the OLD state
@@ -1135,12 +1182,13 @@ __device__ __forceinline__ bool gridworld_hist_step_k(const Problem& P, Rng& g, 
     entry = hist_entry(sp, hist_pack(vx, vy, vg), a);
     return found;
 }
-template <bool WANT_PROB, class Entries>
+template <class Entries>
 __device__ __forceinline__ bool gridworld_hist_step(const Problem& P, Rng& g, const Entries& ent, int len, uint32_t mask, uint32_t& sp, int a, int& o,
                                                     double& r, uint32_t& entry, int real_o, double& prob)
 {
-    if (P.gw->G <= 8) return gridworld_hist_step_k<8, WANT_PROB>(P, g, ent, len, mask, sp, a, o, r, entry, real_o, prob);
-    return gridworld_hist_step_k<16, WANT_PROB>(P, g, ent, len, mask, sp, a, o, r, entry, real_o, prob);
+    if (P.gw->G <= 8) return gridworld_hist_step_k<8, 8>(P, g, ent, len, mask, sp, a, o, r, entry, real_o, prob);
+    if (P.gw->N <= 8) return gridworld_hist_step_k<8, 12>(P, g, ent, len, mask, sp, a, o, r, entry, real_o, prob);   // (G <= 10)
+    return gridworld_hist_step_k<16, 12>(P, g, ent, len, mask, sp, a, o, r, entry, real_o, prob);
 }
 __device__ __forceinline__ uint32_t gridworld_pack_state(const GridDesc* gw, int s)
 {
@@ -1150,6 +1198,116 @@ __device__ __forceinline__ uint32_t gridworld_pack_state(const GridDesc* gw, int
 __device__ __forceinline__ int gridworld_unpack_state(const GridDesc* gw, uint32_t sp)
 {
     return ((int)(sp & 15u) * gw->N + (int)((sp >> 4) & 15u)) * gw->G + (int)(sp >> 8);
+}
+
+// ---- the same step shared by the four lanes of a quad (search_hist_kernel) ---------------------------------------
+// Philox for a quad: the draw counter is the same in the four lanes; lane q generates block base + q of the
+// stream, so the quad holds eight consecutive draws at the price of one block each, and a draw is fetched
+// from the lane that made it (ds_bpermute within the quad).  Same streams, same draw numbers as Rng.
+struct QuadRng {
+    uint32_t k0, k1, c1, c2, c3;
+    uint32_t draw, base;   // the same in the four lanes
+    uint32_t w[4];         // this lane's block: draw 2 (base + q) = w[1]:w[0], the next one w[3]:w[2]
+    int q, addr0;          // lane within the quad; ds_bpermute address of the quad's first lane
+    __device__ __forceinline__ void init(uint32_t lo, uint32_t hi, uint32_t run, uint32_t episode, uint32_t t, int lane)
+    {
+        k0 = lo; k1 = hi;
+        c3 = run;
+        c2 = ((t & 0xffu) << 8) | ((episode & 0xffffu) << 16);
+        c1 = 0; draw = 0; base = 0xfffffff0u;
+        q = lane & 3; addr0 = (lane & ~3) * 4;
+        w[0] = w[1] = w[2] = w[3] = 0;
+    }
+    __device__ __forceinline__ void stream(uint32_t phase, uint32_t unit)
+    {
+        c2   = (c2 & 0xffffff00u) | (phase & 0xffu);
+        c1   = unit;
+        draw = 0;
+        base = 0xfffffff0u;
+    }
+    __device__ __forceinline__ void refill()
+    {
+        base = draw >> 1;
+        uint32_t x0 = base + (uint32_t)q, x1 = c1, x2 = c2, x3 = c3;
+        uint32_t a = k0, b = k1;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)x0, p1 = (uint64_t)0xCD9E8D57u * (uint64_t)x2;
+            const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+            const uint32_t n0 = hi1 ^ x1 ^ a, n2 = hi0 ^ x3 ^ b;
+            x0 = n0; x1 = lo1; x2 = n2; x3 = lo0;
+            a += 0x9E3779B9u;
+            b += 0xBB67AE85u;
+        }
+        w[0] = x0; w[1] = x1; w[2] = x2; w[3] = x3;
+    }
+    // the next n draws must all lie in the quad's eight
+    __device__ __forceinline__ void ensure(int n)
+    {
+        const uint32_t lo = (draw >> 1) - base, hi = ((draw + (uint32_t)n - 1u) >> 1) - base;
+        if (lo >= 4u || hi >= 4u) refill();
+    }
+    __device__ __forceinline__ uint64_t at(uint32_t d) const
+    {
+        const int addr = addr0 + 4 * (int)((d >> 1) - base);
+        const uint32_t r0 = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)w[0]), r1 = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)w[1]);
+        const uint32_t r2 = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)w[2]), r3 = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)w[3]);
+        return (d & 1u) ? (((uint64_t)r3 << 32) | r2) : (((uint64_t)r1 << 32) | r0);
+    }
+    __device__ __forceinline__ uint64_t next64() { return at(draw++); }   // a draw all four lanes consume together
+    __device__ __forceinline__ double u01() { return u01_of(next64()); }
+    __device__ __forceinline__ int slow_int(int lo, int hi) { return lo + (int)floor(u01() * (double)(hi - lo)); }
+};
+__device__ __forceinline__ int quad_bcast(int addr0, int from, int v) { return __builtin_amdgcn_ds_bpermute(addr0 + 4 * from, v); }
+
+// Lane f < 3 of the quad owns state / observation feature f (lane 3 repeats lane 2's work): one history pass,
+// one row, one sampling chain per lane and phase instead of three.  Draws 0..2 of the phase go to features 0..2
+// as in the one-lane form; `ent` = the staged entries, [t * STRIDE].
+template <int K, int STRIDE>
+__device__ __forceinline__ bool gridworld_hist_step_quad(const Problem& P, QuadRng& g, const uint32_t* ent, int len, uint32_t mask, uint32_t& sp,
+                                                         int a, int& o, double& r)
+{
+    const GridDesc* gw = P.gw;
+    const HistLayout L(gw->N, gw->G, P.A);
+    const int N = L.N, G = L.G;
+    const int f = min(g.q, 2);
+    const int x = (int)(sp & 15u), y = (int)((sp >> 4) & 15u), gl = (int)(sp >> 8);
+    const int cell = x * N + y, n = f == 2 ? G : N;
+    const bool with_goal = f == 2 || ((mask >> (2 * a + f)) & 1u);
+    HistRow<K> row;
+    row.fetch(f < 2 && with_goal ? P.hist_alt + L.alt_row(a, f, cell, gl) : P.hist_base + L.t_row(a, f, with_goal, cell, gl));
+    RowCount cnt{0, 0};
+    {
+        uint32_t prev = 0;
+        const uint32_t want = with_goal ? sp : (sp & 0xffu), keep = with_goal ? 0xfffu : 0xffu;
+        for (int t = 0; t < len; ++t) {
+            const uint32_t e = ent[t * STRIDE];
+            cnt.add((e >> 24) == (uint32_t)a && (prev & keep) == want, (int)((e >> (4 * f)) & 15u));
+            prev = e & 0xfffu;
+        }
+    }
+    row.add(n, cnt);
+    const int nv = row.sample(u01_of(g.at(g.draw + (uint32_t)f)), n);
+    const int nx = quad_bcast(g.addr0, 0, nv), ny = quad_bcast(g.addr0, 1, nv), ng = quad_bcast(g.addr0, 2, nv);
+    row.fetch(P.hist_base + L.o_row(a, f, nv));
+    cnt = RowCount{0, 0};
+    {
+        uint32_t prev = 0;
+        for (int t = 0; t < len; ++t) {
+            const uint32_t e = ent[t * STRIDE];
+            cnt.add((e >> 24) == (uint32_t)a && ((prev >> (4 * f)) & 15u) == (uint32_t)nv, (int)((e >> (12 + 4 * f)) & 15u));
+            prev = e & 0xfffu;
+        }
+    }
+    row.add(n, cnt);
+    const int ov = row.sample(u01_of(g.at(g.draw + 3u + (uint32_t)f)), n);
+    g.draw += 6;
+    const int vx = quad_bcast(g.addr0, 0, ov), vy = quad_bcast(g.addr0, 1, ov), vg = quad_bcast(g.addr0, 2, ov);
+    o = (vx * N + vy) * G + vg;
+    const bool found = gw->goal[gl][0] == x && gw->goal[gl][1] == y;
+    r  = found ? 1 : 0;
+    sp = hist_pack(nx, ny, ng);
+    return found;
 }
 
 // BABNModel::computeObservationProbability (BABNModel.cpp:328-352)

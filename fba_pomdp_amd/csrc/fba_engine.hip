@@ -40,7 +40,8 @@ struct fba_ctx {
     float* d_prior       = nullptr;
     float* d_prior_dense = nullptr;  // packed / history particles: the dense prior table on the device
     std::vector<float> prior_alt;    // history particles: the x / y transition nodes with the goal as third parent, [A][2][N*N*G*N]
-    float* d_prior_alt   = nullptr;
+    float* d_hist_base   = nullptr;  // ... and both tables on the device, rows padded to 16 bytes (HistLayout)
+    float* d_hist_alt    = nullptr;
     FDesc fdesc{};          // host copy of the factored model description
     FDesc* d_fdesc       = nullptr;
     GridDesc gdesc{};
@@ -791,9 +792,30 @@ bool increments_exact(const std::vector<float>& table, int most)
 int upload_prior(fba_ctx* c)
 {
     std::vector<float> padded((size_t)c->P.Cs, 0.f);
-    if (c->P.hist) {  // records carry no counts: the tables sit beside them
-        HIPCHK(c, hipMemcpyAsync(c->d_prior_dense, c->prior.data(), c->prior.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->d_prior_alt, c->prior_alt.data(), c->prior_alt.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (c->P.hist) {  // records carry no counts: the tables sit beside them, rows padded to 16 bytes (HistLayout, fba_device.h)
+        const HistLayout L(c->gdesc.N, c->gdesc.G, c->P.A);
+        const int N = L.N, G = L.G, A = L.A, XYd = N * N * G * N, GGd = N * N * G * G, NNd = N * N;
+        std::vector<float> base((size_t)L.total + 16, 0.f), alt((size_t)L.alt_total + 16, 0.f);
+        const float* pr = c->prior.data();
+        for (int a = 0; a < A; ++a) {
+            const int td = a * (2 * XYd + GGd), od = A * (2 * XYd + GGd) + a * (2 * NNd + G * G);
+            for (int f = 0; f < 2; ++f)
+                for (int row = 0; row < N * N * G; ++row)
+                    for (int i = 0; i < N; ++i) {
+                        if (row < N * N) base[(size_t)a * L.tstride + f * L.XY + row * L.NS + i] = pr[td + f * XYd + row * N + i];
+                        alt[(size_t)(a * 2 + f) * L.XY + row * L.NS + i] = c->prior_alt[(size_t)(a * 2 + f) * XYd + row * N + i];
+                    }
+            for (int row = 0; row < N * N * G; ++row)
+                for (int i = 0; i < G; ++i) base[(size_t)a * L.tstride + 2 * L.XY + row * L.GS + i] = pr[td + 2 * XYd + row * G + i];
+            for (int f = 0; f < 3; ++f) {
+                const int n = f == 2 ? G : N;
+                for (int v = 0; v < n; ++v)
+                    for (int i = 0; i < n; ++i) base[(size_t)L.o_row(a, f, v) + i] = pr[od + (f == 2 ? 2 * NNd : f * NNd) + v * n + i];
+            }
+        }
+        HIPCHK(c, hipMemcpyAsync(c->d_hist_base, base.data(), base.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_hist_alt, alt.data(), alt.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
     } else if (c->P.packed) {  // records start as "no increments yet"; the table itself goes beside them
         if (!packable_prior(c->prior))
             return fail(c, FBA_EINVAL, "this context stores particles packed (uint16 increments over the prior), which needs prior counts c with "
@@ -1226,7 +1248,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     // shared prior tables -- 100-500 bytes instead of 191 KB (N = 7) -- where the importance filter is the plain one,
     // the run fits the record (one entry per update and per reset) and prior + j is exact in fp32 for every count a
     // run can reach (so a row read through the entries is bit for bit the dense row).
-    P.hist = 0; P.hist_cap = 0; P.hist_base = nullptr; P.hist_alt = nullptr;
+    P.hist = 0; P.hist_cap = 0; P.hist_row = 0; P.hist_base = nullptr; P.hist_alt = nullptr;
     if (cfg->model == FBA_MODEL_BA_FACTORED && cfg->domain == FBA_DOM_GRIDWORLD && cfg->belief == FBA_BELIEF_IMPORTANCE &&
         !cfg->dirichlet_regular && cfg->particles <= IS_MAX_CHUNKS * 256 && !std::getenv("FBA_IS_MULTI_MIN") &&
         !std::getenv("FBA_DENSE_PARTICLES") && (long long)cfg->episodes * (cfg->horizon + 1) <= HIST_MAX_CAP) {
@@ -1236,6 +1258,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         if (increments_exact(counts, cap + 1) && increments_exact(c->prior_alt, cap + 1)) {
             P.hist     = 1;
             P.hist_cap = cap;
+            P.hist_row = std::max(c->gdesc.N, c->gdesc.G);
             P.C        = 0;  // word 0 = state, word 1 = structure bits, words 2.. = entries
         }
     }
@@ -1380,9 +1403,11 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     CHK(dev_alloc(c, &c->d_prior, P.Cs));
     CHK(dev_alloc(c, &c->d_prior_dense, std::max(c->dense_C, 1)));
     if (P.hist) {
-        CHK(dev_alloc(c, &c->d_prior_alt, c->prior_alt.size()));
-        P.hist_base = c->d_prior_dense;
-        P.hist_alt  = c->d_prior_alt;
+        const HistLayout L(c->gdesc.N, c->gdesc.G, P.A);
+        CHK(dev_alloc(c, &c->d_hist_base, (size_t)L.total + 16));   // (+16: a row fetch may run up to a row width past the last row)
+        CHK(dev_alloc(c, &c->d_hist_alt, (size_t)L.alt_total + 16));
+        P.hist_base = c->d_hist_base;
+        P.hist_alt  = c->d_hist_alt;
     }
     CHK(dev_alloc(c, &c->d_uni_scan, (size_t)P.N + 1));
     CHK(dev_alloc(c, &c->d_log1p, (size_t)P.sims + 2));

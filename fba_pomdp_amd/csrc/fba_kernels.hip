@@ -132,8 +132,8 @@ __device__ __forceinline__ void child_set(const Problem& P, const DeviceState& D
 // UCB(m, n) = u * sqrt(log1p(m) / n), DBL_MAX for n = 0 (POUCT.cpp:330-338); ties are collected in
 // action order and one slowRandomInt is ALWAYS drawn, also for a single candidate.
 // The node's statistics arrive in registers (cn / cq), L = log1p(visits).
-template <int AMAX>
-__device__ __forceinline__ int ucb_pick(const Problem& P, Rng& g, double L, const int (&cn)[AMAX], const double (&cq)[AMAX], bool explore)
+template <int AMAX, class RNG>
+__device__ __forceinline__ int ucb_pick(const Problem& P, RNG& g, double L, const int (&cn)[AMAX], const double (&cq)[AMAX], bool explore)
 {
     double best_q = -DBL_MAX;
     uint32_t mask = 0;
@@ -192,8 +192,8 @@ __device__ __forceinline__ int ucb_pick(const Problem& P, Rng& g, double L, cons
     return __ffs(mask) - 1;
 }
 
-template <int AMAX>
-__device__ __forceinline__ int ucb_select(const Problem& P, const DeviceState& D, Rng& g, const int32_t* rec, bool explore)
+template <int AMAX, class RNG>
+__device__ __forceinline__ int ucb_select(const Problem& P, const DeviceState& D, RNG& g, const int32_t* rec, bool explore)
 {
     int cn[AMAX];
     double cq[AMAX];
@@ -238,9 +238,7 @@ __host__ __device__ __forceinline__ bool root_children_in_lds(const Problem& P, 
     return P.A * P.O <= ROOT_CHILDREN && D.max_nodes <= 32767;
 }
 
-// HIST: the particles are history records (fba_device.h "History particles"): a simulation stages its root particle's
-// entries in LDS and every step reads its Dirichlet rows through them (gridworld_hist_step).
-template <bool STAGE, int AMAX, bool REG, int TIGER_TABLE, int MODEL, int FTIGER = 0, bool TIGER_POMDP = false, bool HIST = false>
+template <bool STAGE, int AMAX, bool REG, int TIGER_TABLE, int MODEL, int FTIGER = 0, bool TIGER_POMDP = false>
 __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceState D)
 {
     if (TIGER_POMDP) {
@@ -276,7 +274,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
         if (lane < 24) s_prior[lane] = D.prior_dense[lane];
         __syncthreads();
     }
-    if (MODEL == FBA_MODEL_BA_FACTORED && !HIST) {
+    if (MODEL == FBA_MODEL_BA_FACTORED) {
         // the factored model's description (which parents, how many values, where the rows start) is
         // consulted several times per sampled feature: keep the part in use in LDS, at the end of
         // this workgroup's allocation, instead of chasing it through global memory
@@ -342,8 +340,6 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
     }
 
     const bool lazy = slot_lazy(D, e);  // particle states are still the episode's start-state draws (lazy_state)
-    const int hist_n = HIST ? D.hist_len[e] : 0;  // entries in every record of this slot
-    uint32_t sp = 0, hist_mask = 0;               // HIST: the simulated state as hist_pack(x, y, goal); the root particle's structure bits
     // -P ts: TSPlanner / BATSPlanner (src/planners/ts/TSPlanner.cpp:16-29, bayes-adaptive/BATSPlanner.cpp:19-34) sample
     // the belief once and plan on that point estimate, whose sample() draws nothing: every simulation starts
     // from the same particle and its stream begins with the UCB tie-break.
@@ -364,7 +360,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
             cnt = prec + (size_t)src * P.Cs;
             if (STAGE) {
                 const float4* rp = reinterpret_cast<const float4*>(cnt);
-                const int n4 = HIST ? (hist_n + 5) >> 2 : (P.C + 4) >> 2;  // counts and the state word (HIST: state, structure bits, entries); the padding behind them is not needed
+                const int n4 = (P.C + 4) >> 2;  // counts and the state word; the padding behind them is not needed
                 for (int k = 0; k < n4; ++k) {
                     const float4 v = rp[k];
                     stage[(4 * k + 0) * SEARCH_BLOCK] = v.x;
@@ -377,10 +373,6 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
                 s = rec_state(cnt, P.C);
             }
             if (lazy) s = lazy_state(P, D, e, src);
-            if (HIST) {
-                sp        = gridworld_pack_state(P.gw, s);
-                hist_mask = __float_as_uint(stage[1 * SEARCH_BLOCK]);
-            }
             node = 0; dtg = max_tree_depth; plen = 0; mode = 1;
         }
         bool finish = false, do_step = true;
@@ -398,12 +390,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
             int o;
             double r;
             bool term;
-            if (HIST) {
-                uint32_t entry;
-                double prob;
-                term = gridworld_hist_step<false>(P, g, LdsEntries<SEARCH_BLOCK>{reinterpret_cast<const uint32_t*>(stage) + 2 * SEARCH_BLOCK}, hist_n,
-                                                  hist_mask, sp, a, o, r, entry, 0, prob);
-            } else if (FTIGER > 0 && STAGE) term = ftiger_step<(FTIGER > 0 ? FTIGER : 1)>(P, g, LdsView<SEARCH_BLOCK>{stage}, s, a, o, r, NoInc{});
+            if (FTIGER > 0 && STAGE) term = ftiger_step<(FTIGER > 0 ? FTIGER : 1)>(P, g, LdsView<SEARCH_BLOCK>{stage}, s, a, o, r, NoInc{});
             else if (FTIGER > 0) term = ftiger_step<(FTIGER > 0 ? FTIGER : 1)>(P, g, GlobalSearchView{cnt}, s, a, o, r, NoInc{});
             else if (TIGER_TABLE == 2) term = sim_step<REG>(P, g, PackedView<LdsView<SEARCH_BLOCK>>{LdsView<SEARCH_BLOCK>{stage}, s_prior}, s, a, o, r, NoInc{});
             else if (STAGE) term = sim_step<REG>(P, g, LdsView<SEARCH_BLOCK>{stage}, s, a, o, r, NoInc{});
@@ -494,6 +481,182 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
     for (int a = 0; a < FBA_MAX_ACTIONS; ++a) {
         rec.root_n[a] = a < AMAX && a < P.A ? r_cn[a < AMAX ? a : 0] : 0;
         rec.root_q[a] = a < AMAX && a < P.A ? r_cq[a < AMAX ? a : 0] : 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// search_hist_kernel: the same search (POUCT / RBAPOUCT::selectAction, state machine of search_kernel) for
+// history particles (fba_device.h) -- the gridworld FBA-POMDP of BASELINE configs[3].  A tree of 65 536
+// simulations costs megabytes of HBM, so a GPU holds tens of thousands of them, not the hundreds of thousands that
+// "one lane = one tree" needs to keep its SIMDs busy.  Here FOUR lanes share a tree: every lane carries the whole
+// search state and executes the tree logic redundantly (same addresses, same values: loads coalesce, stores
+// agree), and the simulator step -- where the time goes -- is split: lane q generates Philox block q of the
+// quad's eight draws, lane f < 3 scans the history for, fetches and samples the Dirichlet row of state /
+// observation feature f (gridworld_hist_step_quad).  Sixteen trees per wave, four times the waves per tree count;
+// same draws, same order, same results as search_kernel on dense records.
+// LDS per wave: path [depth][16], the root particle's record [2 + entries][16].
+// ---------------------------------------------------------------------------------------------
+constexpr int HIST_TREES = SEARCH_BLOCK / HIST_QUAD;
+template <int K>
+__global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, DeviceState D)
+{
+    constexpr int AMAX = 4;
+    P.model = FBA_MODEL_BA_FACTORED; P.domain = FBA_DOM_GRIDWORLD; P.A = 4; P.belief = FBA_BELIEF_IMPORTANCE;
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x, tl = lane >> 2;
+    const int e    = blockIdx.x * HIST_TREES + tl;
+    if (e >= P.E || !D.active[e]) return;  // (a quad leaves together)
+
+    const int depth_cap = P.max_depth > 0 ? P.max_depth : 1;
+    float* path_r    = reinterpret_cast<float*>(lds) + tl;                                                        // [depth][trees]
+    int32_t* path_na = reinterpret_cast<int32_t*>(path_r - tl + (size_t)depth_cap * HIST_TREES) + tl;
+    uint32_t* stage  = reinterpret_cast<uint32_t*>(path_na - tl + (size_t)depth_cap * HIST_TREES) + tl;           // [Cs][trees]
+
+    QuadRng g;
+    g.init(P.seed_lo, P.seed_hi, (uint32_t)D.run[e], (uint32_t)D.episode[e], (uint32_t)D.t[e], lane);
+    const int hist_len  = D.t[e];
+    const int max_tree_depth = min(P.horizon - hist_len, P.max_depth);
+    const int W         = D.node_words;
+    int32_t* tree       = D.nodes + (size_t)e * D.max_nodes * W;
+    const float* prec   = D.p_rec + pbase(P, e, D.bufsel[e]) * (size_t)P.Cs;
+    const int hist_n    = D.hist_len[e];  // entries in every record of this slot
+
+    if (P.planner == FBA_PLANNER_RANDOM) {  // RandomPlanner::selectAction RandomPlanner.cpp:14-24
+        g.stream(FBA_PHASE_SEARCH, (uint32_t)P.sims);
+        g.ensure(2);
+        (void)g.u01();                      // the belief sample: GridWorld::generateRandomAction does not look at the state
+        D.action[e] = g.slow_int(0, 4);
+        return;
+    }
+    node_init(D, tree, P.A, P.O);
+    int n_nodes = 1, tree_depth = 0;
+    unsigned long long steps = 0;
+    int r_vis = 0, r_cn[AMAX];
+    double r_cq[AMAX];
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) { r_cn[a] = 0; r_cq[a] = 0.0; }
+    double root_L = D.log1p_tab[0];
+    int4* tab      = D.hash + (size_t)e * (D.hmask + 1);
+    uint32_t epoch = (D.epoch[e] + 1) & 0x0fffffffu;
+    if (epoch == 0) epoch = 1;
+    D.epoch[e] = epoch;
+
+    int ts_src = -1;
+    if (P.planner == FBA_PLANNER_TS) {  // TSPlanner / BATSPlanner: one belief sample, then the search from that particle
+        g.stream(FBA_PHASE_SEARCH, (uint32_t)P.sims + 2u);
+        g.ensure(1);
+        ts_src = uniform_weight_pick(D.uni_scan, P.N, g.u01() * D.uni_total, D.uni_total);
+    }
+    int sim = 0, mode = 0;  // 0 = start a simulation, 1 = in the tree, 2 = rollout
+    int node = 0, dtg = 0, plen = 0, rdepth = 0;
+    uint32_t sp = 0, hist_mask = 0;
+    double rret = 0, rdisc = 1;
+    while (true) {
+        if (mode == 0) {
+            if (sim >= P.sims) break;
+            g.stream(FBA_PHASE_SEARCH, (uint32_t)sim);
+            g.ensure(8);  // the root sample, the first action, six rows
+            const int src = ts_src >= 0 ? ts_src : uniform_weight_pick(D.uni_scan, P.N, g.u01() * D.uni_total, D.uni_total);
+            const uint4* rp = reinterpret_cast<const uint4*>(prec + (size_t)src * P.Cs);
+            const int n4 = (hist_n + 5) >> 2;  // state, structure bits, entries
+            for (int k = g.q; k < n4; k += HIST_QUAD) {
+                const uint4 v = rp[k];
+                stage[(4 * k + 0) * HIST_TREES] = v.x;
+                stage[(4 * k + 1) * HIST_TREES] = v.y;
+                stage[(4 * k + 2) * HIST_TREES] = v.z;
+                stage[(4 * k + 3) * HIST_TREES] = v.w;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the other lanes' pieces (LDS operations of one wave complete in order)
+            sp        = gridworld_pack_state(P.gw, (int)stage[0]);
+            hist_mask = stage[1 * HIST_TREES];
+            node = 0; dtg = max_tree_depth; plen = 0; mode = 1;
+        }
+        bool finish = false, do_step = true;
+        double delayed = 0;
+        int a = 0;
+        if (mode == 1 && dtg == 0) { finish = true; do_step = false; }
+        if (mode == 1) tree_depth = max(tree_depth, max_tree_depth - dtg);
+        if (do_step) {
+            g.ensure(7);  // the action, six rows
+            if (mode == 1) {  // traverseActionNode
+                if (node == 0) a = ucb_pick<AMAX>(P, g, root_L, r_cn, r_cq, true);
+                else a = ucb_select<AMAX>(P, D, g, tree + (size_t)node * W, true);
+            } else {
+                a = g.slow_int(0, 4);  // GridWorld::generateRandomAction :220-226
+            }
+            int o;
+            double r;
+            const bool term = gridworld_hist_step_quad<K, HIST_TREES>(P, g, stage + 2 * HIST_TREES, hist_n, hist_mask, sp, a, o, r);
+            ++steps;
+            if (mode == 1) {  // traverseChanceNode
+                path_r[(size_t)plen * HIST_TREES]  = (float)r;
+                path_na[(size_t)plen * HIST_TREES] = (node << 5) | a;
+                ++plen;
+                if (term) finish = true;
+                else {
+                    const int c = child_get(P, D, tree, tab, epoch, node, a, o);
+                    if (c >= 0) { node = c; --dtg; }
+                    else {  // expand: new leaf, then rollout(depth_to_go - 1)
+                        const int nn = min(n_nodes, D.max_nodes - 1);
+                        ++n_nodes;
+                        node_init(D, tree + (size_t)nn * W, P.A, P.O);
+                        child_set(P, D, tree, tab, epoch, node, a, o, nn);
+                        mode = 2; rdepth = dtg - 1; rret = 0; rdisc = 1;
+                        if (rdepth == 0) finish = true;
+                    }
+                }
+            } else {
+                rret += r * rdisc;
+                rdisc *= P.gamma;
+                --rdepth;
+                if (rdepth == 0 || term) { delayed = rret; finish = true; }
+            }
+        }
+        if (finish) {  // back-up, leaf to root (MCTSTreeNodes.cpp:8-12, 59-62)
+            double del = delayed;
+            for (int k = plen - 1; k >= 0; --k) {
+                const int na     = path_na[(size_t)k * HIST_TREES];
+                const double ret = (double)path_r[(size_t)k * HIST_TREES] + P.gamma * del;
+                const int act    = na & 31;
+                if ((na >> 5) == 0) {
+                    int n = 0;
+                    double q = 0.0;
+#pragma unroll
+                    for (int a2 = 0; a2 < AMAX; ++a2)
+                        if (a2 == act) { n = r_cn[a2]; q = r_cq[a2]; }
+                    ++n;
+                    q += (ret - q) / (double)n;
+#pragma unroll
+                    for (int a2 = 0; a2 < AMAX; ++a2)
+                        if (a2 == act) { r_cn[a2] = n; r_cq[a2] = q; }
+                    ++r_vis;
+                    root_L = D.log1p_tab[r_vis];
+                } else {
+                    int32_t* rec = tree + (size_t)(na >> 5) * W;
+                    double* q    = reinterpret_cast<double*>(rec + D.cq_off) + act;
+                    const int n  = ++rec[1 + act];
+                    ++rec[0];
+                    *q += (ret - *q) / (double)n;
+                }
+                del = ret;
+            }
+            ++sim;
+            mode = 0;
+        }
+    }
+    g.stream(FBA_PHASE_SEARCH, (uint32_t)P.sims + 1u);
+    g.ensure(1);
+    if (n_nodes > D.max_nodes) atomicCAS(D.fault, 0, -(1 + e));
+    const int best = ucb_pick<AMAX>(P, g, 0.0, r_cn, r_cq, false);
+    D.action[e]    = best;
+    if (g.q == 0) D.sim_steps[e] += steps;
+    fba_trace_rec& rec = D.cur[e];
+    rec.n_nodes    = n_nodes;
+    rec.tree_depth = tree_depth;
+#pragma unroll
+    for (int a = 0; a < FBA_MAX_ACTIONS; ++a) {
+        rec.root_n[a] = a < AMAX ? r_cn[a < AMAX ? a : 0] : 0;
+        rec.root_q[a] = a < AMAX ? r_cq[a < AMAX ? a : 0] : 0.0;
     }
 }
 
@@ -1216,7 +1379,7 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
             const uint32_t* rec = reinterpret_cast<const uint32_t*>(cnt);
             uint32_t sp = gridworld_pack_state(P.gw, s), entry;
             double prob;
-            gridworld_hist_step<true>(P, g, GlobalEntries{rec + 2}, hist_n, rec[1], sp, a, so, r, entry, o, prob);
+            gridworld_hist_step(P, g, GlobalEntries{rec + 2}, hist_n, rec[1], sp, a, so, r, entry, o, prob);
             *reinterpret_cast<int2*>(side + (size_t)i * 2) = make_int2(gridworld_unpack_state(P.gw, sp), (int)entry);
             sw[i] *= prob;
             continue;
@@ -1711,10 +1874,10 @@ __device__ void hist_next_cell(const Problem& P, const uint32_t* rec, int len, i
 }
 __device__ uint64_t hist_hash_counts(const Problem& P, const uint32_t* rec, int len, uint64_t h)
 {
-    const int N = P.gw->N, G = P.gw->G, A = P.A;
-    const int XY = N * N * G * N, GG = N * N * G * G, ncounts = A * (2 * XY + GG) + A * (2 * N * N + G * G);
+    const HistLayout L(P.gw->N, P.gw->G, P.A);
+    const int N = L.N, G = L.G, A = L.A, rows = N * N * G;
     const uint32_t mask = rec[1];
-    int k = 0, nxt, mult;
+    int k = 0, nxt, mult;  // k: the cell's index in the dense table (the order the checksum is defined in)
     hist_next_cell(P, rec, len, 0, nxt, mult);
     auto visit = [&](float prior) {
         float v = prior;
@@ -1727,12 +1890,22 @@ __device__ uint64_t hist_hash_counts(const Problem& P, const uint32_t* rec, int 
     };
     for (int a = 0; a < A; ++a) {
         for (int f = 0; f < 2; ++f) {
-            const float* src = ((mask >> (2 * a + f)) & 1u) ? P.hist_alt + (size_t)(a * 2 + f) * XY : P.hist_base + k;
-            for (int i = 0; i < XY; ++i) visit(src[i]);
+            const bool with_goal = (mask >> (2 * a + f)) & 1u;
+            for (int row = 0; row < rows; ++row) {  // the dense node has room for N*N*G rows; without the goal parent N*N are in use, the rest zero
+                const float* src = with_goal ? P.hist_alt + (size_t)(a * 2 + f) * L.XY + row * L.NS
+                                             : (row < N * N ? P.hist_base + a * L.tstride + f * L.XY + row * L.NS : nullptr);
+                for (int i = 0; i < N; ++i) visit(src ? src[i] : 0.f);
+            }
         }
-        for (int i = 0; i < GG; ++i) visit(P.hist_base[k]);
+        for (int row = 0; row < rows; ++row)
+            for (int i = 0; i < G; ++i) visit(P.hist_base[a * L.tstride + 2 * L.XY + row * L.GS + i]);
     }
-    while (k < ncounts) visit(P.hist_base[k]);
+    for (int a = 0; a < A; ++a)
+        for (int f = 0; f < 3; ++f) {
+            const int n = f == 2 ? G : N;
+            for (int v = 0; v < n; ++v)
+                for (int i = 0; i < n; ++i) visit(P.hist_base[L.o_row(a, f, v) + i]);
+        }
     for (int w = 0; w < 2 * A; ++w, ++k) h = mix64(h ^ ((uint64_t)(((mask >> w) & 1u) ? 7u : 3u) + ((uint64_t)k << 32)));
     return h;
 }
@@ -1804,9 +1977,12 @@ void launch_search(const Problem& P, const DeviceState& D, hipStream_t st)
         else if (P.model == FBA_MODEL_BA_TABLE) FBA_LAUNCH_SEARCH_M(STG, AM, FBA_MODEL_BA_TABLE);   \
         else FBA_LAUNCH_SEARCH_M(false, AM, FBA_MODEL_POMDP);                                       \
     } while (0)
-    if (P.hist) {  // history particles (gridworld FBA-POMDP): the record is staged, the model description is not needed
-        lds = (size_t)depth_cap * SEARCH_BLOCK * (sizeof(float) + sizeof(int32_t)) + (size_t)P.Cs * SEARCH_BLOCK * sizeof(float);
-        hipLaunchKernelGGL((search_kernel<true, 4, false, 0, FBA_MODEL_BA_FACTORED, 0, false, true>), grid, block, lds, st, P, D);
+    if (P.hist) {  // history particles (gridworld FBA-POMDP): four lanes per tree
+        lds = (size_t)depth_cap * HIST_TREES * (sizeof(float) + sizeof(int32_t)) + (size_t)P.Cs * HIST_TREES * sizeof(float);
+        const dim3 qgrid(ceil_div(P.E, HIST_TREES));
+        if (P.hist_row <= 8) hipLaunchKernelGGL((search_hist_kernel<8>), qgrid, block, lds, st, P, D);
+        else if (P.hist_row <= 12) hipLaunchKernelGGL((search_hist_kernel<12>), qgrid, block, lds, st, P, D);
+        else hipLaunchKernelGGL((search_hist_kernel<16>), qgrid, block, lds, st, P, D);
         return;
     }
     const bool tiger_table = P.model == FBA_MODEL_BA_TABLE && P.planner == FBA_PLANNER_POUCT && !P.dirichlet_regular && stage &&
