@@ -278,6 +278,8 @@ struct Problem {
     int32_t hist;       // history particles (gridworld FBA-POMDP, importance filter): a record holds the particle's increments as one
                         // 4-byte entry per real step over the shared prior tables (HistView below); C = 0 then, hist_cap entries per record
     int32_t hist_cap;
+    int32_t gw_N, gw_G;          // gridworld: N, number of goals (copies of GridDesc's, as kernel arguments)
+    uint32_t gw_goalcell[4];     // gridworld: x*N + y of goal g, 8 bits each
     int32_t hist_row;   // the longest Dirichlet row of the model (max(N, G)): picks the row width the kernels are instantiated for
     const float* hist_base;  // the prior count table every particle starts from (max layout, x / y nodes without the goal parent)
     const float* hist_alt;   // [A][2][N*N*G*N]: the x / y transition nodes as a particle with the goal as their third parent starts them
@@ -978,15 +980,18 @@ __device__ __forceinline__ bool sysadmin_fact_step(const Problem& P, Rng& g, con
 // has added to it".  A Bayes-adaptive particle never changes a count except by the "+1"s of
 // BABNModel::incrementCountsOf (BABNModel.cpp:354-382) -- six per real step here, one per DBN node of the step's
 // action, at cells that (s, a, s', o') determine -- so instead of the 191 KB count table (N = 7) a record holds
-//   word 0   the domain state            word 1   bit 2a + f: node T(a, f), f in {x, y}, has the goal as third parent
-//   word 2 + t   entry t = the t-th real step of the run:   s' as (x, y, goal) 4 bits each | o' as (x, y, goal)
-//                4 bits each << 12 | a << 24, or bit 31 | start state (resetDomainStateDistribution: no increments)
-// and a count is prior[cell] + (number of entries that incremented the cell).  The reference's own copy-on-write
-// table (BAFlatModel.cpp:185-217) is the same idea at row granularity.  The engine only uses this form when
-// prior[k] + j, j <= hist_cap + 1, is for every k the float that j additions of 1.0f reach (checked on the host),
-// so a row read through the history is bit for bit the row of the dense table.
-// One simulated step = two passes over the entries (the transition rows of (s, a), then the observation rows
-// of (a, s')); an entry costs a few compares and adds, no memory beyond its own 4 bytes.
+//   word 0   the domain state            word 1   bit 2a + f: node T(a, f), f in {x, y}, has the goal as third parent;
+//                                                 bits 16..25: the state again, as hist_pack(x, y, goal)
+//   word 2 + j   entry j = one real step of the run: s | s' << 10 | o' << 20, each as hist_pack (x 3 bits, y 3 bits,
+//                goal 4 bits: N <= 8), the entries of action 0 first, then action 1, ...
+// and a count is prior[cell] + (number of entries that incremented the cell).  All particles of a slot have taken
+// the same actions, so where an action's entries start and how many there are is one word per SLOT
+// (DeviceState::hist_cnt); a belief update inserts its entry at the end of its action's group.  The reference's
+// own copy-on-write table (BAFlatModel.cpp:185-217) is the same idea at row granularity.  The engine only uses
+// this form when prior[k] + j, j <= hist_cap + 1, is for every k the float that j additions of 1.0f reach (checked
+// on the host), so a row read through the history is bit for bit the row of the dense table.
+// One simulated step = two passes over the entries of its action (the transition rows of (s, a), then the
+// observation rows of (a, s')); an entry costs a few compares and adds, no memory beyond its own 4 bytes.
 // The prior tables sit in HBM once per context (L2-resident), rows padded to a multiple of four floats so that
 // a row is two or three aligned 16-byte loads:
 //   hist_base: per action  T(x) [N*N*G rows of NS]  T(y) [same]  T(goal) [N*N*G rows of GS], then per action
@@ -994,11 +999,25 @@ __device__ __forceinline__ bool sysadmin_fact_step(const Problem& P, Rng& g, con
 //              (an x / y node without the goal parent uses its first N*N rows, as in the dense max layout)
 //   hist_alt:  per action and x / y node, the N*N*G rows of NS a particle with the goal parent starts from
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t HIST_START = 0x80000000u;
-constexpr int HIST_MAX_CAP    = 126;  // entries per record: 2 + cap words <= SEARCH_STAGE_WORDS, counts per cell fit 8 bits
-constexpr int HIST_QUAD       = 4;    // lanes that share one tree in search_hist_kernel
-__host__ __device__ __forceinline__ uint32_t hist_pack(int x, int y, int g) { return (uint32_t)x | ((uint32_t)y << 4) | ((uint32_t)g << 8); }
-__host__ __device__ __forceinline__ uint32_t hist_entry(uint32_t ns, uint32_t o, int a) { return ns | (o << 12) | ((uint32_t)a << 24); }
+constexpr int HIST_MAX_CAP = 126;  // entries per record: 2 + cap words <= SEARCH_STAGE_WORDS, counts per cell and per action fit 8 bits
+constexpr int HIST_MAX_N   = 8;    // x, y in 3 bits
+constexpr int HIST_QUAD    = 4;    // lanes that share one tree in search_hist_kernel
+__host__ __device__ __forceinline__ uint32_t hist_pack(int x, int y, int g) { return (uint32_t)x | ((uint32_t)y << 3) | ((uint32_t)g << 6); }
+__host__ __device__ __forceinline__ int hist_x(uint32_t sp) { return (int)(sp & 7u); }
+__host__ __device__ __forceinline__ int hist_y(uint32_t sp) { return (int)((sp >> 3) & 7u); }
+__host__ __device__ __forceinline__ int hist_g(uint32_t sp) { return (int)((sp >> 6) & 15u); }
+__host__ __device__ __forceinline__ uint32_t hist_entry(uint32_t s, uint32_t ns, uint32_t o) { return s | (ns << 10) | (o << 20); }
+// feature f of a packed state: shift and mask
+__host__ __device__ __forceinline__ int hist_field(uint32_t sp, int f) { return (int)((sp >> (3 * f)) & (f == 2 ? 15u : 7u)); }
+// per-slot group bookkeeping (DeviceState::hist_cnt): entries of action a, 8 bits each
+__host__ __device__ __forceinline__ int hist_count(uint32_t cnt, int a) { return (int)((cnt >> (8 * a)) & 0xffu); }
+__host__ __device__ __forceinline__ int hist_offset(uint32_t cnt, int a)
+{
+    int off = 0;
+    for (int k = 0; k < 4; ++k) off += k < a ? hist_count(cnt, k) : 0;
+    return off;
+}
+__host__ __device__ __forceinline__ int hist_total(uint32_t cnt) { return hist_count(cnt, 0) + hist_count(cnt, 1) + hist_count(cnt, 2) + hist_count(cnt, 3); }
 
 // where the rows of the padded tables start (host and device)
 struct HistLayout {
@@ -1036,11 +1055,6 @@ struct RowCount {
 struct GlobalEntries {
     const uint32_t* p;
     __device__ __forceinline__ uint32_t at(int t) const { return p[t]; }
-};
-template <int STRIDE>
-struct LdsEntries {
-    const uint32_t* p;
-    __device__ __forceinline__ uint32_t at(int t) const { return p[t * STRIDE]; }
 };
 
 // a Dirichlet row in registers: prior row (K / 4 aligned 16-byte loads; the words past n belong to the next row
@@ -1092,20 +1106,31 @@ struct HistRow {
     }
 };
 __device__ __forceinline__ double u01_of(uint64_t w) { return (double)(w >> 11) * (1.0 / 9007199254740992.0); }  // rnd::uniform_rand01 of one draw
+__device__ __forceinline__ bool gridworld_on_goal(const Problem& P, int cell, int gl)
+{
+    const uint32_t w = gl < 8 ? (gl < 4 ? P.gw_goalcell[0] : P.gw_goalcell[1]) : (gl < 12 ? P.gw_goalcell[2] : P.gw_goalcell[3]);
+    return ((w >> (8 * (gl & 3))) & 0xffu) == (uint32_t)cell;
+}
+__device__ __forceinline__ uint32_t gridworld_pack_state(const Problem& P, int s)
+{
+    const int N = P.gw_N, G = P.gw_G;
+    return hist_pack(s / (N * G), (s / G) % N, s % G);
+}
+__device__ __forceinline__ int gridworld_unpack_state(const Problem& P, uint32_t sp) { return (hist_x(sp) * P.gw_N + hist_y(sp)) * P.gw_G + hist_g(sp); }
 
 // BAPOMDP::step (BAPOMDP.cpp:111-143) over BABNModel (BABNModel.cpp:292-325) for the gridworld FBA-POMDP on a
 // history particle, one lane per particle (the belief update): the draws, their order and every row value are those
-// of gridworld_fact_step on the dense table.  `sp` = the state as hist_pack(x, y, goal); returns the step's entry
-// (what incrementCountsOf would add, :354-382, App. A #6: observation rows at the OLD state's values) and
-// P(real_o | a, s') from the counts after the step's own increments (BABNModel.cpp:328-352).
-template <int KN, int KG, class Entries>
-__device__ __forceinline__ bool gridworld_hist_step_k(const Problem& P, Rng& g, const Entries& ent, int len, uint32_t mask, uint32_t& sp, int a,
-                                                      int& o, double& r, uint32_t& entry, int real_o, double& prob)
+// of gridworld_fact_step on the dense table.  `ent` = the particle's n entries of action a; `sp` = the state as
+// hist_pack(x, y, goal); returns the step's entry (what incrementCountsOf would add, :354-382, App. A #6:
+// observation rows at the OLD state's values) and P(real_o | a, s') from the counts after the step's own
+// increments (BABNModel.cpp:328-352).
+template <int KN, int KG>
+__device__ __forceinline__ bool gridworld_hist_step_k(const Problem& P, Rng& g, const uint32_t* __restrict__ ent, int n, uint32_t mask, uint32_t& sp,
+                                                      int a, int& o, double& r, uint32_t& entry, int real_o, double& prob)
 {
-    const GridDesc* gw = P.gw;
-    const HistLayout L(gw->N, gw->G, P.A);
+    const HistLayout L(P.gw_N, P.gw_G, P.A);
     const int N = L.N, G = L.G;
-    const int x = (int)(sp & 15u), y = (int)((sp >> 4) & 15u), gl = (int)(sp >> 8);
+    const int x = hist_x(sp), y = hist_y(sp), gl = hist_g(sp);
     const int cell = x * N + y;
     const bool mx = (mask >> (2 * a)) & 1u, my = (mask >> (2 * a + 1)) & 1u;
     HistRow<KN> rx, ry;
@@ -1115,18 +1140,12 @@ __device__ __forceinline__ bool gridworld_hist_step_k(const Problem& P, Rng& g, 
     rg.fetch(P.hist_base + L.t_row(a, 2, true, cell, gl));
     // pass 1: the increments this particle has made to the rows T(a, .)(x, y [, goal])
     RowCount cx{0, 0}, cy{0, 0}, cg{0, 0};
-    {
-        uint32_t prev = 0;
-        const uint32_t want_xy = sp & 0xffu;
-        for (int t = 0; t < len; ++t) {
-            const uint32_t e = ent.at(t);
-            const bool hit_xy = (e >> 24) == (uint32_t)a && (prev & 0xffu) == want_xy;  // (a start entry has bit 31 set: never equal)
-            const bool hit_g  = hit_xy && (prev >> 8) == (uint32_t)gl;
-            cx.add(hit_xy && (!mx || hit_g), (int)(e & 15u));
-            cy.add(hit_xy && (!my || hit_g), (int)((e >> 4) & 15u));
-            cg.add(hit_g, (int)((e >> 8) & 15u));
-            prev = e & 0xfffu;
-        }
+    for (int j = 0; j < n; ++j) {
+        const uint32_t e = ent[j];
+        const bool hit_xy = ((e ^ sp) & 0x3fu) == 0, hit_g = ((e ^ sp) & 0x3ffu) == 0;
+        cx.add(mx ? hit_g : hit_xy, (int)((e >> 10) & 7u));
+        cy.add(my ? hit_g : hit_xy, (int)((e >> 13) & 7u));
+        cg.add(hit_g, (int)((e >> 16) & 15u));
     }
     rx.add(N, cx);
     const int nx = rx.sample(g.u01(), N);
@@ -1140,16 +1159,11 @@ __device__ __forceinline__ bool gridworld_hist_step_k(const Problem& P, Rng& g, 
     // pass 2: the increments to the rows O(a, .)(value of the new state's feature); a step increments them at
     // the row of the state it STARTED from
     RowCount ox{0, 0}, oy{0, 0}, og{0, 0};
-    {
-        uint32_t prev = 0;
-        for (int t = 0; t < len; ++t) {
-            const uint32_t e = ent.at(t);
-            const bool hit_a = (e >> 24) == (uint32_t)a;
-            ox.add(hit_a && (prev & 15u) == (uint32_t)nx, (int)((e >> 12) & 15u));
-            oy.add(hit_a && ((prev >> 4) & 15u) == (uint32_t)ny, (int)((e >> 16) & 15u));
-            og.add(hit_a && (prev >> 8) == (uint32_t)ng, (int)((e >> 20) & 15u));
-            prev = e & 0xfffu;
-        }
+    for (int j = 0; j < n; ++j) {
+        const uint32_t e = ent[j];
+        ox.add((int)(e & 7u) == nx, (int)((e >> 20) & 7u));
+        oy.add((int)((e >> 3) & 7u) == ny, (int)((e >> 23) & 7u));
+        og.add((int)((e >> 6) & 15u) == ng, (int)((e >> 26) & 15u));
     }
     HistRow<KN> px = rx, py = ry;   // the prior rows, for the probability below
     HistRow<KG> pg = rg;
@@ -1176,28 +1190,17 @@ __device__ __forceinline__ bool gridworld_hist_step_k(const Problem& P, Rng& g, 
         pr *= pg.prob(G, qg);
         prob = pr;
     }
-    const bool found = gw->goal[gl][0] == x && gw->goal[gl][1] == y;  // GridWorldBAExtension.cpp:74-99: terminal and reward from the OLD state
+    const bool found = gridworld_on_goal(P, cell, gl);  // GridWorldBAExtension.cpp:74-99: terminal and reward from the OLD state
     r     = found ? 1 : 0;
+    entry = hist_entry(sp, hist_pack(nx, ny, ng), hist_pack(vx, vy, vg));
     sp    = hist_pack(nx, ny, ng);
-    entry = hist_entry(sp, hist_pack(vx, vy, vg), a);
     return found;
 }
-template <class Entries>
-__device__ __forceinline__ bool gridworld_hist_step(const Problem& P, Rng& g, const Entries& ent, int len, uint32_t mask, uint32_t& sp, int a, int& o,
+__device__ __forceinline__ bool gridworld_hist_step(const Problem& P, Rng& g, const uint32_t* ent, int n, uint32_t mask, uint32_t& sp, int a, int& o,
                                                     double& r, uint32_t& entry, int real_o, double& prob)
 {
-    if (P.gw->G <= 8) return gridworld_hist_step_k<8, 8>(P, g, ent, len, mask, sp, a, o, r, entry, real_o, prob);
-    if (P.gw->N <= 8) return gridworld_hist_step_k<8, 12>(P, g, ent, len, mask, sp, a, o, r, entry, real_o, prob);   // (G <= 10)
-    return gridworld_hist_step_k<16, 12>(P, g, ent, len, mask, sp, a, o, r, entry, real_o, prob);
-}
-__device__ __forceinline__ uint32_t gridworld_pack_state(const GridDesc* gw, int s)
-{
-    const int N = gw->N, G = gw->G;
-    return hist_pack(s / (N * G), (s / G) % N, s % G);
-}
-__device__ __forceinline__ int gridworld_unpack_state(const GridDesc* gw, uint32_t sp)
-{
-    return ((int)(sp & 15u) * gw->N + (int)((sp >> 4) & 15u)) * gw->G + (int)(sp >> 8);
+    if (P.gw_G <= 8) return gridworld_hist_step_k<8, 8>(P, g, ent, n, mask, sp, a, o, r, entry, real_o, prob);
+    return gridworld_hist_step_k<8, 12>(P, g, ent, n, mask, sp, a, o, r, entry, real_o, prob);   // (G <= 10)
 }
 
 // ---- the same step shared by the four lanes of a quad (search_hist_kernel) ---------------------------------------
@@ -1262,28 +1265,27 @@ __device__ __forceinline__ int quad_bcast(int addr0, int from, int v) { return _
 
 // Lane f < 3 of the quad owns state / observation feature f (lane 3 repeats lane 2's work): one history pass,
 // one row, one sampling chain per lane and phase instead of three.  Draws 0..2 of the phase go to features 0..2
-// as in the one-lane form; `ent` = the staged entries, [t * STRIDE].
+// as in the one-lane form.  `list` = the root particle's n_list entries of action a, staged as [j * STRIDE].
 template <int K, int STRIDE>
-__device__ __forceinline__ bool gridworld_hist_step_quad(const Problem& P, QuadRng& g, const uint32_t* ent, int len, uint32_t mask, uint32_t& sp,
+__device__ __forceinline__ bool gridworld_hist_step_quad(const Problem& P, QuadRng& g, const uint32_t* list, int n_list, uint32_t mask, uint32_t& sp,
                                                          int a, int& o, double& r)
 {
-    const GridDesc* gw = P.gw;
-    const HistLayout L(gw->N, gw->G, P.A);
+    const HistLayout L(P.gw_N, P.gw_G, 4);
     const int N = L.N, G = L.G;
     const int f = min(g.q, 2);
-    const int x = (int)(sp & 15u), y = (int)((sp >> 4) & 15u), gl = (int)(sp >> 8);
+    const int x = hist_x(sp), y = hist_y(sp), gl = hist_g(sp);
     const int cell = x * N + y, n = f == 2 ? G : N;
     const bool with_goal = f == 2 || ((mask >> (2 * a + f)) & 1u);
+    const int shift = 3 * f;
+    const uint32_t fmask = f == 2 ? 15u : 7u;
     HistRow<K> row;
     row.fetch(f < 2 && with_goal ? P.hist_alt + L.alt_row(a, f, cell, gl) : P.hist_base + L.t_row(a, f, with_goal, cell, gl));
     RowCount cnt{0, 0};
     {
-        uint32_t prev = 0;
-        const uint32_t want = with_goal ? sp : (sp & 0xffu), keep = with_goal ? 0xfffu : 0xffu;
-        for (int t = 0; t < len; ++t) {
-            const uint32_t e = ent[t * STRIDE];
-            cnt.add((e >> 24) == (uint32_t)a && (prev & keep) == want, (int)((e >> (4 * f)) & 15u));
-            prev = e & 0xfffu;
+        const uint32_t keep = with_goal ? 0x3ffu : 0x3fu;
+        for (int j = 0; j < n_list; ++j) {
+            const uint32_t e = list[j * STRIDE];
+            cnt.add(((e ^ sp) & keep) == 0, (int)((e >> (10 + shift)) & fmask));
         }
     }
     row.add(n, cnt);
@@ -1291,20 +1293,16 @@ __device__ __forceinline__ bool gridworld_hist_step_quad(const Problem& P, QuadR
     const int nx = quad_bcast(g.addr0, 0, nv), ny = quad_bcast(g.addr0, 1, nv), ng = quad_bcast(g.addr0, 2, nv);
     row.fetch(P.hist_base + L.o_row(a, f, nv));
     cnt = RowCount{0, 0};
-    {
-        uint32_t prev = 0;
-        for (int t = 0; t < len; ++t) {
-            const uint32_t e = ent[t * STRIDE];
-            cnt.add((e >> 24) == (uint32_t)a && ((prev >> (4 * f)) & 15u) == (uint32_t)nv, (int)((e >> (12 + 4 * f)) & 15u));
-            prev = e & 0xfffu;
-        }
+    for (int j = 0; j < n_list; ++j) {
+        const uint32_t e = list[j * STRIDE];
+        cnt.add(((e >> shift) & fmask) == (uint32_t)nv, (int)((e >> (20 + shift)) & fmask));
     }
     row.add(n, cnt);
     const int ov = row.sample(u01_of(g.at(g.draw + 3u + (uint32_t)f)), n);
     g.draw += 6;
     const int vx = quad_bcast(g.addr0, 0, ov), vy = quad_bcast(g.addr0, 1, ov), vg = quad_bcast(g.addr0, 2, ov);
     o = (vx * N + vy) * G + vg;
-    const bool found = gw->goal[gl][0] == x && gw->goal[gl][1] == y;
+    const bool found = gridworld_on_goal(P, cell, gl);  // GridWorldBAExtension.cpp:74-99: terminal and reward from the OLD state
     r  = found ? 1 : 0;
     sp = hist_pack(nx, ny, ng);
     return found;

@@ -897,7 +897,7 @@ int check_fault(fba_ctx* c)
     if (!f) return FBA_OK;
     HIPCHK(c, hipMemset(c->D.fault, 0, sizeof f));
     if (f >= 0x40000000)
-        return fail(c, FBA_ESTATE, "slot %d: more belief updates and resets in one run than the %d (episodes * (horizon + 1)) a history particle was "
+        return fail(c, FBA_ESTATE, "slot %d: more belief updates in one run than the %d (episodes * horizon) a history particle was "
                     "sized for; create the context with FBA_DENSE_PARTICLES=1 in the environment to drive it beyond that", f - 0x40000000, c->P.hist_cap);
     if (f < 0) return fail(c, FBA_ESTATE, "the search tree of slot %d needed more than the %d node records it has", -f - 1, c->D.max_nodes);
     return fail(c, FBA_ESTATE, "rejection sampling in slot %d accepted fewer than %d particles in %d attempts: no particle of the filter "
@@ -1246,19 +1246,23 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     }
     // History particles (fba_device.h): the gridworld FBA-POMDP particle as one 4-byte entry per real step over the
     // shared prior tables -- 100-500 bytes instead of 191 KB (N = 7) -- where the importance filter is the plain one,
-    // the run fits the record (one entry per update and per reset) and prior + j is exact in fp32 for every count a
-    // run can reach (so a row read through the entries is bit for bit the dense row).
+    // the run fits the record (one entry per belief update), the grid fits 3-bit coordinates and prior + j is exact in
+    // fp32 for every count a run can reach (so a row read through the entries is bit for bit the dense row).
     P.hist = 0; P.hist_cap = 0; P.hist_row = 0; P.hist_base = nullptr; P.hist_alt = nullptr;
     if (cfg->model == FBA_MODEL_BA_FACTORED && cfg->domain == FBA_DOM_GRIDWORLD && cfg->belief == FBA_BELIEF_IMPORTANCE &&
         !cfg->dirichlet_regular && cfg->particles <= IS_MAX_CHUNKS * 256 && !std::getenv("FBA_IS_MULTI_MIN") &&
-        !std::getenv("FBA_DENSE_PARTICLES") && (long long)cfg->episodes * (cfg->horizon + 1) <= HIST_MAX_CAP) {
-        const int cap = cfg->episodes * (cfg->horizon + 1);
+        !std::getenv("FBA_DENSE_PARTICLES") && (long long)cfg->episodes * cfg->horizon <= HIST_MAX_CAP && cfg->size <= HIST_MAX_N) {
+        const int cap = cfg->episodes * cfg->horizon;
         build_gridworld_alt_prior(c);
         std::vector<float> counts(c->prior.begin(), c->prior.begin() + c->fdesc.ncounts);
         if (increments_exact(counts, cap + 1) && increments_exact(c->prior_alt, cap + 1)) {
             P.hist     = 1;
             P.hist_cap = cap;
             P.hist_row = std::max(c->gdesc.N, c->gdesc.G);
+            P.gw_N = c->gdesc.N; P.gw_G = c->gdesc.G;
+            for (int k = 0; k < 4; ++k) P.gw_goalcell[k] = 0;
+            for (int gq = 0; gq < c->gdesc.G; ++gq)
+                P.gw_goalcell[gq >> 2] |= (uint32_t)(c->gdesc.goal[gq][0] * c->gdesc.N + c->gdesc.goal[gq][1]) << (8 * (gq & 3));
             P.C        = 0;  // word 0 = state, word 1 = structure bits, words 2.. = entries
         }
     }
@@ -1318,14 +1322,20 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
                                                                              // of bytes apart -- at exactly 128 KB the search ran 45 % slower)
     if (const char* ev = std::getenv("FBA_NODE_BOUND")) D.max_nodes = std::max(2, std::atoi(ev));  // tests: exercise the overflow guard
     uint32_t hcap = 0;
+    size_t hash_entry = 16;
+    D.hash_compact = 0;
     if (hashed) {
         hcap = 64;
-        while (hcap < 2u * (uint32_t)D.max_nodes) hcap <<= 1;
+        while (hcap < 2u * (uint32_t)(D.max_nodes - 2)) hcap <<= 1;  // at most max_nodes - 2 children (one per simulation): load <= 1/2
         D.hmask = hcap - 1;
+        if ((unsigned long long)D.max_nodes * P.A * P.O < (1ull << 27) && !std::getenv("FBA_WIDE_HASH")) {
+            D.hash_compact = 1;
+            hash_entry     = 8;
+        }
     }
 
     // slots
-    const size_t per_slot = (size_t)P.N * (2 * 8 + 8 + 4 * (MAXINC + 1) + ((P.reinvig || P.cheat) ? 4 : 2) * (size_t)P.Cs * 4) + (size_t)D.max_nodes * D.node_words * 4 + (size_t)hcap * 16 + 1024;
+    const size_t per_slot = (size_t)P.N * (2 * 8 + 8 + 4 * (MAXINC + 1) + ((P.reinvig || P.cheat) ? 4 : 2) * (size_t)P.Cs * 4) + (size_t)D.max_nodes * D.node_words * 4 + (size_t)hcap * hash_entry + 1024;
     int E = cfg->slots;
     if (E <= 0) {
         size_t free_b = 0, total_b = 0;
@@ -1360,7 +1370,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     CHK(dev_alloc(c, &D.wscan, is ? (size_t)E * P.N : 1, false));
     D.side_w = 1 + (P.model == FBA_MODEL_BA_FACTORED ? c->fdesc.FS + c->fdesc.FO : (P.model == FBA_MODEL_BA_TABLE ? 2 : 0));
     if (P.hist) D.side_w = 2;  // {new state, the step's entry}
-    CHK(dev_alloc(c, &D.hist_len, E));
+    CHK(dev_alloc(c, &D.hist_cnt, E));
     CHK(dev_alloc(c, &D.p_side, is ? (size_t)E * P.N * D.side_w : 1, false));
     {
         // one workgroup per slot up to IS_MAX_CHUNKS*256 particles, several launches beyond
@@ -1386,7 +1396,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     }
     CHK(dev_alloc(c, &D.nodes, (size_t)E * D.max_nodes * D.node_words, false));
     if (hashed) {
-        CHK(dev_alloc(c, &D.hash, (size_t)E * hcap));
+        CHK(dev_alloc(c, &D.hash, (size_t)E * hcap * hash_entry / 16));
         CHK(dev_alloc(c, &D.epoch, E));
     }
     CHK(dev_alloc(c, &D.sim_steps, E));
@@ -1629,9 +1639,9 @@ int fba_belief_update(fba_ctx* c, const int32_t* action, const int32_t* obs, con
 }
 
 // History particles: the dense count table of one record, as the API speaks of particles -- the prior (the goal-parent
-// form of the x / y nodes the structure bits name) plus 1.0f per entry and incremented cell, in entry order
-// (BABNModel::incrementCountsOf BABNModel.cpp:354-382 replayed).
-static void hist_materialize(const fba_ctx* c, const uint32_t* rec, int len, float* counts)
+// form of the x / y nodes the structure bits name) plus 1.0f per entry and incremented cell
+// (BABNModel::incrementCountsOf BABNModel.cpp:354-382 replayed; `cnt` = the slot's entries per action).
+static void hist_materialize(const fba_ctx* c, const uint32_t* rec, uint32_t cnt, float* counts)
 {
     const GridDesc& g = c->gdesc;
     const int N = g.N, G = g.G, A = c->P.A;
@@ -1646,21 +1656,20 @@ static void hist_materialize(const fba_ctx* c, const uint32_t* rec, int len, flo
             const uint32_t m = with_goal ? 7u : 3u;
             std::memcpy(&counts[ncounts + 2 * a + f], &m, 4);
         }
-    uint32_t prev = 0;
-    for (int t = 0; t < len; ++t) {
-        const uint32_t en = rec[2 + t];
-        if (!(en >> 31)) {
-            const int a = (int)(en >> 24), x = (int)(prev & 15u), y = (int)((prev >> 4) & 15u), gl = (int)(prev >> 8);
-            const int tbase = a * (2 * XY + GG), obase = A * (2 * XY + GG) + a * (2 * NN + G * G), cell = x * N + y;
-            const bool mx = (mask >> (2 * a)) & 1u, my = (mask >> (2 * a + 1)) & 1u;
-            counts[tbase + (mx ? cell * G + gl : cell) * N + (int)(en & 15u)] += 1.0f;
-            counts[tbase + XY + (my ? cell * G + gl : cell) * N + (int)((en >> 4) & 15u)] += 1.0f;
-            counts[tbase + 2 * XY + (cell * G + gl) * G + (int)((en >> 8) & 15u)] += 1.0f;
-            counts[obase + x * N + (int)((en >> 12) & 15u)] += 1.0f;
-            counts[obase + NN + y * N + (int)((en >> 16) & 15u)] += 1.0f;
-            counts[obase + 2 * NN + gl * G + (int)((en >> 20) & 15u)] += 1.0f;
+    int j = 0;
+    for (int a = 0; a < A; ++a) {
+        const int tbase = a * (2 * XY + GG), obase = A * (2 * XY + GG) + a * (2 * NN + G * G);
+        const bool mx = (mask >> (2 * a)) & 1u, my = (mask >> (2 * a + 1)) & 1u;
+        for (int q = 0; q < hist_count(cnt, a); ++q, ++j) {
+            const uint32_t en = rec[2 + j], s0 = en & 0x3ffu, s1 = (en >> 10) & 0x3ffu, ob = en >> 20;
+            const int x = hist_x(s0), y = hist_y(s0), gl = hist_g(s0), cell = x * N + y;
+            counts[tbase + (mx ? cell * G + gl : cell) * N + hist_x(s1)] += 1.0f;
+            counts[tbase + XY + (my ? cell * G + gl : cell) * N + hist_y(s1)] += 1.0f;
+            counts[tbase + 2 * XY + (cell * G + gl) * G + hist_g(s1)] += 1.0f;
+            counts[obase + x * N + hist_x(ob)] += 1.0f;
+            counts[obase + NN + y * N + hist_y(ob)] += 1.0f;
+            counts[obase + 2 * NN + gl * G + hist_g(ob)] += 1.0f;
         }
-        prev = en & 0xfffu;
     }
 }
 
@@ -1680,12 +1689,12 @@ int fba_belief_get(fba_ctx* c, int32_t slot, int32_t* state, double* weight, flo
     if (state || (counts && (P.C || P.hist))) {
         std::vector<float> tmp((size_t)P.N * P.Cs);
         HIPCHK(c, hipMemcpy(tmp.data(), c->D.p_rec + pb * P.Cs, tmp.size() * 4, hipMemcpyDeviceToHost));
-        int32_t hist_len = 0;
-        if (P.hist) HIPCHK(c, hipMemcpy(&hist_len, c->D.hist_len + slot, 4, hipMemcpyDeviceToHost));
+        uint32_t hist_cnt = 0;
+        if (P.hist) HIPCHK(c, hipMemcpy(&hist_cnt, c->D.hist_cnt + slot, 4, hipMemcpyDeviceToHost));
         for (int i = 0; i < P.N; ++i) {
             const float* rec = tmp.data() + (size_t)i * P.Cs;
             if (state) std::memcpy(&state[i], &rec[P.C], 4);
-            if (counts && P.hist) hist_materialize(c, reinterpret_cast<const uint32_t*>(rec), hist_len, counts + (size_t)i * c->dense_C);
+            if (counts && P.hist) hist_materialize(c, reinterpret_cast<const uint32_t*>(rec), hist_cnt, counts + (size_t)i * c->dense_C);
             else if (counts && P.packed) {  // count = prior + number of increments (PackedView)
                 const uint32_t* w = reinterpret_cast<const uint32_t*>(rec);
                 for (int k = 0; k < c->dense_C; ++k)

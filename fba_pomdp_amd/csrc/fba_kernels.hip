@@ -99,11 +99,45 @@ __device__ __forceinline__ uint32_t child_hash(uint64_t code)
     code ^= code >> 33; code *= 0xff51afd7ed558ccdull; code ^= code >> 29;
     return (uint32_t)code;
 }
+// Compact form (DeviceState::hash_compact, whenever max_nodes * A * O < 2^27, e.g. gridworld N = 7 at 65 536
+// simulations): 8-byte entries {epoch << 27 | code, child}, half the slots (load <= 1/2) -- 1 MB per tree instead of 4;
+// a 5-bit epoch, so the slot's table is cleared once every 31 searches (hash_begin_search).
+__device__ __forceinline__ uint32_t hash_begin_search(const DeviceState& D, int e, int4* tab, int part, int nparts)
+{
+    uint32_t epoch = D.epoch[e] + 1;
+    if (D.hash_compact) {
+        if (epoch > 31u) {
+            uint4* t4 = reinterpret_cast<uint4*>(tab);
+            for (uint32_t k = (uint32_t)part; k < (D.hmask + 1) / 2; k += (uint32_t)nparts) t4[k] = make_uint4(0, 0, 0, 0);
+            epoch = 1;
+        }
+    } else {
+        epoch &= 0x0fffffffu;
+        if (epoch == 0) epoch = 1;
+    }
+    D.epoch[e] = epoch;
+    return epoch;
+}
+__device__ __forceinline__ int4* hash_table(const DeviceState& D, int e)
+{
+    if (!D.hash) return nullptr;
+    if (D.hash_compact) return reinterpret_cast<int4*>(reinterpret_cast<uint2*>(D.hash) + (size_t)e * (D.hmask + 1));
+    return D.hash + (size_t)e * (D.hmask + 1);
+}
 __device__ __forceinline__ int child_get(const Problem& P, const DeviceState& D, const int32_t* tree, int4* tab, uint32_t epoch,
                                          int node, int a, int o)
 {
     if (!D.hash) return tree[(size_t)node * D.node_words + D.child_off + a * P.O + o];
     const uint64_t code = ((uint64_t)node * P.A + a) * P.O + o;
+    if (D.hash_compact) {
+        const uint2* t8 = reinterpret_cast<const uint2*>(tab);
+        const uint32_t key = (uint32_t)code | (epoch << 27);
+        for (uint32_t h = child_hash(code) & D.hmask;; h = (h + 1) & D.hmask) {
+            const uint2 en = t8[h];
+            if ((en.x >> 27) != epoch) return -1;
+            if (en.x == key) return (int)en.y;
+        }
+    }
     const uint32_t lo = (uint32_t)code, hi = (uint32_t)(code >> 32) | (epoch << 4);
     for (uint32_t h = child_hash(code) & D.hmask;; h = (h + 1) & D.hmask) {
         const int4 e = tab[h];
@@ -119,6 +153,15 @@ __device__ __forceinline__ void child_set(const Problem& P, const DeviceState& D
         return;
     }
     const uint64_t code = ((uint64_t)node * P.A + a) * P.O + o;
+    if (D.hash_compact) {
+        uint2* t8 = reinterpret_cast<uint2*>(tab);
+        for (uint32_t h = child_hash(code) & D.hmask;; h = (h + 1) & D.hmask) {
+            if ((t8[h].x >> 27) != epoch) {
+                t8[h] = make_uint2((uint32_t)code | (epoch << 27), (uint32_t)child);
+                return;
+            }
+        }
+    }
     const uint32_t lo = (uint32_t)code, hi = (uint32_t)(code >> 32) | (epoch << 4);
     for (uint32_t h = child_hash(code) & D.hmask;; h = (h + 1) & D.hmask) {
         if (((uint32_t)tab[h].y >> 4) != epoch) {
@@ -331,13 +374,8 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
     double root_L = D.log1p_tab[0];
     if (root_lds)
         for (int k = 0; k < P.A * P.O; ++k) rootch[k * SEARCH_BLOCK] = -1;
-    int4* tab      = D.hash ? D.hash + (size_t)e * (D.hmask + 1) : nullptr;
-    uint32_t epoch = 0;
-    if (D.hash) {
-        epoch      = (D.epoch[e] + 1) & 0x0fffffffu;
-        if (epoch == 0) epoch = 1;
-        D.epoch[e] = epoch;
-    }
+    int4* tab      = hash_table(D, e);
+    const uint32_t epoch = D.hash ? hash_begin_search(D, e, tab, 0, 1) : 0;
 
     const bool lazy = slot_lazy(D, e);  // particle states are still the episode's start-state draws (lazy_state)
     // -P ts: TSPlanner / BATSPlanner (src/planners/ts/TSPlanner.cpp:16-29, bayes-adaptive/BATSPlanner.cpp:19-34) sample
@@ -519,7 +557,9 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, De
     const int W         = D.node_words;
     int32_t* tree       = D.nodes + (size_t)e * D.max_nodes * W;
     const float* prec   = D.p_rec + pbase(P, e, D.bufsel[e]) * (size_t)P.Cs;
-    const int hist_n    = D.hist_len[e];  // entries in every record of this slot
+    const uint32_t hist_cnt = D.hist_cnt[e];  // entries of each action in every record of this slot, and where each group starts
+    const int hist_n        = hist_total(hist_cnt);
+    const uint32_t hist_off = (uint32_t)hist_offset(hist_cnt, 1) << 8 | (uint32_t)hist_offset(hist_cnt, 2) << 16 | (uint32_t)hist_offset(hist_cnt, 3) << 24;
 
     if (P.planner == FBA_PLANNER_RANDOM) {  // RandomPlanner::selectAction RandomPlanner.cpp:14-24
         g.stream(FBA_PHASE_SEARCH, (uint32_t)P.sims);
@@ -536,10 +576,8 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, De
 #pragma unroll
     for (int a = 0; a < AMAX; ++a) { r_cn[a] = 0; r_cq[a] = 0.0; }
     double root_L = D.log1p_tab[0];
-    int4* tab      = D.hash + (size_t)e * (D.hmask + 1);
-    uint32_t epoch = (D.epoch[e] + 1) & 0x0fffffffu;
-    if (epoch == 0) epoch = 1;
-    D.epoch[e] = epoch;
+    int4* tab      = hash_table(D, e);
+    const uint32_t epoch = hash_begin_search(D, e, tab, g.q, HIST_QUAD);
 
     int ts_src = -1;
     if (P.planner == FBA_PLANNER_TS) {  // TSPlanner / BATSPlanner: one belief sample, then the search from that particle
@@ -567,8 +605,8 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, De
                 stage[(4 * k + 3) * HIST_TREES] = v.w;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the other lanes' pieces (LDS operations of one wave complete in order)
-            sp        = gridworld_pack_state(P.gw, (int)stage[0]);
             hist_mask = stage[1 * HIST_TREES];
+            sp        = (hist_mask >> 16) & 0x3ffu;
             node = 0; dtg = max_tree_depth; plen = 0; mode = 1;
         }
         bool finish = false, do_step = true;
@@ -586,7 +624,8 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, De
             }
             int o;
             double r;
-            const bool term = gridworld_hist_step_quad<K, HIST_TREES>(P, g, stage + 2 * HIST_TREES, hist_n, hist_mask, sp, a, o, r);
+            const bool term = gridworld_hist_step_quad<K, HIST_TREES>(P, g, stage + (size_t)(2 + ((hist_off >> (8 * a)) & 0xffu)) * HIST_TREES,
+                                                                      hist_count(hist_cnt, a), hist_mask, sp, a, o, r);
             ++steps;
             if (mode == 1) {  // traverseChanceNode
                 path_r[(size_t)plen * HIST_TREES]  = (float)r;
@@ -846,26 +885,33 @@ __device__ __forceinline__ void gather_records_side(float* __restrict__ dst, con
     }
 }
 
-// History particles (fba_device.h): output record j = source record s_src[j] -- its state word replaced, its structure
-// bits kept, its `len` entries copied -- with the source particle's pending entry (side row {new state, entry})
-// appended as entry `len`.  A power-of-two group of lanes moves one record in 16-byte pieces.
+// History particles (fba_device.h): output record j = source record s_src[j] -- its state replaced, its structure
+// bits kept -- with the source particle's pending entry (side row {new state, entry}) inserted as word `ins`, the
+// end of its action's group: the `len` entries behind it move up by one.  A power-of-two group of lanes moves
+// one record in 16-byte pieces.
 __device__ __forceinline__ void gather_hist_records(float* __restrict__ dst, const float* __restrict__ src, const int32_t* s_src,
-                                                    const int32_t* __restrict__ side, int len, int m, int C4, int group, int nthreads)
+                                                    const int32_t* __restrict__ side, int len, int ins, int m, int C4, int group, int nthreads)
 {
     const int gid = threadIdx.x / group, part0 = threadIdx.x % group, ngroups = nthreads / group;
     const int n4 = (len + 6) >> 2;  // pieces that hold words 0 .. 2 + len
-    const int at = 2 + len;         // the word the new entry goes to
     for (int j = gid; j < m; j += ngroups) {
         const int p      = s_src[j];
-        const float4* sp = reinterpret_cast<const float4*>(src) + (size_t)p * C4;
-        float4* dp       = reinterpret_cast<float4*>(dst) + (size_t)j * C4;
+        const uint4* sp  = reinterpret_cast<const uint4*>(src) + (size_t)p * C4;
+        uint4* dp        = reinterpret_cast<uint4*>(dst) + (size_t)j * C4;
         const int2 sd    = *reinterpret_cast<const int2*>(side + (size_t)p * 2);
         for (int part = part0; part < n4; part += group) {
-            float4 v = sp[part];
-            if (part == 0) v.x = __int_as_float(sd.x);
-            const int d = at - part * 4;
-            const float f = __int_as_float(sd.y);
-            if (d == 0) v.x = f; else if (d == 1) v.y = f; else if (d == 2) v.z = f; else if (d == 3) v.w = f;
+            const uint4 cur = sp[part];
+            const uint32_t before = part > 0 ? sp[part - 1].w : 0u;
+            const int w0 = part * 4;
+            uint4 v;
+            v.x = w0 + 0 < ins ? cur.x : (w0 + 0 == ins ? (uint32_t)sd.y : before);
+            v.y = w0 + 1 < ins ? cur.y : (w0 + 1 == ins ? (uint32_t)sd.y : cur.x);
+            v.z = w0 + 2 < ins ? cur.z : (w0 + 2 == ins ? (uint32_t)sd.y : cur.y);
+            v.w = w0 + 3 < ins ? cur.w : (w0 + 3 == ins ? (uint32_t)sd.y : cur.z);
+            if (part == 0) {  // the new state, as an index and as hist_pack (= the step's s')
+                v.x = (uint32_t)sd.x;
+                v.y = (v.y & 0xffffu) | ((((uint32_t)sd.y >> 10) & 0x3ffu) << 16);
+            }
             dp[part] = v;
         }
     }
@@ -1348,8 +1394,9 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
         __syncthreads();
     }
     const int a = D.action[e], o = D.obs[e], N = P.N;
-    const int hist_n = HIST ? D.hist_len[e] : 0;
-    if (HIST && hist_n >= P.hist_cap) {  // more real steps than the records were sized for (episodes * (horizon + 1)): only the per-step interface can get here
+    const uint32_t hist_cnt = HIST ? D.hist_cnt[e] : 0u;
+    const int hist_n = hist_total(hist_cnt);
+    if (HIST && hist_n >= P.hist_cap) {  // more real steps than the records were sized for (episodes * horizon): only the per-step interface can get here
         if (tid == 0) {
             atomicCAS(D.fault, 0, 0x40000000 + e);
             D.need_update[e] = 0;
@@ -1377,10 +1424,10 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
         double r;
         if (HIST) {
             const uint32_t* rec = reinterpret_cast<const uint32_t*>(cnt);
-            uint32_t sp = gridworld_pack_state(P.gw, s), entry;
+            uint32_t sp = (rec[1] >> 16) & 0x3ffu, entry;
             double prob;
-            gridworld_hist_step(P, g, GlobalEntries{rec + 2}, hist_n, rec[1], sp, a, so, r, entry, o, prob);
-            *reinterpret_cast<int2*>(side + (size_t)i * 2) = make_int2(gridworld_unpack_state(P.gw, sp), (int)entry);
+            gridworld_hist_step(P, g, rec + 2 + hist_offset(hist_cnt, a), hist_count(hist_cnt, a), rec[1], sp, a, so, r, entry, o, prob);
+            *reinterpret_cast<int2*>(side + (size_t)i * 2) = make_int2(gridworld_unpack_state(P, sp), (int)entry);
             sw[i] *= prob;
             continue;
         }
@@ -1418,7 +1465,7 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
         }
         __syncthreads();
         const int m = min(IS_BLOCK, N - j0);
-        if (HIST) gather_hist_records(dcn + (size_t)j0 * P.Cs, scn, s_src, side, hist_n, m, C4, group, IS_BLOCK);
+        if (HIST) gather_hist_records(dcn + (size_t)j0 * P.Cs, scn, s_src, side, hist_n, 2 + hist_offset(hist_cnt, a) + hist_count(hist_cnt, a), m, C4, group, IS_BLOCK);
         else if (defer) gather_records_side(dcn + (size_t)j0 * P.Cs, scn, s_src, side, D.side_w, m, C4, P.C, group, IS_BLOCK, TIGER_TABLE == 2);
         else gather_records(dcn + (size_t)j0 * P.Cs, scn, nullptr, s_src, nullptr, 0, 0, nullptr, m, C4, P.C, group, IS_BLOCK);
         __syncthreads();
@@ -1431,7 +1478,7 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
         D.upd_particles[e] += (unsigned long long)N;
         D.cur[e].update_count = -1;
         D.cur[e].weight_total = total;
-        if (HIST) D.hist_len[e] = hist_n + 1;
+        if (HIST) D.hist_cnt[e] = hist_cnt + (1u << (8 * a));
         if (P.cheat) {  // CheatingReinvigoration::updateEstimation (CheatingReinvigoration.cpp:117-124)
             double lik = D.lik[e] * total;
             if (det_log(lik) < D.lik[P.E]) {
@@ -1689,12 +1736,13 @@ __global__ void __launch_bounds__(256) init_kernel(Problem P, DeviceState D, int
         for (int i = i_lo + tid; i < i_hi; i += 256) {
             g.stream(FBA_PHASE_INIT, (uint32_t)i);
             uint32_t* rec = reinterpret_cast<uint32_t*>(recs + (size_t)i * P.Cs);
-            rec[0] = (uint32_t)domain_start(P, g);
+            const int s0 = domain_start(P, g);
+            rec[0] = (uint32_t)s0;
             uint32_t mask = 0;
             if (P.structure_prior == FBA_SP_MATCH_UNIFORM)
                 for (int k = 0; k < 2 * P.A; ++k)
                     if (g.boolean()) mask |= 1u << k;
-            rec[1] = mask;
+            rec[1] = mask | (gridworld_pack_state(P, s0) << 16);
             D.p_weight[pb + i] = w1h;
         }
         return;
@@ -1757,11 +1805,7 @@ __global__ void __launch_bounds__(256) reset_kernel(Problem P, DeviceState D, in
     }
     const int C4 = P.Cs / 4, group = record_group(C4);
     const double w1 = 1.0 / (double)P.N;
-    const int hist_n = P.hist ? D.hist_len[e] : 0;
-    if (P.hist && hist_n >= P.hist_cap) {  // see importance_kernel
-        if (tid == 0 && blockIdx.x == 0) atomicCAS(D.fault, 0, 0x40000000 + e);
-        return;
-    }
+    const int hist_n = P.hist ? hist_total(D.hist_cnt[e]) : 0;
     for (int j0 = i_lo; j0 < i_hi; j0 += 256) {
         const int j = j0 + tid;
         if (j < i_hi) {
@@ -1773,17 +1817,18 @@ __global__ void __launch_bounds__(256) reset_kernel(Problem P, DeviceState D, in
         __syncthreads();
         const int m = min(256, i_hi - j0);
         if (P.hist) {
-            // the copy of the drawn particle with a "start" entry appended: the next step's rows are those of the new state
-            const int gid = tid / group, part0 = tid % group, ngroups = 256 / group, n4 = (hist_n + 6) >> 2, at = 2 + hist_n;
+            // the copy of the drawn particle (state, structure bits, entries) with its new start state
+            const int gid = tid / group, part0 = tid % group, ngroups = 256 / group, n4 = (hist_n + 5) >> 2;
             for (int q = gid; q < m; q += ngroups) {
                 const float4* sp4 = reinterpret_cast<const float4*>(D.p_rec + sb * (size_t)P.Cs) + (size_t)s_src[q] * C4;
                 float4* dp4       = reinterpret_cast<float4*>(D.p_rec + (db + j0) * (size_t)P.Cs) + (size_t)q * C4;
-                const float fs = __int_as_float(s_ns[q]), fe = __uint_as_float(HIST_START | gridworld_pack_state(P.gw, s_ns[q]));
+                const uint32_t nsp = gridworld_pack_state(P, s_ns[q]);
                 for (int part = part0; part < n4; part += group) {
                     float4 v = sp4[part];
-                    if (part == 0) v.x = fs;
-                    const int d = at - part * 4;
-                    if (d == 0) v.x = fe; else if (d == 1) v.y = fe; else if (d == 2) v.z = fe; else if (d == 3) v.w = fe;
+                    if (part == 0) {
+                        v.x = __int_as_float(s_ns[q]);
+                        v.y = __uint_as_float((__float_as_uint(v.y) & 0xffffu) | (nsp << 16));
+                    }
                     dp4[part] = v;
                 }
             }
@@ -1824,7 +1869,7 @@ __global__ void post_init_kernel(Problem P, DeviceState D)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= P.E) return;
-    if (P.hist && D.need_init[e]) D.hist_len[e] = 0;
+    if (P.hist && D.need_init[e]) D.hist_cnt[e] = 0;
     D.need_init[e] = 0;
 }
 __global__ void post_reset_kernel(Problem P, DeviceState D)
@@ -1832,7 +1877,6 @@ __global__ void post_reset_kernel(Problem P, DeviceState D)
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= P.E || D.need_reset[e] != 1) return;
     if (P.belief == FBA_BELIEF_IMPORTANCE && !P.cheat) D.bufsel[e] ^= 1;
-    if (P.hist && D.hist_len[e] < P.hist_cap) D.hist_len[e] += 1;  // the start entry reset_kernel appended
     D.need_reset[e] = 0;
 }
 
@@ -1843,38 +1887,37 @@ __global__ void post_reset_kernel(Problem P, DeviceState D)
 // History particles: the same checksum over the particle's whole count table -- walked cell by cell in the dense
 // layout, prior value plus the number of entries that incremented the cell -- without ever building the table.
 // hist_next_cell: the smallest incremented cell index >= kmin and how many entries incremented it.
-__device__ void hist_next_cell(const Problem& P, const uint32_t* rec, int len, int kmin, int& nxt, int& mult)
+__device__ void hist_next_cell(const Problem& P, const uint32_t* rec, uint32_t cnt, int kmin, int& nxt, int& mult)
 {
-    const int N = P.gw->N, G = P.gw->G, A = P.A;
+    const int N = P.gw_N, G = P.gw_G, A = P.A;
     const int XY = N * N * G * N, GG = N * N * G * G, NN = N * N;
     const uint32_t mask = rec[1];
     nxt = 0x7fffffff; mult = 0;
-    uint32_t prev = 0;
-    for (int t = 0; t < len; ++t) {
-        const uint32_t en = rec[2 + t];
-        if (!(en >> 31)) {
-            const int a = (int)(en >> 24), x = (int)(prev & 15u), y = (int)((prev >> 4) & 15u), gl = (int)(prev >> 8);
-            const int tbase = a * (2 * XY + GG), obase = A * (2 * XY + GG) + a * (2 * NN + G * G), cell = x * N + y;
-            const bool mx = (mask >> (2 * a)) & 1u, my = (mask >> (2 * a + 1)) & 1u;
-            const int c[6] = {tbase + (mx ? cell * G + gl : cell) * N + (int)(en & 15u),
-                              tbase + XY + (my ? cell * G + gl : cell) * N + (int)((en >> 4) & 15u),
-                              tbase + 2 * XY + (cell * G + gl) * G + (int)((en >> 8) & 15u),
-                              obase + x * N + (int)((en >> 12) & 15u),
-                              obase + NN + y * N + (int)((en >> 16) & 15u),
-                              obase + 2 * NN + gl * G + (int)((en >> 20) & 15u)};
+    int j = 0;
+    for (int a = 0; a < A; ++a) {
+        const int tbase = a * (2 * XY + GG), obase = A * (2 * XY + GG) + a * (2 * NN + G * G);
+        const bool mx = (mask >> (2 * a)) & 1u, my = (mask >> (2 * a + 1)) & 1u;
+        for (int q = 0; q < hist_count(cnt, a); ++q, ++j) {
+            const uint32_t en = rec[2 + j], s0 = en & 0x3ffu, s1 = (en >> 10) & 0x3ffu, ob = en >> 20;
+            const int x = hist_x(s0), y = hist_y(s0), gl = hist_g(s0), cell = x * N + y;
+            const int c[6] = {tbase + (mx ? cell * G + gl : cell) * N + hist_x(s1),
+                              tbase + XY + (my ? cell * G + gl : cell) * N + hist_y(s1),
+                              tbase + 2 * XY + (cell * G + gl) * G + hist_g(s1),
+                              obase + x * N + hist_x(ob),
+                              obase + NN + y * N + hist_y(ob),
+                              obase + 2 * NN + gl * G + hist_g(ob)};
 #pragma unroll
-            for (int q = 0; q < 6; ++q)
-                if (c[q] >= kmin) {
-                    if (c[q] < nxt) { nxt = c[q]; mult = 1; }
-                    else if (c[q] == nxt) ++mult;
+            for (int k = 0; k < 6; ++k)
+                if (c[k] >= kmin) {
+                    if (c[k] < nxt) { nxt = c[k]; mult = 1; }
+                    else if (c[k] == nxt) ++mult;
                 }
         }
-        prev = en & 0xfffu;
     }
 }
-__device__ uint64_t hist_hash_counts(const Problem& P, const uint32_t* rec, int len, uint64_t h)
+__device__ uint64_t hist_hash_counts(const Problem& P, const uint32_t* rec, uint32_t len, uint64_t h)
 {
-    const HistLayout L(P.gw->N, P.gw->G, P.A);
+    const HistLayout L(P.gw_N, P.gw_G, P.A);
     const int N = L.N, G = L.G, A = L.A, rows = N * N * G;
     const uint32_t mask = rec[1];
     int k = 0, nxt, mult;  // k: the cell's index in the dense table (the order the checksum is defined in)
@@ -1926,7 +1969,7 @@ __global__ void __launch_bounds__(256) flush_kernel(Problem P, DeviceState D)
         uint64_t h = mix64((uint64_t)i * 0x9E3779B97F4A7C15ull + (uint64_t)(uint32_t)st);
         const double w = (P.belief == FBA_BELIEF_IMPORTANCE) ? D.p_weight[pb + i] : 0.0;
         h = mix64(h ^ (uint64_t)__double_as_longlong(w));
-        if (P.hist) h = hist_hash_counts(P, reinterpret_cast<const uint32_t*>(cnt), D.hist_len[e], h);
+        if (P.hist) h = hist_hash_counts(P, reinterpret_cast<const uint32_t*>(cnt), D.hist_cnt[e], h);
         else if (P.packed) {  // the checksum is over the counts themselves, whatever the storage (PackedView)
             const PackedView<GlobalView> pv{GlobalView{cnt}, D.prior_dense};
             const int dense = P.phi_len + P.A * P.S * P.O;

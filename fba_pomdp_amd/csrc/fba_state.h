@@ -57,7 +57,7 @@ struct DeviceState {
     uint8_t* cheat_pending;  // [E] the update of this tick pushed log(likelihood) below the threshold
     int32_t* p_side;    // [E][N][side_w] importance filters: {new state, cells to increment} of the pending update (side_w = 1 + FS + FO;
                         // history particles: {new state, the step's entry})
-    int32_t* hist_len;  // [E] history particles: entries every record of the slot holds (one per belief update and per reset of the run so far)
+    uint32_t* hist_cnt; // [E] history particles: how many entries of action a every record of the slot holds, 8 bits per action (fba_device.h)
     int32_t side_w;
     double* wscan;      // [E][N] scratch: inclusive device-order prefix sums of normalised weights
     double* ctot;       // [E][N/256 + 2] scratch: chunk totals / carries of the multi-workgroup filter
@@ -76,6 +76,7 @@ struct DeviceState {
     // the table is never cleared: an entry of an older search reads as empty
     int4* hash;         // [E][hmask + 1] or null (dense child table inside the node record)
     uint32_t hmask;
+    int32_t hash_compact;  // 8-byte entries {epoch << 27 | code, child} instead (codes below 2^27): fba_kernels.hip child_get
     uint32_t* epoch;    // [E]
     const double* log1p_tab; // [sims + 1]
     // --- outputs ---

@@ -379,7 +379,7 @@ def test_history_particles_equal_dense_ones(size, sp, noise, monkeypatch):
     kw = dict(model=N.MODEL_BA_FACTORED, belief="importance_sampling", seed=131 + size, size=size, particles=96, sims=120, runs=6,
               slots=6, episodes=3, horizon=9, structure_prior=sp, noise=noise, trace=1)
     hist = fba.Engine("gridworld", **kw)
-    assert hist.particle_bytes == 4 * ((2 + 3 * 10 + 3) // 4 * 4)          # state, structure bits, episodes * (horizon + 1) entries
+    assert hist.particle_bytes == 4 * ((2 + 3 * 9 + 3) // 4 * 4)           # state, structure bits, episodes * horizon entries
     monkeypatch.setenv("FBA_DENSE_PARTICLES", "1")
     dense = fba.Engine("gridworld", **kw)
     monkeypatch.delenv("FBA_DENSE_PARTICLES")
@@ -409,7 +409,7 @@ def test_history_particles_refuse_more_steps_than_they_hold():
     eng.belief_init()
     eng.belief_reset_domain_state()
     eng.belief_update(0, 0)
-    eng.belief_update(1, 0)                      # episodes * (horizon + 1) = 3 entries: full
+    eng.belief_update(1, 0)                      # episodes * horizon = 2 entries: full
     with pytest.raises(fba.FbaError, match="FBA_DENSE_PARTICLES"):
         eng.belief_update(0, 0)
     with pytest.raises(ValueError, match="FBA_DENSE_PARTICLES"):
