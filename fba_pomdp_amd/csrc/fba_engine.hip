@@ -63,7 +63,7 @@ struct fba_ctx {
     std::vector<EventPair> free_events;
     double k_ms[FBA_K_COUNT]          = {0};
     uint64_t k_launches[FBA_K_COUNT]  = {0};
-    uint64_t base_sim = 0, base_attempts = 0, base_particles = 0;
+    uint64_t base_sim = 0, base_attempts = 0, base_particles = 0, base_entries = 0;
     std::vector<fba_trace_rec> trace_host;
 };
 
@@ -1405,6 +1405,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     CHK(dev_alloc(c, &D.upd_particles, E));
     CHK(dev_alloc(c, &D.ep_sums, (size_t)3 * E));
     CHK(dev_alloc(c, &D.upd_attempts, E));
+    CHK(dev_alloc(c, &D.upd_entries, E));
     CHK(dev_alloc(c, &D.cur, E));
     CHK(dev_alloc(c, &D.trace_count, 1));
     CHK(dev_alloc(c, &c->d_n_active, 1));
@@ -1851,6 +1852,7 @@ int fba_get_kernel_times(fba_ctx* c, fba_kernel_time* out)
     const uint64_t sim       = sum_counter(c, c->D.sim_steps, P.E, &rc) - c->base_sim;
     const uint64_t attempts  = sum_counter(c, c->D.upd_attempts, P.E, &rc) - c->base_attempts;
     const uint64_t particles = sum_counter(c, c->D.upd_particles, P.E, &rc) - c->base_particles;
+    const uint64_t entries   = sum_counter(c, c->D.upd_entries, P.E, &rc) - c->base_entries;
     if (rc) return rc;
     // algorithmic bytes, SURVEY.md section 8(d): Pb = particle payload, Rt / Ro = bytes of the
     // transition / observation rows one step consults
@@ -1880,6 +1882,10 @@ int fba_get_kernel_times(fba_ctx* c, fba_kernel_time* out)
     } else {
         out[FBA_K_BELIEF_IS].units = particles;
         out[FBA_K_BELIEF_IS].bytes = particles * (32 + Rt + Ro) + particles * (8 + 2 * Pb);
+        // history particles (alternative formula, stated in DESIGN.md section 5 before it was measured): per particle the
+        // weight read and written (16), the record -- 8 bytes + 4 per entry -- read once by the update, once as a
+        // resample source, written once with its new entry (+4); the Dirichlet rows come from the shared tables
+        if (P.hist) out[FBA_K_BELIEF_IS].bytes = particles * 44 + entries * 12;
     }
     return FBA_OK;
 }
@@ -1893,6 +1899,7 @@ int fba_reset_kernel_times(fba_ctx* c)
     c->base_sim       = sum_counter(c, c->D.sim_steps, c->P.E, &rc);
     c->base_attempts  = sum_counter(c, c->D.upd_attempts, c->P.E, &rc);
     c->base_particles = sum_counter(c, c->D.upd_particles, c->P.E, &rc);
+    c->base_entries   = sum_counter(c, c->D.upd_entries, c->P.E, &rc);
     return rc;
 }
 

@@ -1478,7 +1478,10 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
         D.upd_particles[e] += (unsigned long long)N;
         D.cur[e].update_count = -1;
         D.cur[e].weight_total = total;
-        if (HIST) D.hist_cnt[e] = hist_cnt + (1u << (8 * a));
+        if (HIST) {
+            D.hist_cnt[e] = hist_cnt + (1u << (8 * a));
+            D.upd_entries[e] += (unsigned long long)N * (unsigned long long)hist_n;
+        }
         if (P.cheat) {  // CheatingReinvigoration::updateEstimation (CheatingReinvigoration.cpp:117-124)
             double lik = D.lik[e] * total;
             if (det_log(lik) < D.lik[P.E]) {

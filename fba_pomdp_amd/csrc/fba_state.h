@@ -90,6 +90,7 @@ struct DeviceState {
     double* ep_sums;    // [E][3] finished episodes of this slot: count, sum of returns, sum of squares
     unsigned long long* upd_particles; // [E] particles written by belief updates
     unsigned long long* upd_attempts;  // [E] rejection attempts / importance particles stepped
+    unsigned long long* upd_entries;   // [E] history particles: sum over updates of N * (entries per record before the update)
     fba_trace_rec* cur;  // [E] record being assembled for the current tick
     fba_trace_rec* trace; // [trace_cap]
     int32_t* trace_count;
