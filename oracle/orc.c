@@ -1788,6 +1788,16 @@ static double rollout(orc_ctx* c, simstate* st, int depth_to_go)
 
 static double traverse_action(orc_ctx* c, int32_t node, simstate* st, int depth_to_go);
 
+/* ref: ChanceNode::addVisit MCTSTreeNodes.cpp:8-12: n++; q += (r - q) / n  (pinned by golden["mcts_nodes"]) */
+void orc_chance_add_visit(int32_t* n, double* q, double ret)
+{
+    (*n)++;
+    *q += (ret - *q) / *n;
+}
+/* BADomainExtension::terminal / reward of the ctx's domain (pinned by golden["ext_*"]) */
+int orc_ext_terminal(orc_ctx* c, int32_t s, int32_t a, int32_t ns) { return ext_terminal(c, s, a, ns); }
+double orc_ext_reward(orc_ctx* c, int32_t s, int32_t a, int32_t ns) { return ext_reward(c, s, a, ns); }
+
 /* ref: POUCT::traverseChanceNode POUCT.cpp:210-257 (= RBAPOUCT.cpp:233-277) */
 static double traverse_chance(orc_ctx* c, int32_t node, int32_t a, simstate* st, int depth_to_go)
 {
@@ -1805,9 +1815,7 @@ static double traverse_chance(orc_ctx* c, int32_t node, int32_t a, simstate* st,
         }
     }
     ret = r + c->gamma * delayed;
-    /* ChanceNode::addVisit MCTSTreeNodes.cpp:8-12 */
-    c->tr.cn[node * c->A + a]++;
-    c->tr.cq[node * c->A + a] += (ret - c->tr.cq[node * c->A + a]) / c->tr.cn[node * c->A + a];
+    orc_chance_add_visit(&c->tr.cn[node * c->A + a], &c->tr.cq[node * c->A + a], ret);
     return ret;
 }
 

@@ -166,6 +166,9 @@ int orc_ftiger_set_structure(orc_ctx* c, float* cnt, uint32_t mask);
 double orc_gamma(orc_ctx* c, double shape);
 int orc_sample_sampled_mult(orc_ctx* c, const float* dir, int n);
 void orc_sample_mult(orc_ctx* c, const float* dir, int n, float* out);
+void orc_chance_add_visit(int32_t* n, double* q, double ret);
+int orc_ext_terminal(orc_ctx* c, int32_t s, int32_t a, int32_t ns);
+double orc_ext_reward(orc_ctx* c, int32_t s, int32_t a, int32_t ns);
 double orc_det_log(double x);
 double orc_det_exp(double x);
 

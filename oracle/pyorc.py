@@ -109,6 +109,11 @@ def lib():
         L.orc_ctx_rng.argtypes = [C.c_void_p]
         L.orc_env_step.argtypes = [C.c_void_p, P(C.c_int32), C.c_int32, P(C.c_int32), P(C.c_double)]
         L.orc_env_start.argtypes = [C.c_void_p]
+        L.orc_chance_add_visit.argtypes = [P(C.c_int32), P(C.c_double), C.c_double]
+        L.orc_chance_add_visit.restype = None
+        L.orc_ext_terminal.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+        L.orc_ext_reward.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+        L.orc_ext_reward.restype = C.c_double
         L.orc_random_action.argtypes = [C.c_void_p, C.c_int32]
         L.orc_belief_initiate.argtypes = [C.c_void_p]
         L.orc_belief_update.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
@@ -213,6 +218,9 @@ class Oracle:
         if getattr(self, "h", None):
             self.L.orc_destroy(self.h)
             self.h = None
+
+    def sizes(self):
+        return self.S, self.A, self.O
 
     @property
     def rng(self):

@@ -9,7 +9,9 @@
  *
  * Not buildable here (they include <boost/program_options.hpp> through configurations/Conf.hpp):
  * planners/mcts/POUCT.cpp, planners/bayes-adaptive/RBAPOUCT.cpp,
- * bayes-adaptive/models/table/BAPOMDP.cpp, every *Priors.cpp and every factory.
+ * bayes-adaptive/models/table/BAPOMDP.cpp, every *Priors.cpp and every factory.  Every other
+ * translation unit on the hot path is driven here: the tree nodes (MCTSTreeNodes.cpp), the BA / FBA
+ * domain extensions, the BAState wrappers.
  */
 #include <cstdio>
 #include <cstring>
@@ -21,6 +23,17 @@
 #include "bayes-adaptive/models/Domain_Size.hpp"
 #include "bayes-adaptive/models/factored/Domain_Feature_Size.hpp"
 #include "bayes-adaptive/states/factored/BABNModel.hpp"
+#include "bayes-adaptive/states/factored/FBAPOMDPState.hpp"
+#include "bayes-adaptive/states/table/BAPOMDPState.hpp"
+#include "domains/collision-avoidance/CollisionAvoidanceBAExtension.hpp"
+#include "domains/collision-avoidance/CollisionAvoidanceFBAExtension.hpp"
+#include "domains/gridworld/GridWorldBAExtension.hpp"
+#include "domains/gridworld/GridWorldFBAExtension.hpp"
+#include "domains/sysadmin/SysAdminFBAExtension.hpp"
+#include "domains/tiger/FactoredTigerBAExtension.hpp"
+#include "domains/tiger/FactoredTigerFBAExtension.hpp"
+#include "domains/tiger/TigerBAExtension.hpp"
+#include "planners/mcts/MCTSTreeNodes.hpp"
 #include "bayes-adaptive/states/table/BAFlatModel.hpp"
 #include "beliefs/particle_filters/FlatFilter.hpp"
 #include "beliefs/particle_filters/ImportanceSampler.hpp"
@@ -637,6 +650,232 @@ static void expected_mult()
     printf("]");
 }
 
+/* BADomainExtension::domainSize / terminal(s, a, s') / reward(s, a, s') as full tables (TigerBAExtension.cpp:21-44,
+ * FactoredTigerBAExtension.cpp, GridWorldBAExtension.cpp:74-100, CollisionAvoidanceBAExtension.cpp:53-82):
+ * pins which of s and s' each extension looks at. */
+static void ext_tables(BADomainExtension const& ext)
+{
+    Domain_Size const sz = ext.domainSize();
+    std::vector<int> term;
+    std::vector<double> rew;
+    for (int s = 0; s < sz._S; ++s)
+        for (int a = 0; a < sz._A; ++a)
+            for (int ns = 0; ns < sz._S; ++ns) {
+                IndexAction ia(a);
+                State const* x = ext.getState(s);
+                State const* y = ext.getState(ns);
+                term.push_back(ext.terminal(x, &ia, y).terminated() ? 1 : 0);
+                rew.push_back(ext.reward(x, &ia, y).toDouble());
+            }
+    printf("{\"S\": %d, \"A\": %d, \"O\": %d, \"terminal\": ", sz._S, sz._A, sz._O);
+    arr(term, pi);
+    printf(", \"reward\": ");
+    arr(rew, pd);
+    printf("}");
+}
+static void feature_sizes(FBADomainExtension const& ext)
+{
+    Domain_Feature_Size const f = ext.domainFeatureSize();
+    printf("{\"S\": ");
+    arr(f._S, pi);
+    printf(", \"O\": ");
+    arr(f._O, pi);
+    printf("}");
+}
+
+/* ChanceNode::addVisit / ActionNode::addVisit / child bookkeeping (MCTSTreeNodes.cpp:8-62): a three-action root whose
+ * chance nodes receive a seeded sequence of returns; visit counts and running-mean Q after every visit. */
+static void mcts_nodes(char const* s)
+{
+    seed(s);
+    IndexAction a0(0), a1(1), a2(2);
+    std::vector<Action const*> legal({&a0, &a1, &a2});
+    ActionNode root(legal);
+    ActionNode leaf(legal);
+    std::vector<int> which, visits, has;
+    std::vector<double> rets, qs;
+    for (int i = 0; i < 400; ++i) {
+        int const a   = rnd::slowRandomInt(0, 3);
+        double const r = (rnd::uniform_rand01() < .3 ? -100.0 : 10.0) * rnd::uniform_rand01() - (double)(i % 7);
+        ChanceNode& c  = *(root.begin() + a);
+        c.addVisit(r);
+        root.addVisit();
+        which.push_back(a);
+        rets.push_back(r);
+        visits.push_back(c.visited());
+        visits.push_back(root.visited());
+        qs.push_back(c.qValue());
+        int const o = i % 5;
+        has.push_back(c.hasChild(o) ? 1 : 0);
+        if (!c.hasChild(o)) c.addChild(o, &leaf);
+        has.push_back(c.child(o) == &leaf ? 1 : 0);
+    }
+    printf("{\"seed\": \"%s\", \"action\": ", s);
+    arr(which, pi);
+    printf(", \"ret\": ");
+    arr(rets, pd);
+    printf(", \"visits\": ");
+    arr(visits, pi);
+    printf(", \"q\": ");
+    arr(qs, pd);
+    printf(", \"child\": ");
+    arr(has, pi);
+    printf("}");
+}
+
+/* BAPOMDPState (BAPOMDPState.cpp) through the BAState interface: sampleStateIndex / sampleObservationIndex /
+ * computeObservationProbability / incrementCountsOf on the counts of flat_model(), with a copy() taken half way
+ * whose counts must not move afterwards (deep copy, BAPOMDPState.cpp copy()). */
+static void bapomdp_state(char const* s)
+{
+    Domain_Size sz(2, 3, 2);
+    bayes_adaptive::table::BAFlatModel m(&sz);
+    for (int st = 0; st < 2; ++st)
+        for (int a = 0; a < 3; ++a)
+            for (int ns = 0; ns < 2; ++ns) {
+                IndexState x(st), y(ns);
+                IndexAction ia(a);
+                m.count(&x, &ia, &y) = (a == 2) ? ((st == ns) ? 5000.f : 0.f) : 5000.f + 7.f * (float)(st + 2 * ns + a);
+            }
+    for (int a = 0; a < 3; ++a)
+        for (int ns = 0; ns < 2; ++ns)
+            for (int o = 0; o < 2; ++o) {
+                IndexState y(ns);
+                IndexAction ia(a);
+                IndexObservation io(o);
+                m.count(&ia, &y, &io) = (a == 2) ? ((ns == o) ? 8500.f : 1500.f) : 5000.f + 3.f * (float)(o + a);
+            }
+    IndexState dom(1);
+    BAPOMDPState state(&dom, m);
+    BAState* ba = &state;
+    BAState* frozen = nullptr;
+    seed(s);
+    std::vector<int> rec;
+    std::vector<double> probs;
+    int st = 1;
+    for (int i = 0; i < 200; ++i) {
+        if (i == 100) frozen = ba->copy(&dom);
+        int a = (i * 7) % 3;
+        IndexState x(st);
+        IndexAction ia(a);
+        int ns = ba->sampleStateIndex(&x, &ia, rnd::sample::Dir::sampleFromExpectedMult);
+        IndexState y(ns);
+        int o = ba->sampleObservationIndex(&ia, &y, rnd::sample::Dir::sampleFromExpectedMult);
+        IndexObservation io(o);
+        ba->incrementCountsOf(&x, &ia, &io, &y);
+        probs.push_back(ba->computeObservationProbability(&io, &ia, &y, rnd::sample::Dir::expectedMult));
+        rec.push_back(a);
+        rec.push_back(ns);
+        rec.push_back(o);
+        st = ns;
+    }
+    auto dump = [&](BAPOMDPState* b, char const* name) {
+        std::vector<double> all;
+        for (int s0 = 0; s0 < 2; ++s0)
+            for (int a = 0; a < 3; ++a)
+                for (int ns = 0; ns < 2; ++ns) {
+                    IndexState x(s0), y(ns);
+                    IndexAction ia(a);
+                    all.push_back(b->model()->count(&x, &ia, &y));
+                }
+        for (int a = 0; a < 3; ++a)
+            for (int ns = 0; ns < 2; ++ns)
+                for (int o = 0; o < 2; ++o) {
+                    IndexState y(ns);
+                    IndexAction ia(a);
+                    IndexObservation io(o);
+                    all.push_back(b->model()->count(&ia, &y, &io));
+                }
+        printf(", \"%s\": ", name);
+        arr(all, pd);
+    };
+    printf("{\"seed\": \"%s\", \"rec\": ", s);
+    arr(rec, pi);
+    printf(", \"obs_prob\": ");
+    arr(probs, pd);
+    dump(&state, "counts_after");
+    dump(static_cast<BAPOMDPState*>(frozen), "counts_of_copy_at_100");
+    printf(", \"domain_state_index\": %d}", ba->index());
+    delete frozen;
+}
+
+/* FBAPOMDPState (FBAPOMDPState.cpp) through the BAState interface on the model of babn_model({0, 2}); a copy() at
+ * step 60 must keep its counts. */
+static void fbapomdp_state(char const* s)
+{
+    using bayes_adaptive::factored::BABNModel;
+    Domain_Size sz(8, 3, 2);
+    Domain_Feature_Size fsz({2, 2, 2}, {2});
+    BABNModel::Indexing_Steps steps(indexing::stepSize(fsz._S), indexing::stepSize(fsz._O));
+    BABNModel m(&sz, &fsz, &steps);
+    IndexAction listen(2);
+    for (int f = 0; f < 3; ++f) {
+        m.resetTransitionNode(&listen, f, std::vector<int>({f}));
+        for (int v = 0; v < 2; ++v) m.transitionNode(&listen, f).count(std::vector<int>({v}), v) = 5000;
+    }
+    for (int a = 0; a < 2; ++a) {
+        IndexAction act(a);
+        for (int f = 0; f < 3; ++f)
+            for (int v = 0; v < 2; ++v) m.transitionNode(&act, f).count({}, v) = 5000 + 11.f * (float)(a + f + 2 * v);
+        m.observationNode(&act, 0).count({}, 0) = 5000;
+        m.observationNode(&act, 0).count({}, 1) = 4000;
+    }
+    std::vector<int> parents({0, 2});
+    m.resetObservationNode(&listen, 0, parents);
+    {
+        std::vector<int> pv(2, 0), pr(2, 2);
+        do {
+            m.observationNode(&listen, 0).count(pv, 0) = pv[0] == 0 ? 8500.f : 1500.f;
+            m.observationNode(&listen, 0).count(pv, 1) = pv[0] == 1 ? 8500.f : 1500.f;
+        } while (!indexing::increment(pv, pr));
+    }
+    IndexState dom(5);
+    FBAPOMDPState state(&dom, m);
+    BAState* ba     = &state;
+    BAState* frozen = nullptr;
+    seed(s);
+    std::vector<int> rec;
+    std::vector<double> probs;
+    int st = 5;
+    for (int i = 0; i < 120; ++i) {
+        if (i == 60) frozen = ba->copy(&dom);
+        int a = (i % 4 == 3) ? (i / 4) % 2 : 2;
+        IndexState x(st);
+        IndexAction ia(a);
+        int ns = ba->sampleStateIndex(&x, &ia, rnd::sample::Dir::sampleFromExpectedMult);
+        IndexState y(ns);
+        int o = ba->sampleObservationIndex(&ia, &y, rnd::sample::Dir::sampleFromExpectedMult);
+        IndexObservation io(o);
+        ba->incrementCountsOf(&x, &ia, &io, &y);
+        probs.push_back(ba->computeObservationProbability(&io, &ia, &y, rnd::sample::Dir::expectedMult));
+        rec.push_back(a);
+        rec.push_back(ns);
+        rec.push_back(o);
+        st = ns;
+    }
+    auto dump = [&](FBAPOMDPState* b, char const* name) {
+        std::vector<double> cpt;
+        std::vector<int> pv(2, 0), pr(2, 2);
+        do {
+            cpt.push_back(b->model()->observationNode(&listen, 0).count(pv, 0));
+            cpt.push_back(b->model()->observationNode(&listen, 0).count(pv, 1));
+        } while (!indexing::increment(pv, pr));
+        for (int f = 0; f < 3; ++f)
+            for (int v = 0; v < 2; ++v)
+                for (int w = 0; w < 2; ++w) cpt.push_back(b->model()->transitionNode(&listen, f).count(std::vector<int>({v}), w));
+        printf(", \"%s\": ", name);
+        arr(cpt, pd);
+    };
+    printf("{\"seed\": \"%s\", \"rec\": ", s);
+    arr(rec, pi);
+    printf(", \"obs_prob\": ");
+    arr(probs, pd);
+    dump(&state, "listen_O_T_after");
+    dump(static_cast<FBAPOMDPState*>(frozen), "listen_O_T_of_copy_at_60");
+    printf("}");
+    delete frozen;
+}
+
 int main(int argc, char** argv)
 {
     START_EASYLOGGINGPP(argc, argv);
@@ -757,6 +996,40 @@ int main(int argc, char** argv)
 
     key("statistic");
     statistic();
+
+    {
+        using namespace bayes_adaptive::domain_extensions;
+        key("ext_tiger_episodic");
+        { TigerBAExtension e(domains::Tiger::EPISODIC); ext_tables(e); }
+        key("ext_tiger_continuous");
+        { TigerBAExtension e(domains::Tiger::CONTINUOUS); ext_tables(e); }
+        key("ext_ftiger2_episodic");
+        { FactoredTigerBAExtension e(domains::FactoredTiger::EPISODIC, 2); ext_tables(e); }
+        key("ext_ftiger1_continuous");
+        { FactoredTigerBAExtension e(domains::FactoredTiger::CONTINUOUS, 1); ext_tables(e); }
+        key("ext_gridworld3");
+        { GridWorldBAExtension e(3); ext_tables(e); }
+        key("ext_gridworld4");
+        { GridWorldBAExtension e(4); ext_tables(e); }
+        key("ext_ca_5_3_1");
+        { CollisionAvoidanceBAExtension e(5, 3, 1); ext_tables(e); }
+        key("ext_ca_3_3_2");
+        { CollisionAvoidanceBAExtension e(3, 3, 2); ext_tables(e); }
+        key("fext_ftiger3");
+        { FactoredTigerFBAExtension e(3); feature_sizes(e); }
+        key("fext_gridworld7");
+        { GridWorldFBAExtension e(7); feature_sizes(e); }
+        key("fext_ca_5_3_2");
+        { CollisionAvoidanceFBAExtension e(5, 3, 2, domains::CollisionAvoidance::INIT_RANDOM_POSITION); feature_sizes(e); }
+        key("fext_sysadmin4");
+        { SysAdminFBAExtension e(4); feature_sizes(e); }
+    }
+    key("mcts_nodes");
+    mcts_nodes("70");
+    key("bapomdp_state");
+    bapomdp_state("71");
+    key("fbapomdp_state");
+    fbapomdp_state("72");
 
     key("expected_mult");
     expected_mult();
