@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- simulated env steps / sec (belief + rollout) of the BA-POMCP hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1: starts its own N worker processes, one per GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One "step" = one real time-step of every resident slot: RBAPOUCT search (`sims` simulations),
@@ -77,17 +77,43 @@ def cpu_baseline(args):
 
 
 def measured_traffic(args, kname, slots):
-    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes
-    (FETCH_SIZE and WRITE_SIZE in separate runs of this same command; profiles/*.json says how
-    they were collected and corrected).  None when the workload differs from the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write.json")
-    if not os.path.exists(path) or slots != 262144 or args.sims != 4096 or args.particles != 4096:
+    """HBM bytes of a FULL launch (every slot updates) of the roofline kernel from the committed rocprofv3 PMC
+    passes (FETCH_SIZE and WRITE_SIZE in separate runs of this same command; profiles/*.json says how they were
+    collected; FETCH_SIZE is corrected by the factor scripts/micro/pmc_calibrate measured for this kernel's access
+    shapes).  None when the workload differs from the profiled one."""
+    for tag in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", f"{tag}_pmc_fetch_write.json")
+        if os.path.exists(path):
+            break
+    else:
+        return None, None
+    if slots != 262144 or args.sims != 4096 or args.particles != 4096:
         return None, None
     with open(path) as f:
         d = json.load(f)
     if d.get("kernel") != kname:
         return None, None
-    return d["traffic_bytes_per_launch_raw"], "profiles/r01_pmc_fetch_write.json"
+    return d.get("traffic_bytes_per_launch_calibrated", d["traffic_bytes_per_launch_raw"]), os.path.relpath(path, ROOT)
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: this process starts N fresh workers (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment, as torch.distributed.run would) BEFORE anything here touches a GPU,
+    waits for them and leaves with the worst exit code.  Rank 0 prints the JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    sys.exit(rc)
 
 
 def main():
@@ -115,6 +141,8 @@ def main():
         cpu_worker(args)
         return
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)   # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -123,20 +151,37 @@ def main():
 
     import torch
     import torch.distributed as dist
-    if not torch.cuda.is_available():
+    ndev = torch.cuda.device_count()
+    if ndev < 1 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: fba_pomdp_amd has no CPU path")
-    if args.all_ranks_on_device is not None:
-        local_rank = args.all_ranks_on_device
+    # every rank its own GPU; with fewer GPUs than ranks (a 1-GPU rehearsal box) ranks share devices, round-robin
+    shared = world > ndev or args.all_ranks_on_device is not None
+    local_rank = args.all_ranks_on_device if args.all_ranks_on_device is not None else local_rank % ndev
     torch.cuda.set_device(local_rank)
     collective = None
     if world > 1:
-        try:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # nccl = RCCL on ROCm
-            collective = "rccl"
-        except Exception as e:  # the statistics reduce is 5 doubles: never lose a scaling run to the transport
-            print(f"[bench] RCCL process group failed ({e}); reducing over gloo instead", file=sys.stderr)
+        if shared:   # RCCL needs one GPU per rank ("Duplicate GPU detected"): the five doubles go over gloo, and the line says so
+            print(f"[bench] rank {rank}: {world} ranks on {ndev} GPU(s), device {local_rank} is shared -> statistics reduce over gloo",
+                  file=sys.stderr)
             dist.init_process_group(backend="gloo")
-            collective = "gloo"
+            collective = "gloo (ranks share a GPU)"
+        else:
+            try:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # nccl = RCCL on ROCm
+                probe = torch.ones(1, dtype=torch.float64, device="cuda")
+                dist.all_reduce(probe)                       # the communicator is built lazily: make it fail here if it will
+                torch.cuda.synchronize()
+                assert int(probe.item()) == world
+                collective = "rccl"
+            except Exception as e:  # the statistics reduce is 5 doubles: never lose a scaling run to the transport
+                print(f"[bench] rank {rank}: RCCL process group failed ({e}); tearing it down, reducing over gloo instead", file=sys.stderr)
+                try:
+                    dist.destroy_process_group()
+                except Exception:
+                    pass
+                dist.init_process_group(backend="gloo", init_method=f"tcp://127.0.0.1:{int(os.environ.get('MASTER_PORT', '29500')) + 1}",
+                                        rank=rank, world_size=world)
+                collective = "gloo (RCCL failed)"
 
     import fba_pomdp_amd as fba
     if args.slots is None:   # one search wave (64 runs) per wave slot of the chip: 4 per SIMD, 16 per CU
@@ -175,7 +220,7 @@ def main():
     steps = (c1.sim_steps - c0.sim_steps) + (c1.belief_steps - c0.belief_steps)
     rets = eng.return_sums()
 
-    red_dev = "cpu" if collective == "gloo" else "cuda"
+    red_dev = "cuda" if collective == "rccl" else "cpu"
     tot = torch.tensor([float(steps), float(c1.sim_steps - c0.sim_steps), rets[0], rets[1], rets[2]],
                        dtype=torch.float64, device=red_dev)
     tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
@@ -201,7 +246,14 @@ def main():
             dense_equiv = k.units * (att * 116.0 + 100.0) / 1e9 / (k.ms / 1e3) if k.ms > 0 else 0.0
         search = kt["search_kernel"]
         n_ep = tot[2]
-        traffic, traffic_src = measured_traffic(args, kname, eng.slots)
+        # `traffic` = PMC bytes for the SAME launches `achieved` is computed over: the profiled figure is that of a launch
+        # in which every slot updates, a timed launch updates `updated_fraction` of them (no update after a terminal step)
+        traffic_full, traffic_src = measured_traffic(args, kname, eng.slots)
+        launches = max(int(k.launches), 1)
+        updated_fraction = k.units / float(launches * eng.slots * args.particles)
+        traffic = traffic_full * updated_fraction if traffic_full else None
+        rec_b = eng.particle_bytes
+        min_traffic = k.units * 2.0 * rec_b     # every written particle read once, written once
         out = {
             "metric": "simulated env steps/sec (belief+rollout)",
             "value": tot[0] / dt_max,
@@ -223,6 +275,12 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "traffic_note": "PMC bytes (FETCH_SIZE calibrated on this kernel's access shapes + WRITE_SIZE) of a launch in which every slot "
+                                "updates, scaled by updated_fraction: per launch, like algorithmic_bytes_per_launch",
+                "traffic_full_launch": traffic_full, "algorithmic_bytes_full_launch": k.bytes / max(k.units, 1) * eng.slots * args.particles,
+                "updated_fraction": updated_fraction,
+                "frac_traffic": (traffic / 1e9) / (k.ms / launches / 1e3) / HBM_PEAK_GBS if traffic and k.ms > 0 else None,
+                "frac_min_traffic": (min_traffic / 1e9) / (k.ms / 1e3) / HBM_PEAK_GBS if k.ms > 0 else None,
                 "launches": int(k.launches), "avg_ms": k.ms / max(int(k.launches), 1),
                 "algorithmic_bytes_per_launch": k.bytes / max(int(k.launches), 1),
                 "algorithmic_basis": basis,

@@ -71,3 +71,41 @@ def test_two_ranks_reproduce_single_process_experiment():
     # pooled variance from the all-reduced sums == variance over all episodes
     pooled_var = (sums[2] - sums[1] ** 2 / sums[0]) / (sums[0] - 1)
     assert abs(pooled_var - np.var(list(ref.values()), ddof=1)) < 1e-9
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_the_engine_equal_one_process():
+    """`python bench.py --gpus 2` starts its own two worker processes (fresh processes, spawned before anything
+    touches the GPU), each runs the HIP engine on its shard of the runs (run_offset = rank * slots) and the
+    statistics are all-reduced: RCCL when every rank has its own GPU, gloo -- logged in the line -- when the box has
+    one.  The two-rank totals must equal one process running the union of the runs: same simulated steps, same
+    number of finished episodes, same return sum."""
+    import json
+    import subprocess
+
+    import fba_pomdp_amd as fba
+
+    slots, steps, warm = 1024, 3, 1
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", str(warm), "--slots", str(slots),
+           "--sims", "256", "--particles", "256", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["slots_per_gpu"] == slots
+    coll = line["returns"]["collective"]
+    assert coll == "rccl" or coll.startswith("gloo")
+    if coll != "rccl":
+        assert "share" in coll or "RCCL failed" in coll         # the fallback names its reason
+    # one process, the union of the two shards: runs 0 .. 2 * slots - 1
+    eng = fba.Engine("episodic-tiger", model=fba.MODEL_BA_TABLE, belief="rejection_sampling", sims=256, particles=256, horizon=10,
+                     episodes=64, runs=1 << 30, slots=2 * slots, run_offset=0, seed=20261003)
+    eng.run_ticks(warm)
+    c0 = eng.counters()
+    eng.run_ticks(steps)
+    c1 = eng.counters()
+    one_steps = (c1.sim_steps - c0.sim_steps) + (c1.belief_steps - c0.belief_steps)
+    n, s1, _ = eng.return_sums()
+    assert round(line["value"] * line["ms_per_step"] * steps / 1e3) == one_steps
+    assert line["returns"]["episodes"] == n
+    assert abs(line["returns"]["mean"] - s1 / n) < 1e-9
