@@ -8,6 +8,7 @@ rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 python3 $R/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 $R/bench.py --no-cpu-baseline > $OUT/stats.log 2>&1
+timeout -k 10 300 python3 $R/bench.py --belief importance_sampling --no-cpu-baseline > $OUT/bench_importance.json 2> $OUT/bench_importance.err
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o run -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o run -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/write.log 2>&1
 find $OUT -name "*.csv" | head -20
