@@ -244,6 +244,10 @@ def main():
                      "the rejection attempts themselves run from LDS")
             att = (c1.belief_steps - c0.belief_steps) / max(k.units, 1)
             dense_equiv = k.units * (att * 116.0 + 100.0) / 1e9 / (k.ms / 1e3) if k.ms > 0 else 0.0
+        if eng.particle_bytes == 64 and kname == "importance_kernel":
+            basis = ("SURVEY.md 8(d)'s formula on the bytes a packed particle has (DESIGN.md section 5): update 32 + Rt + Ro = 48 B, resample "
+                     "8 + 2 x 64 B: 184 B per particle written")
+            dense_equiv = achieved * 256.0 / 184.0
         search = kt["search_kernel"]
         n_ep = tot[2]
         # `traffic` = PMC bytes for the SAME launches `achieved` is computed over: the profiled figure is that of a launch

@@ -1886,6 +1886,10 @@ int fba_get_kernel_times(fba_ctx* c, fba_kernel_time* out)
         // weight read and written (16), the record -- 8 bytes + 4 per entry -- read once by the update, once as a
         // resample source, written once with its new entry (+4); the Dirichlet rows come from the shared tables
         if (P.hist) out[FBA_K_BELIEF_IS].bytes = particles * 44 + entries * 12;
+        // packed tiger particles (64-byte records): the same formula on the bytes a packed particle has -- the update reads
+        // state + weight + its two rows and writes state + weight + two counts (32 + Rt + Ro = 48), the resample reads the
+        // weight and moves a record in and out (8 + 2 * 64)
+        if (P.packed) out[FBA_K_BELIEF_IS].bytes = particles * (32 + Rt + Ro) + particles * (8 + 2 * (uint64_t)(P.Cs * 4));
     }
     return FBA_OK;
 }

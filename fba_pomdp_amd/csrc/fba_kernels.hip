@@ -63,6 +63,38 @@ __device__ __forceinline__ int weighted_pick(const double* __restrict__ incl, in
     return lo;
 }
 
+// weighted_pick started where the threshold would sit if the weights were equal, galloping from there to bracket the
+// answer before bisecting: the same index (incl is non-decreasing and the index is defined by incl alone), three to five
+// dependent loads instead of log2(N) when the weights are of similar size -- the usual case, a filter is resampled
+// after every update.
+__device__ __forceinline__ int weighted_pick_guided(const double* __restrict__ incl, int n, double threshold, double total)
+{
+    if (n <= 1) return 0;
+    int i = (int)(threshold / total * (double)n);
+    i = min(max(i, 1), n - 1);
+    int lo, hi;  // the answer is the largest i in [max(lo, 1), hi] with incl[i - 1] < threshold, or 0 if there is none
+    if (incl[i - 1] < threshold) {   // i qualifies: gallop upwards until a candidate does not
+        int step = 1;
+        lo = i;
+        while (lo + step <= n - 1 && incl[lo + step - 1] < threshold) { lo += step; step <<= 1; }
+        hi = min(lo + step - 1, n - 1);
+    } else {                          // i does not: gallop downwards until one does
+        int cur = i, step = 1;
+        while (true) {
+            const int cand = cur - step;
+            if (cand < 1) { lo = 0; hi = cur - 1; break; }
+            if (incl[cand - 1] < threshold) { lo = cand; hi = cur - 1; break; }
+            cur = cand;
+            step <<= 1;
+        }
+    }
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (incl[mid - 1] < threshold) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
 // weighted_pick on the prefix sums of N equal weights: the answer is within a step or two of
 // threshold / total * N, so start there and walk -- same result as the binary search (incl is
 // non-decreasing), two or three loads instead of log2(N) dependent ones.
@@ -845,6 +877,20 @@ __device__ __forceinline__ void gather_records(float* __restrict__ dst, const fl
         const int t      = s_owner ? s_owner[j] : j;
         const float4* sp = reinterpret_cast<const float4*>(src) + (size_t)s_src[t] * C4;
         float4* dp       = reinterpret_cast<float4*>(dst) + (size_t)j * C4;
+        if (ninc == 0 && !s_state && C4 > 4 * group) {
+            // a plain copy of a record of many pieces (the resample of 3.5 KB collision-avoidance particles): four loads in
+            // flight per lane before the first store
+            for (int part = part0; part < C4; part += 4 * group) {
+                float4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (part + q * group < C4) v[q] = sp[part + q * group];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (part + q * group < C4) dp[part + q * group] = v[q];
+            }
+            continue;
+        }
         for (int part = part0; part < C4; part += group) {
             float4 v = sp[part];
             const int lo = part * 4;
@@ -1301,7 +1347,7 @@ __device__ __forceinline__ double wave_inclusive_scan(double v, int lane)
 
 // in: n doubles; out_incl may be null.  s_carry: LDS, at least n/256 + 2 doubles.  Returns the
 // total to every thread.  All threads of the block must call.
-__device__ double block_device_scan(const double* __restrict__ in, int n, double* __restrict__ out_incl, double* s_carry)
+__device__ __forceinline__ double block_device_scan(const double* in, int n, double* out_incl, double* s_carry)  // (out_incl may be `in`)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int nchunks = (n + 255) >> 8;
@@ -1375,7 +1421,9 @@ __global__ void __launch_bounds__(IS_BLOCK) uniform_scan_kernel(int n, double* w
 // ---------------------------------------------------------------------------------------------
 // HIST: history particles (gridworld FBA-POMDP): the step reads its rows through the particle's entries, the update
 // is one new entry per particle, appended by the gather.
-template <bool REG, int TIGER_TABLE, bool HIST = false>
+// WLDS: the slot's weights live in LDS from the update pass to the last draw (N <= IS_LDS_MAX_N: 8 bytes each): the
+// normalised weights and their prefix sums never go to HBM, the N searches read LDS.  Same sums, same order.
+template <bool REG, int TIGER_TABLE, bool HIST = false, bool WLDS = false>
 __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceState D)
 {
     if (TIGER_TABLE) {  // sizes restated as literals (see search_kernel)
@@ -1386,7 +1434,8 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
     }
     __shared__ float s_prior[TIGER_TABLE == 2 ? 24 : 1];
     __shared__ double s_carry[IS_MAX_CHUNKS + 2];
-    __shared__ int32_t s_src[IS_BLOCK], s_inc[HIST ? 1 : MAXINC * IS_BLOCK];
+    __shared__ int32_t s_src[IS_BLOCK], s_inc[HIST ? 1 : (TIGER_TABLE ? 2 : MAXINC) * IS_BLOCK];
+    extern __shared__ double s_w[];  // WLDS: [N] weights, then normalised weights, then their inclusive prefix sums
     const int e = blockIdx.x, tid = threadIdx.x;
     if (!D.need_update[e]) return;
     if (TIGER_TABLE == 2) {
@@ -1410,7 +1459,8 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
     float* scn   = D.p_rec + sb * (size_t)P.Cs;
     double* dw      = D.p_weight + db;
     float* dcn      = D.p_rec + db * (size_t)P.Cs;
-    double* wscan   = D.wscan + (size_t)e * N;
+    double* wscan   = WLDS ? s_w : D.wscan + (size_t)e * N;
+    double* wcur    = WLDS ? s_w : sw;   // where the update pass leaves the new weights
     int32_t* side   = D.p_side + (size_t)e * N * D.side_w;
     const bool defer = defer_increments(P);
     const int C4 = P.Cs / 4, group = record_group(C4);
@@ -1428,38 +1478,76 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
             double prob;
             gridworld_hist_step(P, g, rec + 2 + hist_offset(hist_cnt, a), hist_count(hist_cnt, a), rec[1], sp, a, so, r, entry, o, prob);
             *reinterpret_cast<int2*>(side + (size_t)i * 2) = make_int2(gridworld_unpack_state(P, sp), (int)entry);
-            sw[i] *= prob;
+            wcur[i] = sw[i] * prob;
             continue;
         }
         if (TIGER_TABLE == 2) sim_step<REG>(P, g, PackedView<GlobalView>{GlobalView{cnt}, s_prior}, s, a, so, r, LdsInc<IS_BLOCK>{s_inc + tid});
         else sim_step<REG>(P, g, GlobalView{cnt}, s, a, so, r, LdsInc<IS_BLOCK>{s_inc + tid});
         // incrementCountsOf (BAFlatModel.cpp:126-139, BABNModel.cpp:354-382) is deferred to the gather: the new
         // state and the cells go to the side array, the record is only read
-        if (defer) {
+        if (TIGER_TABLE == 2 && WLDS) {
+            // packed tiger particles: the pending update {new state, T cell, O cell} is 11 bits and stays in LDS
+            reinterpret_cast<uint16_t*>(s_w + N)[i] = (uint16_t)(s | (s_inc[tid] << 1) | (s_inc[IS_BLOCK + tid] << 6));
+            wcur[i] = sw[i] * sim_obs_prob<REG>(P, g, PendingIncView<PackedView<GlobalView>>{PackedView<GlobalView>{GlobalView{cnt}, s_prior}, s_inc + tid, IS_BLOCK, ninc}, s, a, o);
+        } else if (defer) {
             int32_t* sd = side + (size_t)i * D.side_w;
             sd[0] = s;
             for (int q = 0; q < ninc; ++q) sd[1 + q] = s_inc[q * IS_BLOCK + tid];
             // probability from the updated counts
             if (TIGER_TABLE == 2)
-                sw[i] *= sim_obs_prob<REG>(P, g, PendingIncView<PackedView<GlobalView>>{PackedView<GlobalView>{GlobalView{cnt}, s_prior}, s_inc + tid, IS_BLOCK, ninc}, s, a, o);
-            else sw[i] *= sim_obs_prob<REG>(P, g, PendingIncView<GlobalView>{GlobalView{cnt}, s_inc + tid, IS_BLOCK, ninc}, s, a, o);
+                wcur[i] = sw[i] * sim_obs_prob<REG>(P, g, PendingIncView<PackedView<GlobalView>>{PackedView<GlobalView>{GlobalView{cnt}, s_prior}, s_inc + tid, IS_BLOCK, ninc}, s, a, o);
+            else wcur[i] = sw[i] * sim_obs_prob<REG>(P, g, PendingIncView<GlobalView>{GlobalView{cnt}, s_inc + tid, IS_BLOCK, ninc}, s, a, o);
         } else {
             for (int q = 0; q < ninc; ++q) cnt[s_inc[q * IS_BLOCK + tid]] += 1.0f;
             rec_set_state(cnt, P.C, s);
-            sw[i] *= sim_obs_prob<REG>(P, g, GlobalView{cnt}, s, a, o);
+            wcur[i] = sw[i] * sim_obs_prob<REG>(P, g, GlobalView{cnt}, s, a, o);
         }
     }
     __syncthreads();
-    const double total = block_device_scan(sw, N, nullptr, s_carry);
-    for (int i = tid; i < N; i += IS_BLOCK) sw[i] /= total;
+    const double total = block_device_scan(wcur, N, nullptr, s_carry);
+    for (int i = tid; i < N; i += IS_BLOCK) wcur[i] /= total;
     __syncthreads();
-    const double total_w = block_device_scan(sw, N, wscan, s_carry);
+    const double total_w = block_device_scan(wcur, N, wscan, s_carry);   // (in place when WLDS: every thread reads its four elements before it writes them)
     const double w1 = 1.0 / (double)N;
+    if (TIGER_TABLE == 2 && WLDS) {
+        // all N draws first (their sources as 16-bit indices in LDS), then one pass of N independent 64-byte copies, four
+        // lanes per record and four records in flight per lane, each with its source's pending update applied
+        uint16_t* s_side = reinterpret_cast<uint16_t*>(s_w + N);
+        uint16_t* s_all  = s_side + N;
+        for (int j = tid; j < N; j += IS_BLOCK) {
+            g.stream(FBA_PHASE_RESAMPLE, (uint32_t)j);
+            s_all[j] = (uint16_t)weighted_pick_guided(wscan, N, g.u01() * total_w, total_w);
+            dw[j]    = w1;
+        }
+        __syncthreads();
+        const int part = tid & 3;
+        constexpr int GROUPS = IS_BLOCK / 4, UNROLL = 4;
+        for (int j0 = tid >> 2; j0 < N; j0 += GROUPS * UNROLL) {
+            uint32_t sd[UNROLL];
+            float4 v[UNROLL];
+#pragma unroll
+            for (int q = 0; q < UNROLL; ++q) {
+                const int j = j0 + q * GROUPS;
+                const int p = j < N ? s_all[j] : 0;
+                sd[q] = s_side[p];
+                if (j < N) v[q] = reinterpret_cast<const float4*>(scn)[(size_t)p * 4 + part];
+            }
+#pragma unroll
+            for (int q = 0; q < UNROLL; ++q) {
+                const int j = j0 + q * GROUPS;
+                if (j >= N) continue;
+                bump_cell(v[q], (int)((sd[q] >> 1) & 31u), part * 4, true);
+                bump_cell(v[q], (int)((sd[q] >> 6) & 31u), part * 4, true);
+                if (part == 3) v[q].x = __int_as_float((int)(sd[q] & 1u));  // the state word (12)
+                reinterpret_cast<float4*>(dcn)[(size_t)j * 4 + part] = v[q];
+            }
+        }
+    } else
     for (int j0 = 0; j0 < N; j0 += IS_BLOCK) {
         const int j = j0 + tid;
         if (j < N) {
             g.stream(FBA_PHASE_RESAMPLE, (uint32_t)j);
-            const int src = weighted_pick(wscan, N, g.u01() * total_w);
+            const int src = weighted_pick_guided(wscan, N, g.u01() * total_w, total_w);
             s_src[tid]    = src;
             dw[j]         = w1;
         }
@@ -1548,7 +1636,17 @@ __global__ void __launch_bounds__(256) scan_carry_kernel(double* ctot_base, int 
         __syncthreads();
         if (tid == 0) {
             double carry = s_carry0;
-            for (int k = 0; k < m; ++k) {
+            int k = 0;
+            for (; k + 8 <= m; k += 8) {  // eight totals in registers before the eight dependent additions
+                double t[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) t[q] = tile[k + q];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { carry = carry + t[q]; t[q] = carry; }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) tile[k + q] = t[q];
+            }
+            for (; k < m; ++k) {
                 carry   = carry + tile[k];
                 tile[k] = carry;
             }
@@ -1612,7 +1710,7 @@ __global__ void __launch_bounds__(256) is_multi_step_kernel(Problem P, DeviceSta
             float* cnt = scn + (size_t)i * P.Cs;
             int s = rec_state(cnt, P.C), so;
             double r;
-            sim_step<REG>(P, g, GlobalView{cnt}, s, a, so, r, LdsInc<256>{s_inc + tid});
+            sim_step<REG>(P, g, GlobalSearchView{cnt}, s, a, so, r, LdsInc<256>{s_inc + tid});
             if (defer_increments(P)) {  // see importance_kernel
                 int32_t* sd = D.p_side + ((size_t)e * N + i) * D.side_w;
                 sd[0] = s;
@@ -1643,11 +1741,9 @@ __global__ void __launch_bounds__(256) is_multi_norm_kernel(Problem P, DeviceSta
     double sum = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        double v = 0.0;
-        if (i0 + k < N) {
-            v = sw[i0 + k] / total;
-            sw[i0 + k] = v;
-        }
+        // the normalised weight is not stored: is_multi_scan_kernel forms the same quotient again, and the resampled
+        // filter's weights are 1 / N whatever it was
+        const double v = (i0 + k < N) ? sw[i0 + k] / total : 0.0;
         sum = (k == 0) ? v : sum + v;
     }
     const double incl = wave_inclusive_scan(sum, lane);
@@ -1667,7 +1763,7 @@ __global__ void __launch_bounds__(256) is_multi_resample_kernel(Problem P, Devic
     if (j < N) {
         Rng g = slot_rng(P, D, e);
         g.stream(FBA_PHASE_RESAMPLE, (uint32_t)j);
-        s_src[tid] = weighted_pick(wscan, N, g.u01() * D.is_tot[2 * e + 1]);
+        s_src[tid] = weighted_pick_guided(wscan, N, g.u01() * D.is_tot[2 * e + 1], D.is_tot[2 * e + 1]);
         D.p_weight[db + j] = 1.0 / (double)N;
     }
     __syncthreads();
@@ -1686,9 +1782,15 @@ __global__ void __launch_bounds__(256) is_multi_scan_kernel(Problem P, DeviceSta
     const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6), N = P.N;
     if (c * 256 >= N) return;
     const double* sw = D.p_weight + pbase(P, e, D.bufsel[e]);
+    const double total = D.is_tot[2 * e + 0];
     const int i0 = c * 256 + lane * 4;
-    double x[4];
-    const double incl = wave_inclusive_scan(chunk_lane_sum(sw, N, i0, x), lane);
+    double x[4], s4 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {   // the normalised weights (WeightedFilter::normalize), as is_multi_norm_kernel summed them
+        x[k] = (i0 + k < N) ? sw[i0 + k] / total : 0.0;
+        s4   = (k == 0) ? x[k] : s4 + x[k];
+    }
+    const double incl = wave_inclusive_scan(s4, lane);
     double excl       = __shfl_up(incl, 1, 64);
     if (lane == 0) excl = 0.0;
     double run  = D.ctot[(size_t)e * D.ctot_stride + c] + excl;
@@ -2106,11 +2208,25 @@ void launch_belief_update(const Problem& P, const DeviceState& D, hipStream_t st
     if (!D.is_multi) {
         const bool tiger_table = P.model == FBA_MODEL_BA_TABLE && !P.dirichlet_regular &&
                                  (P.domain == FBA_DOM_TIGER_EPISODIC || P.domain == FBA_DOM_TIGER_CONTINUOUS);
-        if (P.hist) hipLaunchKernelGGL((importance_kernel<false, 0, true>), dim3(P.E), dim3(IS_BLOCK), 0, st, P, D);
-        else if (P.dirichlet_regular) hipLaunchKernelGGL((importance_kernel<true, 0>), dim3(P.E), dim3(IS_BLOCK), 0, st, P, D);
-        else if (tiger_table && P.packed) hipLaunchKernelGGL((importance_kernel<false, 2>), dim3(P.E), dim3(IS_BLOCK), 0, st, P, D);
-        else if (tiger_table) hipLaunchKernelGGL((importance_kernel<false, 1>), dim3(P.E), dim3(IS_BLOCK), 0, st, P, D);
-        else hipLaunchKernelGGL((importance_kernel<false, 0>), dim3(P.E), dim3(IS_BLOCK), 0, st, P, D);
+        // weights and prefix sums of a slot in LDS while its workgroup works on them (8 bytes per particle)
+        const bool wlds = P.N <= IS_LDS_MAX_N && !P.dirichlet_regular;
+        const size_t wl = wlds ? (size_t)P.N * (sizeof(double) + ((tiger_table && P.packed) ? 4 : 0)) : 0;  // (packed tiger: + pending updates and sources, 16 bits each)
+#define FBA_LAUNCH_IS(...)                                                                                         \
+    do {                                                                                                           \
+        static bool raised = false;                                                                                \
+        if (wl > 16384 && !raised) {                                                                               \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&importance_kernel<__VA_ARGS__>),              \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, IS_LDS_MAX_N * 12); \
+            raised = true;                                                                                         \
+        }                                                                                                          \
+        hipLaunchKernelGGL((importance_kernel<__VA_ARGS__>), dim3(P.E), dim3(IS_BLOCK), wl, st, P, D);             \
+    } while (0)
+        if (P.hist) { if (wlds) FBA_LAUNCH_IS(false, 0, true, true); else FBA_LAUNCH_IS(false, 0, true, false); }
+        else if (P.dirichlet_regular) FBA_LAUNCH_IS(true, 0, false, false);
+        else if (tiger_table && P.packed) { if (wlds) FBA_LAUNCH_IS(false, 2, false, true); else FBA_LAUNCH_IS(false, 2, false, false); }
+        else if (tiger_table) { if (wlds) FBA_LAUNCH_IS(false, 1, false, true); else FBA_LAUNCH_IS(false, 1, false, false); }
+        else { if (wlds) FBA_LAUNCH_IS(false, 0, false, true); else FBA_LAUNCH_IS(false, 0, false, false); }
+#undef FBA_LAUNCH_IS
         if (P.cheat) hipLaunchKernelGGL(cheat_kernel, dim3(P.E), dim3(256), 0, st, P, D);
         return;
     }
