@@ -1565,6 +1565,41 @@ int fba_get_factored_layout(const fba_ctx* c, fba_factored_layout* out)
     return FBA_OK;
 }
 
+int fba_set_model_factored(fba_ctx* c, const fba_factored_layout* layout, const float* counts)
+{
+    if (!c || !layout || !counts) return FBA_EINVAL;
+    if (c->P.model != FBA_MODEL_BA_FACTORED) return fail(c, FBA_EINVAL, "fba_set_model_factored needs model = BA_FACTORED");
+    fba_factored_layout mine;
+    int rc = fba_get_factored_layout(c, &mine);
+    if (rc) return rc;
+    bool same = layout->n_state_features == mine.n_state_features && layout->n_obs_features == mine.n_obs_features &&
+                layout->n_nodes == mine.n_nodes && layout->n_counts == mine.n_counts && layout->n_mask_words == mine.n_mask_words;
+    for (int k = 0; same && k < mine.n_nodes; ++k) {
+        const fba_factored_node &a = layout->node[k], &b = mine.node[k];
+        same = a.offset == b.offset && a.out == b.out && a.n_candidates == b.n_candidates && a.mask_word == b.mask_word &&
+               std::memcmp(a.candidate, b.candidate, (size_t)b.n_candidates) == 0;
+    }
+    if (!same)
+        return fail(c, FBA_EINVAL, "fba_set_model_factored: the layout is not this context's (obtain it with fba_get_factored_layout and fill "
+                                   "the counts where it says each node's rows are)");
+    for (int k = 0; k < mine.n_counts; ++k)
+        if (!(counts[k] >= 0.f)) return fail(c, FBA_EINVAL, "fba_set_model_factored: count %d is %g: Dirichlet counts cannot be negative", k, (double)counts[k]);
+    std::vector<float> keep = c->prior;
+    c->prior.assign(counts, counts + mine.n_counts + mine.n_mask_words);
+    if (c->P.hist) {  // history particles read rows as prior + j: the new table must keep that exact (fba_create checked the built-in one)
+        std::vector<float> only(c->prior.begin(), c->prior.begin() + mine.n_counts);
+        if (!increments_exact(only, c->P.hist_cap + 1)) {
+            c->prior = keep;
+            return fail(c, FBA_EINVAL, "this context stores particles as histories over the prior table, which needs prior counts c with c + j exact "
+                                       "in fp32 for every j up to episodes * horizon; create it with FBA_DENSE_PARTICLES=1 in the environment for this table");
+        }
+    }
+    rc = upload_prior(c);
+    if (rc) c->prior = keep;
+    else c->belief_ready = false;
+    return rc;
+}
+
 int fba_get_prior(const fba_ctx* c, float* counts)
 {
     if (!c || !counts) return FBA_EINVAL;

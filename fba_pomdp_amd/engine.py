@@ -134,6 +134,14 @@ class Engine:
         psi = np.ascontiguousarray(psi, np.float32)
         self._chk(self.L.fba_set_model_tabular(self.h, phi.ctypes.data, psi.ctypes.data))
 
+    def set_model_factored(self, counts, layout=None):
+        """Replace the factored base prior: `counts` = a particle's whole blob (CPT counts, then the parent-set words) in
+        the engine's layout (factored_layout())."""
+        layout = layout or self.factored_layout()
+        c = np.ascontiguousarray(counts, np.float32)
+        assert c.size == self.ncnt
+        self._chk(self.L.fba_set_model_factored(self.h, C.byref(layout), c.ctypes.data))
+
     def set_position(self, run=None, episode=None, t=None):
         def arr(x):
             if x is None:

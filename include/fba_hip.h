@@ -210,6 +210,13 @@ typedef struct fba_factored_layout {
     fba_factored_node node[FBA_MAX_NODES];
 } fba_factored_layout;
 int fba_get_factored_layout(const fba_ctx* ctx, fba_factored_layout* out);
+/* The factored counterpart of fba_set_model_tabular: replaces the base prior every particle starts from with CPTs built
+ * by the caller -- what FBAPOMDPPrior::sample copies into a new FBAPOMDPState (FBAPOMDPPrior.cpp:27-37: the prior's
+ * BABNModel, node by node, DBNNode::count order).  `layout` must be the engine's own (fba_get_factored_layout: the host
+ * walks it to know where node (a, f)'s rows go); `counts` = n_counts floats followed by n_mask_words parent-set words,
+ * exactly a particle's blob.  Per-particle structure draws of the configured structure prior still apply on top.  Takes
+ * effect at the next fba_belief_init, which is required before the belief is used again. */
+int fba_set_model_factored(fba_ctx* ctx, const fba_factored_layout* layout, const float* counts);
 
 /* ---- per-step interface: one call per reference virtual call -------------------------- */
 

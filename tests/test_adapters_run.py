@@ -1,0 +1,56 @@
+"""The C++ adapters executed, not only compiled: linked with the reference's own Boost-free objects (episode::run,
+Tiger, the environment types: oracle/_ref/obj, `make -C oracle ref`) against a recording stub of the C-ABI
+(tests/adapters/stub_fba.cpp), they must hand the engine a stream position that advances the way the reference's
+loops do -- run per Belief::initiate, episode per resetDomainStateDistribution, t = History::length() -- or every
+episode of every run would replay the streams of (run 0, episode 0).  Only where /root/reference exists."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF + "/src"), reason="reference sources not present")
+def test_adapters_advance_run_episode_and_step(tmp_path):
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref", "-j8"], stdout=subprocess.DEVNULL)
+    obj = os.path.join(ROOT, "oracle", "_ref", "obj")
+    objs = [os.path.join(obj, p) for p in (
+        "experiments/Episode.o", "domains/tiger/Tiger.o", "utils/random.o", "utils/index.o", "utils/distributions.o",
+        "environment/Discount.o", "environment/History.o", "environment/Horizon.o", "environment/Return.o",
+        "environment/Reward.o", "environment/Terminal.o")]
+    exe = str(tmp_path / "drive")
+    cmd = ["g++", "-std=c++11", "-O1", "-w", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "fba_pomdp_amd", "csrc", "host"),
+           "-I" + REF + "/src", "-I" + REF + "/includes", os.path.join(ROOT, "tests", "adapters", "drive.cpp"),
+           os.path.join(ROOT, "tests", "adapters", "stub_fba.cpp")] + objs + ["-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = subprocess.run([exe], capture_output=True, text=True, cwd=str(tmp_path), timeout=60)
+    assert out.returncode == 0, out.stderr[-2000:]
+    text = out.stdout
+    plan, ba = text.split("# bapomdp")
+    pos = lambda line: tuple(int(v) for v in re.findall(r"(?:run|episode|t)=(-?\d+)", line)[:3])
+
+    # planning: three runs of one episode; listen, listen, open (terminal: no update after the third step)
+    calls = [l for l in plan.splitlines() if l.split(" ")[0] in ("init", "select", "update")]
+    expect = []
+    for run in range(3):
+        expect += [("init", (run, 0, 0)), ("select", (run, 0, 0)), ("update", (run, 0, 0)), ("select", (run, 0, 1)),
+                   ("update", (run, 0, 1)), ("select", (run, 0, 2))]
+    assert [(l.split(" ")[0], pos(l)) for l in calls] == expect
+    assert plan.count("episode length=3") == 3
+
+    # bapomdp: two runs of three episodes; the episode index advances with every resetDomainStateDistribution
+    calls = [l for l in ba.splitlines() if l.split(" ")[0] in ("init", "reset", "select", "update")]
+    expect = []
+    for run in range(2):
+        expect.append(("init", (run, 0, 0)))
+        for ep in range(3):
+            expect += [("reset", (run, ep, 0)), ("select", (run, ep, 0)), ("update", (run, ep, 0)), ("select", (run, ep, 1)),
+                       ("update", (run, ep, 1)), ("select", (run, ep, 2))]
+    assert [(l.split(" ")[0], pos(l)) for l in calls] == expect
+    assert len(set(pos(l) for l in calls if l.startswith("select"))) == 2 * 3 * 3   # no position is ever used twice
+    # the belief's particle 0 is downloaded once per belief state, not once per sample()
+    assert plan.count("get") <= plan.count("select")

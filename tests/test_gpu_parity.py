@@ -866,3 +866,50 @@ def test_regular_dirichlet_mode(domain, model, belief, kw):
 def test_regular_mode_rejects_long_rows():
     with pytest.raises(ValueError, match="rows of at most"):
         fba.Engine("episodic-factored-tiger", model=N.MODEL_BA_TABLE, size=4, particles=4, sims=4, slots=1, dirichlet_regular=1)
+
+
+def test_set_model_factored_replaces_the_prior_every_particle_starts_from():
+    """fba_set_model_factored: a reference-side FBAPOMDPPrior's CPTs injected through the C-ABI, in the
+    layout fba_get_factored_layout describes.  Factored tiger, fixed structure: after the call a freshly initiated
+    belief holds exactly the injected counts, and a search + update from there equals the oracle's on particles
+    that were given the same counts."""
+    kw = dict(size=2, particles=40, sims=60, structure_prior=0, horizon=6)
+    eng = fba.Engine("episodic-factored-tiger", model=N.MODEL_BA_FACTORED, belief="rejection_sampling", seed=57, slots=1, **kw)
+    o = orc.Oracle(domain=orc.DOM_FTIGER_EPISODIC, model=orc.MODEL_BA_FACTORED, belief=orc.BELIEF_REJECTION, rng_mode=orc.RNG_PHILOX,
+                   arith=orc.ARITH_DEV, philox_seed=57, **kw)
+    lay = eng.factored_layout()
+    prior = eng.prior()
+    mine = prior.copy()
+    rng = np.random.default_rng(3)
+    mine[:lay.n_counts] += rng.integers(0, 40, lay.n_counts).astype(np.float32) * (prior[:lay.n_counts] > 0)
+    eng.set_model_factored(mine)
+    with pytest.raises(fba.FbaError, match="not initiated"):
+        eng.select_action(0)
+    assert np.array_equal(eng.prior().view(np.uint32), mine.view(np.uint32))
+    L = orc.lib()
+    L.orc_rng_episode(o.rng, 0, 0, 0)
+    o.belief_initiate()
+    eng.belief_init()
+    s0, _, _ = o.belief_get()
+    o.belief_set(s=s0, cnt=np.tile(mine, (kw["particles"], 1)))
+    s, _, cnt = eng.belief_get(0)
+    assert np.array_equal(s, s0)
+    assert np.array_equal(cnt.view(np.uint32), np.tile(mine, (kw["particles"], 1)).view(np.uint32))
+    o.belief_reset_domain_state()
+    eng.belief_reset_domain_state()
+    for t, ob in enumerate([0, 1]):
+        L.orc_rng_episode(o.rng, 0, 0, t)
+        eng.set_position(run=0, episode=0, t=t)
+        a_ref, rec = o.select_action(t)
+        a = eng.select_action(hist_len=t)[0]
+        info = eng.last_step_info()[0]
+        assert a == a_ref and np.array_equal(info["root_q"], rec["root_q"]) and np.array_equal(info["root_n"], rec["root_n"])
+        o.belief_update(2, ob)
+        eng.belief_update(2, ob)
+        s, _, cnt = eng.belief_get(0)
+        os_, _, ocnt = o.belief_get()
+        assert np.array_equal(s, os_) and np.array_equal(cnt.view(np.uint32), ocnt.view(np.uint32))
+    # a layout that is not the engine's is refused
+    lay.node[0].offset += 2
+    with pytest.raises(ValueError, match="fba_get_factored_layout"):
+        eng.set_model_factored(mine, layout=lay)
