@@ -11,5 +11,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s
 timeout -k 10 300 python3 $R/bench.py --belief importance_sampling --no-cpu-baseline > $OUT/bench_importance.json 2> $OUT/bench_importance.err
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o run -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o run -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/write.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/l2 -o run -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/l2.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/sq -o run -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/sq.log 2>&1
 find $OUT -name "*.csv" | head -20
 cat $OUT/bench_default.json
