@@ -110,7 +110,7 @@ class KernelTime(C.Structure):
 # every symbol include/fba_hip.h declares
 EXPORTS = [
     "fba_abi_version", "fba_default_config", "fba_create", "fba_destroy", "fba_last_error",
-    "fba_domain_sizes", "fba_counts_len", "fba_slots", "fba_particle_bytes", "fba_set_model_tabular", "fba_set_model_factored", "fba_get_prior", "fba_get_factored_layout",
+    "fba_domain_sizes", "fba_counts_len", "fba_slots", "fba_particle_bytes", "fba_set_model_tabular", "fba_set_model_factored", "fba_log_bd_score", "fba_selftest_lgamma", "fba_get_prior", "fba_get_factored_layout",
     "fba_set_position", "fba_belief_init", "fba_belief_reset_domain_state", "fba_select_action",
     "fba_belief_update", "fba_belief_get", "fba_belief_set", "fba_belief_get_fully_connected", "fba_last_step_info",
     "fba_run_planning", "fba_run_bapomdp", "fba_run_ticks", "fba_get_returns", "fba_get_counters", "fba_get_return_sums",
@@ -173,6 +173,8 @@ def load():
     L.fba_slots.argtypes = [vp]
     L.fba_set_model_tabular.argtypes = [vp, vp, vp]
     L.fba_set_model_factored.argtypes = [vp, vp, vp]
+    L.fba_log_bd_score.argtypes = [vp, vp, vp, vp]
+    L.fba_selftest_lgamma.argtypes = [vp, vp, C.c_int32, vp]
     L.fba_get_prior.argtypes = [vp, vp]
     L.fba_get_factored_layout.argtypes = [vp, vp]
     L.fba_set_position.argtypes = [vp, vp, vp, vp]

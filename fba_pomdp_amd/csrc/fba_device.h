@@ -621,6 +621,27 @@ __device__ __forceinline__ double det_pow(double x, double y)
     return det_exp(y * det_log(x));
 }
 
+// lgamma as one fixed sequence of IEEE operations (the CPU checker carries the same one): x >= 1 is shifted up to >= 16
+// with lgamma(x) = lgamma(x + n) - log(x (x + 1) ... (x + n - 1)), then Stirling's series to 1 / x^13.  Within a few
+// ulp of libm for the counts a run can reach.  For DBNNode::LogBDScore (DBNNode.cpp:82-117), the score the
+// structure-learning beliefs accept and reject models by.
+__device__ __forceinline__ double det_lgamma(double x)
+{
+    double prod = 1.0, shift = 0.0;
+    while (x < 16.0) {
+        prod *= x;
+        x += 1.0;
+        if (prod > 1e250) { shift += det_log(prod); prod = 1.0; }
+    }
+    shift += det_log(prod);
+    const double xi = 1.0 / x, x2 = xi * xi;
+    const double series = xi * (1.0 / 12.0 + x2 * (-1.0 / 360.0 + x2 * (1.0 / 1260.0 + x2 * (-1.0 / 1680.0 + x2 * (1.0 / 1188.0 +
+                          x2 * (-691.0 / 360360.0 + x2 * (1.0 / 156.0)))))));
+    return ((x - 0.5) * det_log(x) - x + 0.91893853320467274178) + series - shift;
+}
+// rnd::math::logGamma (random.cpp:127-135): 0 below 1
+__device__ __forceinline__ double log_gamma(double x) { return x < 1 ? 0.0 : det_lgamma(x); }
+
 // randomLong (random.cpp:40-44): 31 random bits, never negative
 __device__ __forceinline__ long long random_long(Rng& g) { return (long long)(g.next64() >> 33); }
 
@@ -1330,6 +1351,35 @@ __device__ __forceinline__ double fact_obs_prob(const Problem& P, Rng& g, const 
             }
         }
     return prob;
+}
+
+// BABNModel::LogBDScore (BABNModel.cpp:451-478) over DBNNode::LogBDScore (DBNNode.cpp:82-117): per action the transition
+// nodes, then the observation nodes; per node every Dirichlet row in CPT order, one running double sum.  `cnt` and
+// `prior` are particle blobs of the same structure.
+template <class View>
+__device__ double log_bd_score(const Problem& P, const View& cnt, const View& prior)
+{
+    const FDesc* fd = P.fd;
+    double bd = 0;
+    for (int a = 0; a < P.A; ++a)
+        for (int k = 0; k < fd->FS + fd->FO; ++k) {
+            const FNode& nd = k < fd->FS ? fd->nodes[a * fd->FS + k] : fd->nodes[P.A * fd->FS + a * fd->FO + (k - fd->FS)];
+            const uint32_t mask = node_mask(fd, nd, cnt);
+            int rows = 1;
+            for (int j = 0; j < nd.nmax; ++j)
+                if ((mask >> j) & 1u) rows *= nd.psz[j];
+            for (int r = 0; r < rows; ++r) {
+                double tot = 0, ptot = 0;
+                for (int v = 0; v < nd.out; ++v) {
+                    const float x = cnt.at(nd.off + r * nd.out + v), y = prior.at(nd.off + r * nd.out + v);
+                    tot += (double)x;
+                    ptot += (double)y;
+                    bd += log_gamma((double)x) - log_gamma((double)y);
+                }
+                bd += log_gamma(ptot) - log_gamma(tot);
+            }
+        }
+    return bd;
 }
 
 // ---- simulator.step for the three simulators --------------------------------------------------

@@ -1985,6 +1985,39 @@ int fba_selftest_ucb(fba_ctx* c, const double* L, const int32_t* n, int32_t coun
     return FBA_OK;
 }
 
+int fba_selftest_lgamma(fba_ctx* c, const double* x, int32_t count, double* out)
+{
+    if (!c || !x || !out || count <= 0) return FBA_EINVAL;
+    double *dx = nullptr, *dout = nullptr;
+    HIPCHK(c, hipMalloc(&dx, (size_t)count * 8));
+    HIPCHK(c, hipMalloc(&dout, (size_t)count * 8));
+    HIPCHK(c, hipMemcpy(dx, x, (size_t)count * 8, hipMemcpyHostToDevice));
+    launch_selftest_lgamma(dx, count, dout, c->stream);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, dout, (size_t)count * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(dx); (void)hipFree(dout);
+    return FBA_OK;
+}
+
+int fba_log_bd_score(fba_ctx* c, const float* counts, const float* prior, double* out)
+{
+    if (!c || !counts || !prior || !out) return FBA_EINVAL;
+    if (c->P.model != FBA_MODEL_BA_FACTORED) return fail(c, FBA_EINVAL, "fba_log_bd_score: not a factored model");
+    float *dc = nullptr, *dp = nullptr;
+    double* dout = nullptr;
+    const size_t n = (size_t)c->dense_C * 4;
+    HIPCHK(c, hipMalloc(&dc, n));
+    HIPCHK(c, hipMalloc(&dp, n));
+    HIPCHK(c, hipMalloc(&dout, 8));
+    HIPCHK(c, hipMemcpy(dc, counts, n, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dp, prior, n, hipMemcpyHostToDevice));
+    launch_selftest_bd(c->P, dc, dp, dout, c->stream);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, dout, 8, hipMemcpyDeviceToHost));
+    (void)hipFree(dc); (void)hipFree(dp); (void)hipFree(dout);
+    return FBA_OK;
+}
+
 // utils::Statistic (reference src/utils/Statistic.cpp:5-46)
 void fba_stat_add(fba_stat* s, double v)
 {

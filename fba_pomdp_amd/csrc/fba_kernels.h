@@ -28,6 +28,8 @@ void launch_init(const Problem& P, const DeviceState& D, hipStream_t st);
 void launch_reset(const Problem& P, const DeviceState& D, hipStream_t st);
 void launch_materialize_reset(const Problem& P, const DeviceState& D, hipStream_t st);
 void launch_flush(const Problem& P, const DeviceState& D, hipStream_t st);
+void launch_selftest_lgamma(const double* x, int count, double* out, hipStream_t st);
+void launch_selftest_bd(const Problem& P, const float* cnt, const float* prior, double* out, hipStream_t st);
 void launch_selftest_ucb(const double* L, const int32_t* n, int count, double u, double* out, hipStream_t st);
 void launch_uniform_scan(int n, double* w_tmp, double* out, double* total, double* ctot, hipStream_t st);
 

@@ -2092,6 +2092,17 @@ __global__ void __launch_bounds__(256) flush_kernel(Problem P, DeviceState D)
     }
 }
 
+// diagnostics: det_lgamma, and BABNModel::LogBDScore of one particle blob against another (one lane: the sum is sequential)
+__global__ void selftest_lgamma_kernel(const double* x, int count, double* out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = det_lgamma(x[i]);
+}
+__global__ void selftest_bd_kernel(Problem P, const float* cnt, const float* prior, double* out)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) *out = log_bd_score(P, GlobalView{cnt}, GlobalView{prior});
+}
+
 // diagnostic: the UCB bonus expression exactly as ucb_select evaluates it
 __global__ void selftest_ucb_kernel(const double* L, const int32_t* n, int count, double u, double* out)
 {
@@ -2265,6 +2276,14 @@ void launch_reset(const Problem& P, const DeviceState& D, hipStream_t st)
 void launch_flush(const Problem& P, const DeviceState& D, hipStream_t st)
 {
     hipLaunchKernelGGL(flush_kernel, dim3(P.E), dim3(256), 0, st, P, D);
+}
+void launch_selftest_lgamma(const double* x, int count, double* out, hipStream_t st)
+{
+    hipLaunchKernelGGL(selftest_lgamma_kernel, dim3(ceil_div(count, 256)), dim3(256), 0, st, x, count, out);
+}
+void launch_selftest_bd(const Problem& P, const float* cnt, const float* prior, double* out, hipStream_t st)
+{
+    hipLaunchKernelGGL(selftest_bd_kernel, dim3(1), dim3(64), 0, st, P, cnt, prior, out);
 }
 void launch_selftest_ucb(const double* L, const int32_t* n, int count, double u, double* out, hipStream_t st)
 {

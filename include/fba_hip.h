@@ -272,6 +272,13 @@ int fba_get_trace(const fba_ctx* ctx, fba_trace_rec* out, int32_t cap);
  * engine's fp64 divide and square root round like the host's (they must, for UCB parity) */
 int fba_selftest_ucb(fba_ctx* ctx, const double* L, const int32_t* n, int32_t count, double u, double* out);
 
+/* BABNModel::LogBDScore(prior) (src/bayes-adaptive/states/factored/BABNModel.cpp:451-478 over DBNNode::LogBDScore,
+ * DBNNode.cpp:82-117): the log Bayesian-Dirichlet score of one particle's counts against a prior blob of the same
+ * structure -- what the structure-learning beliefs (MHwithinGibbs.cpp:334-395, MHNIPS2018.cpp) accept and reject models by.
+ * Evaluated on the device with the engine's deterministic lgamma; fba_selftest_lgamma exposes that function. */
+int fba_log_bd_score(fba_ctx* ctx, const float* counts, const float* prior, double* out);
+int fba_selftest_lgamma(fba_ctx* ctx, const double* x, int32_t count, double* out);
+
 /* utils::Statistic::add / var / stder, exported so hosts merge returns exactly as the
  * reference does */
 void fba_stat_add(fba_stat* s, double v);

@@ -1076,6 +1076,61 @@ static int node_row(const orc_ctx* c, const fnode* nd, uint32_t mask, const int*
     return nd->off + idx * nd->out;
 }
 
+/* lgamma as one fixed sequence of IEEE operations (the HIP engine carries the same sequence, fba_device.h det_lgamma):
+ * x >= 1 is shifted up to >= 16 with the recurrence lgamma(x) = lgamma(x + n) - log(x (x + 1) ... (x + n - 1)), then
+ * Stirling's series to 1 / x^13 (truncation error below 2e-18 at 16).  Absolute error against libm below 1e-13 for
+ * the counts a run can reach; relative error is large only next to the zeros at 1 and 2, where the value is tiny. */
+double orc_det_lgamma(double x)
+{
+    double prod = 1.0, shift = 0.0, xi, x2, series;
+    while (x < 16.0) {
+        prod *= x;
+        x += 1.0;
+        if (prod > 1e250) { shift += orc_det_log(prod); prod = 1.0; }
+    }
+    shift += orc_det_log(prod);
+    xi = 1.0 / x;
+    x2 = xi * xi;
+    series = xi * (1.0 / 12.0 + x2 * (-1.0 / 360.0 + x2 * (1.0 / 1260.0 + x2 * (-1.0 / 1680.0 + x2 * (1.0 / 1188.0 +
+             x2 * (-691.0 / 360360.0 + x2 * (1.0 / 156.0)))))));
+    return ((x - 0.5) * orc_det_log(x) - x + 0.91893853320467274178) + series - shift;
+}
+/* rnd::math::logGamma (random.cpp:127-135): 0 below 1, lgamma otherwise */
+static double log_gamma(const orc_ctx* c, double x)
+{
+    if (x < 1) return 0;
+    return c->cfg.arith == ORC_ARITH_DEV ? orc_det_lgamma(x) : lgamma(x);
+}
+/* BABNModel::LogBDScore (BABNModel.cpp:451-478) over DBNNode::LogBDScore (DBNNode.cpp:82-117): per action the
+ * transition nodes, then the observation nodes; per node every Dirichlet row in CPT order: the cells' logGamma
+ * differences as they come, then logGamma(prior total) - logGamma(total), one running double sum.
+ * `cnt` and `prior` are particle blobs of the same structure (pinned by golden["log_bd_score"]). */
+double orc_log_bd_score(orc_ctx* c, const float* cnt, const float* prior)
+{
+    const fdesc* d = &c->fd;
+    double bd = 0;
+    int a, k;
+    for (a = 0; a < c->A; ++a)
+        for (k = 0; k < d->FS + d->FO; ++k) {
+            const fnode* nd = k < d->FS ? &d->T[a * d->FS + k] : &d->O[a * d->FO + (k - d->FS)];
+            uint32_t mask   = node_mask(c, nd, cnt);
+            int rows = 1, j, r, v;
+            for (j = 0; j < nd->nmax; ++j)
+                if ((mask >> j) & 1u) rows *= d->Ssz[nd->maxp[j]];
+            for (r = 0; r < rows; ++r) {
+                double tot = 0, ptot = 0;
+                for (v = 0; v < nd->out; ++v) {
+                    float x = cnt[nd->off + r * nd->out + v], y = prior[nd->off + r * nd->out + v];
+                    tot += x;
+                    ptot += y;
+                    bd += log_gamma(c, x) - log_gamma(c, y);
+                }
+                bd += log_gamma(c, ptot) - log_gamma(c, tot);
+            }
+        }
+    return bd;
+}
+
 /* BAPOMDP::step with BABNModel::sampleStateIndex / sampleObservationIndex / incrementCountsOf
  * ref: BABNModel.cpp:292-325, 354-382.  Quirk kept: the observation CPTs are
  * incremented at the row of the PREVIOUS state's parent values (parent_values = features(s)). */

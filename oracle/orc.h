@@ -169,6 +169,8 @@ void orc_sample_mult(orc_ctx* c, const float* dir, int n, float* out);
 void orc_chance_add_visit(int32_t* n, double* q, double ret);
 int orc_ext_terminal(orc_ctx* c, int32_t s, int32_t a, int32_t ns);
 double orc_ext_reward(orc_ctx* c, int32_t s, int32_t a, int32_t ns);
+double orc_det_lgamma(double x);
+double orc_log_bd_score(orc_ctx* c, const float* cnt, const float* prior);
 double orc_det_log(double x);
 double orc_det_exp(double x);
 

@@ -114,6 +114,10 @@ def lib():
         L.orc_ext_terminal.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
         L.orc_ext_reward.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
         L.orc_ext_reward.restype = C.c_double
+        L.orc_det_lgamma.argtypes = [C.c_double]
+        L.orc_det_lgamma.restype = C.c_double
+        L.orc_log_bd_score.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_log_bd_score.restype = C.c_double
         L.orc_random_action.argtypes = [C.c_void_p, C.c_int32]
         L.orc_belief_initiate.argtypes = [C.c_void_p]
         L.orc_belief_update.argtypes = [C.c_void_p, C.c_int32, C.c_int32]

@@ -872,6 +872,14 @@ static void fbapomdp_state(char const* s)
     arr(probs, pd);
     dump(&state, "listen_O_T_after");
     dump(static_cast<FBAPOMDPState*>(frozen), "listen_O_T_of_copy_at_60");
+    /* BABNModel::LogBDScore (BABNModel.cpp:451-478, DBNNode.cpp:82-117) of the model after the walk, and of the copy
+     * taken at step 60, against the model the walk started from */
+    printf(", \"log_bd_score_after\": ");
+    pd(state.model()->LogBDScore(m));
+    printf(", \"log_bd_score_copy_at_60\": ");
+    pd(static_cast<FBAPOMDPState*>(frozen)->model()->LogBDScore(m));
+    printf(", \"log_bd_score_of_prior\": ");
+    pd(m.LogBDScore(m));
     printf("}");
     delete frozen;
 }

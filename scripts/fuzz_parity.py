@@ -30,7 +30,7 @@ def draw(rng):
     elif "factored-tiger" in domain:
         kw["size"] = rng.choice([1, 2, 3])
     elif domain == "gridworld":
-        kw["size"] = rng.choice([3, 4])
+        kw["size"] = rng.choice([3, 3, 4, 4, 5])
         kw["particles"] = rng.choice([64, 130])   # a filter without the true goal can never be updated
     elif "sysadmin" in domain:
         kw["size"] = rng.choice([1, 2, 3, 4])

@@ -913,3 +913,31 @@ def test_set_model_factored_replaces_the_prior_every_particle_starts_from():
     lay.node[0].offset += 2
     with pytest.raises(ValueError, match="fba_get_factored_layout"):
         eng.set_model_factored(mine, layout=lay)
+
+
+def test_log_bd_score_and_lgamma_equal_the_oracle():
+    """DBNNode::LogBDScore / BABNModel::LogBDScore on the device (fba_log_bd_score, det_lgamma) against the oracle in
+    device arithmetic, bit for bit -- the oracle's reference-arithmetic twin is pinned against the real
+    DBNNode.cpp through oracle/_ref (test_fbapomdp_state_matches_reference).  The first building block of the
+    MH structure beliefs."""
+    eng = fba.Engine("episodic-factored-tiger", model=N.MODEL_BA_FACTORED, size=2, structure_prior=3, particles=8, sims=4, slots=1)
+    o = orc.Oracle(domain=orc.DOM_FTIGER_EPISODIC, size=2, model=orc.MODEL_BA_FACTORED, structure_prior=orc.SP_FULLY_CONNECTED,
+                   arith=orc.ARITH_DEV, rng_mode=orc.RNG_PHILOX, philox_seed=9)
+    L = orc.lib()
+    xs = np.concatenate([np.linspace(1, 40, 3000), np.logspace(0, 7, 3000)])
+    out = np.zeros_like(xs)
+    eng._chk(eng.L.fba_selftest_lgamma(eng.h, xs.ctypes.data, len(xs), out.ctypes.data))
+    assert np.array_equal(out, np.array([L.orc_det_lgamma(float(x)) for x in xs]))
+    prior = o.prior_counts()
+    o.ftiger_set_structure(prior, 0b101)
+    assert np.array_equal(eng.prior()[:8], prior[:8])
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        cnt = prior.copy()
+        s = 3
+        L.orc_rng_episode(o.rng, trial, 0, 0)
+        for i in range(40 * (trial + 1)):
+            s, _, _, _ = o.model_step(cnt, s, int(rng.integers(0, 3)), update=True)
+        got = C.c_double()
+        eng._chk(eng.L.fba_log_bd_score(eng.h, cnt.ctypes.data, prior.ctypes.data, C.byref(got)))
+        assert got.value == L.orc_log_bd_score(o.h, cnt.ctypes.data, prior.ctypes.data) != 0.0
