@@ -126,6 +126,40 @@ struct PackedView {
     }
 };
 
+// Packed factored-tiger particle (Problem::ft_packed, FS = K + 1 binary state features): the record holds, per cell of
+// the count table, how many "+1"s the cell has received (uint16, two per word, dense order), then the parent set of
+// the listen observation node (one word), then the state.  A count is prior(cell, parent set) + that number: the prior
+// of this model is a function of the cell and the structure bits alone -- FactoredTigerFactoredPrior's nodes
+// (FactoredTigerPriors.cpp:95-195) and setObservationModel (:221-263), layout of build_ftiger_factored_prior:
+//   T(open a, f) 2 counts at (a*FS + f)*2: 5000, 5000      T(listen, f) 4 counts at 4FS + 4f: 5000 where the value is kept
+//   O(open a) 2 counts at 8FS + 2a: 5000, 5000             O(listen) rows of 2 at 8FS + 4: (acc, inacc) / (inacc, acc) by the
+//   tiger's door when feature 0 is a parent, (unif, unif) otherwise, nothing beyond the 2^(#parents) rows in use.
+// Used only when every such prior value p has p + 65535 exact in fp32 (checked on the host), so the sum is the
+// very float the reference reaches by adding 1.0f that many times.  144 B instead of 288 B at K = 3.
+template <int FS, class Base>
+struct PackedFtigerView {
+    Base words;
+    uint32_t mask;       // the structure bits (word NC / 2 of the record), read once
+    float acc, inacc, unif;
+    static constexpr bool row_regs = false;
+    static constexpr int NC = 8 * FS + 4 + (2 << FS);   // counts; the dense blob has the mask word behind them
+    __device__ __forceinline__ float prior(int k) const
+    {
+        if (k < 4 * FS) return 5000.f;
+        if (k < 8 * FS) { const int j = k - 4 * FS; return (((j >> 1) ^ j) & 1) ? 0.f : 5000.f; }
+        if (k < 8 * FS + 4) return 5000.f;
+        const int j = k - (8 * FS + 4), row = j >> 1, np = __popc(mask);
+        if (row >= (1 << np)) return 0.f;
+        if (!(mask & 1u)) return unif;
+        return ((row >> (np - 1)) == (j & 1)) ? acc : inacc;
+    }
+    __device__ __forceinline__ float at(int k) const
+    {
+        if (k >= NC) return __uint_as_float(mask);
+        const uint32_t w = __float_as_uint(words.at(k >> 1));
+        return prior(k) + (float)((k & 1) ? (w >> 16) : (w & 0xffffu));
+    }
+};
 // ---------------------------------------------------------------------------------------------
 // Sampling primitives (reference src/utils/random.hpp:93-115, random.cpp:244-279)
 // ---------------------------------------------------------------------------------------------
@@ -273,6 +307,8 @@ struct Problem {
     int32_t fd_bytes;   // bytes of *fd in use (header + A*(FS+FO) nodes): what a kernel stages in LDS
     int32_t cheat;      // cheating belief: particles copied from the correct-graph filter per cheat (belief = IMPORTANCE then); 0 = off
     int32_t packed;     // tabular tiger particles stored as uint16 increment counts over the shared prior (PackedView); C, Cs are then in words of that record
+    int32_t ft_packed;  // factored-tiger particles stored packed (PackedFtigerView): uint16 increments, then the structure bits, then the state
+    float ft_acc, ft_inacc, ft_unif;   // ... and the three prior counts of its listen observation node (FactoredTigerPriors.cpp:221-263)
     int32_t point;      // point-estimate belief: N = 1 and Belief::sample() returns the state without a draw
     int32_t reinvig;    // reinvigoration belief: particles bred per update (belief = REJECTION then); 0 = off
     int32_t hist;       // history particles (gridworld FBA-POMDP, importance filter): a record holds the particle's increments as one
@@ -293,6 +329,12 @@ struct Problem {
     double exploration, gamma;
     uint32_t seed_lo, seed_hi;
 };
+
+template <int FS, class Base>
+__device__ __forceinline__ PackedFtigerView<FS, Base> packed_ftiger_view(const Problem& P, const Base& words)
+{
+    return PackedFtigerView<FS, Base>{words, __float_as_uint(words.at(PackedFtigerView<FS, Base>::NC / 2)), P.ft_acc, P.ft_inacc, P.ft_unif};
+}
 
 __device__ __forceinline__ bool dom_is_tiger(int d) { return d == FBA_DOM_TIGER_EPISODIC || d == FBA_DOM_TIGER_CONTINUOUS; }
 __device__ __forceinline__ bool dom_is_ftiger(int d) { return d == FBA_DOM_FTIGER_EPISODIC || d == FBA_DOM_FTIGER_CONTINUOUS; }
@@ -863,6 +905,62 @@ __device__ __forceinline__ bool ftiger_step(const Problem& P, Rng& g, const View
         row_new = row_old = OBS + 2 * a;
     }
     o = sample_expected_mult(g, cnt, row_new, 2);
+    inc.add(FS, row_old + o);
+    const bool t = dom_is_episodic(P.domain) && a != 2;
+    r = a == 2 ? -1.0 : (a == loc ? 10.0 : -100.0);
+    s = ns;
+    return t;
+}
+
+// ftiger_step on packed records (Problem::ft_packed, PackedFtigerView's format): every Dirichlet row of this model has two
+// cells and starts at an even cell, so a row is ONE word of the record -- its two uint16 increment counts -- plus two
+// prior values that the action, the parent value and the structure bits determine.  `words.at(w)` = word w of the
+// record.  Same draws, same order, same sums as ftiger_step on the dense table.
+template <int FS, class Words, class Sink>
+__device__ __forceinline__ bool ftiger_step_packed(const Problem& P, Rng& g, const Words& words, int& s, int a, int& o, double& r, const Sink& inc)
+{
+    constexpr int OBS = 8 * FS, MASKW = (8 * FS + 4 + (2 << FS)) / 2;
+    const int loc = (s >> (FS - 1)) & 1;
+    const bool listen = a == 2;
+    int ns = 0;
+#pragma unroll
+    for (int f = 0; f < FS; ++f) {
+        const int v   = (s >> (FS - 1 - f)) & 1;
+        const int row = listen ? 4 * FS + 4 * f + 2 * v : (a * FS + f) * 2;
+        const uint32_t w = __float_as_uint(words.at(row >> 1));
+        const float c0 = ((listen && v) ? 0.f : 5000.f) + (float)(w & 0xffffu), c1 = ((listen && !v) ? 0.f : 5000.f) + (float)(w >> 16);
+        const double p = g.u01() * ((double)c0 + (double)c1);   // sampleFromExpectedMult on a row of two
+        const int nv   = (p < (double)c0) ? 0 : 1;
+        inc.add(f, row + nv);
+        ns = ns * 2 + nv;
+    }
+    int row_new, row_old;
+    float p0 = 5000.f, p1 = 5000.f;
+    if (listen) {
+        const uint32_t mask = __float_as_uint(words.at(MASKW));
+        int in = 0, io = 0;
+#pragma unroll
+        for (int f = 0; f < FS; ++f)
+            if ((mask >> f) & 1u) {
+                in = in * 2 + ((ns >> (FS - 1 - f)) & 1);
+                io = io * 2 + ((s >> (FS - 1 - f)) & 1);
+            }
+        row_new = OBS + 4 + 2 * in;
+        row_old = OBS + 4 + 2 * io;
+        if (mask & 1u) {  // informed by the tiger's door: feature 0 of the NEW state
+            const bool left = ((ns >> (FS - 1)) & 1) == 0;
+            p0 = left ? P.ft_acc : P.ft_inacc;
+            p1 = left ? P.ft_inacc : P.ft_acc;
+        } else p0 = p1 = P.ft_unif;
+    } else {
+        row_new = row_old = OBS + 2 * a;
+    }
+    {
+        const uint32_t w = __float_as_uint(words.at(row_new >> 1));
+        const float c0 = p0 + (float)(w & 0xffffu), c1 = p1 + (float)(w >> 16);
+        const double p = g.u01() * ((double)c0 + (double)c1);
+        o = (p < (double)c0) ? 0 : 1;
+    }
     inc.add(FS, row_old + o);
     const bool t = dom_is_episodic(P.domain) && a != 2;
     r = a == 2 ? -1.0 : (a == loc ? 10.0 : -100.0);

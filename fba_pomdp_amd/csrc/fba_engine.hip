@@ -740,6 +740,19 @@ int build_ftiger_factored_prior(fba_ctx* c)
     return FBA_OK;
 }
 
+// PackedFtigerView::prior on the host (fba_device.h): the prior count of cell k of the factored-tiger model under the
+// listen observation node's parent set `mask`
+float ftiger_prior_host(int FS, int k, uint32_t mask, float acc, float inacc, float unif)
+{
+    if (k < 4 * FS) return 5000.f;
+    if (k < 8 * FS) { const int j = k - 4 * FS; return (((j >> 1) ^ j) & 1) ? 0.f : 5000.f; }
+    if (k < 8 * FS + 4) return 5000.f;
+    const int j = k - (8 * FS + 4), row = j >> 1, np = __builtin_popcount(mask);
+    if (row >= (1 << np)) return 0.f;
+    if (!(mask & 1u)) return unif;
+    return ((row >> (np - 1)) == (j & 1)) ? acc : inacc;
+}
+
 // prior[k] + j is the float the reference reaches by j additions of 1.0f for every j a uint16 holds
 bool packable_prior(const std::vector<float>& prior)
 {
@@ -792,7 +805,10 @@ bool increments_exact(const std::vector<float>& table, int most)
 int upload_prior(fba_ctx* c)
 {
     std::vector<float> padded((size_t)c->P.Cs, 0.f);
-    if (c->P.hist) {  // records carry no counts: the tables sit beside them, rows padded to 16 bytes (HistLayout, fba_device.h)
+    if (c->P.ft_packed) {  // the prior record in packed form: no increments, the correct structure's bits
+        const uint32_t m = 1u;
+        std::memcpy(&padded[(size_t)c->fdesc.ncounts / 2], &m, 4);
+    } else if (c->P.hist) {  // records carry no counts: the tables sit beside them, rows padded to 16 bytes (HistLayout, fba_device.h)
         const HistLayout L(c->gdesc.N, c->gdesc.G, c->P.A);
         const int N = L.N, G = L.G, A = L.A, XYd = N * N * G * N, GGd = N * N * G * G, NNd = N * N;
         std::vector<float> base((size_t)L.total + 16, 0.f), alt((size_t)L.alt_total + 16, 0.f);
@@ -821,7 +837,7 @@ int upload_prior(fba_ctx* c)
             return fail(c, FBA_EINVAL, "this context stores particles packed (uint16 increments over the prior), which needs prior counts c with "
                                        "c + 65535 exact in fp32; create it with FBA_DENSE_PARTICLES=1 in the environment for other tables");
         HIPCHK(c, hipMemcpyAsync(c->d_prior_dense, c->prior.data(), c->prior.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    } else
+    } else if (!c->P.ft_packed)
         std::copy(c->prior.begin(), c->prior.end(), padded.begin());
     HIPCHK(c, hipMemcpyAsync(c->d_prior, padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1244,6 +1260,21 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
             P.C      = (c->dense_C + 1) / 2;  // words holding the uint16 pairs; the state word follows
         }
     }
+    // Packed factored-tiger particles (PackedFtigerView, fba_device.h): uint16 increments over a prior that is a function of
+    // the cell and the particle's structure bits -- 144 B instead of 288 B at --size 3, so twice the beliefs per gigabyte and
+    // per kilobyte of LDS.  Only where every kernel that touches the records is a factored-tiger instantiation (po-uct,
+    // plain rejection filter, expected Dirichlet, --size 1..3) and the prior's five values are exact under "+ 65535".
+    P.ft_packed = 0; P.ft_acc = P.ft_inacc = P.ft_unif = 0.f;
+    if (cfg->model == FBA_MODEL_BA_FACTORED && is_ftiger(cfg->domain) && cfg->belief == FBA_BELIEF_REJECTION && !point &&
+        cfg->planner == FBA_PLANNER_POUCT && !cfg->dirichlet_regular && cfg->size >= 1 && cfg->size <= 3 &&
+        !std::getenv("FBA_DENSE_PARTICLES") && (long long)cfg->episodes * cfg->horizon <= 65535) {
+        const float acc = (.85f - cfg->noise) * cfg->counts_total, inacc = (.15f + cfg->noise) * cfg->counts_total, unif = .5f * cfg->counts_total;
+        if (packable_prior({acc, inacc, unif, 5000.f, 0.f})) {
+            P.ft_packed = 1;
+            P.ft_acc = acc; P.ft_inacc = inacc; P.ft_unif = unif;
+            P.C = c->fdesc.ncounts / 2 + 1;   // words of uint16 pairs, the structure word; the state word follows
+        }
+    }
     // History particles (fba_device.h): the gridworld FBA-POMDP particle as one 4-byte entry per real step over the
     // shared prior tables -- 100-500 bytes instead of 191 KB (N = 7) -- where the importance filter is the plain one,
     // the run fits the record (one entry per belief update), the grid fits 3-bit coordinates and prior + j is exact in
@@ -1267,6 +1298,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         }
     }
     if (P.hist) P.Cs = (2 + P.hist_cap + 3) & ~3;
+    else if (P.ft_packed) P.Cs = (P.C + 1 + 3) & ~3;   // 36 words at --size 3: the point is the bytes, not a power of two
     else {
         int need = P.C + 1, cs = 4;
         if (need <= 64) { while (cs < need) cs <<= 1; }
@@ -1586,6 +1618,11 @@ int fba_set_model_factored(fba_ctx* c, const fba_factored_layout* layout, const 
         if (!(counts[k] >= 0.f)) return fail(c, FBA_EINVAL, "fba_set_model_factored: count %d is %g: Dirichlet counts cannot be negative", k, (double)counts[k]);
     std::vector<float> keep = c->prior;
     c->prior.assign(counts, counts + mine.n_counts + mine.n_mask_words);
+    if (c->P.ft_packed) {
+        c->prior = keep;
+        return fail(c, FBA_EINVAL, "this context stores factored-tiger particles packed over the built-in prior; create it with "
+                                   "FBA_DENSE_PARTICLES=1 in the environment to replace the prior");
+    }
     if (c->P.hist) {  // history particles read rows as prior + j: the new table must keep that exact (fba_create checked the built-in one)
         std::vector<float> only(c->prior.begin(), c->prior.begin() + mine.n_counts);
         if (!increments_exact(only, c->P.hist_cap + 1)) {
@@ -1730,7 +1767,15 @@ int fba_belief_get(fba_ctx* c, int32_t slot, int32_t* state, double* weight, flo
         for (int i = 0; i < P.N; ++i) {
             const float* rec = tmp.data() + (size_t)i * P.Cs;
             if (state) std::memcpy(&state[i], &rec[P.C], 4);
-            if (counts && P.hist) hist_materialize(c, reinterpret_cast<const uint32_t*>(rec), hist_cnt, counts + (size_t)i * c->dense_C);
+            if (counts && P.ft_packed) {  // count = prior(cell, structure) + increments, then the structure word (PackedFtigerView)
+                const uint32_t* w = reinterpret_cast<const uint32_t*>(rec);
+                const int nc = c->fdesc.ncounts;
+                const uint32_t mask = w[nc / 2];
+                float* out = counts + (size_t)i * c->dense_C;
+                for (int k = 0; k < nc; ++k)
+                    out[k] = ftiger_prior_host(c->fdesc.FS, k, mask, P.ft_acc, P.ft_inacc, P.ft_unif) + (float)((k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffffu));
+                std::memcpy(&out[nc], &mask, 4);
+            } else if (counts && P.hist) hist_materialize(c, reinterpret_cast<const uint32_t*>(rec), hist_cnt, counts + (size_t)i * c->dense_C);
             else if (counts && P.packed) {  // count = prior + number of increments (PackedView)
                 const uint32_t* w = reinterpret_cast<const uint32_t*>(rec);
                 for (int k = 0; k < c->dense_C; ++k)
@@ -1781,7 +1826,23 @@ int fba_belief_set(fba_ctx* c, int32_t slot, const int32_t* state, const double*
         for (int i = 0; i < P.N; ++i) {
             float* rec = tmp.data() + (size_t)i * P.Cs;
             if (state) std::memcpy(&rec[P.C], &state[i], 4);
-            if (counts && P.packed) {
+            if (counts && P.ft_packed) {
+                uint32_t* w = reinterpret_cast<uint32_t*>(rec);
+                const int nc = c->fdesc.ncounts;
+                const float* in = counts + (size_t)i * c->dense_C;
+                uint32_t mask;
+                std::memcpy(&mask, &in[nc], 4);
+                for (int k = 0; k < P.C; ++k) w[k] = 0;
+                w[nc / 2] = mask;
+                for (int k = 0; k < nc; ++k) {
+                    const double inc = (double)in[k] - (double)ftiger_prior_host(c->fdesc.FS, k, mask, P.ft_acc, P.ft_inacc, P.ft_unif);
+                    if (inc < 0 || inc > 65535 || inc != std::floor(inc))
+                        return fail(c, FBA_EINVAL, "particle %d, count %d: %g is not the prior of its structure plus 0..65535 increments, which packed "
+                                                   "particles need; create the context with FBA_DENSE_PARTICLES=1 in the environment for arbitrary counts",
+                                    i, k, (double)in[k]);
+                    w[k >> 1] |= (uint32_t)inc << (16 * (k & 1));
+                }
+            } else if (counts && P.packed) {
                 uint32_t* w = reinterpret_cast<uint32_t*>(rec);
                 for (int k = 0; k < P.C; ++k) w[k] = 0;
                 for (int k = 0; k < c->dense_C; ++k) {

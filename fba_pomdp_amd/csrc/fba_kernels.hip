@@ -313,7 +313,8 @@ __host__ __device__ __forceinline__ bool root_children_in_lds(const Problem& P, 
     return P.A * P.O <= ROOT_CHILDREN && D.max_nodes <= 32767;
 }
 
-template <bool STAGE, int AMAX, bool REG, int TIGER_TABLE, int MODEL, int FTIGER = 0, bool TIGER_POMDP = false>
+// FTP: the factored-tiger records are packed (PackedFtigerView).
+template <bool STAGE, int AMAX, bool REG, int TIGER_TABLE, int MODEL, int FTIGER = 0, bool TIGER_POMDP = false, bool FTP = false>
 __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceState D)
 {
     if (TIGER_POMDP) {
@@ -460,7 +461,9 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
             int o;
             double r;
             bool term;
-            if (FTIGER > 0 && STAGE) term = ftiger_step<(FTIGER > 0 ? FTIGER : 1)>(P, g, LdsView<SEARCH_BLOCK>{stage}, s, a, o, r, NoInc{});
+            if (FTIGER > 0 && STAGE && FTP)
+                term = ftiger_step_packed<(FTIGER > 0 ? FTIGER : 1)>(P, g, LdsView<SEARCH_BLOCK>{stage}, s, a, o, r, NoInc{});
+            else if (FTIGER > 0 && STAGE) term = ftiger_step<(FTIGER > 0 ? FTIGER : 1)>(P, g, LdsView<SEARCH_BLOCK>{stage}, s, a, o, r, NoInc{});
             else if (FTIGER > 0) term = ftiger_step<(FTIGER > 0 ? FTIGER : 1)>(P, g, GlobalSearchView{cnt}, s, a, o, r, NoInc{});
             else if (TIGER_TABLE == 2) term = sim_step<REG>(P, g, PackedView<LdsView<SEARCH_BLOCK>>{LdsView<SEARCH_BLOCK>{stage}, s_prior}, s, a, o, r, NoInc{});
             else if (STAGE) term = sim_step<REG>(P, g, LdsView<SEARCH_BLOCK>{stage}, s, a, o, r, NoInc{});
@@ -987,7 +990,7 @@ __device__ __forceinline__ int record_group(int C4)
 // per CU changes nothing -- the kernel is bound by the memory system's rate for random 128-byte lines.
 // `fc` = 1 runs the update on the reinvigoration belief's fully connected filter (launched before
 // the main filter's update, which is the one that clears the request flag).
-template <bool REG, int TIGER_TABLE, int FTIGER = 0, int BLK = REJECT_BLOCK>
+template <bool REG, int TIGER_TABLE, int FTIGER = 0, int BLK = REJECT_BLOCK, bool FTP = false>
 __global__ void __launch_bounds__(BLK) reject_kernel(Problem P, DeviceState D, int fc)
 {
     if (FTIGER > 0) {  // factored tiger with FTIGER binary state features (see search_kernel)
@@ -1044,7 +1047,8 @@ __global__ void __launch_bounds__(BLK) reject_kernel(Problem P, DeviceState D, i
         int s = (!fc && lazy) ? lazy_state(P, D, e, src) : rec_state(rec, P.C), so;
         double r;
         // UpdateCounts: the +1s land in the copy
-        if (FTIGER > 0) ftiger_step<(FTIGER > 0 ? FTIGER : 1)>(P, g, GlobalView{rec}, s, a, so, r, LdsInc<BLK>{s_inc + tid});
+        if (FTIGER > 0 && FTP) ftiger_step_packed<(FTIGER > 0 ? FTIGER : 1)>(P, g, GlobalView{rec}, s, a, so, r, LdsInc<BLK>{s_inc + tid});
+        else if (FTIGER > 0) ftiger_step<(FTIGER > 0 ? FTIGER : 1)>(P, g, GlobalView{rec}, s, a, so, r, LdsInc<BLK>{s_inc + tid});
         else if (TIGER_TABLE == 2) sim_step<REG>(P, g, PackedView<GlobalView>{GlobalView{rec}, s_prior}, s, a, so, r, LdsInc<BLK>{s_inc + tid});
         else sim_step<REG>(P, g, GlobalView{rec}, s, a, so, r, LdsInc<BLK>{s_inc + tid});
         s_src[tid] = src;
@@ -1066,7 +1070,7 @@ __global__ void __launch_bounds__(BLK) reject_kernel(Problem P, DeviceState D, i
         }
         __syncthreads();
         const int m = min(chunk, N - acc);
-        gather_records(dcn + (size_t)acc * P.Cs, scn, s_owner, s_src, s_inc, ninc, BLK, s_ns, m, C4, P.C, group, BLK, TIGER_TABLE == 2);
+        gather_records(dcn + (size_t)acc * P.Cs, scn, s_owner, s_src, s_inc, ninc, BLK, s_ns, m, C4, P.C, group, BLK, TIGER_TABLE == 2 || FTP);
         acc += m;
         base += BLK;
         __syncthreads();
@@ -1852,6 +1856,27 @@ __global__ void __launch_bounds__(256) init_kernel(Problem P, DeviceState D, int
         }
         return;
     }
+    if (P.ft_packed) {
+        // packed factored-tiger particles: no increments yet, the structure the prior draws (factored_prior_sample:
+        // FactoredTigerPriors.cpp:197-219, 265-291), the start state
+        const int FS = P.fd->FS, maskw = (8 * FS + 4 + (2 << FS)) / 2;
+        for (int i = i_lo + tid; i < i_hi; i += 256) {
+            g.stream(FBA_PHASE_INIT, (uint32_t)i);
+            uint32_t* rec = reinterpret_cast<uint32_t*>(recs + (size_t)i * P.Cs);
+            for (int k = 0; k < maskw; ++k) rec[k] = 0;
+            rec[P.C] = (uint32_t)domain_start(P, g);
+            uint32_t mask = 1u;   // the correct structure: the tiger's door
+            if (P.structure_prior == FBA_SP_FULLY_CONNECTED) mask = (1u << FS) - 1u;
+            else if (P.structure_prior == FBA_SP_UNIFORM || P.structure_prior == FBA_SP_MATCH_UNIFORM) {
+                mask = 0;
+                for (int f = 0; f < FS; ++f)
+                    if (g.boolean()) mask |= 1u << f;
+                if (P.structure_prior == FBA_SP_MATCH_UNIFORM) mask |= 1u;
+            }
+            rec[maskw] = mask;
+        }
+        return;
+    }
     // every particle starts from the prior record ...
     const int C4 = P.Cs / 4;
     const float4* pr = reinterpret_cast<const float4*>(D.prior);
@@ -2074,7 +2099,16 @@ __global__ void __launch_bounds__(256) flush_kernel(Problem P, DeviceState D)
         uint64_t h = mix64((uint64_t)i * 0x9E3779B97F4A7C15ull + (uint64_t)(uint32_t)st);
         const double w = (P.belief == FBA_BELIEF_IMPORTANCE) ? D.p_weight[pb + i] : 0.0;
         h = mix64(h ^ (uint64_t)__double_as_longlong(w));
-        if (P.hist) h = hist_hash_counts(P, reinterpret_cast<const uint32_t*>(cnt), D.hist_cnt[e], h);
+        if (P.ft_packed) {  // the counts themselves, then the mask word, as the dense blob has them
+            const int FS = P.fd->FS, nc = 8 * FS + 4 + (2 << FS);
+            for (int k = 0; k <= nc; ++k) {
+                float v;
+                if (FS == 2) v = packed_ftiger_view<2>(P, GlobalView{cnt}).at(k);
+                else if (FS == 3) v = packed_ftiger_view<3>(P, GlobalView{cnt}).at(k);
+                else v = packed_ftiger_view<4>(P, GlobalView{cnt}).at(k);
+                h = mix64(h ^ ((uint64_t)__float_as_uint(v) + ((uint64_t)k << 32)));
+            }
+        } else if (P.hist) h = hist_hash_counts(P, reinterpret_cast<const uint32_t*>(cnt), D.hist_cnt[e], h);
         else if (P.packed) {  // the checksum is over the counts themselves, whatever the storage (PackedView)
             const PackedView<GlobalView> pv{GlobalView{cnt}, D.prior_dense};
             const int dense = P.phi_len + P.A * P.S * P.O;
@@ -2161,7 +2195,8 @@ void launch_search(const Problem& P, const DeviceState& D, hipStream_t st)
         const int FS = 31 - __builtin_clz((unsigned)P.S);  // S = 2^FS
 #define FBA_LAUNCH_FTIGER(FSV)                                                                                                    \
     do {                                                                                                                          \
-        if (stage) hipLaunchKernelGGL((search_kernel<true, 4, false, 0, FBA_MODEL_BA_FACTORED, FSV>), grid, block, lds, st, P, D); \
+        if (P.ft_packed) hipLaunchKernelGGL((search_kernel<true, 4, false, 0, FBA_MODEL_BA_FACTORED, FSV, false, true>), grid, block, lds, st, P, D); \
+        else if (stage) hipLaunchKernelGGL((search_kernel<true, 4, false, 0, FBA_MODEL_BA_FACTORED, FSV>), grid, block, lds, st, P, D); \
         else hipLaunchKernelGGL((search_kernel<false, 4, false, 0, FBA_MODEL_BA_FACTORED, FSV>), grid, block, lds, st, P, D);      \
         return;                                                                                                                   \
     } while (0)
@@ -2199,7 +2234,10 @@ void launch_belief_update(const Problem& P, const DeviceState& D, hipStream_t st
                         (P.domain == FBA_DOM_FTIGER_EPISODIC || P.domain == FBA_DOM_FTIGER_CONTINUOUS))
                            ? 31 - __builtin_clz((unsigned)P.S) : 0;  // S = 2^FS
         for (int fc = P.reinvig ? 1 : 0; fc >= 0; --fc) {  // the main filter's launch clears the request flag: last
-            if (ft == 2) hipLaunchKernelGGL((reject_kernel<false, 0, 2>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
+            if (ft == 2 && P.ft_packed) hipLaunchKernelGGL((reject_kernel<false, 0, 2, REJECT_BLOCK, true>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
+            else if (ft == 3 && P.ft_packed) hipLaunchKernelGGL((reject_kernel<false, 0, 3, REJECT_BLOCK, true>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
+            else if (ft == 4 && P.ft_packed) hipLaunchKernelGGL((reject_kernel<false, 0, 4, REJECT_BLOCK, true>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
+            else if (ft == 2) hipLaunchKernelGGL((reject_kernel<false, 0, 2>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
             else if (ft == 3) hipLaunchKernelGGL((reject_kernel<false, 0, 3>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
             else if (ft == 4) hipLaunchKernelGGL((reject_kernel<false, 0, 4>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
             else if (P.dirichlet_regular) hipLaunchKernelGGL((reject_kernel<true, 0>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);

@@ -874,8 +874,8 @@ def test_set_model_factored_replaces_the_prior_every_particle_starts_from():
     belief holds exactly the injected counts, and a search + update from there equals the oracle's on particles
     that were given the same counts."""
     kw = dict(size=2, particles=40, sims=60, structure_prior=0, horizon=6)
-    eng = fba.Engine("episodic-factored-tiger", model=N.MODEL_BA_FACTORED, belief="rejection_sampling", seed=57, slots=1, **kw)
-    o = orc.Oracle(domain=orc.DOM_FTIGER_EPISODIC, model=orc.MODEL_BA_FACTORED, belief=orc.BELIEF_REJECTION, rng_mode=orc.RNG_PHILOX,
+    eng = fba.Engine("episodic-factored-tiger", model=N.MODEL_BA_FACTORED, belief="importance_sampling", seed=57, slots=1, **kw)
+    o = orc.Oracle(domain=orc.DOM_FTIGER_EPISODIC, model=orc.MODEL_BA_FACTORED, belief=orc.BELIEF_IMPORTANCE, rng_mode=orc.RNG_PHILOX,
                    arith=orc.ARITH_DEV, philox_seed=57, **kw)
     lay = eng.factored_layout()
     prior = eng.prior()
@@ -941,3 +941,41 @@ def test_log_bd_score_and_lgamma_equal_the_oracle():
         got = C.c_double()
         eng._chk(eng.L.fba_log_bd_score(eng.h, cnt.ctypes.data, prior.ctypes.data, C.byref(got)))
         assert got.value == L.orc_log_bd_score(o.h, cnt.ctypes.data, prior.ctypes.data) != 0.0
+
+
+@pytest.mark.parametrize("size,sp,noise", [(1, 0, 0.0), (2, 2, 0.1), (3, 1, 0.0), (3, 3, -0.1)])
+def test_packed_factored_tiger_particles_equal_dense_ones(size, sp, noise, monkeypatch):
+    """Factored-tiger particles stored as uint16 increments over a prior that is a function of the cell and the
+    particle's structure bits (PackedFtigerView: 144 B instead of 288 B at --size 3) against fp32 count tables
+    (FBA_DENSE_PARTICLES=1): same experiment, same trace (checksum over every count included), same particles through
+    the API; both equal the oracle through every other factored-tiger test."""
+    kw = dict(model=N.MODEL_BA_FACTORED, belief="rejection_sampling", size=size, structure_prior=sp, noise=noise, particles=200, sims=150,
+              runs=8, episodes=4, slots=4, seed=311 + size, trace=1)
+    out = []
+    for dense in (False, True):
+        if dense:
+            monkeypatch.setenv("FBA_DENSE_PARTICLES", "1")
+        eng = fba.Engine("episodic-factored-tiger", **kw)
+        monkeypatch.delenv("FBA_DENSE_PARTICLES", raising=False)
+        FS = size + 1
+        nc = 8 * FS + 4 + (2 << FS)
+        assert eng.ncnt == nc + 1
+        if not dense and noise >= 0:   # (a prior value that is not exact under + 65535 keeps the records dense: -0.1 here)
+            assert eng.particle_bytes == 4 * ((nc // 2 + 2 + 3) // 4 * 4)   # increments, structure word, state
+        stats = eng.run_bapomdp()
+        out.append(([(s.count, s.mean, s.m2) for s in stats], eng.trace(), [eng.belief_get(k) for k in range(4)], eng))
+    assert out[0][3].particle_bytes <= out[1][3].particle_bytes
+    assert out[0][0] == out[1][0]
+    assert out[0][1].tobytes() == out[1][1].tobytes()
+    for a, b in zip(out[0][2], out[1][2]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
+    packed, dense = out[0][3], out[1][3]
+    s, _, cnt = dense.belief_get(2)
+    packed.belief_set(0, state=s, counts=cnt)
+    s2, _, cnt2 = packed.belief_get(0)
+    assert np.array_equal(s, s2) and np.array_equal(cnt.view(np.uint32), cnt2.view(np.uint32))
+    if packed.particle_bytes < dense.particle_bytes:
+        bad = cnt.copy()
+        bad[:, 0] += 0.5
+        with pytest.raises(ValueError, match="plus 0..65535 increments"):
+            packed.belief_set(0, counts=bad)
