@@ -1509,6 +1509,39 @@ __device__ __forceinline__ bool sim_step(const Problem& P, Rng& g, const View& c
     return t;
 }
 
+// BAPOMDP::step (sim_step's tabular branch) for packed tiger records (Problem::packed): both Dirichlet rows of a tiger
+// step have two cells and start at an even cell -- T(s, a, .) at 6s + 2a, O(a, s', .) at 12 + 4a + 2s' -- so a row is ONE
+// word of the record (its two uint16 increment counts) plus the two prior values beside it in the prior table (one
+// 8-byte read).  `word(w)` = word w of the record.  Same draws, same sums, same results as sim_step through PackedView.
+template <class WordFn, class Sink>
+__device__ __forceinline__ bool tiger_step_packed(const Problem& P, Rng& g, const WordFn& word, const float* prior, int& s, int a, int& o, double& r,
+                                                  const Sink& inc)
+{
+    const int t_off = s * 6 + a * 2;
+    int ns;
+    {
+        const uint32_t w = word(t_off >> 1);
+        const float2 p2  = *reinterpret_cast<const float2*>(prior + t_off);
+        const float c0 = p2.x + (float)(w & 0xffffu), c1 = p2.y + (float)(w >> 16);
+        const double p = g.u01() * ((double)c0 + (double)c1);   // sampleFromExpectedMult on a row of two
+        ns = (p < (double)c0) ? 0 : 1;
+    }
+    const int o_off = 12 + a * 4 + ns * 2;
+    {
+        const uint32_t w = word(o_off >> 1);
+        const float2 p2  = *reinterpret_cast<const float2*>(prior + o_off);
+        const float c0 = p2.x + (float)(w & 0xffffu), c1 = p2.y + (float)(w >> 16);
+        const double p = g.u01() * ((double)c0 + (double)c1);
+        o = (p < (double)c0) ? 0 : 1;
+    }
+    const bool t = ext_terminal(P, s, a, ns);
+    r            = ext_reward(P, s, a, ns);
+    inc.add(0, t_off + ns);
+    inc.add(1, o_off + o);
+    s = ns;
+    return t;
+}
+
 // POMDP::computeObservationProbability of the simulator in use
 // (BAPOMDP.cpp:93-99 -> BAFlatModel::computeObservationProbability BAFlatModel.cpp:106-124)
 template <bool REG, class View>

@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
         if (TIGER_TABLE == 2) { P.C = 12; P.Cs = 16; }  // packed particles (PackedView): 24 uint16 + state in 64 bytes
     }
     extern __shared__ double lds[];
-    __shared__ float s_prior[TIGER_TABLE == 2 ? 24 : 1];
+    __shared__ __attribute__((aligned(8))) float s_prior[TIGER_TABLE == 2 ? 24 : 2];
     const int lane = threadIdx.x;
     const int e    = blockIdx.x * SEARCH_BLOCK + lane;
     if (TIGER_TABLE == 2) {
@@ -465,7 +465,8 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
                 term = ftiger_step_packed<(FTIGER > 0 ? FTIGER : 1)>(P, g, LdsView<SEARCH_BLOCK>{stage}, s, a, o, r, NoInc{});
             else if (FTIGER > 0 && STAGE) term = ftiger_step<(FTIGER > 0 ? FTIGER : 1)>(P, g, LdsView<SEARCH_BLOCK>{stage}, s, a, o, r, NoInc{});
             else if (FTIGER > 0) term = ftiger_step<(FTIGER > 0 ? FTIGER : 1)>(P, g, GlobalSearchView{cnt}, s, a, o, r, NoInc{});
-            else if (TIGER_TABLE == 2) term = sim_step<REG>(P, g, PackedView<LdsView<SEARCH_BLOCK>>{LdsView<SEARCH_BLOCK>{stage}, s_prior}, s, a, o, r, NoInc{});
+            else if (TIGER_TABLE == 2)
+                term = tiger_step_packed(P, g, [&](int w) { return __float_as_uint(stage[w * SEARCH_BLOCK]); }, s_prior, s, a, o, r, NoInc{});
             else if (STAGE) term = sim_step<REG>(P, g, LdsView<SEARCH_BLOCK>{stage}, s, a, o, r, NoInc{});
             else term = sim_step<REG>(P, g, GlobalSearchView{cnt}, s, a, o, r, NoInc{});
             ++steps;
@@ -1005,7 +1006,7 @@ __global__ void __launch_bounds__(BLK) reject_kernel(Problem P, DeviceState D, i
         if (TIGER_TABLE == 2) { P.C = 12; P.Cs = 16; }  // packed particles (PackedView)
         if (P.domain != FBA_DOM_TIGER_CONTINUOUS) P.domain = FBA_DOM_TIGER_EPISODIC;
     }
-    __shared__ float s_prior[TIGER_TABLE == 2 ? 24 : 1];
+    __shared__ __attribute__((aligned(8))) float s_prior[TIGER_TABLE == 2 ? 24 : 2];
     __shared__ int32_t s_src[BLK], s_ns[BLK], s_owner[BLK], s_inc[MAXINC * BLK];
     __shared__ int32_t s_wave[BLK / 64];
     __shared__ int32_t s_count;
@@ -1049,7 +1050,7 @@ __global__ void __launch_bounds__(BLK) reject_kernel(Problem P, DeviceState D, i
         // UpdateCounts: the +1s land in the copy
         if (FTIGER > 0 && FTP) ftiger_step_packed<(FTIGER > 0 ? FTIGER : 1)>(P, g, GlobalView{rec}, s, a, so, r, LdsInc<BLK>{s_inc + tid});
         else if (FTIGER > 0) ftiger_step<(FTIGER > 0 ? FTIGER : 1)>(P, g, GlobalView{rec}, s, a, so, r, LdsInc<BLK>{s_inc + tid});
-        else if (TIGER_TABLE == 2) sim_step<REG>(P, g, PackedView<GlobalView>{GlobalView{rec}, s_prior}, s, a, so, r, LdsInc<BLK>{s_inc + tid});
+        else if (TIGER_TABLE == 2) tiger_step_packed(P, g, [&](int w) { return __float_as_uint(rec[w]); }, s_prior, s, a, so, r, LdsInc<BLK>{s_inc + tid});
         else sim_step<REG>(P, g, GlobalView{rec}, s, a, so, r, LdsInc<BLK>{s_inc + tid});
         s_src[tid] = src;
         s_ns[tid]  = s;
@@ -1121,7 +1122,7 @@ __global__ void __launch_bounds__(BLK) reject_tiger_lds_kernel(Problem P, Device
     if (P.domain != FBA_DOM_TIGER_CONTINUOUS) P.domain = FBA_DOM_TIGER_EPISODIC;
     extern __shared__ uint32_t s_tab[];  // [N][3] words, then [N] state bytes
     __shared__ uint16_t s_acc[TIGER_LDS_MAX_N];
-    __shared__ float s_prior[24];
+    __shared__ __attribute__((aligned(8))) float s_prior[24];
     __shared__ int32_t s_wave[BLK / 64];
     __shared__ int32_t s_count;
     const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1161,7 +1162,11 @@ __global__ void __launch_bounds__(BLK) reject_tiger_lds_kernel(Problem P, Device
         const int s0  = s_st[src];
         int s = s0, so;
         double r;
-        sim_step<false>(P, g, TigerRowView{s_tab[3 * src], s_tab[3 * src + 1], s_tab[3 * src + 2], a, s_prior}, s, a, so, r, NoInc{});
+        {
+            // the three parked words ARE the rows a step of action a from this particle can read: T(s, a, .), O(a, 0, .), O(a, 1, .)
+            const uint32_t wt = s_tab[3 * src], wo0 = s_tab[3 * src + 1], wo1 = s_tab[3 * src + 2];
+            tiger_step_packed(P, g, [&](int w) { return w < 6 ? wt : (w & 1 ? wo1 : wo0); }, s_prior, s, a, so, r, NoInc{});
+        }
         const bool ok = (so == o);
         const unsigned long long ballot = __ballot(ok);
         const int prefix = __popcll(ballot & ((1ull << lane) - 1ull));
@@ -1436,7 +1441,7 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
         if (TIGER_TABLE == 2) { P.C = 12; P.Cs = 16; }  // packed particles (PackedView)
         if (P.domain != FBA_DOM_TIGER_CONTINUOUS) P.domain = FBA_DOM_TIGER_EPISODIC;
     }
-    __shared__ float s_prior[TIGER_TABLE == 2 ? 24 : 1];
+    __shared__ __attribute__((aligned(8))) float s_prior[TIGER_TABLE == 2 ? 24 : 2];
     __shared__ double s_carry[IS_MAX_CHUNKS + 2];
     __shared__ int32_t s_src[IS_BLOCK], s_inc[HIST ? 1 : (TIGER_TABLE ? 2 : MAXINC) * IS_BLOCK];
     extern __shared__ double s_w[];  // WLDS: [N] weights, then normalised weights, then their inclusive prefix sums
@@ -1485,7 +1490,7 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
             wcur[i] = sw[i] * prob;
             continue;
         }
-        if (TIGER_TABLE == 2) sim_step<REG>(P, g, PackedView<GlobalView>{GlobalView{cnt}, s_prior}, s, a, so, r, LdsInc<IS_BLOCK>{s_inc + tid});
+        if (TIGER_TABLE == 2) tiger_step_packed(P, g, [&](int w) { return __float_as_uint(cnt[w]); }, s_prior, s, a, so, r, LdsInc<IS_BLOCK>{s_inc + tid});
         else sim_step<REG>(P, g, GlobalView{cnt}, s, a, so, r, LdsInc<IS_BLOCK>{s_inc + tid});
         // incrementCountsOf (BAFlatModel.cpp:126-139, BABNModel.cpp:354-382) is deferred to the gather: the new
         // state and the cells go to the side array, the record is only read
