@@ -32,7 +32,7 @@ DOM_SYSADMIN_INDEPENDENT, DOM_SYSADMIN_LINEAR = 7, 8
 DOM_COFFEE, DOM_COFFEE_BOUTILIER = 9, 10
 DOM_AGR = 11
 MODEL_POMDP, MODEL_BA_TABLE, MODEL_BA_FACTORED = range(3)
-BELIEF_REJECTION, BELIEF_IMPORTANCE, BELIEF_REINVIGORATION, BELIEF_CHEATING, BELIEF_POINT = range(5)
+BELIEF_REJECTION, BELIEF_IMPORTANCE, BELIEF_REINVIGORATION, BELIEF_CHEATING, BELIEF_POINT, BELIEF_MH_GIBBS = range(6)
 PLANNER_POUCT, PLANNER_RANDOM, PLANNER_TS = range(3)
 OK, EINVAL, EHIP, ENODEVICE, ESTATE = 0, -1, -2, -3, -4
 
@@ -46,7 +46,7 @@ DOMAIN_NAMES = {  # reference -D strings (DomainConf.cpp)
 }
 BELIEF_NAMES = {"rejection_sampling": BELIEF_REJECTION, "importance_sampling": BELIEF_IMPORTANCE,
                 "reinvigoration": BELIEF_REINVIGORATION, "cheating-reinvigoration": BELIEF_CHEATING,
-                "point_estimate": BELIEF_POINT}
+                "point_estimate": BELIEF_POINT, "mh-within-gibbs": BELIEF_MH_GIBBS}
 PLANNER_NAMES = {"po-uct": PLANNER_POUCT, "random": PLANNER_RANDOM, "ts": PLANNER_TS}
 
 
@@ -60,7 +60,7 @@ class Config(C.Structure):
         ("noise", C.c_float), ("counts_total", C.c_float), ("structure_prior", C.c_int32),
         ("seed", C.c_uint64), ("run_offset", C.c_int32), ("slots", C.c_int32),
         ("device", C.c_int32), ("trace", C.c_int32), ("dirichlet_regular", C.c_int32),
-        ("resample_amount", C.c_int32), ("threshold", C.c_double),
+        ("resample_amount", C.c_int32), ("threshold", C.c_double), ("belief_option", C.c_int32),
     ]
 
 

@@ -912,6 +912,9 @@ int check_fault(fba_ctx* c)
     HIPCHK(c, hipMemcpy(&f, c->D.fault, sizeof f, hipMemcpyDeviceToHost));
     if (!f) return FBA_OK;
     HIPCHK(c, hipMemset(c->D.fault, 0, sizeof f));
+    if (f >= 0x20000000 && f < 0x40000000)
+        return fail(c, FBA_ESTATE, "mh-within-gibbs in slot %d: the sampled model cannot reproduce the run's history (the reference would never "
+                    "return from rejectionSampleStateHistory, MHwithinGibbs.cpp:38-94)", f - 0x20000000);
     if (f >= 0x40000000)
         return fail(c, FBA_ESTATE, "slot %d: more belief updates in one run than the %d (episodes * horizon) a history particle was "
                     "sized for; create the context with FBA_DENSE_PARTICLES=1 in the environment to drive it beyond that", f - 0x40000000, c->P.hist_cap);
@@ -1110,6 +1113,28 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         }
         P.belief = FBA_BELIEF_IMPORTANCE;
         P.cheat  = cfg->resample_amount;
+    }
+    P.mh = 0;
+    if (cfg->belief == FBA_BELIEF_MH_GIBBS) {
+        // an importance filter + the run's (a, o) history + a Metropolis-Hastings chain that re-draws the filter when the
+        // log likelihood drops below --threshold (MHwithinGibbs.cpp); built for the factored-tiger prior
+        if (cfg->model != FBA_MODEL_BA_FACTORED || !is_ftiger(cfg->domain) || cfg->dirichlet_regular) {
+            fail(nullptr, FBA_EINVAL, "mh-within-gibbs belief: built for the factored-tiger FBA-POMDP (fbapomdp -D *-factored-tiger), expected Dirichlet mode");
+            delete c;
+            return FBA_EINVAL;
+        }
+        if (cfg->particles < 1) {  // MHwithinGibbs.cpp:243-246
+            fail(nullptr, FBA_EINVAL, "MHwithinGibbs::cannot initiate MH with size 0");
+            delete c;
+            return FBA_EINVAL;
+        }
+        if (cfg->threshold >= 0) {  // :248-252
+            fail(nullptr, FBA_EINVAL, "MHwithinGibbs::cannot initiate with threshold >= 0 (is:%f)", cfg->threshold);
+            delete c;
+            return FBA_EINVAL;
+        }
+        P.belief = FBA_BELIEF_IMPORTANCE;
+        P.mh     = cfg->belief_option == 1 ? 2 : 1;
     }
     if (cfg->belief == FBA_BELIEF_REINVIGORATION) {
         // two rejection filters + breeding (ReinvigoratingRejectionSampling.hpp); the reference has fully
@@ -1413,6 +1438,27 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         D.ctot_stride = (P.N + 255) / 256 + 2;
         CHK(dev_alloc(c, &D.ctot, is ? (size_t)E * D.ctot_stride : 1));
         CHK(dev_alloc(c, &D.is_tot, (size_t)2 * E));
+    }
+    if (P.mh) {
+        if (D.is_multi) {
+            fail(c, FBA_EINVAL, "mh-within-gibbs belief: at most %d particles per slot", IS_MAX_CHUNKS * 256);
+            g_create_error = c->err;
+            fba_destroy(c);
+            return FBA_EINVAL;
+        }
+        const size_t cap = (size_t)P.episodes * P.horizon;
+        CHK(dev_alloc(c, &D.lik, (size_t)E + 1));
+        CHK(dev_alloc(c, &D.cheat_pending, E));
+        CHK(dev_alloc(c, &D.mh_a, (size_t)E * cap));
+        CHK(dev_alloc(c, &D.mh_o, (size_t)E * cap));
+        CHK(dev_alloc(c, &D.mh_ep_len, (size_t)E * (P.episodes + 1)));
+        CHK(dev_alloc(c, &D.mh_n_ep, E));
+        size_t words = (size_t)3 * P.Cs + (size_t)P.S * P.A * P.S + (size_t)P.A * P.S * P.O + 2;
+        words += 2 * ((size_t)(P.horizon + 1) * P.S + P.S) + (size_t)P.episodes * (P.horizon + 1) + 2;
+        D.mh_scratch_words = (int32_t)((words + 3) & ~(size_t)3);
+        CHK(dev_alloc(c, &D.mh_scratch, (size_t)E * D.mh_scratch_words));
+        const double thr = cfg->threshold;
+        HIPC(hipMemcpy(D.lik + E, &thr, sizeof thr, hipMemcpyHostToDevice));
     }
     if (P.cheat) {
         if (D.is_multi) {

@@ -1339,6 +1339,245 @@ __global__ void __launch_bounds__(256) cheat_kernel(Problem P, DeviceState D)
     if (tid == 0) D.cheat_pending[e] = 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// mh_kernel: the rest of MHwithinGibbs::updateEstimation (MHwithinGibbs.cpp:316-332) after the importance update and
+// resample: record (a, o) in the run's history, add log(likelihood), and when the sum falls below --threshold re-draw
+// the whole filter (reinvigorate, :334-395): a Metropolis-Hastings chain over structures -- mutate, prior of the
+// structure (computePriorModel, FactoredTigerPriors.cpp:293-321), posterior counts along a sampled state history
+// (computePosteriorCounts :397-436), LogBDScore, accept if log(u) < score difference -- inside a Gibbs loop that
+// re-samples the state history (msgSampleStateHistory :96-213 or rejectionSampleStateHistory :38-94) after every
+// accepted model.  The chain is sequential by definition and this belief is a research variant, so ONE lane runs
+// one slot's chain, all draws from stream (REINVIG, 0); slots run side by side.  Factored tiger.
+// ---------------------------------------------------------------------------------------------
+struct MhScratch {
+    float *prior, *model, *fresh, *T, *O;
+    double *msg, *probs;
+    int32_t* seq;
+};
+__device__ __forceinline__ MhScratch mh_scratch(const Problem& P, const DeviceState& D, int e)
+{
+    MhScratch m;
+    float* base = D.mh_scratch + (size_t)e * D.mh_scratch_words;
+    m.prior = base; m.model = base + P.Cs; m.fresh = base + 2 * P.Cs;
+    m.T = base + 3 * P.Cs;
+    m.O = m.T + P.S * P.A * P.S;
+    m.msg   = reinterpret_cast<double*>(base + ((3 * P.Cs + P.S * P.A * P.S + P.A * P.S * P.O + 1) & ~1));
+    m.probs = m.msg + (size_t)(P.horizon + 1) * P.S;
+    m.seq   = reinterpret_cast<int32_t*>(m.probs + P.S);
+    return m;
+}
+// BABNModel::incrementCountsOf (BABNModel.cpp:354-382; observation rows at the OLD state's parent values, App. A #6)
+__device__ void mh_increment(const Problem& P, float* cnt, int s, int a, int o, int ns)
+{
+    const FDesc* fd   = P.fd;
+    const GlobalView v{cnt};
+    const uint64_t fv = pack_features(s, fd->Sstep, fd->FS), nf = pack_features(ns, fd->Sstep, fd->FS), of = pack_features(o, fd->Ostep, fd->FO);
+    for (int f = 0; f < fd->FS; ++f) {
+        const FNode& nd = fd->nodes[a * fd->FS + f];
+        cnt[node_row(fd, nd, node_mask(fd, nd, v), fv) + feat(nf, f)] += 1.0f;
+    }
+    for (int f = 0; f < fd->FO; ++f) {
+        const FNode& nd = fd->nodes[P.A * fd->FS + a * fd->FO + f];
+        cnt[node_row(fd, nd, node_mask(fd, nd, v), fv) + feat(of, f)] += 1.0f;
+    }
+}
+__device__ void mh_posterior(const Problem& P, const DeviceState& D, int e, const float* prior, const int32_t* seq, float* out)
+{
+    for (int k = 0; k < P.C; ++k) out[k] = prior[k];
+    const int16_t *ha = D.mh_a + (size_t)e * P.episodes * P.horizon, *ho = D.mh_o + (size_t)e * P.episodes * P.horizon;
+    const int32_t* len = D.mh_ep_len + (size_t)e * (P.episodes + 1);
+    int k = 0, h = 0;
+    for (int ep = 0; ep < D.mh_n_ep[e]; ++ep) {
+        for (int t = 0; t < len[ep]; ++t, ++h, ++k) mh_increment(P, out, seq[k], ha[h], ho[h], seq[k + 1]);
+        ++k;
+    }
+}
+// expectedMult (random.cpp:257-279): float sum, float division, all-zero if the sum underflows
+__device__ __forceinline__ void mh_expected(const float* row, int n, float* out)
+{
+    float sum = row[0];
+    for (int i = 1; i < n; ++i) sum += row[i];
+    for (int i = 0; i < n; ++i) out[i] = ((double)sum <= 1e-300) ? 0.f : row[i] / sum;
+}
+// BABNModel::flattenT / flattenO (BABNModel.cpp:89-181)
+__device__ void mh_flatten(const Problem& P, const float* model, float* T, float* O)
+{
+    const FDesc* fd = P.fd;
+    const GlobalView v{model};
+    const int S = P.S, A = P.A, NO = P.O;
+    for (int a = 0; a < A; ++a)
+        for (int s = 0; s < S; ++s) {
+            float ex[MAXF][MAXROW];
+            const uint64_t fv = pack_features(s, fd->Sstep, fd->FS);
+            for (int f = 0; f < fd->FS; ++f) {
+                const FNode& nd = fd->nodes[a * fd->FS + f];
+                mh_expected(model + node_row(fd, nd, node_mask(fd, nd, v), fv), nd.out, ex[f]);
+            }
+            for (int ns = 0; ns < S; ++ns) {
+                const uint64_t nf = pack_features(ns, fd->Sstep, fd->FS);
+                float p = 1;
+                for (int f = 0; f < fd->FS; ++f) p *= ex[f][feat(nf, f)];
+                T[((size_t)s * A + a) * S + ns] = p;
+            }
+            for (int f = 0; f < fd->FO; ++f) {  // (s plays the new state here)
+                const FNode& nd = fd->nodes[A * fd->FS + a * fd->FO + f];
+                mh_expected(model + node_row(fd, nd, node_mask(fd, nd, v), fv), nd.out, ex[f]);
+            }
+            for (int o = 0; o < NO; ++o) {
+                const uint64_t of = pack_features(o, fd->Ostep, fd->FO);
+                float p = 1;
+                for (int f = 0; f < fd->FO; ++f) p *= ex[f][feat(of, f)];
+                O[((size_t)a * S + s) * NO + o] = p;
+            }
+        }
+}
+// rnd::sample::Dir::sampleFromMult<double> (random.hpp:93-115)
+__device__ __forceinline__ int mh_sample_d(Rng& g, const double* m, int n, double total)
+{
+    const double p = g.u01() * total;
+    double sum = m[0];
+    for (int i = 1; i < n; ++i) {
+        if (p < sum) return i - 1;
+        sum += m[i];
+    }
+    return n - 1;
+}
+__device__ bool mh_sample_history(const Problem& P, const DeviceState& D, int e, Rng& g, const MhScratch& m, const float* model)
+{
+    const int S = P.S, A = P.A, NO = P.O;
+    const int16_t *ha = D.mh_a + (size_t)e * P.episodes * P.horizon, *ho = D.mh_o + (size_t)e * P.episodes * P.horizon;
+    const int32_t* len = D.mh_ep_len + (size_t)e * (P.episodes + 1);
+    int k = 0, h0 = 0;
+    if (P.mh == 2) {  // rejectionSampleStateHistory
+        for (int ep = 0; ep < D.mh_n_ep[e]; ++ep) {
+            const int L = len[ep];
+            bool ok = false;
+            for (int tries = 0; !ok; ++tries) {
+                if (tries >= (1 << 22)) return false;
+                int s = domain_start(P, g);
+                m.seq[k] = s;
+                ok = true;
+                for (int t = 0; t < L; ++t) {
+                    int so;
+                    double r;
+                    fact_step<false>(P, g, GlobalView{model}, s, ha[h0 + t], so, r, NoInc{});
+                    if (so != ho[h0 + t]) { ok = false; break; }
+                    m.seq[k + 1 + t] = s;
+                }
+            }
+            k += L + 1;
+            h0 += L;
+        }
+        return true;
+    }
+    // msgSampleStateHistory
+    mh_flatten(P, model, m.T, m.O);
+    const float init = 1.0f / (float)S;
+    const float prior_p = (float)((double)init / (double)(init * (float)S));  // categoricalDistr(size, init)::prob (distributions.cpp:12-35)
+    for (int ep = 0; ep < D.mh_n_ep[e]; ++ep) {
+        const int L = len[ep];
+        const int16_t *ea = ha + h0, *eo = ho + h0;
+        for (int st = 0; st < S; ++st) m.msg[(size_t)L * S + st] = (double)m.O[((size_t)ea[L - 1] * S + st) * NO + eo[L - 1]];
+        for (int step = L - 1; step >= 0; --step) {
+            const int a = ea[step];
+            double tot = 0;
+            for (int st = 0; st < S; ++st) {
+                double acc = 0.0;
+                for (int ns = 0; ns < S; ++ns) acc = acc + (double)m.T[((size_t)st * A + a) * S + ns] * m.msg[(size_t)(step + 1) * S + ns];
+                if (step != 0) acc *= (double)m.O[((size_t)ea[step - 1] * S + st) * NO + eo[step - 1]];
+                else acc *= (double)prior_p;
+                m.msg[(size_t)step * S + st] = acc;
+                tot += acc;
+            }
+            for (int st = 0; st < S; ++st) m.msg[(size_t)step * S + st] = m.msg[(size_t)step * S + st] / tot;
+        }
+        int st = mh_sample_d(g, m.msg, S, 1);
+        m.seq[k++] = st;
+        for (int step = 0; step < L; ++step) {
+            double tot = 0;
+            for (int ns = 0; ns < S; ++ns) {
+                m.probs[ns] = (double)m.T[((size_t)st * A + ea[step]) * S + ns] * m.msg[(size_t)(step + 1) * S + ns];
+                tot += m.probs[ns];
+            }
+            st = mh_sample_d(g, m.probs, S, tot);
+            m.seq[k++] = st;
+        }
+        h0 += L;
+    }
+    return true;
+}
+__global__ void __launch_bounds__(64) mh_kernel(Problem P, DeviceState D)
+{
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= P.E || !D.cheat_pending[e]) return;
+    D.cheat_pending[e] = 0;
+    // history.back().add(a, o); log likelihood
+    int16_t *ha = D.mh_a + (size_t)e * P.episodes * P.horizon, *ho = D.mh_o + (size_t)e * P.episodes * P.horizon;
+    int32_t* len = D.mh_ep_len + (size_t)e * (P.episodes + 1);
+    const int n_ep = D.mh_n_ep[e];
+    int h = 0, nseq = 0;
+    for (int ep = 0; ep < n_ep; ++ep) h += len[ep];
+    if (h >= P.episodes * P.horizon) {  // more updates than a run has steps: only the per-step interface can get here
+        atomicCAS(D.fault, 0, 0x40000000 + e);
+        return;
+    }
+    ha[h] = (int16_t)D.action[e];
+    ho[h] = (int16_t)D.obs[e];
+    len[n_ep - 1] += 1;
+    const double ll = D.lik[e] + det_log(D.cur[e].weight_total);
+    D.lik[e] = ll;
+    if (!(ll < D.lik[P.E])) return;
+
+    // reinvigorate
+    for (int ep = 0; ep < n_ep; ++ep) nseq += len[ep] + 1;
+    const FDesc* fd = P.fd;
+    const MhScratch m = mh_scratch(P, D, e);
+    const int cur = D.bufsel[e], N = P.N;
+    const float* old_recs = D.p_rec + pbase(P, e, cur) * (size_t)P.Cs;
+    float* new_recs       = D.p_rec + pbase(P, e, cur ^ 1) * (size_t)P.Cs;
+    double* new_w         = D.p_weight + pbase(P, e, cur ^ 1);
+    Rng g = slot_rng(P, D, e);
+    g.stream(FBA_PHASE_REINVIG, 0);
+    {
+        const float* src = old_recs + (size_t)uniform_weight_pick(D.uni_scan, N, g.u01() * D.uni_total, D.uni_total) * P.Cs;  // old_belief.sample()->model()
+        for (int k = 0; k < P.C; ++k) m.model[k] = src[k];
+    }
+    bool ok = mh_sample_history(P, D, e, g, m, m.model);
+    uint32_t mask = __float_as_uint(m.model[fd->ncounts]);
+    for (int k = 0; k < P.C; ++k) m.prior[k] = D.prior[k];
+    ftiger_set_observation_model(P, m.prior, mask);
+    mh_posterior(P, D, e, m.prior, m.seq, m.model);
+    double score = log_bd_score(P, GlobalView{m.model}, GlobalView{m.prior});
+    const double w1 = 1.0 / (double)N;
+    int made = 0;
+    for (int iters = 0; ok && made < N; ++iters) {
+        if (iters >= (1 << 24)) { ok = false; break; }
+        const uint32_t nmask = mask ^ (1u << g.slow_int(0, fd->FS));   // FactoredTigerFactoredPrior::mutate: flip_random_edge of O[listen][0]
+        for (int k = 0; k < P.C; ++k) m.prior[k] = D.prior[k];
+        ftiger_set_observation_model(P, m.prior, nmask);
+        mh_posterior(P, D, e, m.prior, m.seq, m.fresh);
+        const double new_score = log_bd_score(P, GlobalView{m.fresh}, GlobalView{m.prior});
+        if (det_log(g.u01()) < (new_score - score)) {
+            float* dst = new_recs + (size_t)made * P.Cs;
+            for (int k = 0; k < P.C; ++k) dst[k] = m.fresh[k];
+            rec_set_state(dst, P.C, m.seq[nseq - 1]);
+            new_w[made] = w1;
+            ++made;
+            ok = mh_sample_history(P, D, e, g, m, m.model);   // (from the model of the LAST accepted structure, as the reference does)
+            mh_posterior(P, D, e, m.prior, m.seq, m.model);
+            mask  = nmask;
+            score = log_bd_score(P, GlobalView{m.model}, GlobalView{m.prior});
+        }
+    }
+    if (!ok) {
+        atomicCAS(D.fault, 0, 0x20000000 + e);
+        return;
+    }
+    D.bufsel[e] = cur ^ 1;
+    D.lik[e]    = 0.0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Device-order prefix sums (DESIGN.md "device-order sums"; oracle/orc.c dev_scan is the CPU twin):
 // each lane sums 4 consecutive elements sequentially, a 64-lane Kogge-Stone scan combines the
@@ -1579,6 +1818,7 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
             D.hist_cnt[e] = hist_cnt + (1u << (8 * a));
             D.upd_entries[e] += (unsigned long long)N * (unsigned long long)hist_n;
         }
+        if (P.mh) D.cheat_pending[e] = 1;  // mh_kernel: append (a, o) to the history, add log(total), maybe re-draw the filter
         if (P.cheat) {  // CheatingReinvigoration::updateEstimation (CheatingReinvigoration.cpp:117-124)
             double lik = D.lik[e] * total;
             if (det_log(lik) < D.lik[P.E]) {
@@ -1930,7 +2170,7 @@ __global__ void __launch_bounds__(256) reset_kernel(Problem P, DeviceState D, in
     const size_t sb = pbase(P, e, cur), db = pbase(P, e, cur ^ 1);
     Rng g = slot_rng(P, D, e);
     g.position((uint32_t)D.run[e], (uint32_t)D.episode[e], 0);
-    if (P.belief == FBA_BELIEF_REJECTION || fc || P.cheat) {  // (the cheating belief resets its weighted filter in place too, CheatingReinvigoration.cpp:48-62)
+    if (P.belief == FBA_BELIEF_REJECTION || fc || P.cheat || P.mh) {  // (the cheating and the mh-within-gibbs beliefs reset their weighted filter in place too, CheatingReinvigoration.cpp:48-62, MHwithinGibbs.cpp:259-275)
         float* recs = (fc ? D.p_rec_fc : D.p_rec) + sb * (size_t)P.Cs;
         for (int i = i_lo + tid; i < i_hi; i += 256) {
             g.stream(fc ? FBA_PHASE_RESET_FC : FBA_PHASE_RESET, (uint32_t)i);
@@ -2005,13 +2245,23 @@ __global__ void post_init_kernel(Problem P, DeviceState D)
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= P.E) return;
     if (P.hist && D.need_init[e]) D.hist_cnt[e] = 0;
+    if (P.mh && D.need_init[e]) {  // MHwithinGibbs::initiate :277-294
+        D.mh_n_ep[e] = 1;
+        D.mh_ep_len[(size_t)e * (P.episodes + 1)] = 0;
+        D.lik[e] = 0.0;
+    }
     D.need_init[e] = 0;
 }
 __global__ void post_reset_kernel(Problem P, DeviceState D)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= P.E || D.need_reset[e] != 1) return;
-    if (P.belief == FBA_BELIEF_IMPORTANCE && !P.cheat) D.bufsel[e] ^= 1;
+    if (P.belief == FBA_BELIEF_IMPORTANCE && !P.cheat && !P.mh) D.bufsel[e] ^= 1;
+    if (P.mh) {  // MHwithinGibbs::resetDomainStateDistribution :270-274: a new episode unless the open one is still empty
+        int32_t* len = D.mh_ep_len + (size_t)e * (P.episodes + 1);
+        const int n = D.mh_n_ep[e];
+        if (len[n - 1] != 0 && n <= P.episodes) { len[n] = 0; D.mh_n_ep[e] = n + 1; }
+    }
     D.need_reset[e] = 0;
 }
 
@@ -2282,6 +2532,7 @@ void launch_belief_update(const Problem& P, const DeviceState& D, hipStream_t st
         else { if (wlds) FBA_LAUNCH_IS(false, 0, false, true); else FBA_LAUNCH_IS(false, 0, false, false); }
 #undef FBA_LAUNCH_IS
         if (P.cheat) hipLaunchKernelGGL(cheat_kernel, dim3(P.E), dim3(256), 0, st, P, D);
+        if (P.mh) hipLaunchKernelGGL(mh_kernel, dim3(ceil_div(P.E, 64)), dim3(64), 0, st, P, D);
         return;
     }
     const int nchunks = (P.N + 255) / 256;

@@ -54,7 +54,14 @@ struct DeviceState {
     double* lik;        // [E] cheating belief: CheatingReinvigoration::_likelihood; [E] holds the threshold
     uint8_t* lazy_reset;  // [E] rejection filter: resetDomainStateDistribution is pending -- particle i's state is the RESET-stream draw, not the record's word
     int32_t* fault;     // [1] 0, or 1 + the slot whose rejection update exceeded REJECT_MAX_ATTEMPTS (host reports it)
-    uint8_t* cheat_pending;  // [E] the update of this tick pushed log(likelihood) below the threshold
+    uint8_t* cheat_pending;  // [E] the update of this tick pushed log(likelihood) below the threshold (mh-within-gibbs: an update has run, mh_kernel has work)
+    // mh-within-gibbs belief: the run's (action, observation) history by episode; lik[e] is the log likelihood, lik[E] the threshold
+    int16_t* mh_a;      // [E][episodes * horizon]
+    int16_t* mh_o;
+    int32_t* mh_ep_len; // [E][episodes + 1]
+    int32_t* mh_n_ep;   // [E] episodes in the history, the open one included
+    float* mh_scratch;  // [E][mh_scratch_words]: three count blobs, T and O tables, messages, probabilities, the state sequence
+    int32_t mh_scratch_words;
     int32_t* p_side;    // [E][N][side_w] importance filters: {new state, cells to increment} of the pending update (side_w = 1 + FS + FO;
                         // history particles: {new state, the step's entry})
     uint32_t* hist_cnt; // [E] history particles: how many entries of action a every record of the slot holds, 8 bits per action (fba_device.h)

@@ -31,7 +31,7 @@ namespace {
 struct Options {
     std::string mode;
     std::string domain, planner = "po-uct", belief = "rejection_sampling", seed, output_file = "results.txt", structure_prior,
-                                dirichlet = "expected", id;
+                                dirichlet = "expected", id, belief_option;
     int verbose = 0, runs = 1, horizon = 10, sims = 1000, max_depth = -1, particles = 100, size = 0, height = 0, width = 0,
         episodes = 1, slots = 0, device = 0, resample_amount = 0;
     double discount = .95, exploration = 100, threshold = 0;
@@ -51,7 +51,7 @@ void usage()
         "  -d, --discount X               Discount for future rewards (0.95)\n"
         "  -P, --planner NAME             random, ts (Thompson sampling) or po-uct (po-uct)\n"
         "  -B, --belief NAME              point_estimate, rejection_sampling, importance_sampling or (fbapomdp) reinvigoration,\n"
-        "                                 cheating-reinvigoration\n"
+        "                                 cheating-reinvigoration, mh-within-gibbs\n"
         "      --seed STR                 Global seed for all random samples\n"
         "      --id STR                   The id to give this process\n"
         "  -s, --simulation-amount N      simulations per search (1000)\n"
@@ -59,7 +59,8 @@ void usage()
         "  -u, --exploration-constant X   UCB exploration constant (100)\n"
         "      --particle-amount N        particles in the filter (100)\n"
         "      --resample-amount N        particles reinvigorated per belief update (reinvigoration beliefs)\n"
-        "      --threshold X              cheating-reinvigoration: log likelihood before cheating (< 0)\n"
+        "      --threshold X              cheating-reinvigoration / mh-within-gibbs: log likelihood below which the belief is repaired (< 0)\n"
+        "      --belief-option rs         mh-within-gibbs: state histories by rejection sampling instead of message passing\n"
         "  -D, --domain NAME              episodic-tiger, continuous-tiger, episodic-factored-tiger,\n"
         "                                 continuous-factored-tiger, gridworld, random-collision-avoidance,\n"
         "                                 centered-collision-avoidance, independent-sysadmin, linear-sysadmin,\n"
@@ -111,6 +112,7 @@ bool parse(int argc, char** argv, Options& o, std::string& err)
             else if (k == "--particle-amount") o.particles = std::stoi(v);
             else if (k == "--resample-amount") o.resample_amount = std::stoi(v);
             else if (k == "--threshold") o.threshold = std::stod(v);
+            else if (k == "--belief-option") o.belief_option = v;
             else if (k == "--domain") o.domain = v;
             else if (k == "--size") o.size = std::stoi(v);
             else if (k == "--height") o.height = std::stoi(v);
@@ -161,6 +163,14 @@ bool to_config(Options const& o, fba_config& c, std::string& err)
     else if (o.belief == "point_estimate") c.belief = FBA_BELIEF_POINT;  // Belief.cpp:13-14, BABelief.cpp:19-20
     else if (o.belief == "reinvigoration" && o.mode == "fbapomdp") c.belief = FBA_BELIEF_REINVIGORATION;  // BABelief.cpp:28-31
     else if (o.belief == "cheating-reinvigoration" && o.mode == "fbapomdp") c.belief = FBA_BELIEF_CHEATING;  // BABelief.cpp:60-65
+    else if (o.belief == "mh-within-gibbs" && o.mode == "fbapomdp") {  // BABelief.cpp:33-47: "" = MSG, "rs" = RS
+        c.belief = FBA_BELIEF_MH_GIBBS;
+        if (!o.belief_option.empty() && o.belief_option != "rs") {  // BeliefConf.cpp:51-56
+            err = "You have set the illegal belief_option '" + o.belief_option + "' with belief " + o.belief + ".";
+            return false;
+        }
+        c.belief_option = o.belief_option == "rs" ? 1 : 0;
+    }
     else { err = "please enter a legit state stimator: point_estimate, rejection_sampling, importance_sampling or (fbapomdp) reinvigoration, provided: " + o.belief; return false; }
     if ((o.resample_amount == 0) ^ (o.belief != "reinvigoration" && o.belief != "cheating-reinvigoration")) {  // BeliefConf.cpp:40-49
         err = "You have set the resample amount (" + std::to_string(o.resample_amount) + "), but are not using one of the beliefs (" + o.belief +

@@ -49,8 +49,11 @@ enum { FBA_MODEL_POMDP = 0, FBA_MODEL_BA_TABLE = 1, FBA_MODEL_BA_FACTORED = 2 };
  * (BABelief.cpp:28-31: ReinvigoratingRejectionSampling, factored models only) */
 enum { FBA_BELIEF_REJECTION = 0, FBA_BELIEF_IMPORTANCE = 1, FBA_BELIEF_REINVIGORATION = 2,
        FBA_BELIEF_CHEATING = 3, /* cheating-reinvigoration (BABelief.cpp:60-65: prototypes::CheatingReinvigoration) */
-       FBA_BELIEF_POINT = 4 /* point_estimate (Belief.cpp:13-14 PointEstimation, BABelief.cpp:19-20 BAPointEstimation): one state,
-                             * updated by rejection; `particles` is ignored (1) and sample() draws nothing */ };
+       FBA_BELIEF_POINT = 4, /* point_estimate (Belief.cpp:13-14 PointEstimation, BABelief.cpp:19-20 BAPointEstimation): one state,
+                             * updated by rejection; `particles` is ignored (1) and sample() draws nothing */
+       FBA_BELIEF_MH_GIBBS = 5 /* mh-within-gibbs (BABelief.cpp:33-47: factored::MHwithinGibbs; `belief_option` 1 = "rs"): importance
+                                * filter whose particles are re-drawn by a Metropolis-Hastings chain over structures when the log
+                                * likelihood falls below `threshold`; factored tiger */ };
 /* -P po-uct | random | ts (Planner.cpp:12-19, BAPlanner.cpp:13-20; ts = Thompson sampling: TSPlanner / BATSPlanner) */
 enum { FBA_PLANNER_POUCT = 0, FBA_PLANNER_RANDOM = 1, FBA_PLANNER_TS = 2 };
 /* --structure-prior (FBAConf.hpp) */
@@ -112,6 +115,7 @@ typedef struct fba_config {
     int32_t resample_amount; /* --resample-amount: particles bred per update by the reinvigoration
                               * belief / copied per cheat by the cheating belief (BeliefConf.cpp:17-21) */
     double threshold;        /* --threshold: log likelihood below which the cheating belief cheats (< 0) */
+    int32_t belief_option;   /* --belief-option: mh-within-gibbs 0 = state histories by message passing (default), 1 = "rs" */
 } fba_config;
 
 /* One record per real time-step: the information the reference prints at -v 2 / -v 3

@@ -85,6 +85,14 @@ struct orc_ctx {
     int32_t ncnt;      /* floats per particle count blob */
     int32_t phi_len;   /* tabular: S*A*S */
     float* prior;      /* tabular prior blob (phi then psi) */
+    /* MH-within-Gibbs belief: the run's (action, observation) history by episode, the log-likelihood, scratch */
+    int16_t *mh_a, *mh_o;
+    int32_t* mh_ep_len;
+    int mh_n_ep;
+    double log_lik;
+    float *mh_prior, *mh_model, *mh_new, *mh_T, *mh_O;
+    double *mh_msg, *mh_probs;
+    int32_t* mh_seq;
     double* log1p_tab; /* log1p(m), m < sims (POUCT.cpp:330-338 factorised) */
     double gamma;
     tree tr;
@@ -1967,7 +1975,7 @@ static void weighted_refresh_scan(orc_ctx* c)
 }
 
 /* the main filter is a WeightedFilter (importance sampling; the cheating belief's _belief) */
-static int is_weighted(const orc_ctx* c) { return c->cfg.belief == ORC_BELIEF_IMPORTANCE || c->cfg.belief == ORC_BELIEF_CHEATING; }
+static int is_weighted(const orc_ctx* c) { return c->cfg.belief == ORC_BELIEF_IMPORTANCE || c->cfg.belief == ORC_BELIEF_CHEATING || c->cfg.belief == ORC_BELIEF_MH_GIBBS; }
 
 static int32_t belief_sample(orc_ctx* c)
 {
@@ -2007,6 +2015,11 @@ static void belief_initiate(orc_ctx* c)
         c->total_w += w; /* WeightedFilter::add(T, w) WeightedFilter.cpp:60-66 */
     }
     if (is_weighted(c)) weighted_refresh_scan(c);
+    if (c->cfg.belief == ORC_BELIEF_MH_GIBBS) {  /* MHwithinGibbs::initiate :277-294 (free() :296-312 clears the history) */
+        c->mh_n_ep      = 1;
+        c->mh_ep_len[0] = 0;
+        c->log_lik      = 0;
+    }
     if (c->cfg.belief == ORC_BELIEF_CHEATING) {
         /* CheatingReinvigoration::initiate (CheatingReinvigoration.cpp:64-90): a second FlatFilter of
          * fbapomdp.sampleCorrectGraphState() particles (the prior's own structure: the base record) */
@@ -2213,6 +2226,223 @@ static void reinvigorate(orc_ctx* c)
     }
 }
 
+
+/* ------------------------------------------------------------------ MH-within-Gibbs belief
+ * ref: src/beliefs/bayes-adaptive/factored/MHwithinGibbs.cpp (needs FBAPOMDP.hpp -> Boost: restated, not built).
+ * A weighted filter updated by importance sampling + resampling; the run's history of (a, o) by episode; when the
+ * accumulated log-likelihood falls below --threshold the whole filter is re-drawn by a Metropolis-Hastings chain over
+ * structures (scored by LogBDScore on the counts a sampled state history gives) inside a Gibbs loop over state
+ * histories.  One Philox stream (REINVIG, 0) serves the chain: its draws are sequential by definition.
+ * Built for the factored-tiger prior (computePriorModel FactoredTigerPriors.cpp:293-321, mutate :351-381). */
+
+/* FBAPOMDPPrior::computePriorModel(structure): the factored-tiger prior for the listen observation node's parent set */
+static void mh_compute_prior(orc_ctx* c, uint32_t mask, float* out)
+{
+    memcpy(out, c->prior, sizeof(float) * (size_t)c->ncnt);
+    ftiger_set_observation_model(c, out, mask);
+}
+/* BABNModel::incrementCountsOf (BABNModel.cpp:354-382): observation rows at the OLD state's parent values (App. A #6) */
+static void fact_increment(orc_ctx* c, float* cnt, int32_t s, int32_t a, int32_t o, int32_t ns)
+{
+    const fdesc* d = &c->fd;
+    int fv[ORC_MAXF], nf[ORC_MAXF], of[ORC_MAXF], f;
+    features_of(s, d->Sstep, d->FS, fv);
+    features_of(ns, d->Sstep, d->FS, nf);
+    features_of(o, d->Ostep, d->FO, of);
+    for (f = 0; f < d->FS; ++f) {
+        const fnode* nd = &d->T[a * d->FS + f];
+        cnt[node_row(c, nd, node_mask(c, nd, cnt), fv) + nf[f]] += 1;
+    }
+    for (f = 0; f < d->FO; ++f) {
+        const fnode* nd = &d->O[a * d->FO + f];
+        cnt[node_row(c, nd, node_mask(c, nd, cnt), fv) + of[f]] += 1;
+    }
+}
+/* MHwithinGibbs::computePosteriorCounts (:397-436): the prior's counts + one incrementCountsOf per step of the history
+ * along the state sequence (one more state than steps per episode) */
+static void mh_posterior(orc_ctx* c, const float* prior, const int32_t* seq, float* out)
+{
+    int e, t, k = 0, h = 0;
+    memcpy(out, prior, sizeof(float) * (size_t)c->ncnt);
+    for (e = 0; e < c->mh_n_ep; ++e) {
+        for (t = 0; t < c->mh_ep_len[e]; ++t, ++h, ++k) fact_increment(c, out, seq[k], c->mh_a[h], c->mh_o[h], seq[k + 1]);
+        k++;
+    }
+}
+/* BABNModel::flattenT / flattenO (BABNModel.cpp:89-181): T[s][a][s'] = prod_f expectedMult(row_f(s))[s'_f] in float,
+ * features in order; O[a][s'][o] likewise over the observation features */
+static void mh_flatten(orc_ctx* c, const float* model)
+{
+    const fdesc* d = &c->fd;
+    int S = c->S, A = c->A, O = c->O, a, s, ns, o, f;
+    float e[ORC_MAXF][16];
+    int fv[ORC_MAXF], nf[ORC_MAXF];
+    for (a = 0; a < A; ++a)
+        for (s = 0; s < S; ++s) {
+            features_of(s, d->Sstep, d->FS, fv);
+            for (f = 0; f < d->FS; ++f) {
+                const fnode* nd = &d->T[a * d->FS + f];
+                orc_expected_mult(model + node_row(c, nd, node_mask(c, nd, model), fv), nd->out, e[f]);
+            }
+            for (ns = 0; ns < S; ++ns) {
+                float p = 1;
+                features_of(ns, d->Sstep, d->FS, nf);
+                for (f = 0; f < d->FS; ++f) p *= e[f][nf[f]];
+                c->mh_T[((size_t)s * A + a) * S + ns] = p;
+            }
+            for (f = 0; f < d->FO; ++f) {   /* (s plays the new state here) */
+                const fnode* nd = &d->O[a * d->FO + f];
+                orc_expected_mult(model + node_row(c, nd, node_mask(c, nd, model), fv), nd->out, e[f]);
+            }
+            for (o = 0; o < O; ++o) {
+                float p = 1;
+                int of[ORC_MAXF];
+                features_of(o, d->Ostep, d->FO, of);
+                for (f = 0; f < d->FO; ++f) p *= e[f][of[f]];
+                c->mh_O[((size_t)a * S + s) * O + o] = p;
+            }
+        }
+}
+/* rnd::sample::Dir::sampleFromMult<double> (random.hpp:93-115) */
+static int sample_from_mult_d(orc_ctx* c, const double* m, int n, double total)
+{
+    double p = orc_u01(&c->rng) * total, sum = m[0];
+    int i;
+    for (i = 1; i < n; ++i) {
+        if (p < sum) return i - 1;
+        sum += m[i];
+    }
+    return n - 1;
+}
+/* msgSampleStateHistory (:96-213): per episode a backward pass of messages p(o_t.. | s_t), each normalised, then a
+ * forward pass sampling s_0, s_1, ... from T x message */
+static void mh_sample_history_msg(orc_ctx* c, const float* model, int32_t* seq)
+{
+    int S = c->S, A = c->A, O = c->O, e, k = 0, h0 = 0, st, step, ns;
+    float prior_p = (float)((double)(1.0f / (float)S) / (double)((1.0f / (float)S) * (float)S)); /* categoricalDistr(size, init)::prob */
+    mh_flatten(c, model);
+    for (e = 0; e < c->mh_n_ep; ++e) {
+        int L = c->mh_ep_len[e];
+        const int16_t *ea = c->mh_a + h0, *eo = c->mh_o + h0;
+        double* msg = c->mh_msg;
+        double tot;
+        for (st = 0; st < S; ++st) msg[(size_t)L * S + st] = c->mh_O[((size_t)ea[L - 1] * S + st) * O + eo[L - 1]];
+        for (step = L - 1; step >= 0; --step) {
+            int a = ea[step];
+            tot = 0;
+            for (st = 0; st < S; ++st) {
+                double m = 0.0;
+                for (ns = 0; ns < S; ++ns) m = m + c->mh_T[((size_t)st * A + a) * S + ns] * msg[(size_t)(step + 1) * S + ns];
+                if (step != 0) m *= c->mh_O[((size_t)ea[step - 1] * S + st) * O + eo[step - 1]];
+                else m *= prior_p;
+                msg[(size_t)step * S + st] = m;
+                tot += m;
+            }
+            for (st = 0; st < S; ++st) msg[(size_t)step * S + st] = msg[(size_t)step * S + st] / tot;
+        }
+        st = sample_from_mult_d(c, msg, S, 1);
+        seq[k++] = st;
+        for (step = 0; step < L; ++step) {
+            tot = 0;
+            for (ns = 0; ns < S; ++ns) {
+                c->mh_probs[ns] = c->mh_T[((size_t)st * A + ea[step]) * S + ns] * msg[(size_t)(step + 1) * S + ns];
+                tot += c->mh_probs[ns];
+            }
+            st = sample_from_mult_d(c, c->mh_probs, S, tot);
+            seq[k++] = st;
+        }
+        h0 += L;
+    }
+}
+/* rejectionSampleStateHistory (:38-94): per episode, a start state and one sampled step per history step, starting the
+ * episode over whenever a sampled observation differs from the recorded one.  Returns 0 if an episode cannot be
+ * reproduced in 2^22 tries (the reference would never return). */
+static int mh_sample_history_rs(orc_ctx* c, const float* model, int32_t* seq)
+{
+    int e, k = 0, h0 = 0, t;
+    for (e = 0; e < c->mh_n_ep; ++e) {
+        int L = c->mh_ep_len[e], tries = 0, ok = 0;
+        while (!ok) {
+            simstate st;
+            if (++tries > (1 << 22)) return 0;
+            st.s   = domain_start(c);
+            st.cnt = (float*)model;
+            seq[k] = st.s;
+            ok = 1;
+            for (t = 0; t < L; ++t) {
+                int32_t so;
+                double r;
+                ba_fact_step(c, &st, c->mh_a[h0 + t], &so, &r, 0);   /* sampleStateIndex, sampleObservationIndex: expected method */
+                if (so != c->mh_o[h0 + t]) { ok = 0; break; }
+                seq[k + 1 + t] = st.s;
+            }
+        }
+        k += L + 1;
+        h0 += L;
+    }
+    return 1;
+}
+static int mh_sample_history(orc_ctx* c, const float* model, int32_t* seq)
+{
+    if (c->cfg.belief_option == 1) return mh_sample_history_rs(c, model, seq);
+    mh_sample_history_msg(c, model, seq);
+    return 1;
+}
+/* MHwithinGibbs::reinvigorate (:334-395) */
+static int mh_reinvigorate(orc_ctx* c)
+{
+    const fdesc* d = &c->fd;
+    int n = c->cfg.particles, made = 0, nseq = 0, e, iters = 0;
+    uint32_t mask;
+    double score, w1 = 1.0 / (double)n;
+    for (e = 0; e < c->mh_n_ep; ++e) nseq += c->mh_ep_len[e] + 1;
+    orc_rng_stream(&c->rng, ORC_PH_REINVIG, 0);
+    memcpy(c->mh_model, c->P[weighted_sample(c)].cnt, sizeof(float) * (size_t)c->ncnt);  /* old_belief.sample()->model() */
+    if (!mh_sample_history(c, c->mh_model, c->mh_seq)) return 0;
+    mask = f2u(c->mh_model[d->ncounts]);
+    mh_compute_prior(c, mask, c->mh_prior);
+    mh_posterior(c, c->mh_prior, c->mh_seq, c->mh_model);
+    score = orc_log_bd_score(c, c->mh_model, c->mh_prior);
+    while (made < n) {
+        double new_score;
+        uint32_t nmask = mask ^ (1u << orc_slow_int(&c->rng, 0, d->FS));  /* FactoredTigerFactoredPrior::mutate: flip_random_edge of O[listen][0] */
+        if (++iters > (1 << 24)) return 0;
+        mh_compute_prior(c, nmask, c->mh_prior);
+        mh_posterior(c, c->mh_prior, c->mh_seq, c->mh_new);
+        new_score = orc_log_bd_score(c, c->mh_new, c->mh_prior);
+        if (m_log(c, orc_u01(&c->rng)) < (new_score - score)) {
+            c->Pnew[made].s = c->mh_seq[nseq - 1];
+            c->Pnew[made].w = w1;
+            memcpy(c->Pnew[made].cnt, c->mh_new, sizeof(float) * (size_t)c->ncnt);
+            made++;
+            if (!mh_sample_history(c, c->mh_model, c->mh_seq)) return 0;   /* (from the model of the LAST accepted structure, as the reference does) */
+            mh_posterior(c, c->mh_prior, c->mh_seq, c->mh_model);
+            mask  = nmask;
+            score = orc_log_bd_score(c, c->mh_model, c->mh_prior);
+        }
+    }
+    swap_pools(c);
+    c->total_w = 0;
+    for (e = 0; e < n; ++e) c->total_w += w1;   /* WeightedFilter::add accumulates */
+    weighted_refresh_scan(c);
+    c->log_lik = 0;
+    return 1;
+}
+/* MHwithinGibbs::updateEstimation (:316-332) */
+static void mh_update(orc_ctx* c, int32_t a, int32_t o)
+{
+    int h = 0, e;
+    double l = is_update(c, a, o);
+    c->log_lik += m_log(c, l);
+    is_resample(c);
+    for (e = 0; e < c->mh_n_ep; ++e) h += c->mh_ep_len[e];
+    c->mh_a[h] = (int16_t)a;
+    c->mh_o[h] = (int16_t)o;
+    c->mh_ep_len[c->mh_n_ep - 1]++;
+    if (c->log_lik < c->cfg.threshold && !mh_reinvigorate(c))
+        snprintf(c->err, sizeof c->err, "mh-within-gibbs: the history cannot be reproduced by the sampled model");
+}
+
 static void belief_update(orc_ctx* c, int32_t a, int32_t o)
 {
     c->last_weight_total = 0;
@@ -2250,6 +2480,8 @@ static void belief_update(orc_ctx* c, int32_t a, int32_t o)
             }
             c->likelihood = 1;
         }
+    } else if (c->cfg.belief == ORC_BELIEF_MH_GIBBS) {
+        mh_update(c, a, o);
     } else {
         is_update(c, a, o);
         is_resample(c);
@@ -2267,6 +2499,8 @@ static void belief_reset_domain_state(orc_ctx* c)
             orc_rng_stream(&c->rng, ORC_PH_RESET, (uint32_t)i);
             c->P[i].s = domain_start(c);
         }
+        if (c->cfg.belief == ORC_BELIEF_MH_GIBBS && c->mh_ep_len[c->mh_n_ep - 1] != 0) /* MHwithinGibbs::resetDomainStateDistribution :259-275: a new episode unless the open one is empty */
+            c->mh_ep_len[c->mh_n_ep++] = 0;
         if (c->cfg.belief == ORC_BELIEF_REINVIGORATION || c->cfg.belief == ORC_BELIEF_CHEATING) /* ReinvigoratingRejectionSampling.cpp:109-119 */
             for (i = 0; i < n; ++i) {
                 orc_rng_stream(&c->rng, ORC_PH_RESET_FC, (uint32_t)i);
@@ -2576,6 +2810,29 @@ orc_ctx* orc_create(const orc_config* cfg)
             return c;
         }
     }
+    if (cfg->belief == ORC_BELIEF_MH_GIBBS) {
+        int cap = cfg->episodes * cfg->horizon;
+        if (cfg->model != ORC_MODEL_BA_FACTORED || !is_ftiger(cfg->domain) || cfg->dirichlet_regular) {
+            snprintf(c->err, sizeof c->err, "mh-within-gibbs belief: built for the factored-tiger FBA-POMDP (fbapomdp -D *-factored-tiger), expected Dirichlet mode");
+            return c;
+        }
+        if (cfg->threshold >= 0) { /* MHwithinGibbs.cpp:248-252 */
+            snprintf(c->err, sizeof c->err, "MHwithinGibbs::cannot initiate with threshold >= 0 (is:%f)", cfg->threshold);
+            return c;
+        }
+        c->mh_a      = (int16_t*)calloc((size_t)cap + 1, sizeof(int16_t));
+        c->mh_o      = (int16_t*)calloc((size_t)cap + 1, sizeof(int16_t));
+        c->mh_ep_len = (int32_t*)calloc((size_t)cfg->episodes + 1, sizeof(int32_t));
+        c->mh_prior  = (float*)malloc(sizeof(float) * (size_t)c->ncnt);
+        c->mh_model  = (float*)malloc(sizeof(float) * (size_t)c->ncnt);
+        c->mh_new    = (float*)malloc(sizeof(float) * (size_t)c->ncnt);
+        c->mh_T      = (float*)malloc(sizeof(float) * (size_t)c->S * c->A * c->S);
+        c->mh_O      = (float*)malloc(sizeof(float) * (size_t)c->A * c->S * c->O);
+        c->mh_msg    = (double*)malloc(sizeof(double) * (size_t)(cfg->horizon + 1) * c->S);
+        c->mh_probs  = (double*)malloc(sizeof(double) * (size_t)c->S);
+        c->mh_seq    = (int32_t*)malloc(sizeof(int32_t) * (size_t)(cfg->episodes * (cfg->horizon + 1) + 1));
+        c->mh_n_ep   = 1;
+    }
     if (cfg->belief == ORC_BELIEF_REINVIGORATION || cfg->belief == ORC_BELIEF_CHEATING) {
         if (cfg->belief == ORC_BELIEF_CHEATING) { /* checked above */
         } else if (cfg->model != ORC_MODEL_BA_FACTORED || !(is_ftiger(cfg->domain) || is_ca(cfg->domain) || is_sys(cfg->domain)) ||
@@ -2608,6 +2865,8 @@ void orc_destroy(orc_ctx* c)
     if (!c) return;
     free(c->prior); free(c->log1p_tab); free(c->fd.T); free(c->fd.O);
     free(c->tr.visits); free(c->tr.cn); free(c->tr.cq); free(c->tr.child);
+    free(c->mh_a); free(c->mh_o); free(c->mh_ep_len); free(c->mh_prior); free(c->mh_model); free(c->mh_new); free(c->mh_T); free(c->mh_O);
+    free(c->mh_msg); free(c->mh_probs); free(c->mh_seq);
     free(c->tr.hkey); free(c->tr.hval);
     free(c->P); free(c->Pnew); free(c->pool); free(c->pool_new);
     free(c->F); free(c->Fnew); free(c->fpool); free(c->fpool_new); free(c->breed_tmp);

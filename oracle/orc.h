@@ -44,7 +44,8 @@ enum { ORC_MODEL_POMDP = 0, ORC_MODEL_BA_TABLE = 1, ORC_MODEL_BA_FACTORED = 2 };
 /* REINVIGORATION = beliefs::bayes_adaptive::factored::ReinvigoratingRejectionSampling (-B reinvigoration) */
 /* CHEATING = beliefs::bayes_adaptive::prototypes::CheatingReinvigoration (-B cheating-reinvigoration) */
 enum { ORC_BELIEF_REJECTION = 0, ORC_BELIEF_IMPORTANCE = 1, ORC_BELIEF_REINVIGORATION = 2, ORC_BELIEF_CHEATING = 3,
-       ORC_BELIEF_POINT = 4 /* -B point_estimate: src/beliefs/point_estimation/PointEstimation.cpp, bayes-adaptive/BAPointEstimation.cpp */ };
+       ORC_BELIEF_POINT = 4, /* -B point_estimate: src/beliefs/point_estimation/PointEstimation.cpp, bayes-adaptive/BAPointEstimation.cpp */
+       ORC_BELIEF_MH_GIBBS = 5 /* -B mh-within-gibbs: src/beliefs/bayes-adaptive/factored/MHwithinGibbs.cpp (belief_option 1 = "rs") */ };
 /* floating-point summation order of the importance-sampling filter:
  * REF = the reference's sequential loops; DEV = the HIP engine's fixed reduction tree */
 enum { ORC_ARITH_REF = 0, ORC_ARITH_DEV = 1 };
@@ -84,6 +85,7 @@ typedef struct orc_config {
     int32_t dirichlet_regular; /* --dirichlet_sampling_method regular (0 = expected, the default) */
     int32_t resample_amount;   /* --resample-amount: particles bred per update (reinvigoration belief) / copied per cheat */
     double threshold;          /* --threshold: log-likelihood below which the cheating belief cheats (< 0) */
+    int32_t belief_option;     /* --belief-option: mh-within-gibbs 0 = message passing (MSG), 1 = "rs" (rejection-sampled state history) */
 } orc_config;
 
 /* One record per real time-step; the HIP engine emits the same layout (fba_trace_rec). */

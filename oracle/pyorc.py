@@ -18,7 +18,7 @@ DOM_SYSADMIN_INDEPENDENT, DOM_SYSADMIN_LINEAR = 7, 8
 DOM_COFFEE, DOM_COFFEE_BOUTILIER = 9, 10
 DOM_AGR = 11
 MODEL_POMDP, MODEL_BA_TABLE, MODEL_BA_FACTORED = range(3)
-BELIEF_REJECTION, BELIEF_IMPORTANCE, BELIEF_REINVIGORATION, BELIEF_CHEATING, BELIEF_POINT = range(5)
+BELIEF_REJECTION, BELIEF_IMPORTANCE, BELIEF_REINVIGORATION, BELIEF_CHEATING, BELIEF_POINT, BELIEF_MH_GIBBS = range(6)
 ARITH_REF, ARITH_DEV = range(2)
 RNG_MT, RNG_PHILOX = range(2)
 PLANNER_POUCT, PLANNER_RANDOM, PLANNER_TS = range(3)
@@ -38,7 +38,7 @@ class Config(C.Structure):
         ("structure_prior", C.c_int32), ("rng_mode", C.c_int32), ("arith", C.c_int32),
         ("philox_seed", C.c_uint64), ("seed_str", C.c_char * 64),
         ("run_offset", C.c_int32), ("trace", C.c_int32), ("planner", C.c_int32), ("ca_centered", C.c_int32), ("dirichlet_regular", C.c_int32),
-        ("resample_amount", C.c_int32), ("threshold", C.c_double),
+        ("resample_amount", C.c_int32), ("threshold", C.c_double), ("belief_option", C.c_int32),
     ]
 
 

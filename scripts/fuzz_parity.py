@@ -62,6 +62,10 @@ def draw(rng):
             belief = "cheating-reinvigoration"
             kw["resample_amount"] = rng.choice([1, 5])
             kw["threshold"] = rng.choice([-0.3, -2.0, -50.0])
+        elif b < 0.55 and "factored-tiger" in domain and kw["particles"] <= 64:
+            belief = "mh-within-gibbs"
+            kw["threshold"] = rng.choice([-0.3, -2.0, -50.0])
+            kw["belief_option"] = rng.choice([0, 1])
     if model != N.MODEL_POMDP and rng.random() < 0.2:
         longest = {"gridworld": 99, "random-collision-avoidance": kw.get("height", 0), "centered-collision-avoidance": kw.get("height", 0)}.get(domain, 2)
         if model == N.MODEL_BA_FACTORED and longest <= 16 or model == N.MODEL_BA_TABLE and "tiger" in domain and "factored" not in domain:
@@ -84,7 +88,7 @@ def one(domain, model, belief, slots, kw, seed):
     try:
         stats = eng.run_bapomdp() if ba else [eng.run_planning()]
     except fba.FbaError as e:
-        if "accepted fewer than" in str(e):   # the reference (and the oracle) would never return from this update
+        if "accepted fewer than" in str(e) or "cannot reproduce the run's history" in str(e):   # the reference (and the oracle) would never return from this update
             print("   degenerate filter, skipped:", str(e)[:70], flush=True)
             eng.close()
             return

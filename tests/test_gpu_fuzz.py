@@ -8,11 +8,40 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_random_configurations_match_the_oracle():
+def _fuzz():
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "fuzz_parity.py")
     spec = importlib.util.spec_from_file_location("fuzz_parity", path)
     fuzz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzz)
+    return fuzz
+
+
+def test_random_configurations_match_the_oracle():
+    fuzz = _fuzz()
     bad, refused = fuzz.run(250, seed=7, verbose=False)
     assert bad == 0
     assert refused < 60          # (model / domain pairs neither side supports)
+
+
+def test_random_mh_within_gibbs_configurations_match_the_oracle():
+    """The MH-within-Gibbs belief over random factored-tiger configurations (sizes, structure priors, thresholds, both
+    state-history samplers, particle counts from 1): engine == oracle on every trace field."""
+    import random
+
+    from fba_pomdp_amd import _native as N
+    fuzz = _fuzz()
+    rng = random.Random(77)
+    ran = 0
+    for i in range(24):
+        domain = rng.choice(["episodic-factored-tiger", "continuous-factored-tiger"])
+        kw = dict(size=rng.choice([1, 2, 3]), particles=rng.choice([1, 5, 24, 50]), sims=rng.choice([4, 30, 90]), horizon=rng.choice([2, 5, 9]),
+                  runs=rng.choice([1, 3]), episodes=rng.choice([1, 2, 4]), structure_prior=rng.choice([0, 1, 2, 3]),
+                  threshold=rng.choice([-0.2, -1.0, -6.0]), belief_option=rng.choice([0, 1]), noise=rng.choice([0.0, 0.1]),
+                  discount=rng.choice([0.7, 0.95]))
+        slots = rng.choice([1, kw["runs"]])
+        try:
+            fuzz.one(domain, N.MODEL_BA_FACTORED, "mh-within-gibbs", slots, kw, seed=4000 + i)
+            ran += 1
+        except ValueError:
+            pass
+    assert ran >= 20

@@ -979,3 +979,31 @@ def test_packed_factored_tiger_particles_equal_dense_ones(size, sp, noise, monke
         bad[:, 0] += 0.5
         with pytest.raises(ValueError, match="plus 0..65535 increments"):
             packed.belief_set(0, counts=bad)
+
+
+@pytest.mark.parametrize("domain,option,sp,thr", [
+    ("continuous-factored-tiger", 0, 2, -1.0), ("continuous-factored-tiger", 1, 2, -1.0),
+    ("episodic-factored-tiger", 0, 1, -0.5), ("continuous-factored-tiger", 0, 0, -3.0),
+])
+def test_fbapomdp_mh_within_gibbs_belief(domain, option, sp, thr):
+    """-B mh-within-gibbs (MHwithinGibbs.cpp; --belief-option "" = message passing, "rs" = rejection-sampled state
+    histories): importance filter + the run's history + a Metropolis-Hastings chain over structures, scored by
+    LogBDScore, that re-draws the filter when the log likelihood falls below --threshold.  Whole experiments, every
+    trace field (the checksum over every particle's counts after every update included) against the oracle."""
+    eng, o = _pair(domain, N.MODEL_BA_FACTORED, "mh-within-gibbs", 601 + option, size=2, particles=48, sims=80, runs=4,
+                   episodes=3, horizon=8, structure_prior=sp, threshold=thr, belief_option=option)
+    _assert_same_experiment(eng, o, ba=True)
+    s, w, cnt = eng.belief_get(0)
+    assert np.all(w == 1.0 / 48)
+    # the chain has really run: with a threshold that is never reached the same experiment leaves other filters behind
+    never = fba.Engine(domain, model=N.MODEL_BA_FACTORED, belief="mh-within-gibbs", seed=601 + option, slots=4, trace=1, size=2, particles=48,
+                       sims=80, runs=4, episodes=3, horizon=8, structure_prior=sp, threshold=-1e9, belief_option=option)
+    never.run_bapomdp()
+    assert not np.array_equal(never.trace()["belief_hash"], eng.trace()["belief_hash"])
+
+
+def test_mh_within_gibbs_refuses_what_it_is_not_built_for():
+    with pytest.raises(ValueError, match="threshold >= 0"):
+        fba.Engine("episodic-factored-tiger", model=N.MODEL_BA_FACTORED, belief="mh-within-gibbs", size=1, particles=8, sims=8, threshold=0.5)
+    with pytest.raises(ValueError, match="factored-tiger"):
+        fba.Engine("gridworld", model=N.MODEL_BA_FACTORED, belief="mh-within-gibbs", size=3, particles=8, sims=8, threshold=-1.0)
