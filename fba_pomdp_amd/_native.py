@@ -32,7 +32,7 @@ DOM_SYSADMIN_INDEPENDENT, DOM_SYSADMIN_LINEAR = 7, 8
 DOM_COFFEE, DOM_COFFEE_BOUTILIER = 9, 10
 DOM_AGR = 11
 MODEL_POMDP, MODEL_BA_TABLE, MODEL_BA_FACTORED = range(3)
-BELIEF_REJECTION, BELIEF_IMPORTANCE, BELIEF_REINVIGORATION, BELIEF_CHEATING, BELIEF_POINT, BELIEF_MH_GIBBS = range(6)
+BELIEF_REJECTION, BELIEF_IMPORTANCE, BELIEF_REINVIGORATION, BELIEF_CHEATING, BELIEF_POINT, BELIEF_MH_GIBBS, BELIEF_MH_NIPS = range(7)
 PLANNER_POUCT, PLANNER_RANDOM, PLANNER_TS = range(3)
 OK, EINVAL, EHIP, ENODEVICE, ESTATE = 0, -1, -2, -3, -4
 
@@ -46,7 +46,7 @@ DOMAIN_NAMES = {  # reference -D strings (DomainConf.cpp)
 }
 BELIEF_NAMES = {"rejection_sampling": BELIEF_REJECTION, "importance_sampling": BELIEF_IMPORTANCE,
                 "reinvigoration": BELIEF_REINVIGORATION, "cheating-reinvigoration": BELIEF_CHEATING,
-                "point_estimate": BELIEF_POINT, "mh-within-gibbs": BELIEF_MH_GIBBS}
+                "point_estimate": BELIEF_POINT, "mh-within-gibbs": BELIEF_MH_GIBBS, "mh-nips": BELIEF_MH_NIPS}
 PLANNER_NAMES = {"po-uct": PLANNER_POUCT, "random": PLANNER_RANDOM, "ts": PLANNER_TS}
 
 

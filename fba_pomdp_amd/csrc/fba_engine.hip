@@ -514,7 +514,7 @@ int build_ca_factored_prior(fba_ctx* c)
     // (on the device, factored_prior_sample); the node owns room for every state feature as a parent
     // (the reinvigoration belief breeds particles with structures of their own: same layout)
     const bool noisy = c->cfg.structure_prior == FBA_SP_UNIFORM || c->cfg.structure_prior == FBA_SP_MATCH_UNIFORM ||
-                       (c->cfg.belief == FBA_BELIEF_REINVIGORATION && !full);
+                       ((c->cfg.belief == FBA_BELIEF_REINVIGORATION || c->cfg.belief == FBA_BELIEF_MH_GIBBS || c->cfg.belief == FBA_BELIEF_MH_NIPS) && !full);
     if (FS > MAXF || A * (FS + n) > MAXNODES) return fail(c, FBA_EINVAL, "too many state features");
     FDesc& d = c->fdesc;
     std::memset(&d, 0, sizeof d);
@@ -913,8 +913,9 @@ int check_fault(fba_ctx* c)
     if (!f) return FBA_OK;
     HIPCHK(c, hipMemset(c->D.fault, 0, sizeof f));
     if (f >= 0x20000000 && f < 0x40000000)
-        return fail(c, FBA_ESTATE, "mh-within-gibbs in slot %d: the sampled model cannot reproduce the run's history (the reference would never "
-                    "return from rejectionSampleStateHistory, MHwithinGibbs.cpp:38-94)", f - 0x20000000);
+        return fail(c, FBA_ESTATE, "%s in slot %d: the sampled model cannot reproduce the run's history (the reference would never "
+                    "return from %s)", c->P.mh == 3 ? "mh-nips" : "mh-within-gibbs", f - 0x20000000,
+                    c->P.mh == 3 ? "computePosterior, MHNIPS2018.cpp:39-105" : "rejectionSampleStateHistory, MHwithinGibbs.cpp:38-94");
     if (f >= 0x40000000)
         return fail(c, FBA_ESTATE, "slot %d: more belief updates in one run than the %d (episodes * horizon) a history particle was "
                     "sized for; create the context with FBA_DENSE_PARTICLES=1 in the environment to drive it beyond that", f - 0x40000000, c->P.hist_cap);
@@ -1115,26 +1116,31 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         P.cheat  = cfg->resample_amount;
     }
     P.mh = 0;
-    if (cfg->belief == FBA_BELIEF_MH_GIBBS) {
-        // an importance filter + the run's (a, o) history + a Metropolis-Hastings chain that re-draws the filter when the
-        // log likelihood drops below --threshold (MHwithinGibbs.cpp); built for the factored-tiger prior
-        if (cfg->model != FBA_MODEL_BA_FACTORED || !is_ftiger(cfg->domain) || cfg->dirichlet_regular) {
-            fail(nullptr, FBA_EINVAL, "mh-within-gibbs belief: built for the factored-tiger FBA-POMDP (fbapomdp -D *-factored-tiger), expected Dirichlet mode");
+    if (cfg->belief == FBA_BELIEF_MH_GIBBS || cfg->belief == FBA_BELIEF_MH_NIPS) {
+        // an importance filter + the run's (a, o) history + a Metropolis-Hastings re-draw of the filter when the log
+        // likelihood drops below --threshold (MHwithinGibbs.cpp, MHNIPS2018.cpp); built for the priors that have
+        // computePriorModel and mutate and a fully enumerable state space: factored tiger, collision avoidance
+        const bool nips  = cfg->belief == FBA_BELIEF_MH_NIPS;
+        const char* name = nips ? "MHNIPS2018" : "MHwithinGibbs";
+        if (cfg->model != FBA_MODEL_BA_FACTORED || !(is_ftiger(cfg->domain) || is_ca(cfg->domain)) || cfg->dirichlet_regular ||
+            (is_ca(cfg->domain) && cfg->structure_prior == FBA_SP_FULLY_CONNECTED)) {
+            fail(nullptr, FBA_EINVAL, "%s belief: built for the factored-tiger and collision-avoidance FBA-POMDPs (fbapomdp), expected Dirichlet mode",
+                 nips ? "mh-nips" : "mh-within-gibbs");
             delete c;
             return FBA_EINVAL;
         }
-        if (cfg->particles < 1) {  // MHwithinGibbs.cpp:243-246
-            fail(nullptr, FBA_EINVAL, "MHwithinGibbs::cannot initiate MH with size 0");
+        if (cfg->particles < 1) {  // MHwithinGibbs.cpp:243-246, MHNIPS2018.cpp:116-119
+            fail(nullptr, FBA_EINVAL, "%s::cannot initiate MH with size 0", name);
             delete c;
             return FBA_EINVAL;
         }
-        if (cfg->threshold >= 0) {  // :248-252
-            fail(nullptr, FBA_EINVAL, "MHwithinGibbs::cannot initiate with threshold >= 0 (is:%f)", cfg->threshold);
+        if (cfg->threshold >= 0) {  // :248-252, MHNIPS2018.cpp:121-126
+            fail(nullptr, FBA_EINVAL, "%s::cannot initiate with threshold >= 0 (is:%f)", name, cfg->threshold);
             delete c;
             return FBA_EINVAL;
         }
         P.belief = FBA_BELIEF_IMPORTANCE;
-        P.mh     = cfg->belief_option == 1 ? 2 : 1;
+        P.mh     = nips ? 3 : cfg->belief_option == 1 ? 2 : 1;
     }
     if (cfg->belief == FBA_BELIEF_REINVIGORATION) {
         // two rejection filters + breeding (ReinvigoratingRejectionSampling.hpp); the reference has fully
@@ -1454,7 +1460,13 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         CHK(dev_alloc(c, &D.mh_ep_len, (size_t)E * (P.episodes + 1)));
         CHK(dev_alloc(c, &D.mh_n_ep, E));
         size_t words = (size_t)3 * P.Cs + (size_t)P.S * P.A * P.S + (size_t)P.A * P.S * P.O + 2;
-        words += 2 * ((size_t)(P.horizon + 1) * P.S + P.S) + (size_t)P.episodes * (P.horizon + 1) + 2;
+        words += 2 * ((size_t)(P.horizon + 1) * P.S + P.S) + (size_t)P.episodes * (P.horizon + 1) + 2 * (size_t)P.horizon + 2;
+        if (c->fdesc.nvar > MH_MAXVAR) {
+            fail(c, FBA_EINVAL, "mh beliefs: at most %d structure words per particle", MH_MAXVAR);
+            g_create_error = c->err;
+            fba_destroy(c);
+            return FBA_EINVAL;
+        }
         D.mh_scratch_words = (int32_t)((words + 3) & ~(size_t)3);
         CHK(dev_alloc(c, &D.mh_scratch, (size_t)E * D.mh_scratch_words));
         const double thr = cfg->threshold;

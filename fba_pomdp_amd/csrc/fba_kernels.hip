@@ -1368,18 +1368,46 @@ __device__ __forceinline__ MhScratch mh_scratch(const Problem& P, const DeviceSt
     return m;
 }
 // BABNModel::incrementCountsOf (BABNModel.cpp:354-382; observation rows at the OLD state's parent values, App. A #6)
-__device__ void mh_increment(const Problem& P, float* cnt, int s, int a, int o, int ns)
+__device__ void mh_increment(const Problem& P, float* cnt, int s, int a, int o, int ns, float amount)
 {
     const FDesc* fd   = P.fd;
     const GlobalView v{cnt};
     const uint64_t fv = pack_features(s, fd->Sstep, fd->FS), nf = pack_features(ns, fd->Sstep, fd->FS), of = pack_features(o, fd->Ostep, fd->FO);
     for (int f = 0; f < fd->FS; ++f) {
         const FNode& nd = fd->nodes[a * fd->FS + f];
-        cnt[node_row(fd, nd, node_mask(fd, nd, v), fv) + feat(nf, f)] += 1.0f;
+        cnt[node_row(fd, nd, node_mask(fd, nd, v), fv) + feat(nf, f)] += amount;
     }
     for (int f = 0; f < fd->FO; ++f) {
         const FNode& nd = fd->nodes[P.A * fd->FS + a * fd->FO + f];
-        cnt[node_row(fd, nd, node_mask(fd, nd, v), fv) + feat(of, f)] += 1.0f;
+        cnt[node_row(fd, nd, node_mask(fd, nd, v), fv) + feat(of, f)] += amount;
+    }
+}
+// FBAPOMDPPrior::computePriorModel(structure): factored tiger (FactoredTigerPriors.cpp:293-321) = the prior with the listen
+// observation node set for its parent set; collision avoidance (CollisionAvoidancePriors.cpp:490-526) = the prior with every
+// obstacle's transition node, per action, set for its parent set
+__device__ void mh_compute_prior(const Problem& P, const DeviceState& D, const uint32_t* masks, float* out)
+{
+    for (int k = 0; k < P.C; ++k) out[k] = D.prior[k];
+    if (dom_is_ca(P.domain)) {
+        const int n = P.ca->n;
+        for (int f = 2; f < P.fd->FS; ++f)
+            for (int a = 0; a < P.A; ++a) ca_fill_obstacle_node(P, out, a, f, masks[a * n + (f - 2)]);
+    } else {
+        ftiger_set_observation_model(P, out, masks[0]);
+    }
+}
+// FBAPOMDP::mutate: FactoredTigerFactoredPrior::mutate (FactoredTigerPriors.cpp:351-381) flips a random edge
+// (BABNModel.cpp:16-31) of O[listen][0]; CollisionAvoidanceFactoredPrior::mutate (CollisionAvoidancePriors.cpp:455-488)
+// draws an action and an obstacle, then flips a random edge of that transition node
+__device__ void mh_mutate(const Problem& P, Rng& g, uint32_t* masks)
+{
+    if (dom_is_ca(P.domain)) {
+        const int n  = P.ca->n;
+        const int a  = g.uniform_int(P.A);
+        const int ob = g.uniform_int(n);
+        masks[a * n + ob] ^= 1u << g.slow_int(0, P.fd->FS);
+    } else {
+        masks[0] ^= 1u << g.slow_int(0, P.fd->FS);
     }
 }
 __device__ void mh_posterior(const Problem& P, const DeviceState& D, int e, const float* prior, const int32_t* seq, float* out)
@@ -1389,7 +1417,7 @@ __device__ void mh_posterior(const Problem& P, const DeviceState& D, int e, cons
     const int32_t* len = D.mh_ep_len + (size_t)e * (P.episodes + 1);
     int k = 0, h = 0;
     for (int ep = 0; ep < D.mh_n_ep[e]; ++ep) {
-        for (int t = 0; t < len[ep]; ++t, ++h, ++k) mh_increment(P, out, seq[k], ha[h], ho[h], seq[k + 1]);
+        for (int t = 0; t < len[ep]; ++t, ++h, ++k) mh_increment(P, out, seq[k], ha[h], ho[h], seq[k + 1], 1.0f);
         ++k;
     }
 }
@@ -1539,35 +1567,85 @@ __global__ void __launch_bounds__(64) mh_kernel(Problem P, DeviceState D)
     double* new_w         = D.p_weight + pbase(P, e, cur ^ 1);
     Rng g = slot_rng(P, D, e);
     g.stream(FBA_PHASE_REINVIG, 0);
-    {
-        const float* src = old_recs + (size_t)uniform_weight_pick(D.uni_scan, N, g.u01() * D.uni_total, D.uni_total) * P.Cs;  // old_belief.sample()->model()
-        for (int k = 0; k < P.C; ++k) m.model[k] = src[k];
-    }
-    bool ok = mh_sample_history(P, D, e, g, m, m.model);
-    uint32_t mask = __float_as_uint(m.model[fd->ncounts]);
-    for (int k = 0; k < P.C; ++k) m.prior[k] = D.prior[k];
-    ftiger_set_observation_model(P, m.prior, mask);
-    mh_posterior(P, D, e, m.prior, m.seq, m.model);
-    double score = log_bd_score(P, GlobalView{m.model}, GlobalView{m.prior});
     const double w1 = 1.0 / (double)N;
+    const int nvar  = fd->nvar;
+    uint32_t masks[MH_MAXVAR], nmasks[MH_MAXVAR];
     int made = 0;
-    for (int iters = 0; ok && made < N; ++iters) {
-        if (iters >= (1 << 24)) { ok = false; break; }
-        const uint32_t nmask = mask ^ (1u << g.slow_int(0, fd->FS));   // FactoredTigerFactoredPrior::mutate: flip_random_edge of O[listen][0]
-        for (int k = 0; k < P.C; ++k) m.prior[k] = D.prior[k];
-        ftiger_set_observation_model(P, m.prior, nmask);
-        mh_posterior(P, D, e, m.prior, m.seq, m.fresh);
-        const double new_score = log_bd_score(P, GlobalView{m.fresh}, GlobalView{m.prior});
-        if (det_log(g.u01()) < (new_score - score)) {
-            float* dst = new_recs + (size_t)made * P.Cs;
-            for (int k = 0; k < P.C; ++k) dst[k] = m.fresh[k];
-            rec_set_state(dst, P.C, m.seq[nseq - 1]);
-            new_w[made] = w1;
-            ++made;
-            ok = mh_sample_history(P, D, e, g, m, m.model);   // (from the model of the LAST accepted structure, as the reference does)
-            mh_posterior(P, D, e, m.prior, m.seq, m.model);
-            mask  = nmask;
-            score = log_bd_score(P, GlobalView{m.model}, GlobalView{m.prior});
+    bool ok  = true;
+    if (P.mh == 3) {
+        // MHNIPS2018::MH (MHNIPS2018.cpp:208-255): independent proposals -- a particle of the old filter, its structure
+        // or (half of the time) a mutation, that structure's prior updated along a freshly simulated history
+        // (computePosterior :39-105: a wrong observation undoes the episode's increments and starts it over), accepted on
+        // the difference of the LogBDScores
+        const int16_t *ca = ha, *co = ho;
+        for (int iters = 0; made < N; ++iters) {
+            if (iters >= (1 << 24)) { ok = false; break; }
+            const float* src = old_recs + (size_t)uniform_weight_pick(D.uni_scan, N, g.u01() * D.uni_total, D.uni_total) * P.Cs;  // old_belief.sample()->model()
+            for (int v = 0; v < nvar; ++v) masks[v] = __float_as_uint(src[fd->ncounts + v]);
+            mh_compute_prior(P, D, masks, m.prior);        // sampled_prior_model
+            if (!g.boolean()) mh_mutate(P, g, masks);      // the same structure half of the time
+            mh_compute_prior(P, D, masks, m.model);        // new_prior_model
+            for (int k = 0; k < P.C; ++k) m.fresh[k] = m.model[k];
+            int last = 0, h0 = 0;
+            for (int ep = 0; ok && ep < n_ep; ++ep) {
+                const int L = len[ep];
+                for (int tries = 0;; ++tries) {
+                    if (tries >= (1 << 22)) { ok = false; break; }
+                    int s = domain_start(P, g), t = 0;
+                    for (; t < L; ++t) {
+                        const int from = s;
+                        int so;
+                        double r;
+                        fact_step<false>(P, g, GlobalView{m.fresh}, s, ca[h0 + t], so, r, NoInc{});
+                        last = s;
+                        if (so != co[h0 + t]) break;
+                        mh_increment(P, m.fresh, from, ca[h0 + t], so, s, 1.0f);
+                        m.seq[2 * t] = from; m.seq[2 * t + 1] = s;
+                    }
+                    if (t == L) break;
+                    for (int u = 0; u < t; ++u) mh_increment(P, m.fresh, m.seq[2 * u], ca[h0 + u], co[h0 + u], m.seq[2 * u + 1], -1.0f);
+                }
+                h0 += L;
+            }
+            if (!ok) break;
+            const double old_score = log_bd_score(P, GlobalView{src}, GlobalView{m.prior});
+            const double new_score = log_bd_score(P, GlobalView{m.fresh}, GlobalView{m.model});
+            if (det_log(g.u01()) < (new_score - old_score)) {
+                float* dst = new_recs + (size_t)made * P.Cs;
+                for (int k = 0; k < P.C; ++k) dst[k] = m.fresh[k];
+                rec_set_state(dst, P.C, last);
+                new_w[made] = w1;
+                ++made;
+            }
+        }
+    } else {
+        {
+            const float* src = old_recs + (size_t)uniform_weight_pick(D.uni_scan, N, g.u01() * D.uni_total, D.uni_total) * P.Cs;  // old_belief.sample()->model()
+            for (int k = 0; k < P.C; ++k) m.model[k] = src[k];
+        }
+        ok = mh_sample_history(P, D, e, g, m, m.model);
+        for (int v = 0; v < nvar; ++v) masks[v] = __float_as_uint(m.model[fd->ncounts + v]);
+        mh_compute_prior(P, D, masks, m.prior);
+        mh_posterior(P, D, e, m.prior, m.seq, m.model);
+        double score = log_bd_score(P, GlobalView{m.model}, GlobalView{m.prior});
+        for (int iters = 0; ok && made < N; ++iters) {
+            if (iters >= (1 << 24)) { ok = false; break; }
+            for (int v = 0; v < nvar; ++v) nmasks[v] = masks[v];
+            mh_mutate(P, g, nmasks);
+            mh_compute_prior(P, D, nmasks, m.prior);
+            mh_posterior(P, D, e, m.prior, m.seq, m.fresh);
+            const double new_score = log_bd_score(P, GlobalView{m.fresh}, GlobalView{m.prior});
+            if (det_log(g.u01()) < (new_score - score)) {
+                float* dst = new_recs + (size_t)made * P.Cs;
+                for (int k = 0; k < P.C; ++k) dst[k] = m.fresh[k];
+                rec_set_state(dst, P.C, m.seq[nseq - 1]);
+                new_w[made] = w1;
+                ++made;
+                ok = mh_sample_history(P, D, e, g, m, m.model);   // (from the model of the LAST accepted structure, as the reference does)
+                mh_posterior(P, D, e, m.prior, m.seq, m.model);
+                for (int v = 0; v < nvar; ++v) masks[v] = nmasks[v];
+                score = log_bd_score(P, GlobalView{m.model}, GlobalView{m.prior});
+            }
         }
     }
     if (!ok) {

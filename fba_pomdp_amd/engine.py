@@ -177,7 +177,7 @@ class Engine:
         storage on the device; ask for counts=False where that is gigabytes."""
         n = self.cfg.particles
         s = np.zeros(n, np.int32)
-        want_w = self.cfg.belief in (N.BELIEF_IMPORTANCE, N.BELIEF_CHEATING, N.BELIEF_MH_GIBBS) if weights is None else weights
+        want_w = self.cfg.belief in (N.BELIEF_IMPORTANCE, N.BELIEF_CHEATING, N.BELIEF_MH_GIBBS, N.BELIEF_MH_NIPS) if weights is None else weights
         w = np.zeros(n, np.float64)
         cnt = np.zeros((n, self.ncnt), np.float32) if counts else None
         self._chk(self.L.fba_belief_get(self.h, slot, s.ctypes.data, w.ctypes.data if want_w else None,

@@ -51,9 +51,11 @@ enum { FBA_BELIEF_REJECTION = 0, FBA_BELIEF_IMPORTANCE = 1, FBA_BELIEF_REINVIGOR
        FBA_BELIEF_CHEATING = 3, /* cheating-reinvigoration (BABelief.cpp:60-65: prototypes::CheatingReinvigoration) */
        FBA_BELIEF_POINT = 4, /* point_estimate (Belief.cpp:13-14 PointEstimation, BABelief.cpp:19-20 BAPointEstimation): one state,
                              * updated by rejection; `particles` is ignored (1) and sample() draws nothing */
-       FBA_BELIEF_MH_GIBBS = 5 /* mh-within-gibbs (BABelief.cpp:33-47: factored::MHwithinGibbs; `belief_option` 1 = "rs"): importance
-                                * filter whose particles are re-drawn by a Metropolis-Hastings chain over structures when the log
-                                * likelihood falls below `threshold`; factored tiger */ };
+       FBA_BELIEF_MH_GIBBS = 5, /* mh-within-gibbs (BABelief.cpp:37-47: factored::MHwithinGibbs; `belief_option` 1 = "rs"): importance
+                                 * filter whose particles are re-drawn by a Metropolis-Hastings chain over structures when the log
+                                 * likelihood falls below `threshold`; factored tiger, collision avoidance */
+       FBA_BELIEF_MH_NIPS = 6   /* mh-nips (BABelief.cpp:33-36: factored::MHNIPS2018): the same filter and trigger; the re-draw makes
+                                 * independent proposals (a particle's structure or a mutation, updated along a simulated history) */ };
 /* -P po-uct | random | ts (Planner.cpp:12-19, BAPlanner.cpp:13-20; ts = Thompson sampling: TSPlanner / BATSPlanner) */
 enum { FBA_PLANNER_POUCT = 0, FBA_PLANNER_RANDOM = 1, FBA_PLANNER_TS = 2 };
 /* --structure-prior (FBAConf.hpp) */

@@ -26,6 +26,12 @@ CASES = {
                                        threshold=-1.0, structure_prior=orc.SP_MATCH_UNIFORM),
     "mh_within_gibbs_ftiger_rs": dict(domain=orc.DOM_FTIGER_CONTINUOUS, size=2, model=orc.MODEL_BA_FACTORED, belief=orc.BELIEF_MH_GIBBS,
                                       threshold=-1.0, belief_option=1, structure_prior=orc.SP_UNIFORM),
+    "mh_nips_ftiger": dict(domain=orc.DOM_FTIGER_CONTINUOUS, size=2, model=orc.MODEL_BA_FACTORED, belief=orc.BELIEF_MH_NIPS,
+                           threshold=-1.0, structure_prior=orc.SP_MATCH_UNIFORM),
+    "mh_within_gibbs_collision_avoidance": dict(domain=orc.DOM_COLLISION_AVOID, width=3, height=3, size=1, model=orc.MODEL_BA_FACTORED,
+                                                belief=orc.BELIEF_MH_GIBBS, threshold=-2.0, structure_prior=orc.SP_MATCH_UNIFORM),
+    "mh_nips_collision_avoidance": dict(domain=orc.DOM_COLLISION_AVOID, width=3, height=3, size=1, model=orc.MODEL_BA_FACTORED,
+                                        belief=orc.BELIEF_MH_NIPS, threshold=-2.0, structure_prior=orc.SP_UNIFORM),
     "bapomdp_sysadmin": dict(domain=orc.DOM_SYSADMIN_INDEPENDENT, size=3, model=orc.MODEL_BA_TABLE),
     "bapomdp_gridworld": dict(domain=orc.DOM_GRIDWORLD, size=3, model=orc.MODEL_BA_TABLE, noise=0.1),
     "bapomdp_collision_avoidance": dict(domain=orc.DOM_COLLISION_AVOID, width=4, height=3, size=1, model=orc.MODEL_BA_TABLE, noise=0.1),

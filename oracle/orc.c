@@ -1054,6 +1054,7 @@ static int ba_table_step(orc_ctx* c, simstate* st, int32_t a, int32_t* o, double
 
 /* ------------------------------------------------------------------ factored BA model */
 
+static int is_mh(const orc_ctx* c) { return c->cfg.belief == ORC_BELIEF_MH_GIBBS || c->cfg.belief == ORC_BELIEF_MH_NIPS; }
 static uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
@@ -1428,7 +1429,7 @@ static int build_ca_factored_prior(orc_ctx* c)
     int full = c->cfg.structure_prior == ORC_SP_FULLY_CONNECTED;
     /* edge noise "uniform" / "match-uniform" (:349-383): every obstacle node's parents are drawn per particle */
     int noisy = c->cfg.structure_prior == ORC_SP_UNIFORM || c->cfg.structure_prior == ORC_SP_MATCH_UNIFORM ||
-                (c->cfg.belief == ORC_BELIEF_REINVIGORATION && !full); /* bred particles carry their own structures */
+                ((c->cfg.belief == ORC_BELIEF_REINVIGORATION || is_mh(c)) && !full); /* bred / re-drawn particles carry their own structures */
     if (c->cfg.noise > .5 || c->cfg.noise < -.5) {
         snprintf(c->err, sizeof c->err, "CollisionAvoidanceFactoredPrior must be intiiated with -.5 < noise < .5 (is: %f)", c->cfg.noise);
         return -1;
@@ -1975,7 +1976,7 @@ static void weighted_refresh_scan(orc_ctx* c)
 }
 
 /* the main filter is a WeightedFilter (importance sampling; the cheating belief's _belief) */
-static int is_weighted(const orc_ctx* c) { return c->cfg.belief == ORC_BELIEF_IMPORTANCE || c->cfg.belief == ORC_BELIEF_CHEATING || c->cfg.belief == ORC_BELIEF_MH_GIBBS; }
+static int is_weighted(const orc_ctx* c) { return c->cfg.belief == ORC_BELIEF_IMPORTANCE || c->cfg.belief == ORC_BELIEF_CHEATING || is_mh(c); }
 
 static int32_t belief_sample(orc_ctx* c)
 {
@@ -2015,7 +2016,7 @@ static void belief_initiate(orc_ctx* c)
         c->total_w += w; /* WeightedFilter::add(T, w) WeightedFilter.cpp:60-66 */
     }
     if (is_weighted(c)) weighted_refresh_scan(c);
-    if (c->cfg.belief == ORC_BELIEF_MH_GIBBS) {  /* MHwithinGibbs::initiate :277-294 (free() :296-312 clears the history) */
+    if (is_mh(c)) {  /* MHwithinGibbs::initiate :277-294 (free() :296-312 clears the history); MHNIPS2018.cpp:132-175 likewise */
         c->mh_n_ep      = 1;
         c->mh_ep_len[0] = 0;
         c->log_lik      = 0;
@@ -2235,14 +2236,42 @@ static void reinvigorate(orc_ctx* c)
  * histories.  One Philox stream (REINVIG, 0) serves the chain: its draws are sequential by definition.
  * Built for the factored-tiger prior (computePriorModel FactoredTigerPriors.cpp:293-321, mutate :351-381). */
 
-/* FBAPOMDPPrior::computePriorModel(structure): the factored-tiger prior for the listen observation node's parent set */
-static void mh_compute_prior(orc_ctx* c, uint32_t mask, float* out)
+#define MH_MAXVAR 64
+/* the structure of a particle: the parent-set words of its variable nodes */
+static void mh_structure_of(const orc_ctx* c, const float* cnt, uint32_t* masks)
+{
+    int v;
+    for (v = 0; v < c->fd.nvar; ++v) masks[v] = f2u(cnt[c->fd.ncounts + v]);
+}
+/* FBAPOMDPPrior::computePriorModel(structure): factored tiger (FactoredTigerPriors.cpp:293-321) = the prior with the
+ * listen observation node set for its parent set; collision avoidance (CollisionAvoidancePriors.cpp:490-526) = the
+ * prior with every obstacle's transition node, per action, set for its parent set (sampleBlockTModel) */
+static void mh_compute_prior(orc_ctx* c, const uint32_t* masks, float* out)
 {
     memcpy(out, c->prior, sizeof(float) * (size_t)c->ncnt);
-    ftiger_set_observation_model(c, out, mask);
+    if (is_ca(c->cfg.domain)) {
+        int a, f;
+        for (f = 2; f < c->fd.FS; ++f)
+            for (a = 0; a < c->A; ++a) ca_fill_obstacle_node(c, out, a, f, masks[a * c->ca_n + (f - 2)]);
+    } else {
+        ftiger_set_observation_model(c, out, masks[0]);
+    }
+}
+/* FBAPOMDP::mutate -> FactoredTigerFactoredPrior::mutate (FactoredTigerPriors.cpp:351-381): flip_random_edge
+ * (BABNModel.cpp:16-31) of O[listen][0]; CollisionAvoidanceFactoredPrior::mutate (CollisionAvoidancePriors.cpp:455-488):
+ * an action, an obstacle, then flip_random_edge of that transition node */
+static void mh_mutate(orc_ctx* c, uint32_t* masks)
+{
+    if (is_ca(c->cfg.domain)) {
+        int a  = orc_int(&c->rng, c->A);
+        int ob = orc_int(&c->rng, c->ca_n);
+        masks[a * c->ca_n + ob] ^= 1u << orc_slow_int(&c->rng, 0, c->fd.FS);
+    } else {
+        masks[0] ^= 1u << orc_slow_int(&c->rng, 0, c->fd.FS);
+    }
 }
 /* BABNModel::incrementCountsOf (BABNModel.cpp:354-382): observation rows at the OLD state's parent values (App. A #6) */
-static void fact_increment(orc_ctx* c, float* cnt, int32_t s, int32_t a, int32_t o, int32_t ns)
+static void fact_increment(orc_ctx* c, float* cnt, int32_t s, int32_t a, int32_t o, int32_t ns, float amount)
 {
     const fdesc* d = &c->fd;
     int fv[ORC_MAXF], nf[ORC_MAXF], of[ORC_MAXF], f;
@@ -2251,11 +2280,11 @@ static void fact_increment(orc_ctx* c, float* cnt, int32_t s, int32_t a, int32_t
     features_of(o, d->Ostep, d->FO, of);
     for (f = 0; f < d->FS; ++f) {
         const fnode* nd = &d->T[a * d->FS + f];
-        cnt[node_row(c, nd, node_mask(c, nd, cnt), fv) + nf[f]] += 1;
+        cnt[node_row(c, nd, node_mask(c, nd, cnt), fv) + nf[f]] += amount;
     }
     for (f = 0; f < d->FO; ++f) {
         const fnode* nd = &d->O[a * d->FO + f];
-        cnt[node_row(c, nd, node_mask(c, nd, cnt), fv) + of[f]] += 1;
+        cnt[node_row(c, nd, node_mask(c, nd, cnt), fv) + of[f]] += amount;
     }
 }
 /* MHwithinGibbs::computePosteriorCounts (:397-436): the prior's counts + one incrementCountsOf per step of the history
@@ -2265,7 +2294,7 @@ static void mh_posterior(orc_ctx* c, const float* prior, const int32_t* seq, flo
     int e, t, k = 0, h = 0;
     memcpy(out, prior, sizeof(float) * (size_t)c->ncnt);
     for (e = 0; e < c->mh_n_ep; ++e) {
-        for (t = 0; t < c->mh_ep_len[e]; ++t, ++h, ++k) fact_increment(c, out, seq[k], c->mh_a[h], c->mh_o[h], seq[k + 1]);
+        for (t = 0; t < c->mh_ep_len[e]; ++t, ++h, ++k) fact_increment(c, out, seq[k], c->mh_a[h], c->mh_o[h], seq[k + 1], 1);
         k++;
     }
 }
@@ -2391,23 +2420,23 @@ static int mh_sample_history(orc_ctx* c, const float* model, int32_t* seq)
 /* MHwithinGibbs::reinvigorate (:334-395) */
 static int mh_reinvigorate(orc_ctx* c)
 {
-    const fdesc* d = &c->fd;
-    int n = c->cfg.particles, made = 0, nseq = 0, e, iters = 0;
-    uint32_t mask;
+    int n = c->cfg.particles, made = 0, nseq = 0, e, iters = 0, nvar = c->fd.nvar;
+    uint32_t masks[MH_MAXVAR], nmasks[MH_MAXVAR];
     double score, w1 = 1.0 / (double)n;
     for (e = 0; e < c->mh_n_ep; ++e) nseq += c->mh_ep_len[e] + 1;
     orc_rng_stream(&c->rng, ORC_PH_REINVIG, 0);
     memcpy(c->mh_model, c->P[weighted_sample(c)].cnt, sizeof(float) * (size_t)c->ncnt);  /* old_belief.sample()->model() */
     if (!mh_sample_history(c, c->mh_model, c->mh_seq)) return 0;
-    mask = f2u(c->mh_model[d->ncounts]);
-    mh_compute_prior(c, mask, c->mh_prior);
+    mh_structure_of(c, c->mh_model, masks);
+    mh_compute_prior(c, masks, c->mh_prior);
     mh_posterior(c, c->mh_prior, c->mh_seq, c->mh_model);
     score = orc_log_bd_score(c, c->mh_model, c->mh_prior);
     while (made < n) {
         double new_score;
-        uint32_t nmask = mask ^ (1u << orc_slow_int(&c->rng, 0, d->FS));  /* FactoredTigerFactoredPrior::mutate: flip_random_edge of O[listen][0] */
+        memcpy(nmasks, masks, sizeof(uint32_t) * (size_t)nvar);
+        mh_mutate(c, nmasks);
         if (++iters > (1 << 24)) return 0;
-        mh_compute_prior(c, nmask, c->mh_prior);
+        mh_compute_prior(c, nmasks, c->mh_prior);
         mh_posterior(c, c->mh_prior, c->mh_seq, c->mh_new);
         new_score = orc_log_bd_score(c, c->mh_new, c->mh_prior);
         if (m_log(c, orc_u01(&c->rng)) < (new_score - score)) {
@@ -2417,13 +2446,86 @@ static int mh_reinvigorate(orc_ctx* c)
             made++;
             if (!mh_sample_history(c, c->mh_model, c->mh_seq)) return 0;   /* (from the model of the LAST accepted structure, as the reference does) */
             mh_posterior(c, c->mh_prior, c->mh_seq, c->mh_model);
-            mask  = nmask;
+            memcpy(masks, nmasks, sizeof(uint32_t) * (size_t)nvar);
             score = orc_log_bd_score(c, c->mh_model, c->mh_prior);
         }
     }
     swap_pools(c);
     c->total_w = 0;
     for (e = 0; e < n; ++e) c->total_w += w1;   /* WeightedFilter::add accumulates */
+    weighted_refresh_scan(c);
+    c->log_lik = 0;
+    return 1;
+}
+
+/* ------------------------------------------------------------------ MH belief of the NIPS 2018 paper
+ * ref: src/beliefs/bayes-adaptive/factored/MHNIPS2018.cpp.  The same filter, history and trigger; the re-draw (MH,
+ * :208-255) makes independent proposals: a particle of the old filter, its structure or (half of the time) a mutation,
+ * the prior of that structure updated along a freshly simulated history (computePosterior, :39-105), accepted on the
+ * difference of LogBDScores.  Stream (REINVIG, 0), sequential. */
+
+/* computePosterior (:39-105): per episode a start state and one sampled step per history step (expected Dirichlet
+ * method), counts incremented as it goes; a wrong observation undoes the episode's increments and starts it over.
+ * Returns the last state, or -1 if an episode cannot be reproduced in 2^22 tries (the reference would never return). */
+static int32_t mhnips_posterior(orc_ctx* c, float* model)
+{
+    int e, h0 = 0, t;
+    int32_t last = 0;
+    for (e = 0; e < c->mh_n_ep; ++e) {
+        int L = c->mh_ep_len[e], tries = 0, done = 0;
+        while (!done) {
+            simstate st;
+            int32_t* from = c->mh_seq;       /* state_transitions: (s, s') per applied step */
+            if (++tries > (1 << 22)) return -1;
+            st.s   = domain_start(c);
+            st.cnt = model;
+            for (t = 0; t < L; ++t) {
+                int32_t so, s = st.s;
+                double r;
+                ba_fact_step(c, &st, c->mh_a[h0 + t], &so, &r, 0);
+                last = st.s;
+                if (so != c->mh_o[h0 + t]) break;
+                fact_increment(c, model, s, c->mh_a[h0 + t], so, st.s, 1);
+                from[2 * t] = s; from[2 * t + 1] = st.s;
+            }
+            if (t == L) { done = 1; break; }
+            { int u; for (u = 0; u < t; ++u) fact_increment(c, model, from[2 * u], c->mh_a[h0 + u], c->mh_o[h0 + u], from[2 * u + 1], -1); }
+        }
+        h0 += L;
+    }
+    return last;
+}
+/* MHNIPS2018::MH (:208-255) */
+static int mhnips_redraw(orc_ctx* c)
+{
+    int n = c->cfg.particles, made = 0, e, iters = 0;
+    uint32_t masks[MH_MAXVAR];
+    double w1 = 1.0 / (double)n;
+    orc_rng_stream(&c->rng, ORC_PH_REINVIG, 0);
+    while (made < n) {
+        const float* sampled = c->P[weighted_sample(c)].cnt;   /* old_belief.sample()->model() */
+        double old_score, new_score;
+        int32_t s_index;
+        if (++iters > (1 << 24)) return 0;
+        mh_structure_of(c, sampled, masks);
+        mh_compute_prior(c, masks, c->mh_prior);               /* sampled_prior_model */
+        if (!orc_bool(&c->rng)) mh_mutate(c, masks);           /* the same structure half of the time */
+        mh_compute_prior(c, masks, c->mh_model);               /* new_prior_model */
+        memcpy(c->mh_new, c->mh_model, sizeof(float) * (size_t)c->ncnt);
+        s_index = mhnips_posterior(c, c->mh_new);
+        if (s_index < 0) return 0;
+        old_score = orc_log_bd_score(c, sampled, c->mh_prior);
+        new_score = orc_log_bd_score(c, c->mh_new, c->mh_model);
+        if (m_log(c, orc_u01(&c->rng)) < (new_score - old_score)) {
+            c->Pnew[made].s = s_index;
+            c->Pnew[made].w = w1;
+            memcpy(c->Pnew[made].cnt, c->mh_new, sizeof(float) * (size_t)c->ncnt);
+            made++;
+        }
+    }
+    swap_pools(c);
+    c->total_w = 0;
+    for (e = 0; e < n; ++e) c->total_w += w1;
     weighted_refresh_scan(c);
     c->log_lik = 0;
     return 1;
@@ -2439,8 +2541,8 @@ static void mh_update(orc_ctx* c, int32_t a, int32_t o)
     c->mh_a[h] = (int16_t)a;
     c->mh_o[h] = (int16_t)o;
     c->mh_ep_len[c->mh_n_ep - 1]++;
-    if (c->log_lik < c->cfg.threshold && !mh_reinvigorate(c))
-        snprintf(c->err, sizeof c->err, "mh-within-gibbs: the history cannot be reproduced by the sampled model");
+    if (c->log_lik < c->cfg.threshold && !(c->cfg.belief == ORC_BELIEF_MH_NIPS ? mhnips_redraw(c) : mh_reinvigorate(c)))
+        snprintf(c->err, sizeof c->err, "%s: the history cannot be reproduced by the sampled model", c->cfg.belief == ORC_BELIEF_MH_NIPS ? "mh-nips" : "mh-within-gibbs");
 }
 
 static void belief_update(orc_ctx* c, int32_t a, int32_t o)
@@ -2480,7 +2582,7 @@ static void belief_update(orc_ctx* c, int32_t a, int32_t o)
             }
             c->likelihood = 1;
         }
-    } else if (c->cfg.belief == ORC_BELIEF_MH_GIBBS) {
+    } else if (is_mh(c)) {
         mh_update(c, a, o);
     } else {
         is_update(c, a, o);
@@ -2499,7 +2601,7 @@ static void belief_reset_domain_state(orc_ctx* c)
             orc_rng_stream(&c->rng, ORC_PH_RESET, (uint32_t)i);
             c->P[i].s = domain_start(c);
         }
-        if (c->cfg.belief == ORC_BELIEF_MH_GIBBS && c->mh_ep_len[c->mh_n_ep - 1] != 0) /* MHwithinGibbs::resetDomainStateDistribution :259-275: a new episode unless the open one is empty */
+        if (is_mh(c) && c->mh_ep_len[c->mh_n_ep - 1] != 0) /* MHwithinGibbs::resetDomainStateDistribution :259-275 (MHNIPS2018.cpp:114-130): a new episode unless the open one is empty */
             c->mh_ep_len[c->mh_n_ep++] = 0;
         if (c->cfg.belief == ORC_BELIEF_REINVIGORATION || c->cfg.belief == ORC_BELIEF_CHEATING) /* ReinvigoratingRejectionSampling.cpp:109-119 */
             for (i = 0; i < n; ++i) {
@@ -2810,14 +2912,17 @@ orc_ctx* orc_create(const orc_config* cfg)
             return c;
         }
     }
-    if (cfg->belief == ORC_BELIEF_MH_GIBBS) {
+    if (is_mh(c)) {
         int cap = cfg->episodes * cfg->horizon;
-        if (cfg->model != ORC_MODEL_BA_FACTORED || !is_ftiger(cfg->domain) || cfg->dirichlet_regular) {
-            snprintf(c->err, sizeof c->err, "mh-within-gibbs belief: built for the factored-tiger FBA-POMDP (fbapomdp -D *-factored-tiger), expected Dirichlet mode");
+        const char* name = cfg->belief == ORC_BELIEF_MH_NIPS ? "MHNIPS2018" : "MHwithinGibbs";
+        if (cfg->model != ORC_MODEL_BA_FACTORED || !(is_ftiger(cfg->domain) || is_ca(cfg->domain)) || cfg->dirichlet_regular ||
+            (is_ca(cfg->domain) && cfg->structure_prior == ORC_SP_FULLY_CONNECTED) || c->fd.nvar > MH_MAXVAR) {
+            snprintf(c->err, sizeof c->err, "%s belief: built for the factored-tiger and collision-avoidance FBA-POMDPs (fbapomdp), expected Dirichlet mode",
+                     cfg->belief == ORC_BELIEF_MH_NIPS ? "mh-nips" : "mh-within-gibbs");
             return c;
         }
-        if (cfg->threshold >= 0) { /* MHwithinGibbs.cpp:248-252 */
-            snprintf(c->err, sizeof c->err, "MHwithinGibbs::cannot initiate with threshold >= 0 (is:%f)", cfg->threshold);
+        if (cfg->threshold >= 0) { /* MHwithinGibbs.cpp:248-252, MHNIPS2018.cpp:121-126 */
+            snprintf(c->err, sizeof c->err, "%s::cannot initiate with threshold >= 0 (is:%f)", name, cfg->threshold);
             return c;
         }
         c->mh_a      = (int16_t*)calloc((size_t)cap + 1, sizeof(int16_t));
@@ -2830,7 +2935,7 @@ orc_ctx* orc_create(const orc_config* cfg)
         c->mh_O      = (float*)malloc(sizeof(float) * (size_t)c->A * c->S * c->O);
         c->mh_msg    = (double*)malloc(sizeof(double) * (size_t)(cfg->horizon + 1) * c->S);
         c->mh_probs  = (double*)malloc(sizeof(double) * (size_t)c->S);
-        c->mh_seq    = (int32_t*)malloc(sizeof(int32_t) * (size_t)(cfg->episodes * (cfg->horizon + 1) + 1));
+        c->mh_seq    = (int32_t*)malloc(sizeof(int32_t) * (size_t)(cfg->episodes * (cfg->horizon + 1) + 2 * cfg->horizon + 1));
         c->mh_n_ep   = 1;
     }
     if (cfg->belief == ORC_BELIEF_REINVIGORATION || cfg->belief == ORC_BELIEF_CHEATING) {

@@ -45,7 +45,8 @@ enum { ORC_MODEL_POMDP = 0, ORC_MODEL_BA_TABLE = 1, ORC_MODEL_BA_FACTORED = 2 };
 /* CHEATING = beliefs::bayes_adaptive::prototypes::CheatingReinvigoration (-B cheating-reinvigoration) */
 enum { ORC_BELIEF_REJECTION = 0, ORC_BELIEF_IMPORTANCE = 1, ORC_BELIEF_REINVIGORATION = 2, ORC_BELIEF_CHEATING = 3,
        ORC_BELIEF_POINT = 4, /* -B point_estimate: src/beliefs/point_estimation/PointEstimation.cpp, bayes-adaptive/BAPointEstimation.cpp */
-       ORC_BELIEF_MH_GIBBS = 5 /* -B mh-within-gibbs: src/beliefs/bayes-adaptive/factored/MHwithinGibbs.cpp (belief_option 1 = "rs") */ };
+       ORC_BELIEF_MH_GIBBS = 5, /* -B mh-within-gibbs: src/beliefs/bayes-adaptive/factored/MHwithinGibbs.cpp (belief_option 1 = "rs") */
+       ORC_BELIEF_MH_NIPS = 6   /* -B mh-nips: src/beliefs/bayes-adaptive/factored/MHNIPS2018.cpp */ };
 /* floating-point summation order of the importance-sampling filter:
  * REF = the reference's sequential loops; DEV = the HIP engine's fixed reduction tree */
 enum { ORC_ARITH_REF = 0, ORC_ARITH_DEV = 1 };

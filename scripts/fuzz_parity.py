@@ -62,10 +62,11 @@ def draw(rng):
             belief = "cheating-reinvigoration"
             kw["resample_amount"] = rng.choice([1, 5])
             kw["threshold"] = rng.choice([-0.3, -2.0, -50.0])
-        elif b < 0.55 and "factored-tiger" in domain and kw["particles"] <= 64:
-            belief = "mh-within-gibbs"
+        elif b < 0.6 and ("factored-tiger" in domain or "collision" in domain) and kw["particles"] <= 64:
+            belief = rng.choice(["mh-within-gibbs", "mh-nips"])
             kw["threshold"] = rng.choice([-0.3, -2.0, -50.0])
-            kw["belief_option"] = rng.choice([0, 1])
+            if belief == "mh-within-gibbs":
+                kw["belief_option"] = rng.choice([0, 1])
     if model != N.MODEL_POMDP and rng.random() < 0.2:
         longest = {"gridworld": 99, "random-collision-avoidance": kw.get("height", 0), "centered-collision-avoidance": kw.get("height", 0)}.get(domain, 2)
         if model == N.MODEL_BA_FACTORED and longest <= 16 or model == N.MODEL_BA_TABLE and "tiger" in domain and "factored" not in domain:

@@ -23,25 +23,34 @@ def test_random_configurations_match_the_oracle():
     assert refused < 60          # (model / domain pairs neither side supports)
 
 
-def test_random_mh_within_gibbs_configurations_match_the_oracle():
-    """The MH-within-Gibbs belief over random factored-tiger configurations (sizes, structure priors, thresholds, both
-    state-history samplers, particle counts from 1): engine == oracle on every trace field."""
+def test_random_mh_belief_configurations_match_the_oracle():
+    """The MH beliefs (mh-within-gibbs with both state-history samplers, mh-nips) over random factored-tiger and
+    collision-avoidance configurations (sizes, structure priors, thresholds, particle counts from 1): engine == oracle
+    on every trace field."""
     import random
 
     from fba_pomdp_amd import _native as N
     fuzz = _fuzz()
     rng = random.Random(77)
     ran = 0
-    for i in range(24):
-        domain = rng.choice(["episodic-factored-tiger", "continuous-factored-tiger"])
-        kw = dict(size=rng.choice([1, 2, 3]), particles=rng.choice([1, 5, 24, 50]), sims=rng.choice([4, 30, 90]), horizon=rng.choice([2, 5, 9]),
+    for i in range(40):
+        domain = rng.choice(["episodic-factored-tiger", "continuous-factored-tiger", "random-collision-avoidance", "centered-collision-avoidance"])
+        belief = rng.choice(["mh-within-gibbs", "mh-nips"])
+        kw = dict(particles=rng.choice([1, 5, 24, 50]), sims=rng.choice([4, 30, 90]), horizon=rng.choice([2, 5, 9]),
                   runs=rng.choice([1, 3]), episodes=rng.choice([1, 2, 4]), structure_prior=rng.choice([0, 1, 2, 3]),
-                  threshold=rng.choice([-0.2, -1.0, -6.0]), belief_option=rng.choice([0, 1]), noise=rng.choice([0.0, 0.1]),
-                  discount=rng.choice([0.7, 0.95]))
+                  threshold=rng.choice([-0.2, -1.0, -6.0]), noise=rng.choice([0.0, 0.1]), discount=rng.choice([0.7, 0.95]))
+        if "tiger" in domain:
+            kw["size"] = rng.choice([1, 2, 3])
+        else:
+            kw["width"], kw["height"], kw["size"] = rng.choice([(3, 3, 1), (4, 3, 2), (3, 5, 1)])
+            if kw["structure_prior"] == 3:
+                kw["structure_prior"] = 2   # (no fully connected prior for the MH beliefs: refused)
+        if belief == "mh-within-gibbs":
+            kw["belief_option"] = rng.choice([0, 1])
         slots = rng.choice([1, kw["runs"]])
         try:
-            fuzz.one(domain, N.MODEL_BA_FACTORED, "mh-within-gibbs", slots, kw, seed=4000 + i)
+            fuzz.one(domain, N.MODEL_BA_FACTORED, belief, slots, kw, seed=4000 + i)
             ran += 1
         except ValueError:
             pass
-    assert ran >= 20
+    assert ran >= 36

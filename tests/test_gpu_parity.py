@@ -981,29 +981,40 @@ def test_packed_factored_tiger_particles_equal_dense_ones(size, sp, noise, monke
             packed.belief_set(0, counts=bad)
 
 
-@pytest.mark.parametrize("domain,option,sp,thr", [
-    ("continuous-factored-tiger", 0, 2, -1.0), ("continuous-factored-tiger", 1, 2, -1.0),
-    ("episodic-factored-tiger", 0, 1, -0.5), ("continuous-factored-tiger", 0, 0, -3.0),
+@pytest.mark.parametrize("belief,domain,option,sp,thr", [
+    ("mh-within-gibbs", "continuous-factored-tiger", 0, 2, -1.0), ("mh-within-gibbs", "continuous-factored-tiger", 1, 2, -1.0),
+    ("mh-within-gibbs", "episodic-factored-tiger", 0, 1, -0.5), ("mh-within-gibbs", "continuous-factored-tiger", 0, 0, -3.0),
+    ("mh-nips", "continuous-factored-tiger", 0, 2, -1.0), ("mh-nips", "episodic-factored-tiger", 0, 1, -0.5),
+    ("mh-nips", "continuous-factored-tiger", 0, 0, -3.0),
+    ("mh-within-gibbs", "random-collision-avoidance", 0, 2, -2.0), ("mh-within-gibbs", "centered-collision-avoidance", 1, 1, -2.0),
+    ("mh-nips", "random-collision-avoidance", 0, 2, -2.0), ("mh-nips", "centered-collision-avoidance", 0, 0, -1.0),
 ])
-def test_fbapomdp_mh_within_gibbs_belief(domain, option, sp, thr):
+def test_fbapomdp_mh_beliefs(belief, domain, option, sp, thr):
     """-B mh-within-gibbs (MHwithinGibbs.cpp; --belief-option "" = message passing, "rs" = rejection-sampled state
-    histories): importance filter + the run's history + a Metropolis-Hastings chain over structures, scored by
-    LogBDScore, that re-draws the filter when the log likelihood falls below --threshold.  Whole experiments, every
-    trace field (the checksum over every particle's counts after every update included) against the oracle."""
-    eng, o = _pair(domain, N.MODEL_BA_FACTORED, "mh-within-gibbs", 601 + option, size=2, particles=48, sims=80, runs=4,
-                   episodes=3, horizon=8, structure_prior=sp, threshold=thr, belief_option=option)
+    histories) and -B mh-nips (MHNIPS2018.cpp): importance filter + the run's history + a Metropolis-Hastings re-draw of
+    the filter over structures, scored by LogBDScore, when the log likelihood falls below --threshold.  Factored tiger
+    (one structure word: the listen node's parents) and collision avoidance (one word per action and obstacle).  Whole
+    experiments, every trace field (the checksum over every particle's counts after every update included) against the oracle."""
+    ca = "collision" in domain
+    kw = dict(width=3, height=3, size=1, particles=24, sims=48, horizon=5) if ca else dict(size=2, particles=48, sims=80, horizon=8)
+    eng, o = _pair(domain, N.MODEL_BA_FACTORED, belief, 601 + option, runs=4, episodes=3, structure_prior=sp, threshold=thr,
+                   belief_option=option, **kw)
     _assert_same_experiment(eng, o, ba=True)
     s, w, cnt = eng.belief_get(0)
-    assert np.all(w == 1.0 / 48)
+    assert np.all(w == 1.0 / kw["particles"])
     # the chain has really run: with a threshold that is never reached the same experiment leaves other filters behind
-    never = fba.Engine(domain, model=N.MODEL_BA_FACTORED, belief="mh-within-gibbs", seed=601 + option, slots=4, trace=1, size=2, particles=48,
-                       sims=80, runs=4, episodes=3, horizon=8, structure_prior=sp, threshold=-1e9, belief_option=option)
+    never = fba.Engine(domain, model=N.MODEL_BA_FACTORED, belief=belief, seed=601 + option, slots=4, trace=1, runs=4, episodes=3,
+                       structure_prior=sp, threshold=-1e9, belief_option=option, **kw)
     never.run_bapomdp()
     assert not np.array_equal(never.trace()["belief_hash"], eng.trace()["belief_hash"])
 
 
-def test_mh_within_gibbs_refuses_what_it_is_not_built_for():
-    with pytest.raises(ValueError, match="threshold >= 0"):
+def test_mh_beliefs_refuse_what_they_are_not_built_for():
+    with pytest.raises(ValueError, match="MHwithinGibbs::cannot initiate with threshold >= 0"):
         fba.Engine("episodic-factored-tiger", model=N.MODEL_BA_FACTORED, belief="mh-within-gibbs", size=1, particles=8, sims=8, threshold=0.5)
-    with pytest.raises(ValueError, match="factored-tiger"):
+    with pytest.raises(ValueError, match="MHNIPS2018::cannot initiate with threshold >= 0"):
+        fba.Engine("episodic-factored-tiger", model=N.MODEL_BA_FACTORED, belief="mh-nips", size=1, particles=8, sims=8, threshold=0.0)
+    with pytest.raises(ValueError, match="factored-tiger and collision-avoidance"):
         fba.Engine("gridworld", model=N.MODEL_BA_FACTORED, belief="mh-within-gibbs", size=3, particles=8, sims=8, threshold=-1.0)
+    with pytest.raises(ValueError, match="factored-tiger and collision-avoidance"):
+        fba.Engine("independent-sysadmin", model=N.MODEL_BA_FACTORED, belief="mh-nips", size=3, particles=8, sims=8, threshold=-1.0)
