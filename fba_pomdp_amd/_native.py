@@ -11,7 +11,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-LIB_PATH = os.path.join(HERE, "libfba_hip.so")
+LIB_PATH = os.environ.get("FBA_LIB") or os.path.join(HERE, "libfba_hip.so")   # (FBA_LIB: an instrumented build of the same sources, scripts/search_regions.py)
 SOURCES = [os.path.join(HERE, "csrc", f) for f in ("fba_kernels.hip", "fba_engine.hip")]
 HEADERS = [os.path.join(HERE, "csrc", f) for f in ("fba_device.h", "fba_state.h", "fba_kernels.h")] + [
     os.path.join(ROOT, "include", "fba_hip.h")]

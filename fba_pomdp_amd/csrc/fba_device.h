@@ -41,8 +41,13 @@ struct Rng {
         if ((draw & 1u) == 0) {
             uint32_t x0 = draw >> 1, x1 = c1, x2 = c2, x3 = c3;
             uint32_t a = k0, b = k1;
+#ifdef FBA_CHEAP_RNG   /* measurement builds only (scripts/search_regions.py): what the search would cost with a nearly free generator */
+#define FBA_PHILOX_ROUNDS 5
+#else
+#define FBA_PHILOX_ROUNDS 10
+#endif
 #pragma unroll
-            for (int i = 0; i < 10; ++i) {
+            for (int i = 0; i < FBA_PHILOX_ROUNDS; ++i) {
                 const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)x0, p1 = (uint64_t)0xCD9E8D57u * (uint64_t)x2;  // one 32x32->64 multiply each
                 const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
                 uint32_t n0 = hi1 ^ x1 ^ a, n2 = hi0 ^ x3 ^ b;

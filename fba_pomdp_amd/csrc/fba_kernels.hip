@@ -13,6 +13,7 @@
 // HBM-streaming (one workgroup per slot, wave ballot / prefix-sum compaction, whole-record
 // gathers); the search kernel is latency bound and gets its throughput from running one
 // independent tree per lane, all lanes executing the common "simulate one step" body together.
+#include <cstdlib>
 #include "fba_kernels.h"
 
 #include <float.h>
@@ -294,6 +295,48 @@ __device__ __forceinline__ int ucb_select(const Problem& P, const DeviceState& D
     return ucb_pick<AMAX>(P, g, explore ? D.log1p_tab[visits] : 0.0, cn, cq, explore);
 }
 
+// ucb_select for a node a simulation passes through on its way down: every such node is backed up exactly once
+// before anybody reads it again (the tree belongs to one lane), so ActionNode::addVisit and the chosen action's
+// visit count (MCTSTreeNodes.cpp:59-62, :8-12) are written here, from the header this function has just loaded, and
+// the back-up is left with Q alone: it gets the count to divide by and the old Q value, and needs no load.
+template <int AMAX, class RNG>
+__device__ __forceinline__ int ucb_select_visit(const Problem& P, const DeviceState& D, RNG& g, int32_t* rec, int& n_new, double& q_old)
+{
+    int cn[AMAX];
+    double cq[AMAX];
+    int visits;
+    if (AMAX >= 3 && P.A == 3) {
+        const int4 pre    = *reinterpret_cast<const int4*>(rec);
+        const double2 q01 = *reinterpret_cast<const double2*>(rec + 4);
+        const double q2   = *reinterpret_cast<const double*>(rec + 8);
+        visits = pre.x;
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a) { cn[a] = 0; cq[a] = 0.0; }
+        cn[0] = pre.y; cn[1] = pre.z; cn[2] = pre.w;
+        cq[0] = q01.x; cq[1] = q01.y; cq[2] = q2;
+    } else {
+        const double* q = reinterpret_cast<const double*>(rec + D.cq_off);
+        visits = rec[0];
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a) {
+            cn[a] = a < P.A ? rec[1 + a] : 0;
+            cq[a] = a < P.A ? q[a] : 0.0;
+        }
+    }
+    const int act = ucb_pick<AMAX>(P, g, D.log1p_tab[visits], cn, cq, true);
+    n_new = 0; q_old = 0.0;
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a)
+        if (a == act) { n_new = cn[a] + 1; q_old = cq[a]; }
+    if (AMAX >= 3 && P.A == 3) {
+        *reinterpret_cast<int4*>(rec) = make_int4(visits + 1, cn[0] + (act == 0), cn[1] + (act == 1), cn[2] + (act == 2));
+    } else {
+        rec[0]       = visits + 1;
+        rec[1 + act] = n_new;
+    }
+    return act;
+}
+
 // ---------------------------------------------------------------------------------------------
 // search_kernel: one lane = one slot = one tree; `sims` simulations, sequential semantics.
 // POUCT::selectAction POUCT.cpp:63-129, RBAPOUCT::selectAction RBAPOUCT.cpp:67-153 (the root
@@ -314,6 +357,13 @@ __host__ __device__ __forceinline__ bool root_children_in_lds(const Problem& P, 
 }
 
 // FTP: the factored-tiger records are packed (PackedFtigerView).
+#ifdef FBA_PROFILE_SEARCH
+// profiling build only (scripts/search_regions.py): shader-clock cycles a wave spends in each region of the search loop
+__device__ unsigned long long g_search_prof[8];
+#define PROF_MARK(r) { const long long now_ = clock64(); prof_[r] += now_ - prev_; prev_ = now_; }
+#else
+#define PROF_MARK(r)
+#endif
 template <bool STAGE, int AMAX, bool REG, int TIGER_TABLE, int MODEL, int FTIGER = 0, bool TIGER_POMDP = false, bool FTP = false>
 __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceState D)
 {
@@ -423,7 +473,15 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
     int s = 0, node = 0, dtg = 0, plen = 0, rdepth = 0;
     const float* cnt = prec;
     double rret = 0, rdisc = 1;
+    int st_n[BACKUP_STASH];
+    double st_q[BACKUP_STASH];
+#pragma unroll
+    for (int j = 0; j < BACKUP_STASH; ++j) { st_n[j] = 0; st_q[j] = 0.0; }
+#ifdef FBA_PROFILE_SEARCH
+    long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prev_ = clock64();
+#endif
     while (true) {
+        PROF_MARK(6)
         if (mode == 0) {
             if (sim >= P.sims) break;
             g.stream(FBA_PHASE_SEARCH, (uint32_t)sim);
@@ -446,6 +504,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
             if (lazy) s = lazy_state(P, D, e, src);
             node = 0; dtg = max_tree_depth; plen = 0; mode = 1;
         }
+        PROF_MARK(0)
         bool finish = false, do_step = true;
         double delayed = 0;
         int a = 0;
@@ -453,14 +512,22 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
             tree_depth = max(tree_depth, max_tree_depth - dtg);
             if (dtg == 0) { finish = true; do_step = false; }
             else if (node == 0) a = ucb_pick<AMAX>(P, g, root_L, r_cn, r_cq, true);
-            else a = ucb_select<AMAX>(P, D, g, tree + (size_t)node * W, true);
+            else {
+                int vn;
+                double vq;
+                a = ucb_select_visit<AMAX>(P, D, g, tree + (size_t)node * W, vn, vq);
+#pragma unroll
+                for (int j = 0; j < BACKUP_STASH; ++j)
+                    if (plen - 1 == j) { st_n[j] = vn; st_q[j] = vq; }
+            }
         } else {          // rollout: uniformly random action
             a = domain_random_action(P, g, s);
         }
+        PROF_MARK(1)
+        int o;
+        double r;
+        bool term;
         if (do_step) {
-            int o;
-            double r;
-            bool term;
             if (FTIGER > 0 && STAGE && FTP)
                 term = ftiger_step_packed<(FTIGER > 0 ? FTIGER : 1)>(P, g, LdsView<SEARCH_BLOCK>{stage}, s, a, o, r, NoInc{});
             else if (FTIGER > 0 && STAGE) term = ftiger_step<(FTIGER > 0 ? FTIGER : 1)>(P, g, LdsView<SEARCH_BLOCK>{stage}, s, a, o, r, NoInc{});
@@ -470,6 +537,11 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
             else if (STAGE) term = sim_step<REG>(P, g, LdsView<SEARCH_BLOCK>{stage}, s, a, o, r, NoInc{});
             else term = sim_step<REG>(P, g, GlobalSearchView{cnt}, s, a, o, r, NoInc{});
             ++steps;
+#ifdef FBA_PROFILE_SEARCH
+        }
+        PROF_MARK(2)
+        if (do_step) {
+#endif
             if (mode == 1) {  // traverseChanceNode
                 path_r[(size_t)plen * SEARCH_BLOCK]  = (float)r;
                 path_na[(size_t)plen * SEARCH_BLOCK] = (node << 5) | a  /* a < FBA_MAX_ACTIONS <= 32 */;
@@ -499,6 +571,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
                 if (rdepth == 0 || term) { delayed = rret; finish = true; }
             }
         }
+        PROF_MARK(3)
         if (finish) {
             // back-up, leaf to root: ret = r + gamma * delayed; ChanceNode::addVisit(ret)
             // (MCTSTreeNodes.cpp:8-12); ActionNode::addVisit() (:59-62)
@@ -522,27 +595,36 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
                     ++r_vis;
                     root_L = D.log1p_tab[r_vis];
                 } else {
+                    // (the visit counts were written on the way down, ucb_select_visit; what is left is Q.  The first
+                    // BACKUP_STASH levels below the root kept {count, old Q} in registers: no load on this path)
                     int32_t* rec = tree + (size_t)(na >> 5) * W;
                     double* q    = reinterpret_cast<double*>(rec + D.cq_off) + act;
-                    int n;
-                    if (P.A == 3) {  // {visits, n0, n1, n2} is one 16-byte word: one load, one store
-                        int4* hp = reinterpret_cast<int4*>(rec);
-                        int4 h   = *hp;
-                        n = act == 0 ? ++h.y : (act == 1 ? ++h.z : ++h.w);
-                        ++h.x;
-                        *hp = h;
+                    int n        = 0;
+                    double qo    = 0.0;
+                    if (k - 1 < BACKUP_STASH) {
+#pragma unroll
+                        for (int j = 0; j < BACKUP_STASH; ++j)
+                            if (k - 1 == j) { n = st_n[j]; qo = st_q[j]; }
                     } else {
-                        n = ++rec[1 + act];
-                        ++rec[0];
+                        n  = rec[1 + act];
+                        qo = *q;
                     }
-                    *q += (ret - *q) / (double)n;
+                    *q = qo + (ret - qo) / (double)n;
                 }
                 del = ret;
             }
             ++sim;
             mode = 0;
         }
+        PROF_MARK(4)
+#ifdef FBA_PROFILE_SEARCH
+        prof_[5] += 1;
+#endif
     }
+#ifdef FBA_PROFILE_SEARCH
+    if (lane == 0)
+        for (int r = 0; r < 8; ++r) atomicAdd(&g_search_prof[r], (unsigned long long)prof_[r]);
+#endif
     g.stream(FBA_PHASE_SEARCH, (uint32_t)P.sims + 1u);
     if (n_nodes > D.max_nodes) atomicCAS(D.fault, 0, -(1 + e));  // -> FBA_ESTATE on the host
     const int best = ucb_pick<AMAX>(P, g, 0.0, r_cn, r_cq, false);
@@ -2490,6 +2572,8 @@ void launch_search(const Problem& P, const DeviceState& D, hipStream_t st)
                  (stage ? (size_t)P.Cs * SEARCH_BLOCK * sizeof(float) : 0) +
                  (root_children_in_lds(P, D) ? (size_t)P.A * P.O * SEARCH_BLOCK * sizeof(int16_t) : 0);
     if (P.model == FBA_MODEL_BA_FACTORED) lds = ((lds + 15) & ~(size_t)15) + (((size_t)P.fd_bytes + 15) & ~(size_t)15);  // + the model description
+    static const size_t lds_pad = std::getenv("FBA_SEARCH_LDS_PAD") ? (size_t)std::atoi(std::getenv("FBA_SEARCH_LDS_PAD")) : 0;  // occupancy experiments
+    lds += lds_pad;
     const dim3 grid(ceil_div(P.E, SEARCH_BLOCK)), block(SEARCH_BLOCK);
 #define FBA_LAUNCH_SEARCH_M(STG, AM, MODEL)                                                                              \
     do {                                                                                                                 \
@@ -2649,6 +2733,17 @@ void launch_flush(const Problem& P, const DeviceState& D, hipStream_t st)
 {
     hipLaunchKernelGGL(flush_kernel, dim3(P.E), dim3(256), 0, st, P, D);
 }
+#ifdef FBA_PROFILE_SEARCH
+extern "C" int fba_debug_search_profile(unsigned long long* out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_search_prof), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) {
+        const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_search_prof), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 void launch_selftest_lgamma(const double* x, int count, double* out, hipStream_t st)
 {
     hipLaunchKernelGGL(selftest_lgamma_kernel, dim3(ceil_div(count, 256)), dim3(256), 0, st, x, count, out);

@@ -1,0 +1,43 @@
+"""Where a wave of search_kernel spends its cycles: an instrumented build of the same sources (-DFBA_PROFILE_SEARCH:
+clock64() marks between the regions of the search loop, summed per wave) run on the bench workload.
+python scripts/search_regions.py build   (here: hipcc, no GPU needed)  ->  fba_pomdp_amd/libfba_hip_prof.so
+python scripts/search_regions.py [slots] (on the GPU box)              ->  one JSON line"""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROF = os.path.join(ROOT, "fba_pomdp_amd", "libfba_hip_prof.so")
+sys.path.insert(0, ROOT)
+
+if len(sys.argv) > 1 and sys.argv[1] == "build":
+    from fba_pomdp_amd import _native as N
+    subprocess.check_call(["hipcc"] + N.HIPCC_FLAGS + ["-DFBA_PROFILE_SEARCH", "-I" + os.path.join(ROOT, "include")] + N.SOURCES + ["-o", PROF])
+    print("built", PROF)
+    sys.exit(0)
+
+os.environ["FBA_LIB"] = PROF
+import fba_pomdp_amd as fba  # noqa: E402
+from fba_pomdp_amd import _native as N  # noqa: E402
+
+slots = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+kw = dict(sims=4096, particles=4096, horizon=10, episodes=64) if os.environ.get("FBA_CFG", "c2") == "c2" else dict(sims=1024, particles=1024, horizon=10, episodes=64)
+eng = fba.Engine("episodic-tiger", model=fba.MODEL_BA_TABLE, belief="rejection_sampling", runs=1 << 30, slots=slots, seed=20261003, **kw)
+L = N.load()
+out = (C.c_ulonglong * 8)()
+eng.run_ticks(2)
+L.fba_debug_search_profile(out, 1)
+c0 = eng.counters()
+eng.run_ticks(3)
+L.fba_debug_search_profile(out, 0)
+c1 = eng.counters()
+names = ["root sample + particle fetch", "action (UCB / rollout draw)", "simulator step", "child lookup / expand / rollout sums", "back-up", "iterations", "loop head"]
+v = list(out)
+total = sum(v[i] for i in (0, 1, 2, 3, 4, 6))
+steps = c1.sim_steps - c0.sim_steps
+print(json.dumps({"slots": slots, "config": kw, "waves": slots // 64, "sim_steps": steps, "wave_iterations": v[5],
+                  "steps_per_wave_iteration": steps / max(v[5], 1),
+                  "cycles_per_wave_iteration": total / max(v[5], 1),
+                  "share": {names[i]: round(v[i] / total, 4) for i in (0, 1, 2, 3, 4, 6)}}))
