@@ -1142,6 +1142,28 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         P.belief = FBA_BELIEF_IMPORTANCE;
         P.mh     = nips ? 3 : cfg->belief_option == 1 ? 2 : 1;
     }
+    P.nested = 0;
+    if (cfg->belief == FBA_BELIEF_NESTED) {
+        // NestedBelief(particle_amount, particle_amount^2) (BABelief.cpp:67-70): a weighted filter of count particles, each
+        // with its own flat filter of domain states; the BABelief factory only, i.e. bapomdp / fbapomdp
+        if (cfg->model == FBA_MODEL_POMDP) {
+            fail(nullptr, FBA_EINVAL, "nested belief: needs a Bayes-adaptive model (bapomdp / fbapomdp)");
+            delete c;
+            return FBA_EINVAL;
+        }
+        if (cfg->particles < 1) {  // NestedBelief.cpp:22-27
+            fail(nullptr, FBA_EINVAL, "NestedBelief: cannot initiate with filter size < 1 (top: %d, bottom: %d)", cfg->particles, cfg->particles * cfg->particles);
+            delete c;
+            return FBA_EINVAL;
+        }
+        if (cfg->particles > 256) {
+            fail(nullptr, FBA_EINVAL, "nested belief: at most 256 count particles (each carries particles^2 domain states)");
+            delete c;
+            return FBA_EINVAL;
+        }
+        P.belief = FBA_BELIEF_IMPORTANCE;
+        P.nested = cfg->particles * cfg->particles;
+    }
     if (cfg->belief == FBA_BELIEF_REINVIGORATION) {
         // two rejection filters + breeding (ReinvigoratingRejectionSampling.hpp); the reference has fully
         // connected priors for factored tiger, collision avoidance and sysadmin
@@ -1444,6 +1466,12 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         D.ctot_stride = (P.N + 255) / 256 + 2;
         CHK(dev_alloc(c, &D.ctot, is ? (size_t)E * D.ctot_stride : 1));
         CHK(dev_alloc(c, &D.is_tot, (size_t)2 * E));
+    }
+    if (P.nested) {
+        CHK(dev_alloc(c, &D.nest_s, (size_t)2 * E * P.N * P.nested));
+        CHK(dev_alloc(c, &D.nest_sel, E));
+        CHK(dev_alloc(c, &D.nest_scan, (size_t)E * P.N));
+        CHK(dev_alloc(c, &D.nest_total, E));
     }
     if (P.mh) {
         if (D.is_multi) {
@@ -1862,10 +1890,23 @@ int fba_belief_get_fully_connected(fba_ctx* c, int32_t slot, int32_t* state, flo
     return FBA_OK;
 }
 
+int fba_belief_get_nested(fba_ctx* c, int32_t slot, int32_t* states)
+{
+    if (!c || slot < 0 || slot >= c->P.E || !states) return FBA_EINVAL;
+    const Problem& P = c->P;
+    if (!P.nested) return fail(c, FBA_EINVAL, "only the nested belief has flat filters of domain states");
+    int32_t sel = 0;
+    HIPCHK(c, hipMemcpy(&sel, c->D.nest_sel + slot, sizeof sel, hipMemcpyDeviceToHost));
+    const size_t per = (size_t)P.N * P.nested, off = ((size_t)sel * P.E + slot) * per;
+    HIPCHK(c, hipMemcpy(states, c->D.nest_s + off, per * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return FBA_OK;
+}
+
 int fba_belief_set(fba_ctx* c, int32_t slot, const int32_t* state, const double* weight, const float* counts)
 {
     if (!c || slot < 0 || slot >= c->P.E) return FBA_EINVAL;
     const Problem& P = c->P;
+    if (P.nested) return fail(c, FBA_EINVAL, "the nested belief cannot be set from the host (its weights' prefix sums and flat filters live on the device)");
     launch_materialize_reset(c->P, c->D, c->stream);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     uint8_t sel = 0;

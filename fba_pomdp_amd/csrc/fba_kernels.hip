@@ -115,6 +115,17 @@ __device__ __forceinline__ int belief_sample_uniform(const Problem& P, const Dev
     return uniform_weight_pick(D.uni_scan, P.N, g.u01() * D.uni_total, D.uni_total);
 }
 
+// Belief::sample() of the nested belief (NestedBelief::sample NestedBelief.cpp:116-125): a count particle by weight,
+// then one of its domain states
+__device__ __forceinline__ size_t nest_base(const Problem& P, int e, int buf) { return ((size_t)buf * P.E + e) * (size_t)P.N * (size_t)P.nested; }
+template <class RNG>
+__device__ __forceinline__ int nested_sample(const Problem& P, const DeviceState& D, int e, RNG& g, int& state)
+{
+    const int src = weighted_pick(D.nest_scan + (size_t)e * P.N, P.N, g.u01() * D.nest_total[e]);
+    state = D.nest_s[nest_base(P, e, D.nest_sel[e]) + (size_t)src * P.nested + g.uniform_int(P.nested)];
+    return src;
+}
+
 __device__ __forceinline__ void node_init(const DeviceState& D, int32_t* rec, int A, int O)
 {
     rec[0] = 0;
@@ -435,10 +446,13 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
     int32_t* tree       = D.nodes + (size_t)e * D.max_nodes * W;
     const float* prec   = D.p_rec + pbase(P, e, D.bufsel[e]) * (size_t)P.Cs;
 
+    // (the nested belief stores dense records only: never with the packed instantiations)
+    const bool nested = TIGER_TABLE != 2 && !TIGER_POMDP && !FTP && MODEL != FBA_MODEL_POMDP && P.nested != 0;
     if (P.planner == FBA_PLANNER_RANDOM) {  // RandomPlanner::selectAction RandomPlanner.cpp:14-24
         g.stream(FBA_PHASE_SEARCH, (uint32_t)P.sims);
-        const int src = belief_sample_uniform(P, D, g);
-        D.action[e]   = domain_random_action(P, g, slot_lazy(D, e) ? lazy_state(P, D, e, src) : rec_state(prec + (size_t)src * P.Cs, P.C));
+        int ns = 0;
+        const int src = nested ? nested_sample(P, D, e, g, ns) : belief_sample_uniform(P, D, g);
+        D.action[e]   = domain_random_action(P, g, nested ? ns : slot_lazy(D, e) ? lazy_state(P, D, e, src) : rec_state(prec + (size_t)src * P.Cs, P.C));
         return;
     }
 
@@ -464,10 +478,10 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
     // -P ts: TSPlanner / BATSPlanner (src/planners/ts/TSPlanner.cpp:16-29, bayes-adaptive/BATSPlanner.cpp:19-34) sample
     // the belief once and plan on that point estimate, whose sample() draws nothing: every simulation starts
     // from the same particle and its stream begins with the UCB tie-break.
-    int ts_src = -1;
+    int ts_src = -1, ts_state = 0;
     if (P.planner == FBA_PLANNER_TS) {
         g.stream(FBA_PHASE_SEARCH, (uint32_t)P.sims + 2u);
-        ts_src = belief_sample_uniform(P, D, g);
+        ts_src = nested ? nested_sample(P, D, e, g, ts_state) : belief_sample_uniform(P, D, g);
     }
     int sim = 0, mode = 0;  // 0 = start a simulation, 1 = in the tree, 2 = rollout
     int s = 0, node = 0, dtg = 0, plen = 0, rdepth = 0;
@@ -485,7 +499,8 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
         if (mode == 0) {
             if (sim >= P.sims) break;
             g.stream(FBA_PHASE_SEARCH, (uint32_t)sim);
-            const int src = ts_src >= 0 ? ts_src : belief_sample_uniform(P, D, g);
+            int nest_state = ts_state;
+            const int src = ts_src >= 0 ? ts_src : (nested ? nested_sample(P, D, e, g, nest_state) : belief_sample_uniform(P, D, g));
             cnt = prec + (size_t)src * P.Cs;
             if (STAGE) {
                 const float4* rp = reinterpret_cast<const float4*>(cnt);
@@ -502,6 +517,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
                 s = rec_state(cnt, P.C);
             }
             if (lazy) s = lazy_state(P, D, e, src);
+            if (nested) s = nest_state;
             node = 0; dtg = max_tree_depth; plen = 0; mode = 1;
         }
         PROF_MARK(0)
@@ -1820,6 +1836,102 @@ __global__ void __launch_bounds__(IS_BLOCK) uniform_scan_kernel(int n, double* w
 }
 
 // ---------------------------------------------------------------------------------------------
+// The nested belief (NestedBelief.cpp; -B nested): a weighted filter of N count particles, each with its own flat
+// filter of M = N^2 domain states.  One lane = one count particle: its update is sequential by definition (every
+// accepted sample changes the counts the next attempt samples from), the N particles of a slot and the slots run side
+// by side.  Dense records only (the increments are 1/M).
+//   nested_fill_kernel   initiate (:61-87, stream INIT_FC i: M start states; the count particle itself comes from
+//                        init_kernel, stream INIT i, its own domain state released) / resetDomainStateDistribution
+//                        (:35-58, stream RESET i: M start states)
+//   nested_update_kernel updateEstimation (:127-192, stream REJECT i): until M samples are accepted -- a state of the
+//                        filter, one KeepCounts step on the particle's own counts, accept on the observation,
+//                        incrementCountsOf(old, a, o, new, 1/M) -- then weight *= 1 / attempts; WeightedFilter::normalize
+//                        and the prefix sums sample() needs, in device order.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) nested_fill_kernel(Problem P, DeviceState D, int reset)
+{
+    __shared__ double s_carry[4];
+    const int e = blockIdx.x, i = threadIdx.x;
+    if (reset ? D.need_reset[e] != 1 : !D.need_init[e]) return;
+    const int M = P.nested;
+    if (!reset && i == 0) D.nest_sel[e] = 0;
+    __syncthreads();
+    const size_t pb = pbase(P, e, D.bufsel[e]);
+    if (i < P.N) {
+        int32_t* filter = D.nest_s + nest_base(P, e, reset ? D.nest_sel[e] : 0) + (size_t)i * M;
+        Rng g = slot_rng(P, D, e);
+        g.position((uint32_t)D.run[e], reset ? (uint32_t)D.episode[e] : 0u, 0);
+        g.stream(reset ? FBA_PHASE_RESET : FBA_PHASE_INIT_FC, (uint32_t)i);
+        for (int j = 0; j < M; ++j) filter[j] = domain_start(P, g);
+        if (!reset) rec_set_state(D.p_rec + (pb + i) * (size_t)P.Cs, P.C, 0);  // (the count particle's own domain state is released at once)
+    }
+    if (reset) return;
+    __syncthreads();
+    // WeightedFilter(n, alloc): weights 1/n (init_kernel); the prefix sums sample() walks
+    const double total = block_device_scan(D.p_weight + pb, P.N, D.nest_scan + (size_t)e * P.N, s_carry);
+    if (i == 0) D.nest_total[e] = total;
+}
+
+template <bool REG>
+__global__ void __launch_bounds__(256) nested_update_kernel(Problem P, DeviceState D)
+{
+    __shared__ double s_carry[4];
+    __shared__ unsigned long long s_attempts;
+    const int e = blockIdx.x, i = threadIdx.x;
+    if (!D.need_update[e]) return;
+    if (i == 0) s_attempts = 0;
+    __syncthreads();
+    const int M = P.nested, a = D.action[e], o = D.obs[e], cur = D.nest_sel[e];
+    const size_t pb = pbase(P, e, D.bufsel[e]);
+    double* w = D.p_weight + pb;
+    if (i < P.N) {
+        const int32_t* filter = D.nest_s + nest_base(P, e, cur) + (size_t)i * M;
+        int32_t* fresh        = D.nest_s + nest_base(P, e, cur ^ 1) + (size_t)i * M;
+        float* rec            = D.p_rec + (pb + i) * (size_t)P.Cs;
+        const float amount    = (float)(1.0 / (double)(float)M);
+        Rng g = slot_rng(P, D, e);
+        g.stream(FBA_PHASE_REJECT, (uint32_t)i);
+        int acc = 0, count = 0;
+        while (acc < M) {
+            const int old = filter[g.uniform_int(M)];
+            int s = old, so;
+            double r;
+            sim_step<REG>(P, g, GlobalView{rec}, s, a, so, r, NoInc{});
+            ++count;
+            if (so == o) {
+                fresh[acc++] = s;
+                if (P.model == FBA_MODEL_BA_FACTORED) mh_increment(P, rec, old, a, o, s, amount);
+                else {  // BAFlatModel::incrementCountsOf (BAFlatModel.cpp:130-139)
+                    rec[old * P.A * P.S + a * P.S + s] += amount;
+                    rec[P.phi_len + a * P.S * P.O + s * P.O + o] += amount;
+                }
+            }
+            if (count >= (1 << 24)) {  // no state of this filter can produce the observation: the reference would never return
+                atomicCAS(D.fault, 0, 1 + e);
+                break;
+            }
+        }
+        w[i] *= 1.0 / (double)count;
+        atomicAdd(&s_attempts, (unsigned long long)count);
+    }
+    __syncthreads();
+    const double total = block_device_scan(w, P.N, nullptr, s_carry);
+    if (i < P.N) w[i] = w[i] / total;
+    __syncthreads();
+    const double norm = block_device_scan(w, P.N, D.nest_scan + (size_t)e * P.N, s_carry);
+    if (i == 0) {
+        D.nest_total[e]  = norm;
+        D.nest_sel[e]    = cur ^ 1;
+        D.need_update[e] = 0;
+        D.belief_steps[e] += s_attempts;
+        D.upd_attempts[e] += s_attempts;
+        D.upd_particles[e] += (unsigned long long)P.N * (unsigned long long)M;
+        D.cur[e].update_count = (int32_t)s_attempts;
+        D.cur[e].weight_total = total;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // importance_kernel: importance_sampling::update + resample (ImportanceSampler.hpp:31-94,
 // WeightedFilter::normalize WeightedFilter.cpp:130-143, ::sample :163-191), one workgroup per slot.
 //   1. every particle steps in place (UpdateCounts) and multiplies its weight by P(o | a, s')
@@ -2416,7 +2528,7 @@ __global__ void post_reset_kernel(Problem P, DeviceState D)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= P.E || D.need_reset[e] != 1) return;
-    if (P.belief == FBA_BELIEF_IMPORTANCE && !P.cheat && !P.mh) D.bufsel[e] ^= 1;
+    if (P.belief == FBA_BELIEF_IMPORTANCE && !P.cheat && !P.mh && !P.nested) D.bufsel[e] ^= 1;
     if (P.mh) {  // MHwithinGibbs::resetDomainStateDistribution :270-274: a new episode unless the open one is still empty
         int32_t* len = D.mh_ep_len + (size_t)e * (P.episodes + 1);
         const int n = D.mh_n_ep[e];
@@ -2532,6 +2644,11 @@ __global__ void __launch_bounds__(256) flush_kernel(Problem P, DeviceState D)
             for (int k = 0; k < P.C; ++k) h = mix64(h ^ ((uint64_t)__float_as_uint(cnt[k]) + ((uint64_t)k << 32)));
         local += h;
     }
+    if (P.nested) {  // + every domain state of every flat filter, keyed by its position
+        const int32_t* st = D.nest_s + nest_base(P, e, D.nest_sel[e]);
+        const size_t tot  = (size_t)P.N * (size_t)P.nested;
+        for (size_t k = tid; k < tot; k += 256) local += mix64(((uint64_t)P.N + k) * 0x9E3779B97F4A7C15ull + (uint64_t)(uint32_t)st[k]);
+    }
     atomicAdd(&s_sum, local);
     __syncthreads();
     if (tid == 0) {
@@ -2643,6 +2760,11 @@ void launch_advance(const Problem& P, const DeviceState& D, int32_t* n_active, h
 }
 void launch_belief_update(const Problem& P, const DeviceState& D, hipStream_t st)
 {
+    if (P.nested) {
+        if (P.dirichlet_regular) hipLaunchKernelGGL(nested_update_kernel<true>, dim3(P.E), dim3(256), 0, st, P, D);
+        else hipLaunchKernelGGL(nested_update_kernel<false>, dim3(P.E), dim3(256), 0, st, P, D);
+        return;
+    }
     if (P.belief == FBA_BELIEF_REJECTION) {
         const bool tiger_table = P.model == FBA_MODEL_BA_TABLE && !P.dirichlet_regular &&
                                  (P.domain == FBA_DOM_TIGER_EPISODIC || P.domain == FBA_DOM_TIGER_CONTINUOUS);
@@ -2712,6 +2834,7 @@ void launch_init(const Problem& P, const DeviceState& D, hipStream_t st)
 {
     hipLaunchKernelGGL(init_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), P.E), dim3(256), 0, st, P, D, 0);
     if (P.reinvig || P.cheat) hipLaunchKernelGGL(init_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), P.E), dim3(256), 0, st, P, D, 1);
+    if (P.nested) hipLaunchKernelGGL(nested_fill_kernel, dim3(P.E), dim3(256), 0, st, P, D, 0);
     hipLaunchKernelGGL(post_init_kernel, dim3(ceil_div(P.E, 256)), dim3(256), 0, st, P, D);
 }
 void launch_materialize_reset(const Problem& P, const DeviceState& D, hipStream_t st)
@@ -2723,6 +2846,11 @@ void launch_reset(const Problem& P, const DeviceState& D, hipStream_t st)
 {
     if (P.belief == FBA_BELIEF_REJECTION && !P.reinvig && !P.cheat) {  // the plain rejection filter resets lazily
         hipLaunchKernelGGL(lazy_reset_kernel, dim3(ceil_div(P.E, 256)), dim3(256), 0, st, P, D);
+        return;
+    }
+    if (P.nested) {
+        hipLaunchKernelGGL(nested_fill_kernel, dim3(P.E), dim3(256), 0, st, P, D, 1);
+        hipLaunchKernelGGL(post_reset_kernel, dim3(ceil_div(P.E, 256)), dim3(256), 0, st, P, D);
         return;
     }
     hipLaunchKernelGGL(reset_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), P.E), dim3(256), 0, st, P, D, 0);

@@ -60,6 +60,11 @@ struct DeviceState {
     int16_t* mh_o;
     int32_t* mh_ep_len; // [E][episodes + 1]
     int32_t* mh_n_ep;   // [E] episodes in the history, the open one included
+    // nested belief (NestedBelief.cpp): per count particle a flat filter of P.nested domain states, double-buffered
+    int32_t* nest_s;     // [2][E][N][P.nested]
+    int32_t* nest_sel;   // [E] the buffer that holds the current filters
+    double* nest_scan;   // [E][N] inclusive prefix sums (device order) of the count particles' weights
+    double* nest_total;  // [E]
     float* mh_scratch;  // [E][mh_scratch_words]: three count blobs, T and O tables, messages, probabilities, the state sequence
     int32_t mh_scratch_words;
     int32_t* p_side;    // [E][N][side_w] importance filters: {new state, cells to increment} of the pending update (side_w = 1 + FS + FO;

@@ -177,7 +177,7 @@ class Engine:
         storage on the device; ask for counts=False where that is gigabytes."""
         n = self.cfg.particles
         s = np.zeros(n, np.int32)
-        want_w = self.cfg.belief in (N.BELIEF_IMPORTANCE, N.BELIEF_CHEATING, N.BELIEF_MH_GIBBS, N.BELIEF_MH_NIPS) if weights is None else weights
+        want_w = self.cfg.belief in (N.BELIEF_IMPORTANCE, N.BELIEF_CHEATING, N.BELIEF_MH_GIBBS, N.BELIEF_MH_NIPS, N.BELIEF_NESTED) if weights is None else weights
         w = np.zeros(n, np.float64)
         cnt = np.zeros((n, self.ncnt), np.float32) if counts else None
         self._chk(self.L.fba_belief_get(self.h, slot, s.ctypes.data, w.ctypes.data if want_w else None,
@@ -191,6 +191,13 @@ class Engine:
         cnt = np.zeros((n, self.ncnt), np.float32)
         self._chk(self.L.fba_belief_get_fully_connected(self.h, slot, s.ctypes.data, cnt.ctypes.data))
         return s, cnt
+
+    def belief_get_nested(self, slot=0):
+        """The nested belief's flat filters of domain states, [particles][particles^2] (belief_get returns the count particles)."""
+        n = self.cfg.particles
+        st = np.zeros((n, n * n), np.int32)
+        self._chk(self.L.fba_belief_get_nested(self.h, slot, st.ctypes.data))
+        return st
 
     def belief_set(self, slot, state=None, weight=None, counts=None):
         s = None if state is None else np.ascontiguousarray(state, np.int32)

@@ -54,8 +54,10 @@ enum { FBA_BELIEF_REJECTION = 0, FBA_BELIEF_IMPORTANCE = 1, FBA_BELIEF_REINVIGOR
        FBA_BELIEF_MH_GIBBS = 5, /* mh-within-gibbs (BABelief.cpp:37-47: factored::MHwithinGibbs; `belief_option` 1 = "rs"): importance
                                  * filter whose particles are re-drawn by a Metropolis-Hastings chain over structures when the log
                                  * likelihood falls below `threshold`; factored tiger, collision avoidance */
-       FBA_BELIEF_MH_NIPS = 6   /* mh-nips (BABelief.cpp:33-36: factored::MHNIPS2018): the same filter and trigger; the re-draw makes
-                                 * independent proposals (a particle's structure or a mutation, updated along a simulated history) */ };
+       FBA_BELIEF_MH_NIPS = 6,  /* mh-nips (BABelief.cpp:33-36: factored::MHNIPS2018): the same filter and trigger; the re-draw makes
+                                 * independent proposals (a particle's structure or a mutation, updated along a simulated history) */
+       FBA_BELIEF_NESTED = 7    /* nested (BABelief.cpp:67-70: NestedBelief(particles, particles^2)): a weighted filter of count particles,
+                                 * each with its own flat filter of particles^2 domain states (fba_belief_get_nested); bapomdp / fbapomdp */ };
 /* -P po-uct | random | ts (Planner.cpp:12-19, BAPlanner.cpp:13-20; ts = Thompson sampling: TSPlanner / BATSPlanner) */
 enum { FBA_PLANNER_POUCT = 0, FBA_PLANNER_RANDOM = 1, FBA_PLANNER_TS = 2 };
 /* --structure-prior (FBAConf.hpp) */
@@ -247,6 +249,9 @@ int fba_belief_set(fba_ctx* ctx, int32_t slot, const int32_t* state, const doubl
  * _fully_connected_belief) or of the cheating belief (CheatingReinvigoration.hpp:
  * _correct_structured_belief), for tests */
 int fba_belief_get_fully_connected(fba_ctx* ctx, int32_t slot, int32_t* state, float* counts);
+/* the nested belief's flat filters of domain states (NestedBelief.hpp: the FlatFilter<State const*> of every top
+ * particle): states[particles][particles^2]; fba_belief_get returns the count particles and their weights */
+int fba_belief_get_nested(fba_ctx* ctx, int32_t slot, int32_t* states);
 /* per-slot record of the last select_action / belief_update (root statistics, rejection count,
  * belief checksum) */
 int fba_last_step_info(fba_ctx* ctx, fba_trace_rec* recs /* [slots] */);

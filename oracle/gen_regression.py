@@ -32,6 +32,9 @@ CASES = {
                                                 belief=orc.BELIEF_MH_GIBBS, threshold=-2.0, structure_prior=orc.SP_MATCH_UNIFORM),
     "mh_nips_collision_avoidance": dict(domain=orc.DOM_COLLISION_AVOID, width=3, height=3, size=1, model=orc.MODEL_BA_FACTORED,
                                         belief=orc.BELIEF_MH_NIPS, threshold=-2.0, structure_prior=orc.SP_UNIFORM),
+    "nested_bapomdp_tiger": dict(domain=orc.DOM_TIGER_EPISODIC, model=orc.MODEL_BA_TABLE, belief=orc.BELIEF_NESTED, particles=9),
+    "nested_fbapomdp_collision_avoidance": dict(domain=orc.DOM_COLLISION_AVOID, width=3, height=3, size=1, model=orc.MODEL_BA_FACTORED,
+                                                belief=orc.BELIEF_NESTED, particles=6, structure_prior=orc.SP_UNIFORM),
     "bapomdp_sysadmin": dict(domain=orc.DOM_SYSADMIN_INDEPENDENT, size=3, model=orc.MODEL_BA_TABLE),
     "bapomdp_gridworld": dict(domain=orc.DOM_GRIDWORLD, size=3, model=orc.MODEL_BA_TABLE, noise=0.1),
     "bapomdp_collision_avoidance": dict(domain=orc.DOM_COLLISION_AVOID, width=4, height=3, size=1, model=orc.MODEL_BA_TABLE, noise=0.1),
@@ -52,7 +55,7 @@ def _legacy_layout(tr):
 
 
 def run(name):
-    o = orc.Oracle(seed_str="7", **COMMON, **CASES[name])
+    o = orc.Oracle(seed_str="7", **{**COMMON, **CASES[name]})
     stats, res = o.run_bapomdp()
     tr = _legacy_layout(o.trace(res.n_trace))
     return {"means": [s.mean for s in stats], "sim_steps": res.sim_steps, "belief_steps": res.belief_steps,

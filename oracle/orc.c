@@ -93,6 +93,10 @@ struct orc_ctx {
     float *mh_prior, *mh_model, *mh_new, *mh_T, *mh_O;
     double *mh_msg, *mh_probs;
     int32_t* mh_seq;
+    /* nested belief: per count particle a flat filter of nest_m domain states; one update's accepted states */
+    int32_t *nest_s, *nest_new;
+    int nest_m;
+    int32_t ts_state;
     double* log1p_tab; /* log1p(m), m < sims (POUCT.cpp:330-338 factorised) */
     double gamma;
     tree tr;
@@ -1976,11 +1980,19 @@ static void weighted_refresh_scan(orc_ctx* c)
 }
 
 /* the main filter is a WeightedFilter (importance sampling; the cheating belief's _belief) */
-static int is_weighted(const orc_ctx* c) { return c->cfg.belief == ORC_BELIEF_IMPORTANCE || c->cfg.belief == ORC_BELIEF_CHEATING || is_mh(c); }
+static int is_nested(const orc_ctx* c) { return c->cfg.belief == ORC_BELIEF_NESTED; }
+static int is_weighted(const orc_ctx* c) { return c->cfg.belief == ORC_BELIEF_IMPORTANCE || c->cfg.belief == ORC_BELIEF_CHEATING || is_mh(c) || is_nested(c); }
 
 static int32_t belief_sample(orc_ctx* c)
 {
     return is_weighted(c) ? weighted_sample(c) : flat_sample(c);
+}
+/* the domain state that comes with belief sample `src`: the particle's own, or -- NestedBelief::sample
+ * (NestedBelief.cpp:116-125) -- one of the count particle's flat filter of domain states */
+static int32_t belief_sample_state(orc_ctx* c, int32_t src)
+{
+    if (!is_nested(c)) return c->P[src].s;
+    return c->nest_s[(size_t)src * c->nest_m + orc_int(&c->rng, c->nest_m)];
 }
 
 static void swap_pools(orc_ctx* c)
@@ -2009,6 +2021,23 @@ static void belief_initiate(orc_ctx* c)
     int i, n = c->cfg.particles;
     double w = 1.0 / (double)n;
     c->total_w = 0;
+    if (is_nested(c)) {
+        /* NestedBelief::initiate (NestedBelief.cpp:61-87): WeightedFilter(n, alloc) -- weights 1/n, total weight 1 -- of
+         * pairs {sampleStartState(), FlatFilter(n^2, sampleDomainState)}; g++ builds the pair's second member first.  The
+         * count particle's own domain state is released at once: kept as 0 here. */
+        int j;
+        for (i = 0; i < n; ++i) {
+            orc_rng_stream(&c->rng, ORC_PH_INIT_FC, (uint32_t)i);
+            for (j = 0; j < c->nest_m; ++j) c->nest_s[(size_t)i * c->nest_m + j] = domain_start(c);
+            orc_rng_stream(&c->rng, ORC_PH_INIT, (uint32_t)i);
+            sample_start_into(c, &c->P[i]);
+            c->P[i].s = 0;
+            c->P[i].w = w;
+        }
+        c->total_w = 1;
+        weighted_refresh_scan(c);
+        return;
+    }
     for (i = 0; i < n; ++i) {
         orc_rng_stream(&c->rng, ORC_PH_INIT, (uint32_t)i);
         sample_start_into(c, &c->P[i]);
@@ -2545,9 +2574,66 @@ static void mh_update(orc_ctx* c, int32_t a, int32_t o)
         snprintf(c->err, sizeof c->err, "%s: the history cannot be reproduced by the sampled model", c->cfg.belief == ORC_BELIEF_MH_NIPS ? "mh-nips" : "mh-within-gibbs");
 }
 
+/* BAState::incrementCountsOf with an amount: BAFlatModel (BAFlatModel.cpp:130-139) or BABNModel (fact_increment) */
+static void model_increment(orc_ctx* c, float* cnt, int32_t s, int32_t a, int32_t o, int32_t ns, float amount)
+{
+    if (c->cfg.model == ORC_MODEL_BA_FACTORED) { fact_increment(c, cnt, s, a, o, ns, amount); return; }
+    cnt[s * c->A * c->S + a * c->S + ns] += amount;
+    cnt[c->phi_len + a * c->S * c->O + ns * c->O + o] += amount;
+}
+/* NestedBelief::updateEstimation (NestedBelief.cpp:127-192): per count particle, rejection sampling of its domain-state
+ * filter with KeepCounts steps on the particle's own counts, every accepted sample adding 1/n^2 to the counts the next
+ * attempt samples from; weight *= 1 / attempts; normalise.  One stream per count particle (REJECT, i). */
+static void nested_update(orc_ctx* c, int32_t a, int32_t o)
+{
+    int n = c->cfg.particles, M = c->nest_m, i;
+    float step = (float)(1.0 / (float)M);
+    double total = 0, accw = 0;
+    long long all = 0;
+    c->step_counter = &c->belief_steps;
+    for (i = 0; i < n; ++i) {
+        int32_t* filter = c->nest_s + (size_t)i * M;
+        int acc = 0, count = 0;
+        orc_rng_stream(&c->rng, ORC_PH_REJECT, (uint32_t)i);
+        while (acc < M) {
+            int32_t so, old = filter[orc_int(&c->rng, M)];
+            double r;
+            simstate st;
+            st.s   = old;
+            st.cnt = c->P[i].cnt;
+            sim_step(c, &st, a, &so, &r, 0);
+            if (so == o) {
+                c->nest_new[acc++] = st.s;
+                model_increment(c, c->P[i].cnt, old, a, o, st.s, step);
+            }
+            if (++count > (1 << 24)) {
+                snprintf(c->err, sizeof c->err, "nested belief: count particle %d cannot produce the observation", i);
+                return;
+            }
+        }
+        memcpy(filter, c->nest_new, sizeof(int32_t) * (size_t)M);
+        c->P[i].w *= 1.0 / (double)count;
+        total += c->P[i].w;
+        all += count;
+    }
+    if (c->cfg.arith == ORC_ARITH_DEV) {
+        for (i = 0; i < n; ++i) c->wscratch[i] = c->P[i].w;
+        total = dev_scan(c->wscratch, n, NULL);
+    }
+    c->last_weight_total = total;
+    for (i = 0; i < n; ++i) {   /* WeightedFilter::normalize WeightedFilter.cpp:113-143 */
+        c->P[i].w /= total;
+        accw += c->P[i].w;
+    }
+    c->total_w = accw;
+    weighted_refresh_scan(c);
+    c->last_update_count = (int32_t)all;
+}
+
 static void belief_update(orc_ctx* c, int32_t a, int32_t o)
 {
     c->last_weight_total = 0;
+    if (is_nested(c)) { nested_update(c, a, o); return; }
     if (c->cfg.belief == ORC_BELIEF_REJECTION) reject_sample(c, a, o, ORC_PH_REJECT);
     else if (c->cfg.belief == ORC_BELIEF_REINVIGORATION) {
         /* ReinvigoratingRejectionSampling::updateEstimation (ReinvigoratingRejectionSampling.cpp:89-107) */
@@ -2596,6 +2682,14 @@ static void belief_update(orc_ctx* c, int32_t a, int32_t o)
 static void belief_reset_domain_state(orc_ctx* c)
 {
     int i, n = c->cfg.particles;
+    if (is_nested(c)) { /* NestedBelief::resetDomainStateDistribution (NestedBelief.cpp:35-58): every flat filter drawn anew */
+        int j;
+        for (i = 0; i < n; ++i) {
+            orc_rng_stream(&c->rng, ORC_PH_RESET, (uint32_t)i);
+            for (j = 0; j < c->nest_m; ++j) c->nest_s[(size_t)i * c->nest_m + j] = domain_start(c);
+        }
+        return;
+    }
     if (c->cfg.belief != ORC_BELIEF_IMPORTANCE) { /* (the cheating belief resets its weighted filter in place too, CheatingReinvigoration.cpp:48-62) */
         for (i = 0; i < n; ++i) {
             orc_rng_stream(&c->rng, ORC_PH_RESET, (uint32_t)i);
@@ -2633,6 +2727,10 @@ static uint64_t belief_hash(orc_ctx* c)
     for (i = 0; i < n; ++i)
         h += particle_hash((uint64_t)i, c->P[i].s, weighted ? c->P[i].w : 0.0, c->P[i].cnt,
                            c->ncnt);
+    if (is_nested(c)) { /* + every domain state of every flat filter, keyed by its position */
+        size_t k, tot = (size_t)n * c->nest_m;
+        for (k = 0; k < tot; ++k) h += mix64(((uint64_t)n + k) * 0x9E3779B97F4A7C15ull + (uint64_t)(uint32_t)c->nest_s[k]);
+    }
     return h;
 }
 
@@ -2648,19 +2746,20 @@ static int32_t select_action(orc_ctx* c, int hist_len, orc_trace_rec* rec)
     if (c->cfg.planner == ORC_PLANNER_RANDOM) {
         /* ref: RandomPlanner::selectAction src/planners/random/RandomPlanner.cpp:14-24 */
         orc_rng_stream(&c->rng, ORC_PH_SEARCH, (uint32_t)n);
-        return domain_random_action(c, c->P[belief_sample(c)].s);
+        return domain_random_action(c, belief_sample_state(c, belief_sample(c)));
     }
     if (c->cfg.planner == ORC_PLANNER_TS) {
         /* TSPlanner::selectAction (src/planners/ts/TSPlanner.cpp:16-29) / BATSPlanner (BATSPlanner.cpp:19-34):
          * one belief.sample(), then PO-UCT on a point-estimate belief whose sample() draws nothing */
         orc_rng_stream(&c->rng, ORC_PH_SEARCH, (uint32_t)n + 2);
         ts_src = belief_sample(c);
+        c->ts_state = belief_sample_state(c, ts_src);
     }
     tree_reset(c);
     /* simulator.addLegalActions(belief.sample(), ...) : one belief draw, result unused here
      * because every supported domain has state-independent legal actions */
     orc_rng_stream(&c->rng, ORC_PH_SEARCH, (uint32_t)n);
-    if (ts_src < 0) (void)belief_sample(c);
+    if (ts_src < 0) (void)belief_sample_state(c, belief_sample(c));
     root = tree_new_node(c);
     {
         int d = c->cfg.horizon - hist_len;
@@ -2671,7 +2770,7 @@ static int32_t select_action(orc_ctx* c, int hist_len, orc_trace_rec* rec)
         int32_t src;
         orc_rng_stream(&c->rng, ORC_PH_SEARCH, (uint32_t)i);
         src    = ts_src >= 0 ? ts_src : belief_sample(c);
-        st.s   = c->P[src].s;
+        st.s   = ts_src >= 0 ? c->ts_state : belief_sample_state(c, src);
         st.cnt = c->P[src].cnt;
         traverse_action(c, root, &st, c->tr.max_tree_depth);
     }
@@ -2938,6 +3037,19 @@ orc_ctx* orc_create(const orc_config* cfg)
         c->mh_seq    = (int32_t*)malloc(sizeof(int32_t) * (size_t)(cfg->episodes * (cfg->horizon + 1) + 2 * cfg->horizon + 1));
         c->mh_n_ep   = 1;
     }
+    if (cfg->belief == ORC_BELIEF_NESTED) {
+        if (cfg->model == ORC_MODEL_POMDP) {
+            snprintf(c->err, sizeof c->err, "nested belief: needs a Bayes-adaptive model (bapomdp / fbapomdp)");
+            return c;
+        }
+        if (n > 256) {
+            snprintf(c->err, sizeof c->err, "nested belief: at most 256 count particles (each carries particles^2 domain states)");
+            return c;
+        }
+        c->nest_m   = n * n;   /* BABelief.cpp:67-70: NestedBelief(particle_amount, particle_amount^2) */
+        c->nest_s   = (int32_t*)calloc((size_t)n * c->nest_m, sizeof(int32_t));
+        c->nest_new = (int32_t*)calloc((size_t)c->nest_m, sizeof(int32_t));
+    }
     if (cfg->belief == ORC_BELIEF_REINVIGORATION || cfg->belief == ORC_BELIEF_CHEATING) {
         if (cfg->belief == ORC_BELIEF_CHEATING) { /* checked above */
         } else if (cfg->model != ORC_MODEL_BA_FACTORED || !(is_ftiger(cfg->domain) || is_ca(cfg->domain) || is_sys(cfg->domain)) ||
@@ -2972,6 +3084,7 @@ void orc_destroy(orc_ctx* c)
     free(c->tr.visits); free(c->tr.cn); free(c->tr.cq); free(c->tr.child);
     free(c->mh_a); free(c->mh_o); free(c->mh_ep_len); free(c->mh_prior); free(c->mh_model); free(c->mh_new); free(c->mh_T); free(c->mh_O);
     free(c->mh_msg); free(c->mh_probs); free(c->mh_seq);
+    free(c->nest_s); free(c->nest_new);
     free(c->tr.hkey); free(c->tr.hval);
     free(c->P); free(c->Pnew); free(c->pool); free(c->pool_new);
     free(c->F); free(c->Fnew); free(c->fpool); free(c->fpool_new); free(c->breed_tmp);
@@ -3023,6 +3136,10 @@ void orc_belief_get(const orc_ctx* c, int32_t* s, double* w, float* cnt)
     }
 }
 /* the fully connected filter of the reinvigoration belief */
+void orc_belief_get_nested(const orc_ctx* c, int32_t* states)
+{
+    if (c->nest_s) memcpy(states, c->nest_s, sizeof(int32_t) * (size_t)c->cfg.particles * c->nest_m);
+}
 void orc_belief_get_fc(const orc_ctx* c, int32_t* s, float* cnt)
 {
     int i;

@@ -46,7 +46,8 @@ enum { ORC_MODEL_POMDP = 0, ORC_MODEL_BA_TABLE = 1, ORC_MODEL_BA_FACTORED = 2 };
 enum { ORC_BELIEF_REJECTION = 0, ORC_BELIEF_IMPORTANCE = 1, ORC_BELIEF_REINVIGORATION = 2, ORC_BELIEF_CHEATING = 3,
        ORC_BELIEF_POINT = 4, /* -B point_estimate: src/beliefs/point_estimation/PointEstimation.cpp, bayes-adaptive/BAPointEstimation.cpp */
        ORC_BELIEF_MH_GIBBS = 5, /* -B mh-within-gibbs: src/beliefs/bayes-adaptive/factored/MHwithinGibbs.cpp (belief_option 1 = "rs") */
-       ORC_BELIEF_MH_NIPS = 6   /* -B mh-nips: src/beliefs/bayes-adaptive/factored/MHNIPS2018.cpp */ };
+       ORC_BELIEF_MH_NIPS = 6,  /* -B mh-nips: src/beliefs/bayes-adaptive/factored/MHNIPS2018.cpp */
+       ORC_BELIEF_NESTED = 7    /* -B nested: src/beliefs/bayes-adaptive/NestedBelief.cpp (`particles` count particles, each with particles^2 domain states) */ };
 /* floating-point summation order of the importance-sampling filter:
  * REF = the reference's sequential loops; DEV = the HIP engine's fixed reduction tree */
 enum { ORC_ARITH_REF = 0, ORC_ARITH_DEV = 1 };
@@ -159,6 +160,7 @@ uint64_t orc_belief_hash(orc_ctx* c);
 int orc_last_update_count(const orc_ctx* c);
 void orc_belief_get(const orc_ctx* c, int32_t* s, double* w, float* cnt);
 void orc_belief_get_fc(const orc_ctx* c, int32_t* s, float* cnt);
+void orc_belief_get_nested(const orc_ctx* c, int32_t* states); /* [particles][particles^2] */
 int orc_marginalize(orc_ctx* c, const float* cnt, const uint32_t* new_masks, float* out);
 void orc_belief_set(orc_ctx* c, const int32_t* s, const double* w, const float* cnt);
 int orc_model_step(orc_ctx* c, float* cnt, int32_t* s, int32_t a, int32_t* o, double* r, int update);

@@ -67,6 +67,11 @@ def draw(rng):
             kw["threshold"] = rng.choice([-0.3, -2.0, -50.0])
             if belief == "mh-within-gibbs":
                 kw["belief_option"] = rng.choice([0, 1])
+    if model != N.MODEL_POMDP and belief in ("rejection_sampling", "importance_sampling") and rng.random() < 0.12:
+        belief = "nested"            # NestedBelief: `particles` count particles, particles^2 domain states each
+        kw["particles"] = rng.choice([1, 3, 8, 14])
+        if domain == "gridworld":
+            kw["particles"] = rng.choice([8, 14])
     if model != N.MODEL_POMDP and rng.random() < 0.2:
         longest = {"gridworld": 99, "random-collision-avoidance": kw.get("height", 0), "centered-collision-avoidance": kw.get("height", 0)}.get(domain, 2)
         if model == N.MODEL_BA_FACTORED and longest <= 16 or model == N.MODEL_BA_TABLE and "tiger" in domain and "factored" not in domain:

@@ -1018,3 +1018,41 @@ def test_mh_beliefs_refuse_what_they_are_not_built_for():
         fba.Engine("gridworld", model=N.MODEL_BA_FACTORED, belief="mh-within-gibbs", size=3, particles=8, sims=8, threshold=-1.0)
     with pytest.raises(ValueError, match="factored-tiger and collision-avoidance"):
         fba.Engine("independent-sysadmin", model=N.MODEL_BA_FACTORED, belief="mh-nips", size=3, particles=8, sims=8, threshold=-1.0)
+
+
+@pytest.mark.parametrize("domain,model,kw", [
+    ("episodic-tiger", N.MODEL_BA_TABLE, dict(particles=12, sims=96, horizon=8)),
+    ("continuous-tiger", N.MODEL_BA_TABLE, dict(particles=5, sims=64, horizon=6, dirichlet_regular=1)),
+    ("episodic-factored-tiger", N.MODEL_BA_FACTORED, dict(size=2, particles=9, sims=80, horizon=8, structure_prior=2)),
+    ("gridworld", N.MODEL_BA_TABLE, dict(size=3, particles=7, sims=48, horizon=6)),
+    ("gridworld", N.MODEL_BA_FACTORED, dict(size=3, particles=6, sims=48, horizon=6, structure_prior=2)),
+    ("random-collision-avoidance", N.MODEL_BA_FACTORED, dict(width=3, height=3, size=1, particles=6, sims=48, horizon=5, structure_prior=1)),
+    ("independent-sysadmin", N.MODEL_BA_TABLE, dict(size=2, particles=8, sims=48, horizon=6, planner="ts")),
+    ("linear-sysadmin", N.MODEL_BA_FACTORED, dict(size=3, particles=4, sims=32, horizon=5, planner="random")),
+])
+def test_nested_belief(domain, model, kw):
+    """-B nested (NestedBelief.cpp): `particles` count particles by weight, each with its own flat filter of particles^2
+    domain states; the update is a rejection sampler per count particle whose accepted samples add 1 / particles^2 to the
+    counts the next attempt samples from, the weight is multiplied by 1 / attempts, the top filter is never resampled.
+    Whole experiments: every trace field (attempt totals, the weight total before normalisation, the checksum over every
+    count particle's counts and weight and every domain state of every flat filter) against the oracle, then the filters
+    themselves."""
+    eng, o = _pair(domain, model, "nested", 811, runs=3, episodes=3, **kw)
+    _assert_same_experiment(eng, o, ba=True)
+    s, w, cnt = eng.belief_get(0)
+    os_, ow, ocnt = o.belief_get()       # (the oracle holds the last run: slot = run here, so compare with the last slot)
+    s, w, cnt = eng.belief_get(2)
+    assert np.array_equal(w, ow) and np.array_equal(cnt.view(np.uint32), ocnt.view(np.uint32)) and not s.any()
+    assert np.array_equal(eng.belief_get_nested(2), o.belief_get_nested())
+    assert abs(w.sum() - 1) < 1e-12 and len(set(w.tolist())) > 1      # normalised, and no longer uniform
+
+
+def test_nested_belief_refusals():
+    with pytest.raises(ValueError, match="Bayes-adaptive"):
+        fba.Engine("episodic-tiger", model=N.MODEL_POMDP, belief="nested", particles=4, sims=8)
+    with pytest.raises(ValueError, match="at most 256"):
+        fba.Engine("episodic-tiger", model=N.MODEL_BA_TABLE, belief="nested", particles=300, sims=8)
+    eng = fba.Engine("episodic-tiger", model=N.MODEL_BA_TABLE, belief="nested", particles=4, sims=8)
+    eng.belief_init()
+    with pytest.raises(ValueError, match="cannot be set from the host"):
+        eng.belief_set(0, state=np.zeros(4, np.int32))
