@@ -32,7 +32,7 @@ DOM_SYSADMIN_INDEPENDENT, DOM_SYSADMIN_LINEAR = 7, 8
 DOM_COFFEE, DOM_COFFEE_BOUTILIER = 9, 10
 DOM_AGR = 11
 MODEL_POMDP, MODEL_BA_TABLE, MODEL_BA_FACTORED = range(3)
-BELIEF_REJECTION, BELIEF_IMPORTANCE, BELIEF_REINVIGORATION, BELIEF_CHEATING, BELIEF_POINT, BELIEF_MH_GIBBS, BELIEF_MH_NIPS, BELIEF_NESTED = range(8)
+BELIEF_REJECTION, BELIEF_IMPORTANCE, BELIEF_REINVIGORATION, BELIEF_CHEATING, BELIEF_POINT, BELIEF_MH_GIBBS, BELIEF_MH_NIPS, BELIEF_NESTED, BELIEF_INCUBATOR = range(9)
 PLANNER_POUCT, PLANNER_RANDOM, PLANNER_TS = range(3)
 OK, EINVAL, EHIP, ENODEVICE, ESTATE = 0, -1, -2, -3, -4
 
@@ -46,7 +46,7 @@ DOMAIN_NAMES = {  # reference -D strings (DomainConf.cpp)
 }
 BELIEF_NAMES = {"rejection_sampling": BELIEF_REJECTION, "importance_sampling": BELIEF_IMPORTANCE,
                 "reinvigoration": BELIEF_REINVIGORATION, "cheating-reinvigoration": BELIEF_CHEATING,
-                "point_estimate": BELIEF_POINT, "mh-within-gibbs": BELIEF_MH_GIBBS, "mh-nips": BELIEF_MH_NIPS, "nested": BELIEF_NESTED}
+                "point_estimate": BELIEF_POINT, "mh-within-gibbs": BELIEF_MH_GIBBS, "mh-nips": BELIEF_MH_NIPS, "nested": BELIEF_NESTED, "incubator": BELIEF_INCUBATOR}
 PLANNER_NAMES = {"po-uct": PLANNER_POUCT, "random": PLANNER_RANDOM, "ts": PLANNER_TS}
 
 
@@ -112,7 +112,7 @@ EXPORTS = [
     "fba_abi_version", "fba_default_config", "fba_create", "fba_destroy", "fba_last_error",
     "fba_domain_sizes", "fba_counts_len", "fba_slots", "fba_particle_bytes", "fba_set_model_tabular", "fba_set_model_factored", "fba_log_bd_score", "fba_selftest_lgamma", "fba_get_prior", "fba_get_factored_layout",
     "fba_set_position", "fba_belief_init", "fba_belief_reset_domain_state", "fba_select_action",
-    "fba_belief_update", "fba_belief_get", "fba_belief_set", "fba_belief_get_fully_connected", "fba_belief_get_nested", "fba_last_step_info",
+    "fba_belief_update", "fba_belief_get", "fba_belief_set", "fba_belief_get_fully_connected", "fba_belief_get_nested", "fba_belief_get_shadow", "fba_last_step_info",
     "fba_run_planning", "fba_run_bapomdp", "fba_run_ticks", "fba_get_returns", "fba_get_counters", "fba_get_return_sums",
     "fba_get_kernel_times", "fba_reset_kernel_times", "fba_trace_count", "fba_get_trace",
     "fba_selftest_ucb", "fba_stat_add", "fba_stat_var", "fba_stat_stder",
@@ -186,6 +186,7 @@ def load():
     L.fba_belief_set.argtypes = [vp, C.c_int32, vp, vp, vp]
     L.fba_belief_get_fully_connected.argtypes = [vp, C.c_int32, vp, vp]
     L.fba_belief_get_nested.argtypes = [vp, C.c_int32, vp]
+    L.fba_belief_get_shadow.argtypes = [vp, C.c_int32, vp, vp, vp]
     L.fba_last_step_info.argtypes = [vp, vp]
     L.fba_run_planning.argtypes = [vp, P(Stat)]
     L.fba_run_bapomdp.argtypes = [vp, P(Stat)]

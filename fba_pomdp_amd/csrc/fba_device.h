@@ -310,6 +310,7 @@ struct Problem {
     int32_t domain, model, belief, planner;
     int32_t ca_plain;   // collision avoidance / sysadmin, factored model in the prior's own fixed graph (no masks): ca_fact_step / sysadmin_fact_step apply
     int32_t fd_bytes;   // bytes of *fd in use (header + A*(FS+FO) nodes): what a kernel stages in LDS
+    int32_t incub;      // incubator belief (belief = REJECTION then): shadow particles bred per update, 0 = off
     int32_t nested;     // nested belief (belief = IMPORTANCE then): domain states per count particle (N^2), 0 = off
     int32_t mh;         // mh-within-gibbs belief (belief = IMPORTANCE then): 1 = state histories by message passing, 2 = by rejection sampling
     int32_t cheat;      // cheating belief: particles copied from the correct-graph filter per cheat (belief = IMPORTANCE then); 0 = off

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <queue>
 #include <vector>
 
 #include "fba_kernels.h"
@@ -514,7 +515,8 @@ int build_ca_factored_prior(fba_ctx* c)
     // (on the device, factored_prior_sample); the node owns room for every state feature as a parent
     // (the reinvigoration belief breeds particles with structures of their own: same layout)
     const bool noisy = c->cfg.structure_prior == FBA_SP_UNIFORM || c->cfg.structure_prior == FBA_SP_MATCH_UNIFORM ||
-                       ((c->cfg.belief == FBA_BELIEF_REINVIGORATION || c->cfg.belief == FBA_BELIEF_MH_GIBBS || c->cfg.belief == FBA_BELIEF_MH_NIPS) && !full);
+                       ((c->cfg.belief == FBA_BELIEF_REINVIGORATION || c->cfg.belief == FBA_BELIEF_INCUBATOR || c->cfg.belief == FBA_BELIEF_MH_GIBBS ||
+                         c->cfg.belief == FBA_BELIEF_MH_NIPS) && !full);
     if (FS > MAXF || A * (FS + n) > MAXNODES) return fail(c, FBA_EINVAL, "too many state features");
     FDesc& d = c->fdesc;
     std::memset(&d, 0, sizeof d);
@@ -601,7 +603,7 @@ int build_sysadmin_factored_prior(fba_ctx* c)
     Problem& P = c->P;
     const int A = P.A, N = c->sysdesc.N;
     const bool linear = P.domain == FBA_DOM_SYSADMIN_LINEAR;
-    const bool reinvig = c->cfg.belief == FBA_BELIEF_REINVIGORATION;
+    const bool reinvig = c->cfg.belief == FBA_BELIEF_REINVIGORATION || c->cfg.belief == FBA_BELIEF_INCUBATOR;
     if (c->cfg.structure_prior != FBA_SP_NONE) return fail(c, FBA_EINVAL, "Structure noise is not enabled for the Sysadmin problem");
     if (N > MAXF || A * (N + 1) > MAXNODES) return fail(c, FBA_EINVAL, "too many state features");
     FDesc& d = c->fdesc;
@@ -968,6 +970,7 @@ int start_experiment(fba_ctx* c, int runs_total)
     HIPCHK(c, hipMemsetAsync(c->D.bufsel, 0, (size_t)c->P.E, c->stream));
     HIPCHK(c, hipMemsetAsync(c->D.lazy_reset, 0, (size_t)c->P.E, c->stream));
     if (c->D.bufsel_fc) HIPCHK(c, hipMemsetAsync(c->D.bufsel_fc, 0, (size_t)c->P.E, c->stream));
+    if (c->D.bufsel_sh) HIPCHK(c, hipMemsetAsync(c->D.bufsel_sh, 0, (size_t)c->P.E, c->stream));
     launch_start(c->P, c->D, c->stream);
     if ((rc = timed(c, FBA_K_BELIEF_INIT, [&] { launch_init(c->P, c->D, c->stream); }))) return rc;
     if (c->P.model != FBA_MODEL_POMDP)
@@ -1141,6 +1144,42 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         }
         P.belief = FBA_BELIEF_IMPORTANCE;
         P.mh     = nips ? 3 : cfg->belief_option == 1 ? 2 : 1;
+    }
+    P.incub = 0;
+    if (cfg->belief == FBA_BELIEF_INCUBATOR) {
+        // StructureIncubatorSampling(size, reinvigor_amount, threshold) (BABelief.cpp:53-58): the reinvigoration belief's two
+        // rejection filters + a weighted shadow filter of bred particles; same domains (a fully connected prior is needed)
+        const bool ftiger = cfg->domain == FBA_DOM_FTIGER_EPISODIC || cfg->domain == FBA_DOM_FTIGER_CONTINUOUS;
+        if (cfg->model != FBA_MODEL_BA_FACTORED || !(ftiger || is_ca(cfg->domain) || is_sys(cfg->domain)) ||
+            (is_ca(cfg->domain) && cfg->structure_prior == FBA_SP_FULLY_CONNECTED)) {
+            fail(nullptr, FBA_EINVAL, "incubator belief: needs a factored model (fbapomdp) of factored tiger, collision avoidance or sysadmin");
+            delete c;
+            return FBA_EINVAL;
+        }
+        if (cfg->particles < 1 || cfg->resample_amount < 1) {  // StructureIncubatorSampling.cpp:28-33
+            fail(nullptr, FBA_EINVAL, "StructureIncubatorSampling::Cannot initiate Incubator belief update with size < 1 (%d) or resample size < 1 (%d)",
+                 cfg->particles, cfg->resample_amount);
+            delete c;
+            return FBA_EINVAL;
+        }
+        if (cfg->threshold <= 0 || cfg->threshold > 1) {  // :35-39
+            fail(nullptr, FBA_EINVAL, "StructureIncubatorSampling::must initiate with 1 < threshold <= 0 (is:%f)", cfg->threshold);
+            delete c;
+            return FBA_EINVAL;
+        }
+        if (cfg->resample_amount >= cfg->particles || cfg->resample_amount > 1024) {  // WeightedFilter::leastLikely asserts n < size() (WeightedFilter.cpp:207)
+            fail(nullptr, FBA_EINVAL, "incubator belief: the resample amount (%d) must be below the number of particles (%d): WeightedFilter::leastLikely",
+                 cfg->resample_amount, cfg->particles);
+            delete c;
+            return FBA_EINVAL;
+        }
+        if (cfg->particles > IS_LDS_MAX_N) {
+            fail(nullptr, FBA_EINVAL, "incubator belief: at most %d particles per slot", IS_LDS_MAX_N);
+            delete c;
+            return FBA_EINVAL;
+        }
+        P.belief = FBA_BELIEF_REJECTION;
+        P.incub  = cfg->resample_amount;
     }
     P.nested = 0;
     if (cfg->belief == FBA_BELIEF_NESTED) {
@@ -1420,7 +1459,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     }
 
     // slots
-    const size_t per_slot = (size_t)P.N * (2 * 8 + 8 + 4 * (MAXINC + 1) + ((P.reinvig || P.cheat) ? 4 : 2) * (size_t)P.Cs * 4) + (size_t)D.max_nodes * D.node_words * 4 + (size_t)hcap * hash_entry + 1024;
+    const size_t per_slot = (size_t)P.N * (2 * 8 + 8 + 4 * (MAXINC + 1) + ((P.reinvig || P.cheat) ? 4 : (P.incub ? 6 : 2)) * (size_t)P.Cs * 4) + (size_t)D.max_nodes * D.node_words * 4 + (size_t)hcap * hash_entry + 1024;
     int E = cfg->slots;
     if (E <= 0) {
         size_t free_b = 0, total_b = 0;
@@ -1445,12 +1484,33 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     CHK(dev_alloc(c, &D.action, E));
     CHK(dev_alloc(c, &D.obs, E));
     CHK(dev_alloc(c, &D.bufsel, E));
-    const bool is = P.belief == FBA_BELIEF_IMPORTANCE;
+    const bool is = P.belief == FBA_BELIEF_IMPORTANCE || P.incub;   // (the incubator's shadow filter is importance-sampled)
     CHK(dev_alloc(c, &D.p_weight, is ? (size_t)2 * E * P.N : 1));
     CHK(dev_alloc(c, &D.p_rec, (size_t)2 * E * P.N * P.Cs, false));
-    if (P.reinvig || P.cheat) {
+    if (P.reinvig || P.cheat || P.incub) {
         CHK(dev_alloc(c, &D.p_rec_fc, (size_t)2 * E * P.N * P.Cs, false));
         CHK(dev_alloc(c, &D.bufsel_fc, E));
+    }
+    D.shadow = 0;
+    if (P.incub) {
+        CHK(dev_alloc(c, &D.p_rec_sh, (size_t)2 * E * P.N * P.Cs, false));
+        CHK(dev_alloc(c, &D.p_weight_sh, (size_t)2 * E * P.N));
+        CHK(dev_alloc(c, &D.bufsel_sh, E));
+        CHK(dev_alloc(c, &D.need_update_sh, E));
+        // WeightedFilter::leastLikely (WeightedFilter.cpp:193-238) of N equal weights, with the container the reference uses
+        using queue_elements = std::pair<double, int>;
+        struct Less { bool operator()(queue_elements l, queue_elements r) const { return l.first < r.first; } };
+        std::priority_queue<queue_elements, std::vector<queue_elements>, Less> q;
+        const double w = 1.0 / (double)P.N;
+        for (int i = 0; i < P.incub; ++i) q.push({w, i});
+        for (int i = 0; i < P.N; ++i)
+            if (w < q.top().first) { q.pop(); q.push({w, i}); }
+        std::vector<int32_t> order;
+        for (int i = 0; i < P.incub; ++i) { order.push_back(q.top().second); q.pop(); }
+        int32_t* d_order = nullptr;
+        CHK(dev_alloc(c, &d_order, order.size()));
+        HIPC(hipMemcpy(d_order, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        D.inc_order = d_order;
     }
     CHK(dev_alloc(c, &D.wscan, is ? (size_t)E * P.N : 1, false));
     D.side_w = 1 + (P.model == FBA_MODEL_BA_FACTORED ? c->fdesc.FS + c->fdesc.FO : (P.model == FBA_MODEL_BA_TABLE ? 2 : 0));
@@ -1563,6 +1623,17 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         launch_uniform_scan(P.N, tmp, c->d_uni_scan, c->d_uni_scan + P.N, D.ctot, c->stream);
         HIPC(hipMemcpyAsync(&D.uni_total, c->d_uni_scan + P.N, sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPC(hipStreamSynchronize(c->stream));
+    }
+    if (P.incub && (1.0 / (double)P.N) / D.uni_total > cfg->threshold) {
+        // reinvigorateBelief (StructureIncubatorSampling.cpp:155-188) tests normalised shadow weights that are uniform
+        // whenever it runs (every update ends in a resample): none is promoted, or all of them -- and then every
+        // shadow weight is zero and normalize() divides by their sum
+        fail(c, FBA_EINVAL, "incubator belief: with threshold %g every one of the %d shadow particles (normalised weight %g) is promoted at "
+             "once; the shadow filter's total weight is then zero and StructureIncubatorSampling.cpp:160-188 divides by it",
+             cfg->threshold, P.N, (1.0 / (double)P.N) / D.uni_total);
+        g_create_error = c->err;
+        fba_destroy(c);
+        return FBA_EINVAL;
     }
     if (cfg->model == FBA_MODEL_BA_TABLE) CHK(build_tabular_prior(c));
     if (P.dirichlet_regular) {
@@ -1876,12 +1947,31 @@ int fba_belief_get_fully_connected(fba_ctx* c, int32_t slot, int32_t* state, flo
 {
     if (!c || slot < 0 || slot >= c->P.E) return FBA_EINVAL;
     const Problem& P = c->P;
-    if (!P.reinvig && !P.cheat) return fail(c, FBA_EINVAL, "only the reinvigoration and cheating beliefs have a second filter");
+    if (!P.reinvig && !P.cheat && !P.incub) return fail(c, FBA_EINVAL, "only the reinvigoration, incubator and cheating beliefs have a second filter");
     uint8_t sel = 0;
     HIPCHK(c, hipMemcpy(&sel, c->D.bufsel_fc + slot, 1, hipMemcpyDeviceToHost));
     const size_t pb = ((size_t)sel * P.E + slot) * (size_t)P.N;
     std::vector<float> tmp((size_t)P.N * P.Cs);
     HIPCHK(c, hipMemcpy(tmp.data(), c->D.p_rec_fc + pb * P.Cs, tmp.size() * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < P.N; ++i) {
+        const float* rec = tmp.data() + (size_t)i * P.Cs;
+        if (state) std::memcpy(&state[i], &rec[P.C], 4);
+        if (counts) std::copy(rec, rec + P.C, counts + (size_t)i * P.C);
+    }
+    return FBA_OK;
+}
+
+int fba_belief_get_shadow(fba_ctx* c, int32_t slot, int32_t* state, double* weight, float* counts)
+{
+    if (!c || slot < 0 || slot >= c->P.E) return FBA_EINVAL;
+    const Problem& P = c->P;
+    if (!P.incub) return fail(c, FBA_EINVAL, "only the incubator belief has a shadow filter");
+    uint8_t sel = 0;
+    HIPCHK(c, hipMemcpy(&sel, c->D.bufsel_sh + slot, 1, hipMemcpyDeviceToHost));
+    const size_t pb = ((size_t)sel * P.E + slot) * (size_t)P.N;
+    if (weight) HIPCHK(c, hipMemcpy(weight, c->D.p_weight_sh + pb, (size_t)P.N * sizeof(double), hipMemcpyDeviceToHost));
+    std::vector<float> tmp((size_t)P.N * P.Cs);
+    HIPCHK(c, hipMemcpy(tmp.data(), c->D.p_rec_sh + pb * P.Cs, tmp.size() * 4, hipMemcpyDeviceToHost));
     for (int i = 0; i < P.N; ++i) {
         const float* rec = tmp.data() + (size_t)i * P.Cs;
         if (state) std::memcpy(&state[i], &rec[P.C], 4);

@@ -1333,20 +1333,31 @@ __global__ void __launch_bounds__(BLK) reject_tiger_lds_kernel(Problem P, Device
 // Draw order within stream (REINVIG, i): fully connected pick, main pick, edge, victim (g++
 // evaluates breed's arguments right to left).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) reinvigorate_kernel(Problem P, DeviceState D)
+// mode 1, 2: the incubator belief (StructureIncubatorSampling.cpp).  The bred particle goes into the weighted SHADOW filter:
+// mode 1 = reinvigorateShadowBelief (:137-153), P.incub particles, the victims are WeightedFilter::leastLikely of the
+// shadow's weights -- uniform whenever this runs, so a fixed list (D.inc_order, computed by the host with the same
+// std::priority_queue) -- and WeightedFilter::replace(i, s) gives the weight total / N and adjusts the total
+// (WeightedFilter.cpp:70-87); mode 2 = initiate (:81-89), N particles, stream (INIT_SH, i), weight 1 / N.
+__global__ void __launch_bounds__(256) reinvigorate_kernel(Problem P, DeviceState D, int mode)
 {
     __shared__ int32_t s_fc, s_victim, s_state;
     __shared__ uint32_t s_mask[128];  // one parent mask per variable node (collision avoidance: A * obstacles <= 18; sysadmin: 2N * N <= 128)
     const int e = blockIdx.x, tid = threadIdx.x;
-    if (!D.need_update[e]) return;
+    if (mode == 2 ? !D.need_init[e] : !D.need_update[e]) return;
     const FDesc* fd = P.fd;
     float* recs      = D.p_rec + pbase(P, e, D.bufsel[e]) * (size_t)P.Cs;
     const float* fcs = D.p_rec_fc + pbase(P, e, D.bufsel_fc[e]) * (size_t)P.Cs;
+    if (mode == 2 && tid == 0) D.bufsel_sh[e] = 0;
+    const size_t shb = mode ? pbase(P, e, mode == 2 ? 0 : D.bufsel_sh[e]) : 0;
+    float* dsts      = mode ? D.p_rec_sh + shb * (size_t)P.Cs : recs;
+    double sh_total  = D.uni_total;   // the shadow's total weight after a resample / initiate (device order)
     const int nnodes = P.A * (fd->FS + fd->FO);
+    const int rounds = mode == 0 ? P.reinvig : (mode == 1 ? P.incub : P.N);
     Rng g = slot_rng(P, D, e);
-    for (int i = 0; i < P.reinvig; ++i) {
+    if (mode == 2) g.position((uint32_t)D.run[e], 0, 0);
+    for (int i = 0; i < rounds; ++i) {
         if (tid == 0) {
-            g.stream(FBA_PHASE_REINVIG, (uint32_t)i);
+            g.stream(mode == 2 ? FBA_PHASE_INIT_SH : FBA_PHASE_REINVIG, (uint32_t)i);
             s_fc = g.uniform_int(P.N);
             const volatile float* srec = recs + (size_t)g.uniform_int(P.N) * P.Cs;  // may have been written an iteration ago
             for (int k = 0; k < fd->nvar; ++k) s_mask[k] = __float_as_uint(srec[fd->ncounts + k]);
@@ -1362,11 +1373,21 @@ __global__ void __launch_bounds__(256) reinvigorate_kernel(Problem P, DeviceStat
                 s_mask[0] ^= 1u << g.slow_int(0, fd->FS);
             }
             s_state  = __float_as_int(srec[P.C]);
-            s_victim = g.uniform_int(P.N);
+            if (mode == 0) s_victim = g.uniform_int(P.N);
+            else {
+                s_victim = mode == 1 ? D.inc_order[i] : i;
+                double* w = D.p_weight_sh + shb;
+                if (mode == 2) w[s_victim] = 1.0 / (double)P.N;
+                else {
+                    const double nw = sh_total / (double)P.N;
+                    sh_total += nw - w[s_victim];
+                    w[s_victim] = nw;
+                }
+            }
         }
         __syncthreads();
         const float* src = fcs + (size_t)s_fc * P.Cs;
-        float* dst       = recs + (size_t)s_victim * P.Cs;
+        float* dst       = dsts + (size_t)s_victim * P.Cs;
         for (int w = tid; w < P.C; w += 256) dst[w] = src[w];  // nodes with fixed parents: the counts particle's CPTs
         __syncthreads();
         for (int k = 0; k < nnodes; ++k) {
@@ -2445,7 +2466,7 @@ __global__ void __launch_bounds__(256) reset_kernel(Problem P, DeviceState D, in
     if (P.belief == FBA_BELIEF_REJECTION || fc || P.cheat || P.mh) {  // (the cheating and the mh-within-gibbs beliefs reset their weighted filter in place too, CheatingReinvigoration.cpp:48-62, MHwithinGibbs.cpp:259-275)
         float* recs = (fc ? D.p_rec_fc : D.p_rec) + sb * (size_t)P.Cs;
         for (int i = i_lo + tid; i < i_hi; i += 256) {
-            g.stream(fc ? FBA_PHASE_RESET_FC : FBA_PHASE_RESET, (uint32_t)i);
+            g.stream(fc ? FBA_PHASE_RESET_FC : (D.shadow ? FBA_PHASE_RESET_SH : FBA_PHASE_RESET), (uint32_t)i);
             rec_set_state(recs + (size_t)i * P.Cs, P.C, domain_start(P, g));
         }
         return;
@@ -2676,6 +2697,12 @@ __global__ void selftest_ucb_kernel(const double* L, const int32_t* n, int count
     if (i < count) out[i] = u * sqrt(L[i] / (double)n[i]);
 }
 
+__global__ void copy_flags_kernel(const uint8_t* src, uint8_t* dst, int n)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) dst[e] = src[e];
+}
+
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
@@ -2758,6 +2785,31 @@ void launch_advance(const Problem& P, const DeviceState& D, int32_t* n_active, h
 {
     hipLaunchKernelGGL(advance_kernel, dim3(ceil_div(P.E, 256)), dim3(256), 0, st, P, D, n_active);
 }
+// importance_kernel of one slot per workgroup, the instantiation the problem calls for
+static void launch_importance_single(const Problem& P, const DeviceState& D, hipStream_t st)
+{
+    const bool tiger_table = P.model == FBA_MODEL_BA_TABLE && !P.dirichlet_regular &&
+                             (P.domain == FBA_DOM_TIGER_EPISODIC || P.domain == FBA_DOM_TIGER_CONTINUOUS);
+    // weights and prefix sums of a slot in LDS while its workgroup works on them (8 bytes per particle)
+    const bool wlds = P.N <= IS_LDS_MAX_N && !P.dirichlet_regular;
+    const size_t wl = wlds ? (size_t)P.N * (sizeof(double) + ((tiger_table && P.packed) ? 4 : 0)) : 0;  // (packed tiger: + pending updates and sources, 16 bits each)
+#define FBA_LAUNCH_IS(...)                                                                                         \
+    do {                                                                                                           \
+    static bool raised = false;                                                                                \
+    if (wl > 16384 && !raised) {                                                                               \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&importance_kernel<__VA_ARGS__>),              \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, IS_LDS_MAX_N * 12); \
+        raised = true;                                                                                         \
+    }                                                                                                          \
+    hipLaunchKernelGGL((importance_kernel<__VA_ARGS__>), dim3(P.E), dim3(IS_BLOCK), wl, st, P, D);             \
+    } while (0)
+    if (P.hist) { if (wlds) FBA_LAUNCH_IS(false, 0, true, true); else FBA_LAUNCH_IS(false, 0, true, false); }
+    else if (P.dirichlet_regular) FBA_LAUNCH_IS(true, 0, false, false);
+    else if (tiger_table && P.packed) { if (wlds) FBA_LAUNCH_IS(false, 2, false, true); else FBA_LAUNCH_IS(false, 2, false, false); }
+    else if (tiger_table) { if (wlds) FBA_LAUNCH_IS(false, 1, false, true); else FBA_LAUNCH_IS(false, 1, false, false); }
+    else { if (wlds) FBA_LAUNCH_IS(false, 0, false, true); else FBA_LAUNCH_IS(false, 0, false, false); }
+#undef FBA_LAUNCH_IS
+}
 void launch_belief_update(const Problem& P, const DeviceState& D, hipStream_t st)
 {
     if (P.nested) {
@@ -2768,11 +2820,23 @@ void launch_belief_update(const Problem& P, const DeviceState& D, hipStream_t st
     if (P.belief == FBA_BELIEF_REJECTION) {
         const bool tiger_table = P.model == FBA_MODEL_BA_TABLE && !P.dirichlet_regular &&
                                  (P.domain == FBA_DOM_TIGER_EPISODIC || P.domain == FBA_DOM_TIGER_CONTINUOUS);
-        if (P.reinvig) hipLaunchKernelGGL(reinvigorate_kernel, dim3(P.E), dim3(256), 0, st, P, D);
+        if (P.reinvig) hipLaunchKernelGGL(reinvigorate_kernel, dim3(P.E), dim3(256), 0, st, P, D, 0);
+        if (P.incub) {
+            // StructureIncubatorSampling::updateEstimation (:105-131): breed the least likely shadow particles from the two
+            // rejection filters as they are now, importance-sample the shadow filter (it has its own copy of the request
+            // flags: its kernel clears them), then the two rejection updates below
+            hipLaunchKernelGGL(copy_flags_kernel, dim3(ceil_div(P.E, 256)), dim3(256), 0, st, D.need_update, D.need_update_sh, P.E);
+            hipLaunchKernelGGL(reinvigorate_kernel, dim3(P.E), dim3(256), 0, st, P, D, 1);
+            Problem Ps = P;
+            Ps.belief = FBA_BELIEF_IMPORTANCE; Ps.incub = 0;
+            DeviceState Ds = D;
+            Ds.p_rec = D.p_rec_sh; Ds.p_weight = D.p_weight_sh; Ds.bufsel = D.bufsel_sh; Ds.need_update = D.need_update_sh; Ds.shadow = 1;
+            launch_importance_single(Ps, Ds, st);
+        }
         const int ft = (P.model == FBA_MODEL_BA_FACTORED && !P.dirichlet_regular &&
                         (P.domain == FBA_DOM_FTIGER_EPISODIC || P.domain == FBA_DOM_FTIGER_CONTINUOUS))
                            ? 31 - __builtin_clz((unsigned)P.S) : 0;  // S = 2^FS
-        for (int fc = P.reinvig ? 1 : 0; fc >= 0; --fc) {  // the main filter's launch clears the request flag: last
+        for (int fc = (P.reinvig || P.incub) ? 1 : 0; fc >= 0; --fc) {  // the main filter's launch clears the request flag: last
             if (ft == 2 && P.ft_packed) hipLaunchKernelGGL((reject_kernel<false, 0, 2, REJECT_BLOCK, true>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
             else if (ft == 3 && P.ft_packed) hipLaunchKernelGGL((reject_kernel<false, 0, 3, REJECT_BLOCK, true>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
             else if (ft == 4 && P.ft_packed) hipLaunchKernelGGL((reject_kernel<false, 0, 4, REJECT_BLOCK, true>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, fc);
@@ -2794,27 +2858,7 @@ void launch_belief_update(const Problem& P, const DeviceState& D, hipStream_t st
         else hipLaunchKernelGGL((reject_kernel<false, 0>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, 1);
     }
     if (!D.is_multi) {
-        const bool tiger_table = P.model == FBA_MODEL_BA_TABLE && !P.dirichlet_regular &&
-                                 (P.domain == FBA_DOM_TIGER_EPISODIC || P.domain == FBA_DOM_TIGER_CONTINUOUS);
-        // weights and prefix sums of a slot in LDS while its workgroup works on them (8 bytes per particle)
-        const bool wlds = P.N <= IS_LDS_MAX_N && !P.dirichlet_regular;
-        const size_t wl = wlds ? (size_t)P.N * (sizeof(double) + ((tiger_table && P.packed) ? 4 : 0)) : 0;  // (packed tiger: + pending updates and sources, 16 bits each)
-#define FBA_LAUNCH_IS(...)                                                                                         \
-    do {                                                                                                           \
-        static bool raised = false;                                                                                \
-        if (wl > 16384 && !raised) {                                                                               \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&importance_kernel<__VA_ARGS__>),              \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, IS_LDS_MAX_N * 12); \
-            raised = true;                                                                                         \
-        }                                                                                                          \
-        hipLaunchKernelGGL((importance_kernel<__VA_ARGS__>), dim3(P.E), dim3(IS_BLOCK), wl, st, P, D);             \
-    } while (0)
-        if (P.hist) { if (wlds) FBA_LAUNCH_IS(false, 0, true, true); else FBA_LAUNCH_IS(false, 0, true, false); }
-        else if (P.dirichlet_regular) FBA_LAUNCH_IS(true, 0, false, false);
-        else if (tiger_table && P.packed) { if (wlds) FBA_LAUNCH_IS(false, 2, false, true); else FBA_LAUNCH_IS(false, 2, false, false); }
-        else if (tiger_table) { if (wlds) FBA_LAUNCH_IS(false, 1, false, true); else FBA_LAUNCH_IS(false, 1, false, false); }
-        else { if (wlds) FBA_LAUNCH_IS(false, 0, false, true); else FBA_LAUNCH_IS(false, 0, false, false); }
-#undef FBA_LAUNCH_IS
+        launch_importance_single(P, D, st);
         if (P.cheat) hipLaunchKernelGGL(cheat_kernel, dim3(P.E), dim3(256), 0, st, P, D);
         if (P.mh) hipLaunchKernelGGL(mh_kernel, dim3(ceil_div(P.E, 64)), dim3(64), 0, st, P, D);
         return;
@@ -2833,7 +2877,8 @@ void launch_belief_update(const Problem& P, const DeviceState& D, hipStream_t st
 void launch_init(const Problem& P, const DeviceState& D, hipStream_t st)
 {
     hipLaunchKernelGGL(init_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), P.E), dim3(256), 0, st, P, D, 0);
-    if (P.reinvig || P.cheat) hipLaunchKernelGGL(init_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), P.E), dim3(256), 0, st, P, D, 1);
+    if (P.reinvig || P.cheat || P.incub) hipLaunchKernelGGL(init_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), P.E), dim3(256), 0, st, P, D, 1);
+    if (P.incub) hipLaunchKernelGGL(reinvigorate_kernel, dim3(P.E), dim3(256), 0, st, P, D, 2);
     if (P.nested) hipLaunchKernelGGL(nested_fill_kernel, dim3(P.E), dim3(256), 0, st, P, D, 0);
     hipLaunchKernelGGL(post_init_kernel, dim3(ceil_div(P.E, 256)), dim3(256), 0, st, P, D);
 }
@@ -2844,7 +2889,7 @@ void launch_materialize_reset(const Problem& P, const DeviceState& D, hipStream_
 }
 void launch_reset(const Problem& P, const DeviceState& D, hipStream_t st)
 {
-    if (P.belief == FBA_BELIEF_REJECTION && !P.reinvig && !P.cheat) {  // the plain rejection filter resets lazily
+    if (P.belief == FBA_BELIEF_REJECTION && !P.reinvig && !P.cheat && !P.incub) {  // the plain rejection filter resets lazily
         hipLaunchKernelGGL(lazy_reset_kernel, dim3(ceil_div(P.E, 256)), dim3(256), 0, st, P, D);
         return;
     }
@@ -2854,7 +2899,12 @@ void launch_reset(const Problem& P, const DeviceState& D, hipStream_t st)
         return;
     }
     hipLaunchKernelGGL(reset_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), P.E), dim3(256), 0, st, P, D, 0);
-    if (P.reinvig || P.cheat) hipLaunchKernelGGL(reset_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), P.E), dim3(256), 0, st, P, D, 1);
+    if (P.reinvig || P.cheat || P.incub) hipLaunchKernelGGL(reset_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), P.E), dim3(256), 0, st, P, D, 1);
+    if (P.incub) {  // StructureIncubatorSampling::resetDomainStateDistribution (:46-61): the shadow filter too, in place
+        DeviceState Ds = D;
+        Ds.p_rec = D.p_rec_sh; Ds.p_weight = D.p_weight_sh; Ds.bufsel = D.bufsel_sh; Ds.shadow = 1;
+        hipLaunchKernelGGL(reset_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), P.E), dim3(256), 0, st, P, Ds, 0);
+    }
     hipLaunchKernelGGL(post_reset_kernel, dim3(ceil_div(P.E, 256)), dim3(256), 0, st, P, D);
 }
 void launch_flush(const Problem& P, const DeviceState& D, hipStream_t st)

@@ -60,6 +60,13 @@ struct DeviceState {
     int16_t* mh_o;
     int32_t* mh_ep_len; // [E][episodes + 1]
     int32_t* mh_n_ep;   // [E] episodes in the history, the open one included
+    // incubator belief (StructureIncubatorSampling.cpp): the weighted shadow filter, laid out like p_rec / p_weight / bufsel
+    float* p_rec_sh;         // [2][E][N][Cs]
+    double* p_weight_sh;     // [2][E][N]
+    uint8_t* bufsel_sh;      // [E]
+    uint8_t* need_update_sh; // [E] the shadow filter's copy of need_update (its importance update clears it)
+    const int32_t* inc_order;  // [P.incub] WeightedFilter::leastLikely of uniform weights: which shadow particles are bred anew
+    int32_t shadow;          // 1 in the DeviceState the shadow filter's kernels are launched with
     // nested belief (NestedBelief.cpp): per count particle a flat filter of P.nested domain states, double-buffered
     int32_t* nest_s;     // [2][E][N][P.nested]
     int32_t* nest_sel;   // [E] the buffer that holds the current filters

@@ -173,8 +173,9 @@ bool to_config(Options const& o, fba_config& c, std::string& err)
     }
     else if (o.belief == "mh-nips" && o.mode == "fbapomdp") c.belief = FBA_BELIEF_MH_NIPS;  // BABelief.cpp:33-36
     else if (o.belief == "nested" && o.mode != "planning") c.belief = FBA_BELIEF_NESTED;   // BABelief.cpp:67-70
+    else if (o.belief == "incubator" && o.mode == "fbapomdp") c.belief = FBA_BELIEF_INCUBATOR;   // BABelief.cpp:53-58
     else { err = "please enter a legit state stimator: point_estimate, rejection_sampling, importance_sampling or (fbapomdp) reinvigoration, provided: " + o.belief; return false; }
-    if ((o.resample_amount == 0) ^ (o.belief != "reinvigoration" && o.belief != "cheating-reinvigoration")) {  // BeliefConf.cpp:40-49
+    if ((o.resample_amount == 0) ^ (o.belief != "reinvigoration" && o.belief != "cheating-reinvigoration" && o.belief != "incubator")) {  // BeliefConf.cpp:40-49
         err = "You have set the resample amount (" + std::to_string(o.resample_amount) + "), but are not using one of the beliefs (" + o.belief +
               ") that use it: reinvigoration, cheating-reinvigoration and incubator";
         return false;

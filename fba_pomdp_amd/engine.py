@@ -192,6 +192,15 @@ class Engine:
         self._chk(self.L.fba_belief_get_fully_connected(self.h, slot, s.ctypes.data, cnt.ctypes.data))
         return s, cnt
 
+    def belief_get_shadow(self, slot=0):
+        """The incubator belief's weighted shadow filter: states, weights, counts."""
+        n = self.cfg.particles
+        s = np.zeros(n, np.int32)
+        w = np.zeros(n, np.float64)
+        cnt = np.zeros((n, self.ncnt), np.float32)
+        self._chk(self.L.fba_belief_get_shadow(self.h, slot, s.ctypes.data, w.ctypes.data, cnt.ctypes.data))
+        return s, w, cnt
+
     def belief_get_nested(self, slot=0):
         """The nested belief's flat filters of domain states, [particles][particles^2] (belief_get returns the count particles)."""
         n = self.cfg.particles

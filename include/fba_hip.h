@@ -56,6 +56,9 @@ enum { FBA_BELIEF_REJECTION = 0, FBA_BELIEF_IMPORTANCE = 1, FBA_BELIEF_REINVIGOR
                                  * likelihood falls below `threshold`; factored tiger, collision avoidance */
        FBA_BELIEF_MH_NIPS = 6,  /* mh-nips (BABelief.cpp:33-36: factored::MHNIPS2018): the same filter and trigger; the re-draw makes
                                  * independent proposals (a particle's structure or a mutation, updated along a simulated history) */
+       FBA_BELIEF_INCUBATOR = 8, /* incubator (BABelief.cpp:53-58: factored::StructureIncubatorSampling(particles, resample_amount, threshold)): the
+                                  * reinvigoration belief's two rejection filters + a weighted shadow filter of bred particles
+                                  * (fba_belief_get_shadow), importance-sampled; factored tiger, collision avoidance, sysadmin */
        FBA_BELIEF_NESTED = 7    /* nested (BABelief.cpp:67-70: NestedBelief(particles, particles^2)): a weighted filter of count particles,
                                  * each with its own flat filter of particles^2 domain states (fba_belief_get_nested); bapomdp / fbapomdp */ };
 /* -P po-uct | random | ts (Planner.cpp:12-19, BAPlanner.cpp:13-20; ts = Thompson sampling: TSPlanner / BATSPlanner) */
@@ -76,7 +79,9 @@ enum {
     FBA_PHASE_REINVIG   = 8,  /* reinvigoration: unit = index of the bred particle            */
     FBA_PHASE_INIT_FC   = 9,  /* fully connected filter of the reinvigoration belief: initiate */
     FBA_PHASE_RESET_FC  = 10, /*   ... resetDomainStateDistribution                            */
-    FBA_PHASE_REJECT_FC = 11  /*   ... rejection sampling, unit = attempt index                */
+    FBA_PHASE_REJECT_FC = 11, /*   ... rejection sampling, unit = attempt index                */
+    FBA_PHASE_RESET_SH  = 12, /* incubator belief, shadow filter: resetDomainStateDistribution     */
+    FBA_PHASE_INIT_SH   = 13  /*   ... initiate, unit = index of the bred particle                 */
 };
 
 enum {
@@ -252,6 +257,8 @@ int fba_belief_get_fully_connected(fba_ctx* ctx, int32_t slot, int32_t* state, f
 /* the nested belief's flat filters of domain states (NestedBelief.hpp: the FlatFilter<State const*> of every top
  * particle): states[particles][particles^2]; fba_belief_get returns the count particles and their weights */
 int fba_belief_get_nested(fba_ctx* ctx, int32_t slot, int32_t* states);
+/* the incubator belief's shadow filter (StructureIncubatorSampling.hpp: _shadow_belief), for tests */
+int fba_belief_get_shadow(fba_ctx* ctx, int32_t slot, int32_t* state, double* weight, float* counts);
 /* per-slot record of the last select_action / belief_update (root statistics, rejection count,
  * belief checksum) */
 int fba_last_step_info(fba_ctx* ctx, fba_trace_rec* recs /* [slots] */);

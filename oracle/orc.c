@@ -111,6 +111,12 @@ struct orc_ctx {
     float* fpool;
     float* fpool_new;
     float* breed_tmp;
+    /* StructureIncubatorSampling::_shadow_belief (a WeightedFilter of bred particles) */
+    particle* Sh;
+    particle* Shnew;
+    float* shpool;
+    float* shpool_new;
+    double sh_total;
     double likelihood; /* CheatingReinvigoration::_likelihood */
     double total_w; /* WeightedFilter::_total_weight */
     double* wscratch;
@@ -1059,6 +1065,7 @@ static int ba_table_step(orc_ctx* c, simstate* st, int32_t a, int32_t* o, double
 /* ------------------------------------------------------------------ factored BA model */
 
 static int is_mh(const orc_ctx* c) { return c->cfg.belief == ORC_BELIEF_MH_GIBBS || c->cfg.belief == ORC_BELIEF_MH_NIPS; }
+static int is_breeding(const orc_ctx* c) { return c->cfg.belief == ORC_BELIEF_REINVIGORATION || c->cfg.belief == ORC_BELIEF_INCUBATOR; }
 static uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
@@ -1433,7 +1440,7 @@ static int build_ca_factored_prior(orc_ctx* c)
     int full = c->cfg.structure_prior == ORC_SP_FULLY_CONNECTED;
     /* edge noise "uniform" / "match-uniform" (:349-383): every obstacle node's parents are drawn per particle */
     int noisy = c->cfg.structure_prior == ORC_SP_UNIFORM || c->cfg.structure_prior == ORC_SP_MATCH_UNIFORM ||
-                ((c->cfg.belief == ORC_BELIEF_REINVIGORATION || is_mh(c)) && !full); /* bred / re-drawn particles carry their own structures */
+                ((is_breeding(c) || is_mh(c)) && !full); /* bred / re-drawn particles carry their own structures */
     if (c->cfg.noise > .5 || c->cfg.noise < -.5) {
         snprintf(c->err, sizeof c->err, "CollisionAvoidanceFactoredPrior must be intiiated with -.5 < noise < .5 (is: %f)", c->cfg.noise);
         return -1;
@@ -1561,7 +1568,7 @@ static int build_sysadmin_factored_prior(orc_ctx* c)
     fdesc* d = &c->fd;
     int A = c->A, N = c->sys_N, a, f, k, r, off = 0;
     int linear = c->cfg.domain == ORC_DOM_SYSADMIN_LINEAR;
-    int reinvig = c->cfg.belief == ORC_BELIEF_REINVIGORATION;
+    int reinvig = is_breeding(c);
     if (c->cfg.structure_prior != ORC_SP_NONE) {
         snprintf(c->err, sizeof c->err, "Structure noise is not enabled for the Sysadmin problem");
         return -1;
@@ -2016,6 +2023,7 @@ static void sample_start_into(orc_ctx* c, particle* p)
 
 /* Belief::initiate.  ref: RejectionSampling.cpp:15-20 / BARejectionSampling (FlatFilter(n, alloc));
  *                         ImportanceSampler.cpp:45-55 / BAImportanceSampling (add(start, 1/n)) */
+static void incubator_initiate_shadow(orc_ctx* c);
 static void belief_initiate(orc_ctx* c)
 {
     int i, n = c->cfg.particles;
@@ -2061,7 +2069,7 @@ static void belief_initiate(orc_ctx* c)
         }
         c->likelihood = 1;
     }
-    if (c->cfg.belief == ORC_BELIEF_REINVIGORATION) {
+    if (is_breeding(c)) {
         /* ReinvigoratingRejectionSampling::initiate (ReinvigoratingRejectionSampling.cpp:55-76):
          * after the n start states, n x FBAPOMDP::sampleFullyConnectedState (FBAPOMDP.cpp:63-67 ->
          * FactoredTigerFactoredPrior::sampleFullyConnectedState FactoredTigerPriors.cpp:324-337) */
@@ -2080,6 +2088,7 @@ static void belief_initiate(orc_ctx* c)
                 ftiger_set_observation_model(c, c->F[i].cnt, (1u << c->fd.FS) - 1u);
             }
         }
+        if (c->cfg.belief == ORC_BELIEF_INCUBATOR) incubator_initiate_shadow(c); /* StructureIncubatorSampling::initiate :64-90 */
     }
 }
 
@@ -2224,38 +2233,132 @@ static void breed_counts(const orc_ctx* c, const float* counts_cnt, const uint32
  * BABNModel::Structure::flip_random_edge BABNModel.cpp:16-31: one slowRandomInt over the state
  * features, flips that parent of the listen observation node); then FlatFilter::replace picks the
  * victim (FlatFilter.cpp:39-46).  Iterations are sequential: a bred particle can be sampled by the next. */
+/* breed (:24-35) into c->breed_tmp; returns the structure particle's index in the main filter */
+static int32_t breed_one(orc_ctx* c)
+{
+    int k, n = c->cfg.particles;
+    const fdesc* d = &c->fd;
+    uint32_t masks[128];
+    int32_t fc, b, edge;
+    fc = orc_int(&c->rng, n);
+    b  = orc_int(&c->rng, n);
+    for (k = 0; k < d->nvar; ++k) masks[k] = f2u(c->P[b].cnt[d->ncounts + k]);
+    if (is_sys(c->cfg.domain)) {
+        /* SysAdminFactoredPrior::mutate (:47-55): flip_random_edge(&T[action()][computer()], N).  Under the
+         * reference's --std=c++11 g++ evaluates the second subscript first: computer, action, edge */
+        int mc = orc_int(&c->rng, c->sys_N), ma = orc_int(&c->rng, c->A);
+        edge = orc_slow_int(&c->rng, 0, d->FS);
+        masks[ma * c->sys_N + mc] ^= 1u << edge;
+    } else if (is_ca(c->cfg.domain)) { /* CollisionAvoidanceFactoredPrior::mutate :455-488: action, obstacle, then the edge */
+        int ma = orc_int(&c->rng, c->A), mo = orc_int(&c->rng, c->ca_n);
+        edge = orc_slow_int(&c->rng, 0, d->FS);
+        masks[ma * c->ca_n + mo] ^= 1u << edge;
+    } else {
+        edge = orc_slow_int(&c->rng, 0, d->FS);
+        masks[0] ^= 1u << edge;
+    }
+    breed_counts(c, c->F[fc].cnt, masks, c->breed_tmp);
+    return b;
+}
 static void reinvigorate(orc_ctx* c)
 {
-    int i, k, n = c->cfg.particles;
-    const fdesc* d = &c->fd;
+    int i, n = c->cfg.particles;
     for (i = 0; i < c->cfg.resample_amount; ++i) {
-        uint32_t masks[128];
-        int32_t fc, b, edge, victim;
+        int32_t b, victim;
         orc_rng_stream(&c->rng, ORC_PH_REINVIG, (uint32_t)i);
-        fc = orc_int(&c->rng, n);
-        b  = orc_int(&c->rng, n);
-        for (k = 0; k < d->nvar; ++k) masks[k] = f2u(c->P[b].cnt[d->ncounts + k]);
-        if (is_sys(c->cfg.domain)) {
-            /* SysAdminFactoredPrior::mutate (:47-55): flip_random_edge(&T[action()][computer()], N).  Under the
-             * reference's --std=c++11 g++ evaluates the second subscript first: computer, action, edge */
-            int mc = orc_int(&c->rng, c->sys_N), ma = orc_int(&c->rng, c->A);
-            edge = orc_slow_int(&c->rng, 0, d->FS);
-            masks[ma * c->sys_N + mc] ^= 1u << edge;
-        } else if (is_ca(c->cfg.domain)) { /* CollisionAvoidanceFactoredPrior::mutate :455-488: action, obstacle, then the edge */
-            int ma = orc_int(&c->rng, c->A), mo = orc_int(&c->rng, c->ca_n);
-            edge = orc_slow_int(&c->rng, 0, d->FS);
-            masks[ma * c->ca_n + mo] ^= 1u << edge;
-        } else {
-            edge = orc_slow_int(&c->rng, 0, d->FS);
-            masks[0] ^= 1u << edge;
-        }
-        breed_counts(c, c->F[fc].cnt, masks, c->breed_tmp);
+        b      = breed_one(c);
         victim = orc_int(&c->rng, n);
         c->P[victim].s = c->P[b].s; /* copyDomainState(structure_state->_domain_state) */
         memcpy(c->P[victim].cnt, c->breed_tmp, sizeof(float) * (size_t)c->ncnt);
     }
 }
 
+/* ------------------------------------------------------------------ incubator belief
+ * ref: src/beliefs/bayes-adaptive/factored/StructureIncubatorSampling.cpp (FBAPOMDP.hpp -> Boost: restated).
+ * The two rejection filters of the reinvigoration belief plus a weighted "shadow" filter of bred particles, updated
+ * by importance sampling + resampling.  Per update: shadow particles whose normalised weight exceeds --threshold
+ * replace random particles of the main filter (reinvigorateBelief :155-188), the --resample-amount least likely shadow
+ * particles are bred anew (reinvigorateShadowBelief :137-153), then the three filters are updated (:105-131).
+ * As written, the shadow weights are uniform whenever they are tested (every update ends in a resample), so either
+ * none is promoted or all are -- and then the shadow's total weight is zero and normalize() divides by it; contexts
+ * whose threshold would do that are refused at create. */
+static void swap_main_sh(orc_ctx* c)
+{
+    particle* p; float* q;
+    p = c->P; c->P = c->Sh; c->Sh = p;
+    p = c->Pnew; c->Pnew = c->Shnew; c->Shnew = p;
+    q = c->pool; c->pool = c->shpool; c->shpool = q;
+    q = c->pool_new; c->pool_new = c->shpool_new; c->shpool_new = q;
+}
+static void incubator_initiate_shadow(orc_ctx* c)
+{
+    int i, n = c->cfg.particles;
+    double w = 1.0 / (double)n;
+    c->sh_total = 0;
+    for (i = 0; i < n; ++i) { /* :81-89: _shadow_belief.add(breed(...), 1 / size) */
+        int32_t b;
+        orc_rng_stream(&c->rng, ORC_PH_INIT_SH, (uint32_t)i);
+        b = breed_one(c);
+        c->Sh[i].s = c->P[b].s;
+        c->Sh[i].w = w;
+        memcpy(c->Sh[i].cnt, c->breed_tmp, sizeof(float) * (size_t)c->ncnt);
+        c->sh_total += w;
+    }
+    swap_main_sh(c);
+    c->total_w = c->sh_total;
+    weighted_refresh_scan(c);   /* DEV: total in device order */
+    c->sh_total = c->total_w;
+    swap_main_sh(c);
+}
+static void incubator_update(orc_ctx* c, int32_t a, int32_t o)
+{
+    int n = c->cfg.particles, i, k, added = 0, count;
+    int order[1024];
+    /* reinvigorateBelief (:155-188) */
+    orc_rng_stream(&c->rng, ORC_PH_REINVIG, 0xffffu);
+    for (i = 0; i < n; ++i)
+        if (c->Sh[i].w / c->sh_total > c->cfg.threshold) {
+            int victim = orc_int(&c->rng, n);   /* FlatFilter::replace (FlatFilter.cpp:39-46) */
+            added = 1;
+            c->P[victim].s = c->Sh[i].s;
+            memcpy(c->P[victim].cnt, c->Sh[i].cnt, sizeof(float) * (size_t)c->ncnt);
+            c->Sh[i].w = 0;
+        }
+    if (added) { /* WeightedFilter::normalize (WeightedFilter.cpp:113-143) */
+        double tot = 0, acc = 0;
+        for (i = 0; i < n; ++i) tot += c->Sh[i].w;
+        for (i = 0; i < n; ++i) { c->Sh[i].w /= tot; acc += c->Sh[i].w; }
+        c->sh_total = acc;
+    }
+    /* reinvigorateShadowBelief (:137-153): WeightedFilter::replace(i, bred) gives the weight total / size */
+    for (i = 0; i < n; ++i) c->wscratch[i] = c->Sh[i].w;
+    orc_least_likely(c->wscratch, n, c->cfg.resample_amount, order);
+    for (k = 0; k < c->cfg.resample_amount; ++k) {
+        int32_t b;
+        double w;
+        i = order[k];
+        orc_rng_stream(&c->rng, ORC_PH_REINVIG, (uint32_t)k);
+        b = breed_one(c);
+        c->Sh[i].s = c->P[b].s;
+        memcpy(c->Sh[i].cnt, c->breed_tmp, sizeof(float) * (size_t)c->ncnt);
+        w = c->sh_total / (double)n;
+        c->sh_total += w - c->Sh[i].w;
+        c->Sh[i].w = w;
+    }
+    /* the three filters (:119-127) */
+    reject_sample(c, a, o, ORC_PH_REJECT);
+    count = c->last_update_count;
+    swap_main_fc(c);
+    reject_sample(c, a, o, ORC_PH_REJECT_FC);
+    swap_main_fc(c);
+    swap_main_sh(c);
+    c->total_w = c->sh_total;
+    is_update(c, a, o);
+    is_resample(c);
+    c->sh_total = c->total_w;
+    swap_main_sh(c);
+    c->last_update_count = count;
+}
 
 /* ------------------------------------------------------------------ MH-within-Gibbs belief
  * ref: src/beliefs/bayes-adaptive/factored/MHwithinGibbs.cpp (needs FBAPOMDP.hpp -> Boost: restated, not built).
@@ -2634,6 +2737,7 @@ static void belief_update(orc_ctx* c, int32_t a, int32_t o)
 {
     c->last_weight_total = 0;
     if (is_nested(c)) { nested_update(c, a, o); return; }
+    if (c->cfg.belief == ORC_BELIEF_INCUBATOR) { incubator_update(c, a, o); return; }
     if (c->cfg.belief == ORC_BELIEF_REJECTION) reject_sample(c, a, o, ORC_PH_REJECT);
     else if (c->cfg.belief == ORC_BELIEF_REINVIGORATION) {
         /* ReinvigoratingRejectionSampling::updateEstimation (ReinvigoratingRejectionSampling.cpp:89-107) */
@@ -2697,10 +2801,15 @@ static void belief_reset_domain_state(orc_ctx* c)
         }
         if (is_mh(c) && c->mh_ep_len[c->mh_n_ep - 1] != 0) /* MHwithinGibbs::resetDomainStateDistribution :259-275 (MHNIPS2018.cpp:114-130): a new episode unless the open one is empty */
             c->mh_ep_len[c->mh_n_ep++] = 0;
-        if (c->cfg.belief == ORC_BELIEF_REINVIGORATION || c->cfg.belief == ORC_BELIEF_CHEATING) /* ReinvigoratingRejectionSampling.cpp:109-119 */
+        if (is_breeding(c) || c->cfg.belief == ORC_BELIEF_CHEATING) /* ReinvigoratingRejectionSampling.cpp:109-119 */
             for (i = 0; i < n; ++i) {
                 orc_rng_stream(&c->rng, ORC_PH_RESET_FC, (uint32_t)i);
                 c->F[i].s = domain_start(c);
+            }
+        if (c->cfg.belief == ORC_BELIEF_INCUBATOR) /* StructureIncubatorSampling::resetDomainStateDistribution :46-61: in place, weights kept */
+            for (i = 0; i < n; ++i) {
+                orc_rng_stream(&c->rng, ORC_PH_RESET_SH, (uint32_t)i);
+                c->Sh[i].s = domain_start(c);
             }
     } else {
         double w1 = 1.0 / (double)n, new_total = 0;
@@ -3050,8 +3159,48 @@ orc_ctx* orc_create(const orc_config* cfg)
         c->nest_s   = (int32_t*)calloc((size_t)n * c->nest_m, sizeof(int32_t));
         c->nest_new = (int32_t*)calloc((size_t)c->nest_m, sizeof(int32_t));
     }
-    if (cfg->belief == ORC_BELIEF_REINVIGORATION || cfg->belief == ORC_BELIEF_CHEATING) {
-        if (cfg->belief == ORC_BELIEF_CHEATING) { /* checked above */
+    if (cfg->belief == ORC_BELIEF_INCUBATOR) {
+        double w = 1.0 / (double)n, tot = 0;
+        if (cfg->model != ORC_MODEL_BA_FACTORED || !(is_ftiger(cfg->domain) || is_ca(cfg->domain) || is_sys(cfg->domain)) ||
+            (is_ca(cfg->domain) && cfg->structure_prior == ORC_SP_FULLY_CONNECTED)) {
+            snprintf(c->err, sizeof c->err, "incubator belief: needs a factored model (fbapomdp) of factored tiger, collision avoidance or sysadmin");
+            return c;
+        }
+        if (cfg->resample_amount < 1) { /* StructureIncubatorSampling.cpp:28-33 */
+            snprintf(c->err, sizeof c->err, "StructureIncubatorSampling::Cannot initiate Incubator belief update with size < 1 (%d) or resample size < 1 (%d)", n, cfg->resample_amount);
+            return c;
+        }
+        if (cfg->threshold <= 0 || cfg->threshold > 1) { /* :35-39 */
+            snprintf(c->err, sizeof c->err, "StructureIncubatorSampling::must initiate with 1 < threshold <= 0 (is:%f)", cfg->threshold);
+            return c;
+        }
+        if (cfg->resample_amount >= n || cfg->resample_amount > 1024) { /* WeightedFilter::leastLikely asserts n < size() (WeightedFilter.cpp:207) */
+            snprintf(c->err, sizeof c->err, "incubator belief: the resample amount (%d) must be below the number of particles (%d): WeightedFilter::leastLikely", cfg->resample_amount, n);
+            return c;
+        }
+        if (cfg->arith == ORC_ARITH_DEV) {
+            double* tmp = (double*)malloc(sizeof(double) * (size_t)n);
+            for (i = 0; i < n; ++i) tmp[i] = w;
+            tot = dev_scan(tmp, n, NULL);
+            free(tmp);
+        } else
+            for (i = 0; i < n; ++i) tot += w;
+        if (w / tot > cfg->threshold) {
+            snprintf(c->err, sizeof c->err, "incubator belief: with threshold %g every one of the %d shadow particles (normalised weight %g) is promoted at "
+                     "once; the shadow filter's total weight is then zero and StructureIncubatorSampling.cpp:160-188 divides by it", cfg->threshold, n, w / tot);
+            return c;
+        }
+        c->Sh     = (particle*)calloc((size_t)n, sizeof(particle));
+        c->Shnew  = (particle*)calloc((size_t)n, sizeof(particle));
+        c->shpool     = (float*)malloc(sizeof(float) * (size_t)n * c->ncnt);
+        c->shpool_new = (float*)malloc(sizeof(float) * (size_t)n * c->ncnt);
+        for (i = 0; i < n; ++i) {
+            c->Sh[i].cnt    = c->shpool + (size_t)i * c->ncnt;
+            c->Shnew[i].cnt = c->shpool_new + (size_t)i * c->ncnt;
+        }
+    }
+    if (is_breeding(c) || cfg->belief == ORC_BELIEF_CHEATING) {
+        if (cfg->belief == ORC_BELIEF_CHEATING || cfg->belief == ORC_BELIEF_INCUBATOR) { /* checked above */
         } else if (cfg->model != ORC_MODEL_BA_FACTORED || !(is_ftiger(cfg->domain) || is_ca(cfg->domain) || is_sys(cfg->domain)) ||
             (is_ca(cfg->domain) && cfg->structure_prior == ORC_SP_FULLY_CONNECTED)) {
             /* the reference has fully connected priors for factored tiger, collision avoidance and
@@ -3085,6 +3234,7 @@ void orc_destroy(orc_ctx* c)
     free(c->mh_a); free(c->mh_o); free(c->mh_ep_len); free(c->mh_prior); free(c->mh_model); free(c->mh_new); free(c->mh_T); free(c->mh_O);
     free(c->mh_msg); free(c->mh_probs); free(c->mh_seq);
     free(c->nest_s); free(c->nest_new);
+    free(c->Sh); free(c->Shnew); free(c->shpool); free(c->shpool_new);
     free(c->tr.hkey); free(c->tr.hval);
     free(c->P); free(c->Pnew); free(c->pool); free(c->pool_new);
     free(c->F); free(c->Fnew); free(c->fpool); free(c->fpool_new); free(c->breed_tmp);
@@ -3136,6 +3286,16 @@ void orc_belief_get(const orc_ctx* c, int32_t* s, double* w, float* cnt)
     }
 }
 /* the fully connected filter of the reinvigoration belief */
+void orc_belief_get_shadow(const orc_ctx* c, int32_t* s, double* w, float* cnt)
+{
+    int i;
+    if (!c->Sh) return;
+    for (i = 0; i < c->cfg.particles; ++i) {
+        if (s) s[i] = c->Sh[i].s;
+        if (w) w[i] = c->Sh[i].w;
+        if (cnt) memcpy(cnt + (size_t)i * c->ncnt, c->Sh[i].cnt, sizeof(float) * (size_t)c->ncnt);
+    }
+}
 void orc_belief_get_nested(const orc_ctx* c, int32_t* states)
 {
     if (c->nest_s) memcpy(states, c->nest_s, sizeof(int32_t) * (size_t)c->cfg.particles * c->nest_m);

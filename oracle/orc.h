@@ -47,6 +47,7 @@ enum { ORC_BELIEF_REJECTION = 0, ORC_BELIEF_IMPORTANCE = 1, ORC_BELIEF_REINVIGOR
        ORC_BELIEF_POINT = 4, /* -B point_estimate: src/beliefs/point_estimation/PointEstimation.cpp, bayes-adaptive/BAPointEstimation.cpp */
        ORC_BELIEF_MH_GIBBS = 5, /* -B mh-within-gibbs: src/beliefs/bayes-adaptive/factored/MHwithinGibbs.cpp (belief_option 1 = "rs") */
        ORC_BELIEF_MH_NIPS = 6,  /* -B mh-nips: src/beliefs/bayes-adaptive/factored/MHNIPS2018.cpp */
+       ORC_BELIEF_INCUBATOR = 8, /* -B incubator: src/beliefs/bayes-adaptive/factored/StructureIncubatorSampling.cpp (--resample-amount, --threshold) */
        ORC_BELIEF_NESTED = 7    /* -B nested: src/beliefs/bayes-adaptive/NestedBelief.cpp (`particles` count particles, each with particles^2 domain states) */ };
 /* floating-point summation order of the importance-sampling filter:
  * REF = the reference's sequential loops; DEV = the HIP engine's fixed reduction tree */
@@ -161,6 +162,8 @@ int orc_last_update_count(const orc_ctx* c);
 void orc_belief_get(const orc_ctx* c, int32_t* s, double* w, float* cnt);
 void orc_belief_get_fc(const orc_ctx* c, int32_t* s, float* cnt);
 void orc_belief_get_nested(const orc_ctx* c, int32_t* states); /* [particles][particles^2] */
+void orc_belief_get_shadow(const orc_ctx* c, int32_t* s, double* w, float* cnt); /* the incubator's weighted shadow filter */
+void orc_least_likely(const double* w, int size, int n, int* out); /* WeightedFilter::leastLikely (orc_heap.cpp) */
 int orc_marginalize(orc_ctx* c, const float* cnt, const uint32_t* new_masks, float* out);
 void orc_belief_set(orc_ctx* c, const int32_t* s, const double* w, const float* cnt);
 int orc_model_step(orc_ctx* c, float* cnt, int32_t* s, int32_t a, int32_t* o, double* r, int update);

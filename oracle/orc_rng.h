@@ -50,7 +50,9 @@ enum {
     ORC_PH_REINVIG   = 8, /* reinvigoration / cheating: unit = index of the bred (copied) particle */
     ORC_PH_INIT_FC   = 9, /* fully connected filter, initiate: unit = particle index    */
     ORC_PH_RESET_FC  = 10,/* fully connected filter, reset: unit = particle index       */
-    ORC_PH_REJECT_FC = 11 /* fully connected filter, rejection: unit = attempt index    */
+    ORC_PH_REJECT_FC = 11,/* fully connected filter, rejection: unit = attempt index    */
+    ORC_PH_RESET_SH  = 12,/* incubator belief, shadow filter, reset: unit = particle index */
+    ORC_PH_INIT_SH   = 13 /* incubator belief, shadow filter, initiate: unit = index of the bred particle */
 };
 
 typedef struct orc_rng {

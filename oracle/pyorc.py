@@ -18,7 +18,7 @@ DOM_SYSADMIN_INDEPENDENT, DOM_SYSADMIN_LINEAR = 7, 8
 DOM_COFFEE, DOM_COFFEE_BOUTILIER = 9, 10
 DOM_AGR = 11
 MODEL_POMDP, MODEL_BA_TABLE, MODEL_BA_FACTORED = range(3)
-BELIEF_REJECTION, BELIEF_IMPORTANCE, BELIEF_REINVIGORATION, BELIEF_CHEATING, BELIEF_POINT, BELIEF_MH_GIBBS, BELIEF_MH_NIPS, BELIEF_NESTED = range(8)
+BELIEF_REJECTION, BELIEF_IMPORTANCE, BELIEF_REINVIGORATION, BELIEF_CHEATING, BELIEF_POINT, BELIEF_MH_GIBBS, BELIEF_MH_NIPS, BELIEF_NESTED, BELIEF_INCUBATOR = range(9)
 ARITH_REF, ARITH_DEV = range(2)
 RNG_MT, RNG_PHILOX = range(2)
 PLANNER_POUCT, PLANNER_RANDOM, PLANNER_TS = range(3)
@@ -132,6 +132,8 @@ def lib():
         L.orc_belief_get.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_belief_get_fc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_belief_get_nested.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_belief_get_shadow.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_least_likely.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orc_marginalize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_belief_set.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_model_step.argtypes = [C.c_void_p, C.c_void_p, P(C.c_int32), C.c_int32, P(C.c_int32), P(C.c_double), C.c_int]
@@ -292,6 +294,15 @@ class Oracle:
         w = np.zeros(n, np.float64)
         cnt = np.zeros((n, self.ncnt), np.float32)
         self.L.orc_belief_get(self.h, s.ctypes.data, w.ctypes.data, cnt.ctypes.data if self.ncnt else None)
+        return s, w, cnt
+
+    def belief_get_shadow(self):
+        """the incubator belief's weighted shadow filter"""
+        n = self.cfg.particles
+        s = np.zeros(n, np.int32)
+        w = np.zeros(n, np.float64)
+        cnt = np.zeros((n, self.ncnt), np.float32)
+        self.L.orc_belief_get_shadow(self.h, s.ctypes.data, w.ctypes.data, cnt.ctypes.data)
         return s, w, cnt
 
     def belief_get_nested(self):

@@ -58,6 +58,10 @@ def draw(rng):
         if b < 0.2 and domain != "gridworld" and not ("collision" in domain and kw.get("structure_prior") == 3):
             belief = "reinvigoration"
             kw["resample_amount"] = rng.choice([1, 4, 20])
+        elif b < 0.28 and domain != "gridworld" and not ("collision" in domain and kw.get("structure_prior") == 3) and kw["particles"] > 1:
+            belief = "incubator"
+            kw["resample_amount"] = rng.choice([1, 4, 20])
+            kw["threshold"] = rng.choice([0.05, 0.5, 1.0])
         elif b < 0.4:
             belief = "cheating-reinvigoration"
             kw["resample_amount"] = rng.choice([1, 5])

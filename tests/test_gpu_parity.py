@@ -1056,3 +1056,41 @@ def test_nested_belief_refusals():
     eng.belief_init()
     with pytest.raises(ValueError, match="cannot be set from the host"):
         eng.belief_set(0, state=np.zeros(4, np.int32))
+
+
+@pytest.mark.parametrize("domain,kw", [
+    ("episodic-factored-tiger", dict(size=2, structure_prior=2, particles=48, sims=80, horizon=8, resample_amount=6, threshold=0.5)),
+    ("continuous-factored-tiger", dict(size=3, structure_prior=1, particles=33, sims=64, horizon=8, resample_amount=1, threshold=1.0)),
+    ("random-collision-avoidance", dict(width=4, height=3, size=2, structure_prior=1, particles=24, sims=48, horizon=5, resample_amount=5, threshold=0.2)),
+    ("linear-sysadmin", dict(size=3, particles=20, sims=40, horizon=6, resample_amount=19, threshold=0.06)),
+])
+def test_fbapomdp_incubator_belief(domain, kw):
+    """-B incubator (StructureIncubatorSampling.cpp): the reinvigoration belief's two rejection filters plus a weighted
+    shadow filter of bred particles -- the --resample-amount least likely (WeightedFilter::leastLikely, a
+    std::priority_queue) are bred anew before every update, the filter is importance-sampled and resampled.  Whole
+    experiments against the oracle (the trace carries the main filter's checksum and rejection count and the shadow
+    filter's weight total), then the three filters themselves."""
+    eng, o = _pair(domain, N.MODEL_BA_FACTORED, "incubator", 907, runs=3, episodes=3, **kw)
+    _assert_same_experiment(eng, o, ba=True)
+    assert np.any(eng.trace()["weight_total"] > 0)
+    s, w, cnt = eng.belief_get_shadow(2)
+    os_, ow, ocnt = o.belief_get_shadow()
+    assert np.array_equal(s, os_) and np.array_equal(w, ow) and np.array_equal(cnt.view(np.uint32), ocnt.view(np.uint32))
+    fs, fcnt = eng.belief_get_fully_connected(2)
+    ofs, ofcnt = o.belief_get_fc()
+    assert np.array_equal(fs, ofs) and np.array_equal(fcnt.view(np.uint32), ofcnt.view(np.uint32))
+    ms, _, mcnt = eng.belief_get(2)
+    oms, _, omcnt = o.belief_get()
+    assert np.array_equal(ms, oms) and np.array_equal(mcnt.view(np.uint32), omcnt.view(np.uint32))
+
+
+def test_incubator_belief_refusals():
+    kw = dict(model=N.MODEL_BA_FACTORED, belief="incubator", size=2, sims=8)
+    with pytest.raises(ValueError, match="must initiate with 1 < threshold <= 0"):
+        fba.Engine("episodic-factored-tiger", particles=8, resample_amount=2, threshold=0.0, **kw)
+    with pytest.raises(ValueError, match="is promoted at once"):       # 1/8 > 0.1: the reference would divide by a zero total weight
+        fba.Engine("episodic-factored-tiger", particles=8, resample_amount=2, threshold=0.1, **kw)
+    with pytest.raises(ValueError, match="leastLikely"):
+        fba.Engine("episodic-factored-tiger", particles=8, resample_amount=8, threshold=0.5, **kw)
+    with pytest.raises(ValueError, match="factored tiger, collision avoidance or sysadmin"):
+        fba.Engine("gridworld", model=N.MODEL_BA_FACTORED, belief="incubator", size=3, sims=8, particles=8, resample_amount=2, threshold=0.5)

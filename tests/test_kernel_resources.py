@@ -28,7 +28,10 @@ def test_tiger_kernels_use_no_scratch(tmp_path):
     assert len(tiger) == 9, sorted(seen)
     for name, (scratch, vgprs, spills) in tiger.items():
         assert scratch == 0 and spills == 0, (name, scratch, spills)
-        assert vgprs <= 128, (name, vgprs)       # four waves per SIMD stay possible
+        # four waves per SIMD stay possible -- where LDS allows them: the search over DENSE tiger records (the bench's are
+        # packed) stages 8 KB per wave and holds 11 waves per CU whatever its registers, so three per SIMD (<= 168) cost nothing
+        dense_search = re.search(r"search_kernelILb1ELi4ELb0ELi1ELi1E", name) is not None
+        assert vgprs <= (168 if dense_search else 128), (name, vgprs)
     regular = re.compile(r"search_kernelILb[01]ELi\d+ELb1E|(reject|importance)_kernelILb1E|is_multi_step_kernelILb1E")
     for name, (scratch, vgprs, spills) in seen.items():
         if not regular.search(name):              # (the `regular` Dirichlet instantiations carry the gamma sampler)
