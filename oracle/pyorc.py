@@ -172,6 +172,15 @@ def lib():
     return _lib
 
 
+def least_likely(w, n):
+    """WeightedFilter::leastLikely (oracle/orc_heap.cpp)"""
+    L = lib()
+    w = np.ascontiguousarray(w, np.float64)
+    out = np.zeros(n, np.int32)
+    L.orc_least_likely(w.ctypes.data, len(w), n, out.ctypes.data)
+    return out
+
+
 def make_config(**kw):
     """Defaults = the reference's CLI defaults (Conf.hpp:14-45, PlannerConf.hpp:16-18,
     BeliefConf.hpp:16-21, BAConf.hpp:17-22)."""

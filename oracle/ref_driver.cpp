@@ -335,6 +335,52 @@ static void is_gridworld(char const* s, int size, int n, int steps)
     printf("], \"next_u01\": %.17g}", rnd::uniform_rand01());
 }
 
+/* WeightedFilter::leastLikely / replace / normalizedWeight / normalize (WeightedFilter.cpp:70-87, 113-143, 193-238): what the
+ * incubator belief asks of its shadow filter.  Cases: uniform weights (the only ones that belief ever has when it
+ * asks), weights with ties, distinct weights. */
+static void weighted_filter_ops()
+{
+    domains::Tiger d(domains::Tiger::CONTINUOUS);
+    seed("77");
+    struct Case { int size, n, kind; };
+    Case const cases[] = {{16, 5, 0}, {20, 19, 0}, {33, 1, 0}, {48, 6, 0}, {7, 3, 0}, {24, 20, 0}, {130, 20, 0},
+                          {12, 4, 1}, {12, 11, 1}, {40, 9, 1}, {10, 3, 2}, {64, 17, 2}};
+    printf("[");
+    for (size_t ci = 0; ci < sizeof cases / sizeof cases[0]; ++ci) {
+        Case const c = cases[ci];
+        WeightedFilter<State const*> f;
+        std::vector<double> w;
+        for (int i = 0; i < c.size; ++i) {
+            double wi = 1.0 / (double)c.size;
+            if (c.kind == 1) wi = (double)(1 + (i * 7) % 3) / 8.0;        /* three distinct values: ties */
+            if (c.kind == 2) wi = rnd::uniform_rand01();
+            w.push_back(wi);
+            f.add(d.sampleStartState(), wi);
+        }
+        auto ll = f.leastLikely((size_t)c.n);
+        if (ci) printf(",");
+        printf("{\"w\": ");
+        arr(w, pd);
+        printf(", \"n\": %d, \"least_likely\": ", c.n);
+        arr(ll, pi);
+        /* replace the first of them as the incubator does, then the weights and the normalised weight of particle 0 */
+        f.replace(ll[0], d.sampleStartState(), [&d](State const* st) { d.releaseState(st); });
+        std::vector<double> w2;
+        for (size_t i = 0; i < f.size(); ++i) w2.push_back(f.particle(i)->w);
+        printf(", \"after_replace\": ");
+        arr(w2, pd);
+        printf(", \"normalized_w0\": %.17g", f.normalizedWeight(f.particle(0)->w));
+        f.normalize();
+        w2.clear();
+        for (size_t i = 0; i < f.size(); ++i) w2.push_back(f.particle(i)->w);
+        printf(", \"after_normalize\": ");
+        arr(w2, pd);
+        printf(", \"normalized_w0_again\": %.17g}", f.normalizedWeight(f.particle(0)->w));
+        f.free([&d](State const* st) { d.releaseState(st); });
+    }
+    printf("]");
+}
+
 /* BAFlatModel sampling / probability / increment with the expected-Dirichlet method */
 static void flat_model(char const* s)
 {
@@ -959,6 +1005,9 @@ int main(int argc, char** argv)
     printf(",");
     is_gridworld("23", 3, 64, 6);
     printf("]");
+
+    key("weighted_filter_ops");
+    weighted_filter_ops();
 
     key("reject_tiger");
     printf("[");
