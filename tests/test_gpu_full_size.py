@@ -160,3 +160,47 @@ def test_c4_full_size_many_slots():
     tm, tf = many.trace(), few.trace()
     for name in tm.dtype.names:
         assert np.array_equal(tm[name][:3], tf[name]), name
+
+
+def test_c5_full_size_experiment_equals_the_oracle():
+    """BASELINE configs[4] at its own size: collision avoidance 7 x 7 with two obstacles, ONE belief of 10^6 particles
+    (3.5 KB each: 3.5 GB per buffer), importance-weighted update + resample through the multi-workgroup kernels.  A
+    whole (short) experiment against the oracle: every trace field -- the weight total before normalisation as a double,
+    and the position-keyed checksum over every one of the 10^6 particles' states and 883 counts after every update."""
+    from oracle import pyorc as orc
+    kw = dict(model=N.MODEL_BA_FACTORED, size=2, width=7, height=7, particles=1_000_000, sims=8, horizon=3, episodes=1, runs=1)
+    eng = fba.Engine("random-collision-avoidance", belief="importance_sampling", seed=1033, slots=1, trace=1, **kw)
+    o = orc.Oracle(domain=orc.DOM_COLLISION_AVOID, belief=orc.BELIEF_IMPORTANCE, rng_mode=orc.RNG_PHILOX, arith=orc.ARITH_DEV,
+                   philox_seed=1033, trace=1, **kw)
+    stats = eng.run_bapomdp()
+    ostats, res = o.run_bapomdp()
+    tr, otr = eng.trace(), o.trace(res.n_trace)
+    assert len(tr) == len(otr) >= 1
+    for name in tr.dtype.names:
+        assert np.array_equal(tr[name], otr[name]), name
+    assert np.any(tr["weight_total"] > 0)                      # at least one update of the full filter was compared
+    assert (stats[0].count, stats[0].mean) == (ostats[0].count, ostats[0].mean)
+    c = eng.counters()
+    assert (c.sim_steps, c.belief_steps) == (res.sim_steps, res.belief_steps)
+
+
+@pytest.mark.parametrize("belief", ["rejection_sampling", "importance_sampling"])
+def test_c2_full_size_experiment_equals_the_oracle(belief):
+    """BASELINE configs[1] -- the bench workload -- at its own sizes (episodic tiger BA-POMCP, 4096 simulations, 4096
+    particles, packed records): six runs of three episodes, every trace field of every real step against the oracle."""
+    from oracle import pyorc as orc
+    kw = dict(model=N.MODEL_BA_TABLE, sims=4096, particles=4096, horizon=10, episodes=3, runs=6)
+    eng = fba.Engine("episodic-tiger", belief=belief, seed=20261003, slots=6, trace=1, **kw)
+    assert eng.particle_bytes == 64
+    o = orc.Oracle(domain=orc.DOM_TIGER_EPISODIC, belief=N.BELIEF_NAMES[belief], rng_mode=orc.RNG_PHILOX, arith=orc.ARITH_DEV,
+                   philox_seed=20261003, trace=1, **kw)
+    stats = eng.run_bapomdp()
+    ostats, res = o.run_bapomdp()
+    tr, otr = eng.trace(), o.trace(res.n_trace)
+    assert len(tr) == len(otr) > 18
+    for name in tr.dtype.names:
+        assert np.array_equal(tr[name], otr[name]), name
+    for a, b in zip(stats, ostats):
+        assert (a.count, a.mean, a.m2) == (b.count, b.mean, b.m2)
+    c = eng.counters()
+    assert (c.sim_steps, c.belief_steps, c.env_steps) == (res.sim_steps, res.belief_steps, res.env_steps)

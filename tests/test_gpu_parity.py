@@ -345,17 +345,17 @@ def test_edge_sizes(kw):
 
 
 def test_c3_size_one_search_and_update():
-    """BASELINE configs[2] sizes: factored tiger (K = 3), 16384 simulations, match-uniform structure
-    prior; one selectAction + one updateEstimation per slot, compared with the oracle."""
-    kw = dict(size=3, particles=1024, sims=16384, structure_prior=2)
-    eng = fba.Engine("episodic-factored-tiger", model=N.MODEL_BA_FACTORED, seed=111, slots=2, **kw)
+    """BASELINE configs[2] at its own sizes: factored tiger (K = 3), 16384 simulations, 4096 particles, match-uniform
+    structure prior; one selectAction + one updateEstimation per slot, eight slots, compared with the oracle."""
+    kw = dict(size=3, particles=4096, sims=16384, structure_prior=2)
+    eng = fba.Engine("episodic-factored-tiger", model=N.MODEL_BA_FACTORED, seed=111, slots=8, **kw)
     L = orc.lib()
     eng.belief_init()
     eng.belief_reset_domain_state()
     acts = eng.select_action(hist_len=0)
     info = eng.last_step_info()
     eng.belief_update(2, 1)
-    for e in range(2):
+    for e in range(8):
         o = orc.Oracle(domain=orc.DOM_FTIGER_EPISODIC, model=orc.MODEL_BA_FACTORED, rng_mode=orc.RNG_PHILOX,
                        arith=orc.ARITH_DEV, philox_seed=111, **kw)
         L.orc_rng_episode(o.rng, e, 0, 0)
