@@ -185,8 +185,9 @@ def load():
     L.fba_belief_get.argtypes = [vp, C.c_int32, vp, vp, vp]
     L.fba_belief_set.argtypes = [vp, C.c_int32, vp, vp, vp]
     L.fba_belief_get_fully_connected.argtypes = [vp, C.c_int32, vp, vp]
-    L.fba_belief_get_nested.argtypes = [vp, C.c_int32, vp]
-    L.fba_belief_get_shadow.argtypes = [vp, C.c_int32, vp, vp, vp]
+    if not os.environ.get("FBA_LIB") or hasattr(L, "fba_belief_get_nested"):   # (FBA_LIB may name an older build for an A/B run)
+        L.fba_belief_get_nested.argtypes = [vp, C.c_int32, vp]
+        L.fba_belief_get_shadow.argtypes = [vp, C.c_int32, vp, vp, vp]
     L.fba_last_step_info.argtypes = [vp, vp]
     L.fba_run_planning.argtypes = [vp, P(Stat)]
     L.fba_run_bapomdp.argtypes = [vp, P(Stat)]

@@ -306,48 +306,6 @@ __device__ __forceinline__ int ucb_select(const Problem& P, const DeviceState& D
     return ucb_pick<AMAX>(P, g, explore ? D.log1p_tab[visits] : 0.0, cn, cq, explore);
 }
 
-// ucb_select for a node a simulation passes through on its way down: every such node is backed up exactly once
-// before anybody reads it again (the tree belongs to one lane), so ActionNode::addVisit and the chosen action's
-// visit count (MCTSTreeNodes.cpp:59-62, :8-12) are written here, from the header this function has just loaded, and
-// the back-up is left with Q alone: it gets the count to divide by and the old Q value, and needs no load.
-template <int AMAX, class RNG>
-__device__ __forceinline__ int ucb_select_visit(const Problem& P, const DeviceState& D, RNG& g, int32_t* rec, int& n_new, double& q_old)
-{
-    int cn[AMAX];
-    double cq[AMAX];
-    int visits;
-    if (AMAX >= 3 && P.A == 3) {
-        const int4 pre    = *reinterpret_cast<const int4*>(rec);
-        const double2 q01 = *reinterpret_cast<const double2*>(rec + 4);
-        const double q2   = *reinterpret_cast<const double*>(rec + 8);
-        visits = pre.x;
-#pragma unroll
-        for (int a = 0; a < AMAX; ++a) { cn[a] = 0; cq[a] = 0.0; }
-        cn[0] = pre.y; cn[1] = pre.z; cn[2] = pre.w;
-        cq[0] = q01.x; cq[1] = q01.y; cq[2] = q2;
-    } else {
-        const double* q = reinterpret_cast<const double*>(rec + D.cq_off);
-        visits = rec[0];
-#pragma unroll
-        for (int a = 0; a < AMAX; ++a) {
-            cn[a] = a < P.A ? rec[1 + a] : 0;
-            cq[a] = a < P.A ? q[a] : 0.0;
-        }
-    }
-    const int act = ucb_pick<AMAX>(P, g, D.log1p_tab[visits], cn, cq, true);
-    n_new = 0; q_old = 0.0;
-#pragma unroll
-    for (int a = 0; a < AMAX; ++a)
-        if (a == act) { n_new = cn[a] + 1; q_old = cq[a]; }
-    if (AMAX >= 3 && P.A == 3) {
-        *reinterpret_cast<int4*>(rec) = make_int4(visits + 1, cn[0] + (act == 0), cn[1] + (act == 1), cn[2] + (act == 2));
-    } else {
-        rec[0]       = visits + 1;
-        rec[1 + act] = n_new;
-    }
-    return act;
-}
-
 // ---------------------------------------------------------------------------------------------
 // search_kernel: one lane = one slot = one tree; `sims` simulations, sequential semantics.
 // POUCT::selectAction POUCT.cpp:63-129, RBAPOUCT::selectAction RBAPOUCT.cpp:67-153 (the root
@@ -487,10 +445,6 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
     int s = 0, node = 0, dtg = 0, plen = 0, rdepth = 0;
     const float* cnt = prec;
     double rret = 0, rdisc = 1;
-    int st_n[BACKUP_STASH];
-    double st_q[BACKUP_STASH];
-#pragma unroll
-    for (int j = 0; j < BACKUP_STASH; ++j) { st_n[j] = 0; st_q[j] = 0.0; }
 #ifdef FBA_PROFILE_SEARCH
     long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prev_ = clock64();
 #endif
@@ -505,12 +459,22 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
             if (STAGE) {
                 const float4* rp = reinterpret_cast<const float4*>(cnt);
                 const int n4 = (P.C + 4) >> 2;  // counts and the state word; the padding behind them is not needed
-                for (int k = 0; k < n4; ++k) {
-                    const float4 v = rp[k];
-                    stage[(4 * k + 0) * SEARCH_BLOCK] = v.x;
-                    stage[(4 * k + 1) * SEARCH_BLOCK] = v.y;
-                    stage[(4 * k + 2) * SEARCH_BLOCK] = v.z;
-                    stage[(4 * k + 3) * SEARCH_BLOCK] = v.w;
+                // four 16-byte loads in flight before the first of them is waited for: with a trip count the compiler does not
+                // know, a load-then-store loop is one trip to memory per 16 bytes (C3: nine in a row, 42 % of the kernel)
+                for (int k0 = 0; k0 < n4; k0 += 4) {
+                    float4 v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = rp[min(k0 + q, n4 - 1)];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int k = k0 + q;
+                        if (k < n4) {
+                            stage[(4 * k + 0) * SEARCH_BLOCK] = v[q].x;
+                            stage[(4 * k + 1) * SEARCH_BLOCK] = v[q].y;
+                            stage[(4 * k + 2) * SEARCH_BLOCK] = v[q].z;
+                            stage[(4 * k + 3) * SEARCH_BLOCK] = v[q].w;
+                        }
+                    }
                 }
                 s = __float_as_int(stage[P.C * SEARCH_BLOCK]);
             } else {
@@ -528,14 +492,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
             tree_depth = max(tree_depth, max_tree_depth - dtg);
             if (dtg == 0) { finish = true; do_step = false; }
             else if (node == 0) a = ucb_pick<AMAX>(P, g, root_L, r_cn, r_cq, true);
-            else {
-                int vn;
-                double vq;
-                a = ucb_select_visit<AMAX>(P, D, g, tree + (size_t)node * W, vn, vq);
-#pragma unroll
-                for (int j = 0; j < BACKUP_STASH; ++j)
-                    if (plen - 1 == j) { st_n[j] = vn; st_q[j] = vq; }
-            }
+            else a = ucb_select<AMAX>(P, D, g, tree + (size_t)node * W, true);
         } else {          // rollout: uniformly random action
             a = domain_random_action(P, g, s);
         }
@@ -611,21 +568,20 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
                     ++r_vis;
                     root_L = D.log1p_tab[r_vis];
                 } else {
-                    // (the visit counts were written on the way down, ucb_select_visit; what is left is Q.  The first
-                    // BACKUP_STASH levels below the root kept {count, old Q} in registers: no load on this path)
                     int32_t* rec = tree + (size_t)(na >> 5) * W;
                     double* q    = reinterpret_cast<double*>(rec + D.cq_off) + act;
-                    int n        = 0;
-                    double qo    = 0.0;
-                    if (k - 1 < BACKUP_STASH) {
-#pragma unroll
-                        for (int j = 0; j < BACKUP_STASH; ++j)
-                            if (k - 1 == j) { n = st_n[j]; qo = st_q[j]; }
+                    int n;
+                    if (P.A == 3) {  // {visits, n0, n1, n2} is one 16-byte word: one load, one store
+                        int4* hp = reinterpret_cast<int4*>(rec);
+                        int4 h   = *hp;
+                        n = act == 0 ? ++h.y : (act == 1 ? ++h.z : ++h.w);
+                        ++h.x;
+                        *hp = h;
                     } else {
-                        n  = rec[1 + act];
-                        qo = *q;
+                        n = ++rec[1 + act];
+                        ++rec[0];
                     }
-                    *q = qo + (ret - qo) / (double)n;
+                    *q += (ret - *q) / (double)n;
                 }
                 del = ret;
             }
@@ -723,7 +679,11 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, De
     int node = 0, dtg = 0, plen = 0, rdepth = 0;
     uint32_t sp = 0, hist_mask = 0;
     double rret = 0, rdisc = 1;
+#ifdef FBA_PROFILE_SEARCH
+    long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prev_ = clock64();
+#endif
     while (true) {
+        PROF_MARK(6)
         if (mode == 0) {
             if (sim >= P.sims) break;
             g.stream(FBA_PHASE_SEARCH, (uint32_t)sim);
@@ -731,23 +691,35 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, De
             const int src = ts_src >= 0 ? ts_src : uniform_weight_pick(D.uni_scan, P.N, g.u01() * D.uni_total, D.uni_total);
             const uint4* rp = reinterpret_cast<const uint4*>(prec + (size_t)src * P.Cs);
             const int n4 = (hist_n + 5) >> 2;  // state, structure bits, entries
-            for (int k = g.q; k < n4; k += HIST_QUAD) {
-                const uint4 v = rp[k];
-                stage[(4 * k + 0) * HIST_TREES] = v.x;
-                stage[(4 * k + 1) * HIST_TREES] = v.y;
-                stage[(4 * k + 2) * HIST_TREES] = v.z;
-                stage[(4 * k + 3) * HIST_TREES] = v.w;
+            for (int k0 = g.q; k0 < n4; k0 += 4 * HIST_QUAD) {   // (four loads in flight per lane, as in search_kernel)
+                uint4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = rp[min(k0 + q * HIST_QUAD, n4 - 1)];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int k = k0 + q * HIST_QUAD;
+                    if (k < n4) {
+                        stage[(4 * k + 0) * HIST_TREES] = v[q].x;
+                        stage[(4 * k + 1) * HIST_TREES] = v[q].y;
+                        stage[(4 * k + 2) * HIST_TREES] = v[q].z;
+                        stage[(4 * k + 3) * HIST_TREES] = v[q].w;
+                    }
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the other lanes' pieces (LDS operations of one wave complete in order)
             hist_mask = stage[1 * HIST_TREES];
             sp        = (hist_mask >> 16) & 0x3ffu;
             node = 0; dtg = max_tree_depth; plen = 0; mode = 1;
         }
+        PROF_MARK(0)
         bool finish = false, do_step = true;
         double delayed = 0;
         int a = 0;
         if (mode == 1 && dtg == 0) { finish = true; do_step = false; }
         if (mode == 1) tree_depth = max(tree_depth, max_tree_depth - dtg);
+        int o = 0;
+        double r = 0;
+        bool term = false;
         if (do_step) {
             g.ensure(7);  // the action, six rows
             if (mode == 1) {  // traverseActionNode
@@ -756,11 +728,19 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, De
             } else {
                 a = g.slow_int(0, 4);  // GridWorld::generateRandomAction :220-226
             }
-            int o;
-            double r;
-            const bool term = gridworld_hist_step_quad<K, HIST_TREES>(P, g, stage + (size_t)(2 + ((hist_off >> (8 * a)) & 0xffu)) * HIST_TREES,
-                                                                      hist_count(hist_cnt, a), hist_mask, sp, a, o, r);
+#ifdef FBA_PROFILE_SEARCH
+        }
+        PROF_MARK(1)
+        if (do_step) {
+#endif
+            term = gridworld_hist_step_quad<K, HIST_TREES>(P, g, stage + (size_t)(2 + ((hist_off >> (8 * a)) & 0xffu)) * HIST_TREES,
+                                                           hist_count(hist_cnt, a), hist_mask, sp, a, o, r);
             ++steps;
+#ifdef FBA_PROFILE_SEARCH
+        }
+        PROF_MARK(2)
+        if (do_step) {
+#endif
             if (mode == 1) {  // traverseChanceNode
                 path_r[(size_t)plen * HIST_TREES]  = (float)r;
                 path_na[(size_t)plen * HIST_TREES] = (node << 5) | a;
@@ -785,6 +765,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, De
                 if (rdepth == 0 || term) { delayed = rret; finish = true; }
             }
         }
+        PROF_MARK(3)
         if (finish) {  // back-up, leaf to root (MCTSTreeNodes.cpp:8-12, 59-62)
             double del = delayed;
             for (int k = plen - 1; k >= 0; --k) {
@@ -816,7 +797,15 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, De
             ++sim;
             mode = 0;
         }
+        PROF_MARK(4)
+#ifdef FBA_PROFILE_SEARCH
+        prof_[5] += 1;
+#endif
     }
+#ifdef FBA_PROFILE_SEARCH
+    if (lane == 0)
+        for (int r2 = 0; r2 < 8; ++r2) atomicAdd(&g_search_prof[r2], (unsigned long long)prof_[r2]);
+#endif
     g.stream(FBA_PHASE_SEARCH, (uint32_t)P.sims + 1u);
     g.ensure(1);
     if (n_nodes > D.max_nodes) atomicCAS(D.fault, 0, -(1 + e));

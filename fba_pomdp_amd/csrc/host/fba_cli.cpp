@@ -59,7 +59,8 @@ void usage()
         "  -u, --exploration-constant X   UCB exploration constant (100)\n"
         "      --particle-amount N        particles in the filter (100)\n"
         "      --resample-amount N        particles reinvigorated per belief update (reinvigoration beliefs)\n"
-        "      --threshold X              cheating-reinvigoration / mh-within-gibbs: log likelihood below which the belief is repaired (< 0)\n"
+        "      --threshold X              cheating-reinvigoration / mh-within-gibbs / mh-nips: log likelihood below which the belief is repaired (< 0);\n"
+        "                                 incubator: normalised weight above which a shadow particle is promoted (0 < X <= 1)\n"
         "      --belief-option rs         mh-within-gibbs: state histories by rejection sampling instead of message passing\n"
         "  -D, --domain NAME              episodic-tiger, continuous-tiger, episodic-factored-tiger,\n"
         "                                 continuous-factored-tiger, gridworld, random-collision-avoidance,\n"
@@ -178,6 +179,10 @@ bool to_config(Options const& o, fba_config& c, std::string& err)
     if ((o.resample_amount == 0) ^ (o.belief != "reinvigoration" && o.belief != "cheating-reinvigoration" && o.belief != "incubator")) {  // BeliefConf.cpp:40-49
         err = "You have set the resample amount (" + std::to_string(o.resample_amount) + "), but are not using one of the beliefs (" + o.belief +
               ") that use it: reinvigoration, cheating-reinvigoration and incubator";
+        return false;
+    }
+    if (!o.belief_option.empty() && o.belief != "mh-within-gibbs") {  // BeliefConf.cpp:51-56
+        err = "You have set the illegal belief_option '" + o.belief_option + "' with belief " + o.belief + ".";
         return false;
     }
     c.resample_amount = o.resample_amount;

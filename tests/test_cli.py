@@ -95,3 +95,31 @@ def test_cli_bapomdp_and_fbapomdp_write_one_line_per_episode(cli, tmp_path):
     assert r.returncode == 1 and "planning only" in r.stderr
     r = subprocess.run([cli, "bapomdp", "-D", "episodic-tiger", "--noise", "0.9"], capture_output=True, text=True)
     assert r.returncode == 1 and "noise has to be between" in r.stderr      # TigerPriors.cpp:22-25
+
+
+@pytest.mark.gpu
+def test_cli_structure_beliefs_of_round_two(cli, tmp_path):
+    """-B mh-within-gibbs [--belief-option rs] / mh-nips / incubator / nested through the reference's command line
+    (BABelief.cpp:33-70, BeliefConf.cpp:40-56)."""
+    common = ["-s", "48", "--runs", "3", "--episodes", "2", "-H", "6"]
+    for name, args in (
+            ("mh", ["fbapomdp", "-D", "continuous-factored-tiger", "--size", "2", "-B", "mh-within-gibbs", "--threshold", "-1", "--particle-amount", "24"]),
+            ("mhrs", ["fbapomdp", "-D", "continuous-factored-tiger", "--size", "2", "-B", "mh-within-gibbs", "--belief-option", "rs", "--threshold", "-1",
+                      "--particle-amount", "24"]),
+            ("nips", ["fbapomdp", "-D", "random-collision-avoidance", "--width", "3", "--height", "3", "--size", "1", "-B", "mh-nips", "--threshold", "-2",
+                      "--particle-amount", "16"]),
+            ("incub", ["fbapomdp", "-D", "episodic-factored-tiger", "--size", "2", "-B", "incubator", "--resample-amount", "4", "--threshold", "0.5",
+                       "--particle-amount", "24"]),
+            ("nested", ["bapomdp", "-D", "episodic-tiger", "-B", "nested", "--particle-amount", "6"]),
+            ("nestedf", ["fbapomdp", "-D", "gridworld", "--size", "3", "-B", "nested", "--particle-amount", "5"])):
+        out = tmp_path / (name + ".res")
+        r = subprocess.run([cli] + args + common + ["-f", str(out)], capture_output=True, text=True)
+        assert r.returncode == 0, (name, r.stderr)
+        assert len([l for l in out.read_text().splitlines() if l and not l.startswith("#")]) == 2
+    for args, msg in ((["fbapomdp", "-D", "episodic-factored-tiger", "--size", "2", "-B", "incubator", "--threshold", "0.5"], "resample amount"),
+                      (["fbapomdp", "-D", "episodic-factored-tiger", "--size", "2", "-B", "incubator", "--resample-amount", "4", "--particle-amount", "24"],
+                       "must initiate with 1 < threshold <= 0"),
+                      (["fbapomdp", "-D", "episodic-factored-tiger", "--size", "2", "-B", "mh-nips", "--belief-option", "rs", "--threshold", "-1"], "belief_option"),
+                      (["planning", "-D", "episodic-tiger", "-B", "nested"], "legit state stimator")):
+        r = subprocess.run([cli] + args, capture_output=True, text=True)
+        assert r.returncode == 1 and msg in r.stderr, (args, r.stderr)
