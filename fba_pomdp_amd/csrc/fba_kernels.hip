@@ -968,17 +968,27 @@ __device__ __forceinline__ void gather_records(float* __restrict__ dst, const fl
         const int t      = s_owner ? s_owner[j] : j;
         const float4* sp = reinterpret_cast<const float4*>(src) + (size_t)s_src[t] * C4;
         float4* dp       = reinterpret_cast<float4*>(dst) + (size_t)j * C4;
-        if (ninc == 0 && !s_state && C4 > 4 * group) {
-            // a plain copy of a record of many pieces (the resample of 3.5 KB collision-avoidance particles): four loads in
-            // flight per lane before the first store
+        if (C4 > group) {
+            // a record of several pieces per lane (the 3.5 KB collision-avoidance particles, dense gridworld ones): four loads
+            // in flight per lane before the first is waited for -- piece by piece, every load also waits for the store
+            // before it (vmcnt counts both)
             for (int part = part0; part < C4; part += 4 * group) {
                 float4 v[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (part + q * group < C4) v[q] = sp[part + q * group];
+                for (int q = 0; q < 4; ++q) v[q] = sp[min(part + q * group, C4 - 1)];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (part + q * group < C4) dp[part + q * group] = v[q];
+                for (int q = 0; q < 4; ++q) {
+                    const int pq = part + q * group;
+                    if (pq >= C4) continue;
+                    const int lo = pq * 4;
+                    for (int k = 0; k < ninc; ++k) bump_cell(v[q], s_inc[k * inc_stride + t], lo, packed);
+                    if (s_state) {  // new domain state in word C
+                        const int d = C - lo;
+                        const float f = __int_as_float(s_state[t]);
+                        if (d == 0) v[q].x = f; else if (d == 1) v[q].y = f; else if (d == 2) v[q].z = f; else if (d == 3) v[q].w = f;
+                    }
+                    dp[pq] = v[q];
+                }
             }
             continue;
         }
