@@ -13,7 +13,7 @@ constexpr int ROOT_CHILDREN = 8;        // root child pointers are kept in LDS w
 constexpr int REJECT_BLOCK  = 256;   // attempts per chunk of the rejection filter
 constexpr int TIGER_LDS_MAX_N = 4096;  // reject_tiger_lds_kernel: filters up to this many packed tiger particles are parked in LDS
 constexpr int REJECT_MAX_ATTEMPTS = 1 << 28;  // per update: beyond this the observation is taken to be impossible under the filter
-constexpr int IS_BLOCK      = 1024;  // one workgroup per slot in the importance filter
+constexpr int IS_BLOCK      = 512;   // one workgroup per slot in the importance filter (same-box A/B on the bench shape: 1024 -> 37.3 ms, 512 -> 31.1, 256 -> 32.3: three workgroups per CU overlap their barrier-separated phases)
 constexpr int PARTICLE_TILE = 4096;  // particles one workgroup initialises / resets
 constexpr int CARRY_TILE    = 2048;  // chunk totals staged in LDS per step of the carry chain
 constexpr int IS_MAX_CHUNKS = 256;   // 256-element scan chunks per slot => N <= 65536
