@@ -1125,9 +1125,9 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         // computePriorModel and mutate and a fully enumerable state space: factored tiger, collision avoidance
         const bool nips  = cfg->belief == FBA_BELIEF_MH_NIPS;
         const char* name = nips ? "MHNIPS2018" : "MHwithinGibbs";
-        if (cfg->model != FBA_MODEL_BA_FACTORED || !(is_ftiger(cfg->domain) || is_ca(cfg->domain)) || cfg->dirichlet_regular ||
+        if (cfg->model != FBA_MODEL_BA_FACTORED || !(is_ftiger(cfg->domain) || is_ca(cfg->domain) || cfg->domain == FBA_DOM_GRIDWORLD) || cfg->dirichlet_regular ||
             (is_ca(cfg->domain) && cfg->structure_prior == FBA_SP_FULLY_CONNECTED)) {
-            fail(nullptr, FBA_EINVAL, "%s belief: built for the factored-tiger and collision-avoidance FBA-POMDPs (fbapomdp), expected Dirichlet mode",
+            fail(nullptr, FBA_EINVAL, "%s belief: built for the factored-tiger, collision-avoidance and gridworld FBA-POMDPs (fbapomdp), expected Dirichlet mode",
                  nips ? "mh-nips" : "mh-within-gibbs");
             delete c;
             return FBA_EINVAL;

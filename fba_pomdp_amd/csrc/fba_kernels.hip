@@ -1506,7 +1506,11 @@ __device__ void mh_increment(const Problem& P, float* cnt, int s, int a, int o, 
 __device__ void mh_compute_prior(const Problem& P, const DeviceState& D, const uint32_t* masks, float* out)
 {
     for (int k = 0; k < P.C; ++k) out[k] = D.prior[k];
-    if (dom_is_ca(P.domain)) {
+    if (dom_is_grid(P.domain)) {  // GridWorldFactBAPrior::computePriorModel (GridWorldBAPriors.cpp:227-254)
+        for (int a = 0; a < P.A; ++a)
+            for (int f = 0; f < 2; ++f)
+                if (masks[P.fd->nodes[a * 3 + f].var] == 7u) gw_fill_xy_node_with_goal(P, out, a, f);
+    } else if (dom_is_ca(P.domain)) {
         const int n = P.ca->n;
         for (int f = 2; f < P.fd->FS; ++f)
             for (int a = 0; a < P.A; ++a) ca_fill_obstacle_node(P, out, a, f, masks[a * n + (f - 2)]);
@@ -1519,7 +1523,11 @@ __device__ void mh_compute_prior(const Problem& P, const DeviceState& D, const u
 // draws an action and an obstacle, then flips a random edge of that transition node
 __device__ void mh_mutate(const Problem& P, Rng& g, uint32_t* masks)
 {
-    if (dom_is_ca(P.domain)) {
+    if (dom_is_grid(P.domain)) {  // GridWorldFactBAPrior::mutate (GridWorldBAPriors.cpp:200-225): an action, the x or the y node, the goal edge toggled
+        const int a = g.slow_int(0, P.A);
+        const int f = g.slow_int(0, 2);
+        masks[P.fd->nodes[a * 3 + f].var] ^= 4u;
+    } else if (dom_is_ca(P.domain)) {
         const int n  = P.ca->n;
         const int a  = g.uniform_int(P.A);
         const int ob = g.uniform_int(n);

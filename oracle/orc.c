@@ -2381,7 +2381,17 @@ static void mh_structure_of(const orc_ctx* c, const float* cnt, uint32_t* masks)
 static void mh_compute_prior(orc_ctx* c, const uint32_t* masks, float* out)
 {
     memcpy(out, c->prior, sizeof(float) * (size_t)c->ncnt);
-    if (is_ca(c->cfg.domain)) {
+    if (is_grid(c->cfg.domain)) { /* GridWorldFactBAPrior::computePriorModel (GridWorldBAPriors.cpp:227-254): setNoisyTransitionNode where the goal is a parent */
+        int a, f;
+        for (a = 0; a < c->A; ++a)
+            for (f = 0; f < 2; ++f) {
+                int var = c->fd.T[a * 3 + f].var;
+                if (masks[var] == 7u) {
+                    gw_fill_xy_node(c, out, a, f, 1);
+                    out[c->fd.ncounts + var] = u2f(7u);
+                }
+            }
+    } else if (is_ca(c->cfg.domain)) {
         int a, f;
         for (f = 2; f < c->fd.FS; ++f)
             for (a = 0; a < c->A; ++a) ca_fill_obstacle_node(c, out, a, f, masks[a * c->ca_n + (f - 2)]);
@@ -2394,7 +2404,11 @@ static void mh_compute_prior(orc_ctx* c, const uint32_t* masks, float* out)
  * an action, an obstacle, then flip_random_edge of that transition node */
 static void mh_mutate(orc_ctx* c, uint32_t* masks)
 {
-    if (is_ca(c->cfg.domain)) {
+    if (is_grid(c->cfg.domain)) { /* GridWorldFactBAPrior::mutate (GridWorldBAPriors.cpp:200-225): an action, the x or the y node, the goal edge toggled */
+        int a = orc_slow_int(&c->rng, 0, c->A);
+        int f = orc_slow_int(&c->rng, 0, 2);
+        masks[c->fd.T[a * 3 + f].var] ^= 4u;
+    } else if (is_ca(c->cfg.domain)) {
         int a  = orc_int(&c->rng, c->A);
         int ob = orc_int(&c->rng, c->ca_n);
         masks[a * c->ca_n + ob] ^= 1u << orc_slow_int(&c->rng, 0, c->fd.FS);
@@ -3123,9 +3137,9 @@ orc_ctx* orc_create(const orc_config* cfg)
     if (is_mh(c)) {
         int cap = cfg->episodes * cfg->horizon;
         const char* name = cfg->belief == ORC_BELIEF_MH_NIPS ? "MHNIPS2018" : "MHwithinGibbs";
-        if (cfg->model != ORC_MODEL_BA_FACTORED || !(is_ftiger(cfg->domain) || is_ca(cfg->domain)) || cfg->dirichlet_regular ||
+        if (cfg->model != ORC_MODEL_BA_FACTORED || !(is_ftiger(cfg->domain) || is_ca(cfg->domain) || is_grid(cfg->domain)) || cfg->dirichlet_regular ||
             (is_ca(cfg->domain) && cfg->structure_prior == ORC_SP_FULLY_CONNECTED) || c->fd.nvar > MH_MAXVAR) {
-            snprintf(c->err, sizeof c->err, "%s belief: built for the factored-tiger and collision-avoidance FBA-POMDPs (fbapomdp), expected Dirichlet mode",
+            snprintf(c->err, sizeof c->err, "%s belief: built for the factored-tiger, collision-avoidance and gridworld FBA-POMDPs (fbapomdp), expected Dirichlet mode",
                      cfg->belief == ORC_BELIEF_MH_NIPS ? "mh-nips" : "mh-within-gibbs");
             return c;
         }

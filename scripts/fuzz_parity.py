@@ -66,11 +66,14 @@ def draw(rng):
             belief = "cheating-reinvigoration"
             kw["resample_amount"] = rng.choice([1, 5])
             kw["threshold"] = rng.choice([-0.3, -2.0, -50.0])
-        elif b < 0.6 and ("factored-tiger" in domain or "collision" in domain) and kw["particles"] <= 64:
+        elif b < 0.6 and ("factored-tiger" in domain or "collision" in domain or domain == "gridworld") and kw["particles"] <= 64:
             belief = rng.choice(["mh-within-gibbs", "mh-nips"])
             kw["threshold"] = rng.choice([-0.3, -2.0, -50.0])
             if belief == "mh-within-gibbs":
                 kw["belief_option"] = rng.choice([0, 1])
+            if domain == "gridworld" and (belief == "mh-nips" or kw.get("belief_option") == 1):
+                kw["horizon"] = min(kw["horizon"], 2)   # forward-sampled histories must reproduce every observation of an episode
+                kw["max_depth"] = min(kw["max_depth"], 2)
     if model != N.MODEL_POMDP and belief in ("rejection_sampling", "importance_sampling") and rng.random() < 0.12:
         belief = "nested"            # NestedBelief: `particles` count particles, particles^2 domain states each
         kw["particles"] = rng.choice([1, 3, 8, 14])

@@ -34,19 +34,29 @@ def test_random_mh_belief_configurations_match_the_oracle():
     rng = random.Random(77)
     ran = 0
     for i in range(40):
-        domain = rng.choice(["episodic-factored-tiger", "continuous-factored-tiger", "random-collision-avoidance", "centered-collision-avoidance"])
+        domain = rng.choice(["episodic-factored-tiger", "continuous-factored-tiger", "random-collision-avoidance", "centered-collision-avoidance", "gridworld"])
         belief = rng.choice(["mh-within-gibbs", "mh-nips"])
         kw = dict(particles=rng.choice([1, 5, 24, 50]), sims=rng.choice([4, 30, 90]), horizon=rng.choice([2, 5, 9]),
                   runs=rng.choice([1, 3]), episodes=rng.choice([1, 2, 4]), structure_prior=rng.choice([0, 1, 2, 3]),
                   threshold=rng.choice([-0.2, -1.0, -6.0]), noise=rng.choice([0.0, 0.1]), discount=rng.choice([0.7, 0.95]))
         if "tiger" in domain:
             kw["size"] = rng.choice([1, 2, 3])
+        elif domain == "gridworld":
+            kw["size"] = rng.choice([3, 4])
+            kw["particles"] = 64                  # (a filter without the true goal can never be updated)
+            kw["structure_prior"] = rng.choice([0, 2])
+            kw["horizon"] = min(kw["horizon"], 5)
+            kw["episodes"] = min(kw["episodes"], 2)
+            if belief == "mh-nips":
+                kw["horizon"] = 2                 # (forward-sampled histories: see test_fbapomdp_mh_beliefs)
         else:
             kw["width"], kw["height"], kw["size"] = rng.choice([(3, 3, 1), (4, 3, 2), (3, 5, 1)])
             if kw["structure_prior"] == 3:
                 kw["structure_prior"] = 2   # (no fully connected prior for the MH beliefs: refused)
         if belief == "mh-within-gibbs":
             kw["belief_option"] = rng.choice([0, 1])
+            if domain == "gridworld" and kw["belief_option"] == 1:
+                kw["horizon"] = 2
         slots = rng.choice([1, kw["runs"]])
         try:
             fuzz.one(domain, N.MODEL_BA_FACTORED, belief, slots, kw, seed=4000 + i)
