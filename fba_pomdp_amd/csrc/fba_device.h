@@ -1684,6 +1684,47 @@ __device__ __forceinline__ void sys_fill_fully_connected(const Problem& P, float
         }
 }
 
+// SysAdminFactoredPrior::computeFailureProbability (SysAdminFactoredPrior.cpp:279-353) for computer `comp` under action a,
+// parents = the features in `mask` (ascending), their values = the bits of row r (last parent fastest)
+__device__ __forceinline__ float sys_failure_probability(const Problem& P, int a, int comp, uint32_t mask, int r, int np)
+{
+    const int N = P.sys->N;
+    const bool rebooting = a == N + comp;
+    int own = -1, nfn = 0, j = 0;
+    for (int k = 0; k < N; ++k)
+        if ((mask >> k) & 1u) {
+            const int v = (r >> (np - 1 - j)) & 1;
+            if (k == comp) own = v;
+            if (P.domain == FBA_DOM_SYSADMIN_LINEAR && (k == comp - 1 || k == comp + 1) && v == 0) ++nfn;
+            ++j;
+        }
+    if (own == 0) return rebooting ? 1 - .95f : 1;
+    double fail = 1 - P.sys->keep[nfn];
+    if (rebooting) fail *= (1 - .95f);
+    if (own < 0) {  // the computer is not its own input
+        fail += rebooting ? (1 - .95f) : 1;
+        fail *= .5;
+    }
+    return (float)fail;
+}
+// one transition node of SysAdminFactoredPrior::computePriorModel (:98-127) for parent set `mask`: every parent-value row gets
+// {total * p, total * 1 - p} -- the reference's own precedence: total minus p
+__device__ __forceinline__ void sys_fill_node(const Problem& P, float* rec, int a, int f, uint32_t mask)
+{
+    const FDesc* fd = P.fd;
+    const int N = P.sys->N, np = __popc(mask);
+    const FNode& nd = fd->nodes[a * N + f];
+    const float total = P.counts_total;
+    float* base = rec + nd.off;
+    for (int r = 0; r < (1 << np); ++r) {
+        const float p = sys_failure_probability(P, a, f, mask, r, np);
+        base[2 * r + 0] = total * p;
+        base[2 * r + 1] = total * 1 - p;
+    }
+    for (int k = 2 << np; k < (2 << N); ++k) base[k] = 0.f;
+    rec[fd->ncounts + nd.var] = __uint_as_float(mask);
+}
+
 __device__ __forceinline__ void factored_prior_sample(const Problem& P, Rng& g, float* rec)
 {
     if (dom_is_sys(P.domain)) return;  // fixed structures only

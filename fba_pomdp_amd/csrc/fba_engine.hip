@@ -603,7 +603,8 @@ int build_sysadmin_factored_prior(fba_ctx* c)
     Problem& P = c->P;
     const int A = P.A, N = c->sysdesc.N;
     const bool linear = P.domain == FBA_DOM_SYSADMIN_LINEAR;
-    const bool reinvig = c->cfg.belief == FBA_BELIEF_REINVIGORATION || c->cfg.belief == FBA_BELIEF_INCUBATOR;
+    const bool reinvig = c->cfg.belief == FBA_BELIEF_REINVIGORATION || c->cfg.belief == FBA_BELIEF_INCUBATOR ||
+                         c->cfg.belief == FBA_BELIEF_MH_GIBBS || c->cfg.belief == FBA_BELIEF_MH_NIPS;   // particles with structures of their own
     if (c->cfg.structure_prior != FBA_SP_NONE) return fail(c, FBA_EINVAL, "Structure noise is not enabled for the Sysadmin problem");
     if (N > MAXF || A * (N + 1) > MAXNODES) return fail(c, FBA_EINVAL, "too many state features");
     FDesc& d = c->fdesc;
@@ -1125,10 +1126,18 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         // computePriorModel and mutate and a fully enumerable state space: factored tiger, collision avoidance
         const bool nips  = cfg->belief == FBA_BELIEF_MH_NIPS;
         const char* name = nips ? "MHNIPS2018" : "MHwithinGibbs";
-        if (cfg->model != FBA_MODEL_BA_FACTORED || !(is_ftiger(cfg->domain) || is_ca(cfg->domain) || cfg->domain == FBA_DOM_GRIDWORLD) || cfg->dirichlet_regular ||
+        if (cfg->model != FBA_MODEL_BA_FACTORED || cfg->dirichlet_regular ||
+            !(is_ftiger(cfg->domain) || is_ca(cfg->domain) || cfg->domain == FBA_DOM_GRIDWORLD || is_sys(cfg->domain)) ||
             (is_ca(cfg->domain) && cfg->structure_prior == FBA_SP_FULLY_CONNECTED)) {
-            fail(nullptr, FBA_EINVAL, "%s belief: built for the factored-tiger, collision-avoidance and gridworld FBA-POMDPs (fbapomdp), expected Dirichlet mode",
-                 nips ? "mh-nips" : "mh-within-gibbs");
+            fail(nullptr, FBA_EINVAL, "%s belief: needs a factored model (fbapomdp) in the expected Dirichlet mode, at most %d structure words per particle",
+                 nips ? "mh-nips" : "mh-within-gibbs", MH_MAXVAR);
+            delete c;
+            return FBA_EINVAL;
+        }
+        if (nips && is_sys(cfg->domain)) {
+            fail(nullptr, FBA_EINVAL, "mh-nips belief on sysadmin: MHNIPS2018::MH scores a particle's counts (grown from the domain's prior, 10000 per row) "
+                 "against computePriorModel(structure) (rows {total * p, total - p}, SysAdminFactoredPrior.cpp:98-127): a different prior, "
+                 "whose score difference admits no proposal -- the reference does not return from it");
             delete c;
             return FBA_EINVAL;
         }

@@ -1506,7 +1506,11 @@ __device__ void mh_increment(const Problem& P, float* cnt, int s, int a, int o, 
 __device__ void mh_compute_prior(const Problem& P, const DeviceState& D, const uint32_t* masks, float* out)
 {
     for (int k = 0; k < P.C; ++k) out[k] = D.prior[k];
-    if (dom_is_grid(P.domain)) {  // GridWorldFactBAPrior::computePriorModel (GridWorldBAPriors.cpp:227-254)
+    if (dom_is_sys(P.domain)) {  // SysAdminFactoredPrior::computePriorModel (:98-127): every transition node anew
+        const int N = P.sys->N;
+        for (int a = 0; a < P.A; ++a)
+            for (int f = 0; f < N; ++f) sys_fill_node(P, out, a, f, masks[a * N + f]);
+    } else if (dom_is_grid(P.domain)) {  // GridWorldFactBAPrior::computePriorModel (GridWorldBAPriors.cpp:227-254)
         for (int a = 0; a < P.A; ++a)
             for (int f = 0; f < 2; ++f)
                 if (masks[P.fd->nodes[a * 3 + f].var] == 7u) gw_fill_xy_node_with_goal(P, out, a, f);
@@ -1523,7 +1527,10 @@ __device__ void mh_compute_prior(const Problem& P, const DeviceState& D, const u
 // draws an action and an obstacle, then flips a random edge of that transition node
 __device__ void mh_mutate(const Problem& P, Rng& g, uint32_t* masks)
 {
-    if (dom_is_grid(P.domain)) {  // GridWorldFactBAPrior::mutate (GridWorldBAPriors.cpp:200-225): an action, the x or the y node, the goal edge toggled
+    if (dom_is_sys(P.domain)) {  // SysAdminFactoredPrior::mutate (:47-55): computer, action (g++ evaluates the second subscript first), then the edge
+        const int mc = g.uniform_int(P.sys->N), ma = g.uniform_int(P.A);
+        masks[ma * P.sys->N + mc] ^= 1u << g.slow_int(0, P.fd->FS);
+    } else if (dom_is_grid(P.domain)) {  // GridWorldFactBAPrior::mutate (GridWorldBAPriors.cpp:200-225): an action, the x or the y node, the goal edge toggled
         const int a = g.slow_int(0, P.A);
         const int f = g.slow_int(0, 2);
         masks[P.fd->nodes[a * 3 + f].var] ^= 4u;

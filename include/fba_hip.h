@@ -53,7 +53,7 @@ enum { FBA_BELIEF_REJECTION = 0, FBA_BELIEF_IMPORTANCE = 1, FBA_BELIEF_REINVIGOR
                              * updated by rejection; `particles` is ignored (1) and sample() draws nothing */
        FBA_BELIEF_MH_GIBBS = 5, /* mh-within-gibbs (BABelief.cpp:37-47: factored::MHwithinGibbs; `belief_option` 1 = "rs"): importance
                                  * filter whose particles are re-drawn by a Metropolis-Hastings chain over structures when the log
-                                 * likelihood falls below `threshold`; factored tiger, collision avoidance, gridworld */
+                                 * likelihood falls below `threshold`; factored tiger, collision avoidance, gridworld, sysadmin */
        FBA_BELIEF_MH_NIPS = 6,  /* mh-nips (BABelief.cpp:33-36: factored::MHNIPS2018): the same filter and trigger; the re-draw makes
                                  * independent proposals (a particle's structure or a mutation, updated along a simulated history) */
        FBA_BELIEF_INCUBATOR = 8, /* incubator (BABelief.cpp:53-58: factored::StructureIncubatorSampling(particles, resample_amount, threshold)): the

@@ -41,6 +41,8 @@ CASES = {
                                resample_amount=5, threshold=0.5),
     "mh_within_gibbs_gridworld": dict(domain=orc.DOM_GRIDWORLD, size=3, model=orc.MODEL_BA_FACTORED, belief=orc.BELIEF_MH_GIBBS,
                                       threshold=-3.0, structure_prior=orc.SP_MATCH_UNIFORM, particles=64),
+    "mh_within_gibbs_sysadmin": dict(domain=orc.DOM_SYSADMIN_LINEAR, size=3, model=orc.MODEL_BA_FACTORED, belief=orc.BELIEF_MH_GIBBS,
+                                     threshold=-1.0, belief_option=1),
     "bapomdp_sysadmin": dict(domain=orc.DOM_SYSADMIN_INDEPENDENT, size=3, model=orc.MODEL_BA_TABLE),
     "bapomdp_gridworld": dict(domain=orc.DOM_GRIDWORLD, size=3, model=orc.MODEL_BA_TABLE, noise=0.1),
     "bapomdp_collision_avoidance": dict(domain=orc.DOM_COLLISION_AVOID, width=4, height=3, size=1, model=orc.MODEL_BA_TABLE, noise=0.1),

@@ -1568,7 +1568,7 @@ static int build_sysadmin_factored_prior(orc_ctx* c)
     fdesc* d = &c->fd;
     int A = c->A, N = c->sys_N, a, f, k, r, off = 0;
     int linear = c->cfg.domain == ORC_DOM_SYSADMIN_LINEAR;
-    int reinvig = is_breeding(c);
+    int reinvig = is_breeding(c) || is_mh(c);
     if (c->cfg.structure_prior != ORC_SP_NONE) {
         snprintf(c->err, sizeof c->err, "Structure noise is not enabled for the Sysadmin problem");
         return -1;
@@ -1633,6 +1633,29 @@ static int build_sysadmin_factored_prior(orc_ctx* c)
         c->prior[nd->off + 3] = 10000.0f * SYS_OBSERVE_PROB;
     }
     return 0;
+}
+
+/* one transition node of SysAdminFactoredPrior::computePriorModel (SysAdminFactoredPrior.cpp:98-127) for parent set `mask`:
+ * every parent-value row gets {total * p, total * 1 - p} -- the reference's own precedence: total minus p */
+static void sys_fill_node(orc_ctx* c, float* cnt, int a, int f, uint32_t mask)
+{
+    const fdesc* d  = &c->fd;
+    const fnode* nd = &d->T[a * c->sys_N + f];
+    int parents[ORC_MAXF], pv[ORC_MAXF], np = 0, k, r, rows_max = 1;
+    float total = c->cfg.counts_total;
+    for (k = 0; k < nd->nmax; ++k) {
+        rows_max *= 2;
+        if ((mask >> k) & 1u) parents[np++] = nd->maxp[k];
+    }
+    memset(cnt + nd->off, 0, sizeof(float) * (size_t)rows_max * 2);
+    for (r = 0; r < (1 << np); ++r) {
+        float p;
+        for (k = 0; k < np; ++k) pv[k] = (r >> (np - 1 - k)) & 1; /* last parent fastest */
+        p = sys_failure_probability(c, a, f, parents, pv, np);
+        cnt[nd->off + 2 * r + 0] = total * p;
+        cnt[nd->off + 2 * r + 1] = total * 1 - p;
+    }
+    if (nd->var >= 0) cnt[d->ncounts + nd->var] = u2f(mask);
 }
 
 static int build_factored_prior(orc_ctx* c)
@@ -2368,7 +2391,7 @@ static void incubator_update(orc_ctx* c, int32_t a, int32_t o)
  * histories.  One Philox stream (REINVIG, 0) serves the chain: its draws are sequential by definition.
  * Built for the factored-tiger prior (computePriorModel FactoredTigerPriors.cpp:293-321, mutate :351-381). */
 
-#define MH_MAXVAR 64
+#define MH_MAXVAR 128
 /* the structure of a particle: the parent-set words of its variable nodes */
 static void mh_structure_of(const orc_ctx* c, const float* cnt, uint32_t* masks)
 {
@@ -2381,7 +2404,11 @@ static void mh_structure_of(const orc_ctx* c, const float* cnt, uint32_t* masks)
 static void mh_compute_prior(orc_ctx* c, const uint32_t* masks, float* out)
 {
     memcpy(out, c->prior, sizeof(float) * (size_t)c->ncnt);
-    if (is_grid(c->cfg.domain)) { /* GridWorldFactBAPrior::computePriorModel (GridWorldBAPriors.cpp:227-254): setNoisyTransitionNode where the goal is a parent */
+    if (is_sys(c->cfg.domain)) { /* SysAdminFactoredPrior::computePriorModel (:98-127): every transition node anew, the observation nodes as they are */
+        int a, f;
+        for (a = 0; a < c->A; ++a)
+            for (f = 0; f < c->sys_N; ++f) sys_fill_node(c, out, a, f, masks[a * c->sys_N + f]);
+    } else if (is_grid(c->cfg.domain)) { /* GridWorldFactBAPrior::computePriorModel (GridWorldBAPriors.cpp:227-254): setNoisyTransitionNode where the goal is a parent */
         int a, f;
         for (a = 0; a < c->A; ++a)
             for (f = 0; f < 2; ++f) {
@@ -2404,7 +2431,10 @@ static void mh_compute_prior(orc_ctx* c, const uint32_t* masks, float* out)
  * an action, an obstacle, then flip_random_edge of that transition node */
 static void mh_mutate(orc_ctx* c, uint32_t* masks)
 {
-    if (is_grid(c->cfg.domain)) { /* GridWorldFactBAPrior::mutate (GridWorldBAPriors.cpp:200-225): an action, the x or the y node, the goal edge toggled */
+    if (is_sys(c->cfg.domain)) { /* SysAdminFactoredPrior::mutate (:47-55); g++ evaluates the second subscript first: computer, action, then the edge */
+        int mc = orc_int(&c->rng, c->sys_N), ma = orc_int(&c->rng, c->A);
+        masks[ma * c->sys_N + mc] ^= 1u << orc_slow_int(&c->rng, 0, c->fd.FS);
+    } else if (is_grid(c->cfg.domain)) { /* GridWorldFactBAPrior::mutate (GridWorldBAPriors.cpp:200-225): an action, the x or the y node, the goal edge toggled */
         int a = orc_slow_int(&c->rng, 0, c->A);
         int f = orc_slow_int(&c->rng, 0, 2);
         masks[c->fd.T[a * 3 + f].var] ^= 4u;
@@ -3137,10 +3167,16 @@ orc_ctx* orc_create(const orc_config* cfg)
     if (is_mh(c)) {
         int cap = cfg->episodes * cfg->horizon;
         const char* name = cfg->belief == ORC_BELIEF_MH_NIPS ? "MHNIPS2018" : "MHwithinGibbs";
-        if (cfg->model != ORC_MODEL_BA_FACTORED || !(is_ftiger(cfg->domain) || is_ca(cfg->domain) || is_grid(cfg->domain)) || cfg->dirichlet_regular ||
+        if (cfg->model != ORC_MODEL_BA_FACTORED || cfg->dirichlet_regular ||
+            !(is_ftiger(cfg->domain) || is_ca(cfg->domain) || is_grid(cfg->domain) || is_sys(cfg->domain)) ||
             (is_ca(cfg->domain) && cfg->structure_prior == ORC_SP_FULLY_CONNECTED) || c->fd.nvar > MH_MAXVAR) {
-            snprintf(c->err, sizeof c->err, "%s belief: built for the factored-tiger, collision-avoidance and gridworld FBA-POMDPs (fbapomdp), expected Dirichlet mode",
-                     cfg->belief == ORC_BELIEF_MH_NIPS ? "mh-nips" : "mh-within-gibbs");
+            snprintf(c->err, sizeof c->err, "%s belief: needs a factored model (fbapomdp) in the expected Dirichlet mode, at most %d structure words per particle",
+                     cfg->belief == ORC_BELIEF_MH_NIPS ? "mh-nips" : "mh-within-gibbs", MH_MAXVAR);
+            return c;
+        }
+        if (cfg->belief == ORC_BELIEF_MH_NIPS && is_sys(cfg->domain)) {
+            snprintf(c->err, sizeof c->err, "mh-nips belief on sysadmin: MHNIPS2018::MH scores particles against computePriorModel(structure), "
+                     "not the prior they grew from (SysAdminFactoredPrior.cpp:98-127): no proposal is ever accepted");
             return c;
         }
         if (cfg->threshold >= 0) { /* MHwithinGibbs.cpp:248-252, MHNIPS2018.cpp:121-126 */

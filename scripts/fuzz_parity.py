@@ -66,8 +66,8 @@ def draw(rng):
             belief = "cheating-reinvigoration"
             kw["resample_amount"] = rng.choice([1, 5])
             kw["threshold"] = rng.choice([-0.3, -2.0, -50.0])
-        elif b < 0.6 and ("factored-tiger" in domain or "collision" in domain or domain == "gridworld") and kw["particles"] <= 64:
-            belief = rng.choice(["mh-within-gibbs", "mh-nips"])
+        elif b < 0.6 and ("factored-tiger" in domain or "collision" in domain or domain == "gridworld" or "sysadmin" in domain) and kw["particles"] <= 64:
+            belief = rng.choice(["mh-within-gibbs", "mh-nips"]) if "sysadmin" not in domain else "mh-within-gibbs"
             kw["threshold"] = rng.choice([-0.3, -2.0, -50.0])
             if belief == "mh-within-gibbs":
                 kw["belief_option"] = rng.choice([0, 1])

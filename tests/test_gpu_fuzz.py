@@ -34,13 +34,18 @@ def test_random_mh_belief_configurations_match_the_oracle():
     rng = random.Random(77)
     ran = 0
     for i in range(40):
-        domain = rng.choice(["episodic-factored-tiger", "continuous-factored-tiger", "random-collision-avoidance", "centered-collision-avoidance", "gridworld"])
-        belief = rng.choice(["mh-within-gibbs", "mh-nips"])
+        domain = rng.choice(["episodic-factored-tiger", "continuous-factored-tiger", "random-collision-avoidance", "centered-collision-avoidance", "gridworld",
+                             "linear-sysadmin"])
+        belief = rng.choice(["mh-within-gibbs", "mh-nips"]) if "sysadmin" not in domain else "mh-within-gibbs"
         kw = dict(particles=rng.choice([1, 5, 24, 50]), sims=rng.choice([4, 30, 90]), horizon=rng.choice([2, 5, 9]),
                   runs=rng.choice([1, 3]), episodes=rng.choice([1, 2, 4]), structure_prior=rng.choice([0, 1, 2, 3]),
                   threshold=rng.choice([-0.2, -1.0, -6.0]), noise=rng.choice([0.0, 0.1]), discount=rng.choice([0.7, 0.95]))
         if "tiger" in domain:
             kw["size"] = rng.choice([1, 2, 3])
+        elif "sysadmin" in domain:
+            kw["size"] = rng.choice([2, 3])
+            kw["structure_prior"] = 0
+            kw.pop("noise")
         elif domain == "gridworld":
             kw["size"] = rng.choice([3, 4])
             kw["particles"] = 64                  # (a filter without the true goal can never be updated)
