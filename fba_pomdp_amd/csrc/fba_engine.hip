@@ -1468,7 +1468,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     }
 
     // slots
-    const size_t per_slot = (size_t)P.N * (2 * 8 + 8 + 4 * (MAXINC + 1) + ((P.reinvig || P.cheat) ? 4 : (P.incub ? 6 : 2)) * (size_t)P.Cs * 4) + (size_t)D.max_nodes * D.node_words * 4 + (size_t)hcap * hash_entry + 1024;
+    const size_t per_slot = (size_t)P.N * (2 * 8 + 8 + 4 * (MAXINC + 1) + ((P.reinvig || P.cheat) ? 4 : (P.incub ? 6 : (P.hist ? 1 : 2))) * (size_t)P.Cs * 4) + (size_t)D.max_nodes * D.node_words * 4 + (size_t)hcap * hash_entry + 1024;
     int E = cfg->slots;
     if (E <= 0) {
         size_t free_b = 0, total_b = 0;
@@ -1495,7 +1495,17 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     CHK(dev_alloc(c, &D.bufsel, E));
     const bool is = P.belief == FBA_BELIEF_IMPORTANCE || P.incub;   // (the incubator's shadow filter is importance-sampled)
     CHK(dev_alloc(c, &D.p_weight, is ? (size_t)2 * E * P.N : 1));
-    CHK(dev_alloc(c, &D.p_rec, (size_t)2 * E * P.N * P.Cs, false));
+    // history particles keep ONE record buffer per slot; a resample / reset builds the new filter in a scratch pool shared by a
+    // chunk of slots (launch_belief_update / launch_reset: for_each_chunk) -- the second buffer was a quarter of a slot's memory
+    D.single_rec = P.hist && !std::getenv("FBA_DOUBLE_BUFFER") ? 1 : 0;
+    D.slot_base = 0;
+    D.scratch_slots = D.single_rec ? std::min(E, 1024) : 0;
+    D.rec_scratch = nullptr; D.copy_pending = nullptr;
+    CHK(dev_alloc(c, &D.p_rec, (size_t)(D.single_rec ? 1 : 2) * E * P.N * P.Cs, false));
+    if (D.single_rec) {
+        CHK(dev_alloc(c, &D.rec_scratch, (size_t)D.scratch_slots * P.N * P.Cs, false));
+        CHK(dev_alloc(c, &D.copy_pending, E));
+    }
     if (P.reinvig || P.cheat || P.incub) {
         CHK(dev_alloc(c, &D.p_rec_fc, (size_t)2 * E * P.N * P.Cs, false));
         CHK(dev_alloc(c, &D.bufsel_fc, E));
@@ -1927,7 +1937,8 @@ int fba_belief_get(fba_ctx* c, int32_t slot, int32_t* state, double* weight, flo
     }
     if (state || (counts && (P.C || P.hist))) {
         std::vector<float> tmp((size_t)P.N * P.Cs);
-        HIPCHK(c, hipMemcpy(tmp.data(), c->D.p_rec + pb * P.Cs, tmp.size() * 4, hipMemcpyDeviceToHost));
+        const size_t rb = c->D.single_rec ? (size_t)slot * (size_t)P.N : pb;   // (history particles: one record buffer per slot)
+        HIPCHK(c, hipMemcpy(tmp.data(), c->D.p_rec + rb * P.Cs, tmp.size() * 4, hipMemcpyDeviceToHost));
         uint32_t hist_cnt = 0;
         if (P.hist) HIPCHK(c, hipMemcpy(&hist_cnt, c->D.hist_cnt + slot, 4, hipMemcpyDeviceToHost));
         for (int i = 0; i < P.N; ++i) {

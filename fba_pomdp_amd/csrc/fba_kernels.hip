@@ -13,6 +13,7 @@
 // HBM-streaming (one workgroup per slot, wave ballot / prefix-sum compaction, whole-record
 // gathers); the search kernel is latency bound and gets its throughput from running one
 // independent tree per lane, all lanes executing the common "simulate one step" body together.
+#include <algorithm>
 #include <cstdlib>
 #include "fba_kernels.h"
 
@@ -33,6 +34,12 @@ __device__ __forceinline__ Rng slot_rng(const Problem& P, const DeviceState& D, 
 }
 
 __device__ __forceinline__ size_t pbase(const Problem& P, int e, int buf) { return ((size_t)buf * P.E + e) * (size_t)P.N; }
+// first record of slot e's current filter / of the filter a resample or reset is building (DeviceState::single_rec)
+__device__ __forceinline__ size_t rec_base(const Problem& P, const DeviceState& D, int e, int buf) { return D.single_rec ? (size_t)e * (size_t)P.N : pbase(P, e, buf); }
+__device__ __forceinline__ float* rec_dst(const Problem& P, const DeviceState& D, int e, int other)
+{
+    return D.single_rec ? D.rec_scratch + (size_t)(e - D.slot_base) * (size_t)P.N * (size_t)P.Cs : D.p_rec + pbase(P, e, other) * (size_t)P.Cs;
+}
 
 // particle record accessors (layout: fba_state.h)
 __device__ __forceinline__ int rec_state(const float* rec, int C) { return __float_as_int(rec[C]); }
@@ -646,7 +653,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, De
     const int max_tree_depth = min(P.horizon - hist_len, P.max_depth);
     const int W         = D.node_words;
     int32_t* tree       = D.nodes + (size_t)e * D.max_nodes * W;
-    const float* prec   = D.p_rec + pbase(P, e, D.bufsel[e]) * (size_t)P.Cs;
+    const float* prec   = D.p_rec + rec_base(P, D, e, D.bufsel[e]) * (size_t)P.Cs;
     const uint32_t hist_cnt = D.hist_cnt[e];  // entries of each action in every record of this slot, and where each group starts
     const int hist_n        = hist_total(hist_cnt);
     const uint32_t hist_off = (uint32_t)hist_offset(hist_cnt, 1) << 8 | (uint32_t)hist_offset(hist_cnt, 2) << 16 | (uint32_t)hist_offset(hist_cnt, 3) << 24;
@@ -1991,7 +1998,7 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
     __shared__ double s_carry[IS_MAX_CHUNKS + 2];
     __shared__ int32_t s_src[IS_BLOCK], s_inc[HIST ? 1 : (TIGER_TABLE ? 2 : MAXINC) * IS_BLOCK];
     extern __shared__ double s_w[];  // WLDS: [N] weights, then normalised weights, then their inclusive prefix sums
-    const int e = blockIdx.x, tid = threadIdx.x;
+    const int e = blockIdx.x + D.slot_base, tid = threadIdx.x;
     if (!D.need_update[e]) return;
     if (TIGER_TABLE == 2) {
         if (tid < 24) s_prior[tid] = D.prior_dense[tid];
@@ -2011,9 +2018,9 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
     const int cur = D.bufsel[e];
     const size_t sb = pbase(P, e, cur), db = pbase(P, e, cur ^ 1);
     double* sw   = D.p_weight + sb;
-    float* scn   = D.p_rec + sb * (size_t)P.Cs;
+    float* scn   = D.p_rec + rec_base(P, D, e, cur) * (size_t)P.Cs;
     double* dw      = D.p_weight + db;
-    float* dcn      = D.p_rec + db * (size_t)P.Cs;
+    float* dcn      = rec_dst(P, D, e, cur ^ 1);
     double* wscan   = WLDS ? s_w : D.wscan + (size_t)e * N;
     double* wcur    = WLDS ? s_w : sw;   // where the update pass leaves the new weights
     int32_t* side   = D.p_side + (size_t)e * N * D.side_w;
@@ -2124,6 +2131,7 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
         if (HIST) {
             D.hist_cnt[e] = hist_cnt + (1u << (8 * a));
             D.upd_entries[e] += (unsigned long long)N * (unsigned long long)hist_n;
+            if (D.single_rec) D.copy_pending[e] = 1;
         }
         if (P.mh) D.cheat_pending[e] = 1;  // mh_kernel: append (a, o) to the history, add log(total), maybe re-draw the filter
         if (P.cheat) {  // CheatingReinvigoration::updateEstimation (CheatingReinvigoration.cpp:117-124)
@@ -2387,7 +2395,7 @@ __global__ void __launch_bounds__(256) init_kernel(Problem P, DeviceState D, int
     const int i_lo = blockIdx.x * PARTICLE_TILE, i_hi = min(P.N, i_lo + PARTICLE_TILE);
     if (i_lo >= P.N) return;
     const size_t pb = pbase(P, e, fc ? D.bufsel_fc[e] : D.bufsel[e]);
-    float* recs     = (fc ? D.p_rec_fc : D.p_rec) + pb * (size_t)P.Cs;
+    float* recs     = (fc ? D.p_rec_fc : D.p_rec) + (fc ? pb : rec_base(P, D, e, D.bufsel[e])) * (size_t)P.Cs;
     Rng g = slot_rng(P, D, e);
     g.position((uint32_t)D.run[e], 0, 0);
     if (P.hist) {
@@ -2469,7 +2477,7 @@ __global__ void __launch_bounds__(256) init_kernel(Problem P, DeviceState D, int
 __global__ void __launch_bounds__(256) reset_kernel(Problem P, DeviceState D, int fc)
 {
     __shared__ int32_t s_src[256], s_ns[256];
-    const int e = blockIdx.y, tid = threadIdx.x;
+    const int e = blockIdx.y + D.slot_base, tid = threadIdx.x;
     if (D.need_reset[e] != 1) return;
     const int i_lo = blockIdx.x * PARTICLE_TILE, i_hi = min(P.N, i_lo + PARTICLE_TILE);
     if (i_lo >= P.N) return;
@@ -2502,8 +2510,8 @@ __global__ void __launch_bounds__(256) reset_kernel(Problem P, DeviceState D, in
             // the copy of the drawn particle (state, structure bits, entries) with its new start state
             const int gid = tid / group, part0 = tid % group, ngroups = 256 / group, n4 = (hist_n + 5) >> 2;
             for (int q = gid; q < m; q += ngroups) {
-                const float4* sp4 = reinterpret_cast<const float4*>(D.p_rec + sb * (size_t)P.Cs) + (size_t)s_src[q] * C4;
-                float4* dp4       = reinterpret_cast<float4*>(D.p_rec + (db + j0) * (size_t)P.Cs) + (size_t)q * C4;
+                const float4* sp4 = reinterpret_cast<const float4*>(D.p_rec + rec_base(P, D, e, cur) * (size_t)P.Cs) + (size_t)s_src[q] * C4;
+                float4* dp4       = reinterpret_cast<float4*>(rec_dst(P, D, e, cur ^ 1) + (size_t)j0 * P.Cs) + (size_t)q * C4;
                 const uint32_t nsp = gridworld_pack_state(P, s_ns[q]);
                 for (int part = part0; part < n4; part += group) {
                     float4 v = sp4[part];
@@ -2514,6 +2522,7 @@ __global__ void __launch_bounds__(256) reset_kernel(Problem P, DeviceState D, in
                     dp4[part] = v;
                 }
             }
+            if (D.single_rec && tid == 0) D.copy_pending[e] = 1;
             __syncthreads();
             continue;
         }
@@ -2656,7 +2665,7 @@ __global__ void __launch_bounds__(256) flush_kernel(Problem P, DeviceState D)
     const bool lazy = slot_lazy(D, e);
     unsigned long long local = 0;
     for (int i = tid; i < P.N; i += 256) {
-        const float* cnt = D.p_rec + (pb + i) * (size_t)P.Cs;
+        const float* cnt = D.p_rec + (rec_base(P, D, e, D.bufsel[e]) + i) * (size_t)P.Cs;
         const int st = lazy ? lazy_state(P, D, e, i) : rec_state(cnt, P.C);
         uint64_t h = mix64((uint64_t)i * 0x9E3779B97F4A7C15ull + (uint64_t)(uint32_t)st);
         const double w = (P.belief == FBA_BELIEF_IMPORTANCE) ? D.p_weight[pb + i] : 0.0;
@@ -2711,6 +2720,24 @@ __global__ void selftest_ucb_kernel(const double* L, const int32_t* n, int count
     if (i < count) out[i] = u * sqrt(L[i] / (double)n[i]);
 }
 
+// DeviceState::single_rec: the filter a resample / reset has built in the scratch pool becomes the slot's filter
+__global__ void __launch_bounds__(256) copy_back_kernel(Problem P, DeviceState D)
+{
+    const int e = blockIdx.y + D.slot_base;
+    if (!D.copy_pending[e]) return;
+    const size_t n4 = (size_t)P.N * (size_t)(P.Cs / 4);
+    const float4* src = reinterpret_cast<const float4*>(D.rec_scratch + (size_t)(e - D.slot_base) * (size_t)P.N * (size_t)P.Cs);
+    float4* dst       = reinterpret_cast<float4*>(D.p_rec + (size_t)e * (size_t)P.N * (size_t)P.Cs);
+    const size_t per  = (n4 + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = lo + per < n4 ? lo + per : n4;
+    for (size_t k = lo + threadIdx.x; k < hi; k += 4 * 256) {
+        float4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = src[k + (size_t)q * 256 < hi ? k + (size_t)q * 256 : hi - 1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (k + (size_t)q * 256 < hi) dst[k + (size_t)q * 256] = v[q];
+    }
+}
 __global__ void copy_flags_kernel(const uint8_t* src, uint8_t* dst, int n)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2807,6 +2834,7 @@ static void launch_importance_single(const Problem& P, const DeviceState& D, hip
     // weights and prefix sums of a slot in LDS while its workgroup works on them (8 bytes per particle)
     const bool wlds = P.N <= IS_LDS_MAX_N && !P.dirichlet_regular;
     const size_t wl = wlds ? (size_t)P.N * (sizeof(double) + ((tiger_table && P.packed) ? 4 : 0)) : 0;  // (packed tiger: + pending updates and sources, 16 bits each)
+    const int grid_e = D.single_rec ? std::min(D.scratch_slots, P.E - D.slot_base) : P.E;   // (single_rec: one chunk of slots per launch)
 #define FBA_LAUNCH_IS(...)                                                                                         \
     do {                                                                                                           \
     static bool raised = false;                                                                                \
@@ -2815,7 +2843,7 @@ static void launch_importance_single(const Problem& P, const DeviceState& D, hip
                                   hipFuncAttributeMaxDynamicSharedMemorySize, IS_LDS_MAX_N * 12); \
         raised = true;                                                                                         \
     }                                                                                                          \
-    hipLaunchKernelGGL((importance_kernel<__VA_ARGS__>), dim3(P.E), dim3(IS_BLOCK), wl, st, P, D);             \
+    hipLaunchKernelGGL((importance_kernel<__VA_ARGS__>), dim3(grid_e), dim3(IS_BLOCK), wl, st, P, D);          \
     } while (0)
     if (P.hist) { if (wlds) FBA_LAUNCH_IS(false, 0, true, true); else FBA_LAUNCH_IS(false, 0, true, false); }
     else if (P.dirichlet_regular) FBA_LAUNCH_IS(true, 0, false, false);
@@ -2823,6 +2851,19 @@ static void launch_importance_single(const Problem& P, const DeviceState& D, hip
     else if (tiger_table) { if (wlds) FBA_LAUNCH_IS(false, 1, false, true); else FBA_LAUNCH_IS(false, 1, false, false); }
     else { if (wlds) FBA_LAUNCH_IS(false, 0, false, true); else FBA_LAUNCH_IS(false, 0, false, false); }
 #undef FBA_LAUNCH_IS
+}
+// DeviceState::single_rec: the slots in chunks of as many as the scratch pool holds -- gather into the pool, copy back, next chunk
+template <class F>
+static void for_each_chunk(const Problem& P, const DeviceState& D, hipStream_t st, F launch)
+{
+    for (int e0 = 0; e0 < P.E; e0 += D.scratch_slots) {
+        DeviceState Dc = D;
+        Dc.slot_base   = e0;
+        const int cnt  = std::min(D.scratch_slots, P.E - e0);
+        launch(Dc, cnt);
+        hipLaunchKernelGGL(copy_back_kernel, dim3(16, cnt), dim3(256), 0, st, P, Dc);
+        (void)hipMemsetAsync(D.copy_pending + e0, 0, (size_t)cnt, st);
+    }
 }
 void launch_belief_update(const Problem& P, const DeviceState& D, hipStream_t st)
 {
@@ -2872,7 +2913,8 @@ void launch_belief_update(const Problem& P, const DeviceState& D, hipStream_t st
         else hipLaunchKernelGGL((reject_kernel<false, 0>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, 1);
     }
     if (!D.is_multi) {
-        launch_importance_single(P, D, st);
+        if (D.single_rec) for_each_chunk(P, D, st, [&](const DeviceState& Dc, int) { launch_importance_single(P, Dc, st); });
+        else launch_importance_single(P, D, st);
         if (P.cheat) hipLaunchKernelGGL(cheat_kernel, dim3(P.E), dim3(256), 0, st, P, D);
         if (P.mh) hipLaunchKernelGGL(mh_kernel, dim3(ceil_div(P.E, 64)), dim3(64), 0, st, P, D);
         return;
@@ -2912,7 +2954,11 @@ void launch_reset(const Problem& P, const DeviceState& D, hipStream_t st)
         hipLaunchKernelGGL(post_reset_kernel, dim3(ceil_div(P.E, 256)), dim3(256), 0, st, P, D);
         return;
     }
-    hipLaunchKernelGGL(reset_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), P.E), dim3(256), 0, st, P, D, 0);
+    if (D.single_rec)
+        for_each_chunk(P, D, st, [&](const DeviceState& Dc, int cnt) {
+            hipLaunchKernelGGL(reset_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), cnt), dim3(256), 0, st, P, Dc, 0);
+        });
+    else hipLaunchKernelGGL(reset_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), P.E), dim3(256), 0, st, P, D, 0);
     if (P.reinvig || P.cheat || P.incub) hipLaunchKernelGGL(reset_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), P.E), dim3(256), 0, st, P, D, 1);
     if (P.incub) {  // StructureIncubatorSampling::resetDomainStateDistribution (:46-61): the shadow filter too, in place
         DeviceState Ds = D;

@@ -60,6 +60,13 @@ struct DeviceState {
     int16_t* mh_o;
     int32_t* mh_ep_len; // [E][episodes + 1]
     int32_t* mh_n_ep;   // [E] episodes in the history, the open one included
+    // history particles (C4): ONE record buffer per slot; a resample / reset gathers into a scratch pool shared by a chunk of
+    // slots and is copied back (the second buffer was a quarter of a slot's memory, and slots are what C4 lacks)
+    float* rec_scratch;       // [scratch_slots][N][Cs]
+    uint8_t* copy_pending;    // [E] the slot's new filter is in the scratch pool
+    int32_t single_rec;       // 1: p_rec holds one buffer per slot (records only; weights stay double-buffered)
+    int32_t slot_base;        // first slot of the chunk a chunked launch works on
+    int32_t scratch_slots;
     // incubator belief (StructureIncubatorSampling.cpp): the weighted shadow filter, laid out like p_rec / p_weight / bufsel
     float* p_rec_sh;         // [2][E][N][Cs]
     double* p_weight_sh;     // [2][E][N]
