@@ -466,14 +466,15 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
             if (STAGE) {
                 const float4* rp = reinterpret_cast<const float4*>(cnt);
                 const int n4 = (P.C + 4) >> 2;  // counts and the state word; the padding behind them is not needed
-                // four 16-byte loads in flight before the first of them is waited for: with a trip count the compiler does not
-                // know, a load-then-store loop is one trip to memory per 16 bytes (C3: nine in a row, 42 % of the kernel)
-                for (int k0 = 0; k0 < n4; k0 += 4) {
-                    float4 v[4];
+                // up to twelve 16-byte loads in flight before the first of them is waited for: with a trip count the compiler does
+                // not know, a load-then-store loop is one trip to memory per 16 bytes (C3: nine in a row, 42 % of the kernel)
+                constexpr int NB = TIGER_TABLE == 2 ? 4 : 12;   // (same-box A/B on C3, nine 16-byte pieces: 4 -> 385.9 ms per tick, 8 -> 374, 12 -> 365.5)
+                for (int k0 = 0; k0 < n4; k0 += NB) {
+                    float4 v[NB];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = rp[min(k0 + q, n4 - 1)];
+                    for (int q = 0; q < NB; ++q) v[q] = rp[min(k0 + q, n4 - 1)];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int q = 0; q < NB; ++q) {
                         const int k = k0 + q;
                         if (k < n4) {
                             stage[(4 * k + 0) * SEARCH_BLOCK] = v[q].x;
