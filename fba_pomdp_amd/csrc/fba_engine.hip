@@ -1442,7 +1442,10 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     // node record layout (fba_state.h)
     DeviceState& D = c->D;
     const bool hashed = P.A * P.O > 64;
-    D.cq_off     = (1 + P.A + 1) & ~1;
+    // a hashed tree with an even number of actions drops the visits word (it is the sum of the action counts) and the
+    // padding word with it: 56 -> 48 bytes per node for the four actions of gridworld
+    D.cn_off     = (hashed && P.A % 2 == 0 && !std::getenv("FBA_NODE_VISITS")) ? 0 : 1;
+    D.cq_off     = (D.cn_off + P.A + 1) & ~1;
     D.child_off  = D.cq_off + 2 * P.A;
     D.node_words = hashed ? D.child_off : ((D.child_off + P.A * P.O + 1) & ~1);
     D.max_nodes  = P.sims + 2;  // one new node per simulation at most

@@ -135,8 +135,8 @@ __device__ __forceinline__ int nested_sample(const Problem& P, const DeviceState
 
 __device__ __forceinline__ void node_init(const DeviceState& D, int32_t* rec, int A, int O)
 {
-    rec[0] = 0;
-    for (int a = 0; a < A; ++a) rec[1 + a] = 0;
+    if (D.cn_off) rec[0] = 0;   // (cn_off = 0: no visits word, ActionNode::_visits is the sum of its chance nodes' counts)
+    for (int a = 0; a < A; ++a) rec[D.cn_off + a] = 0;
     double* q = reinterpret_cast<double*>(rec + D.cq_off);
     for (int a = 0; a < A; ++a) q[a] = 0.0;
     if (!D.hash)
@@ -303,11 +303,12 @@ __device__ __forceinline__ int ucb_select(const Problem& P, const DeviceState& D
         cq[0] = q01.x; cq[1] = q01.y; cq[2] = q2;
     } else {
         const double* q = reinterpret_cast<const double*>(rec + D.cq_off);
-        visits = rec[0];
+        visits = D.cn_off ? rec[0] : 0;
 #pragma unroll
         for (int a = 0; a < AMAX; ++a) {
-            cn[a] = a < P.A ? rec[1 + a] : 0;
+            cn[a] = a < P.A ? rec[D.cn_off + a] : 0;
             cq[a] = a < P.A ? q[a] : 0.0;
+            if (!D.cn_off) visits += cn[a];   // every back-up through the node adds one to exactly one of them (MCTSTreeNodes.cpp:8-12, 59-62)
         }
     }
     return ucb_pick<AMAX>(P, g, explore ? D.log1p_tab[visits] : 0.0, cn, cq, explore);
@@ -347,7 +348,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
         P.S = 2; P.A = 3; P.O = 2; P.C = 0; P.Cs = 4; P.planner = FBA_PLANNER_POUCT;
         if (P.domain != FBA_DOM_TIGER_CONTINUOUS) P.domain = FBA_DOM_TIGER_EPISODIC;
         P.belief = P.belief == FBA_BELIEF_IMPORTANCE ? FBA_BELIEF_IMPORTANCE : FBA_BELIEF_REJECTION;
-        D.cq_off = 4; D.child_off = 10; D.node_words = 16; D.hash = nullptr;  // node layout of A = 3, O = 2 (fba_engine.hip)
+        D.cn_off = 1; D.cq_off = 4; D.child_off = 10; D.node_words = 16; D.hash = nullptr;  // node layout of A = 3, O = 2 (fba_engine.hip)
     }
     // one instantiation per simulator: the launcher passes the model it read from P, so restating it
     // here drops the other simulators' code (a plain-POMDP search carries every domain's step(),
@@ -365,7 +366,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
         P.S = 2; P.A = 3; P.O = 2; P.phi_len = 12; P.C = 24; P.Cs = 32;
         if (P.domain != FBA_DOM_TIGER_CONTINUOUS) P.domain = FBA_DOM_TIGER_EPISODIC;
         P.belief = P.belief == FBA_BELIEF_IMPORTANCE ? FBA_BELIEF_IMPORTANCE : FBA_BELIEF_REJECTION;
-        D.cq_off = 4; D.child_off = 10; D.node_words = 16; D.hash = nullptr;  // node layout of A = 3, O = 2 (fba_engine.hip)
+        D.cn_off = 1; D.cq_off = 4; D.child_off = 10; D.node_words = 16; D.hash = nullptr;  // node layout of A = 3, O = 2 (fba_engine.hip)
         if (TIGER_TABLE == 2) { P.C = 12; P.Cs = 16; }  // packed particles (PackedView): 24 uint16 + state in 64 bytes
     }
     extern __shared__ double lds[];
@@ -586,8 +587,8 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
                         ++h.x;
                         *hp = h;
                     } else {
-                        n = ++rec[1 + act];
-                        ++rec[0];
+                        n = ++rec[D.cn_off + act];
+                        if (D.cn_off) ++rec[0];
                     }
                     *q += (ret - *q) / (double)n;
                 }
@@ -796,8 +797,8 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, De
                 } else {
                     int32_t* rec = tree + (size_t)(na >> 5) * W;
                     double* q    = reinterpret_cast<double*>(rec + D.cq_off) + act;
-                    const int n  = ++rec[1 + act];
-                    ++rec[0];
+                    const int n  = ++rec[D.cn_off + act];
+                    if (D.cn_off) ++rec[0];
                     *q += (ret - *q) / (double)n;
                 }
                 del = ret;

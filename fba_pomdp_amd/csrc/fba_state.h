@@ -96,7 +96,7 @@ struct DeviceState {
     double uni_total;
     // --- tree ---
     int32_t* nodes;     // [E][max_nodes][node_words]
-    int32_t max_nodes, node_words, cq_off, child_off;
+    int32_t max_nodes, node_words, cq_off, child_off, cn_off;   // cn_off: 1 = word 0 holds the visits, the action counts follow; 0 = no visits word (hashed trees, even A)
     // large observation spaces (A*O > 64): children live in a per-slot open-addressing table
     // of {code_lo, code_hi | epoch << 4, child, -} entries tagged with the slot's search epoch, so
     // the table is never cleared: an entry of an older search reads as empty
