@@ -1448,6 +1448,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     D.cq_off     = (D.cn_off + P.A + 1) & ~1;
     D.child_off  = D.cq_off + 2 * P.A;
     D.node_words = hashed ? D.child_off : ((D.child_off + P.A * P.O + 1) & ~1);
+    if (const char* ev = std::getenv("FBA_NODE_WORDS")) D.node_words = std::max(D.node_words, std::atoi(ev));   // (layout experiments: padded records)
     D.max_nodes  = P.sims + 2;  // one new node per simulation at most
     // Episodic (factored) tiger: only `listen` continues an episode and it has two observations, so a node has at most
     // two children and the tree of a search of depth D is at most the complete binary tree with levels 0..D:

@@ -301,6 +301,13 @@ __device__ __forceinline__ int ucb_select(const Problem& P, const DeviceState& D
         for (int a = 0; a < AMAX; ++a) { cn[a] = 0; cq[a] = 0.0; }
         cn[0] = h.y; cn[1] = h.z; cn[2] = h.w;
         cq[0] = q01.x; cq[1] = q01.y; cq[2] = q2;
+    } else if (AMAX == 4 && P.A == 4 && D.cn_off == 0) {  // {n0..n3}, {q0, q1}, {q2, q3}: three 16-byte loads of one 48-byte record
+        const int4 h      = *reinterpret_cast<const int4*>(rec);
+        const double2 q01 = *reinterpret_cast<const double2*>(rec + 4);
+        const double2 q23 = *reinterpret_cast<const double2*>(rec + 8);
+        cn[0] = h.x; cn[1] = h.y; cn[2] = h.z; cn[3] = h.w;
+        cq[0] = q01.x; cq[1] = q01.y; cq[2] = q23.x; cq[3] = q23.y;
+        visits = ((h.x + h.y) + h.z) + h.w;
     } else {
         const double* q = reinterpret_cast<const double*>(rec + D.cq_off);
         visits = D.cn_off ? rec[0] : 0;
