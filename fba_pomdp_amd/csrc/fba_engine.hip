@@ -1504,6 +1504,8 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     D.single_rec = P.hist && !std::getenv("FBA_DOUBLE_BUFFER") ? 1 : 0;
     D.slot_base = 0;
     D.scratch_slots = D.single_rec ? std::min(E, 1024) : 0;
+    if (D.single_rec)
+        if (const char* ev = std::getenv("FBA_SCRATCH_SLOTS")) D.scratch_slots = std::max(1, std::min(E, std::atoi(ev)));   // (tests: several chunks with a few slots)
     D.rec_scratch = nullptr; D.copy_pending = nullptr;
     CHK(dev_alloc(c, &D.p_rec, (size_t)(D.single_rec ? 1 : 2) * E * P.N * P.Cs, false));
     if (D.single_rec) {

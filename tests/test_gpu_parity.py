@@ -1106,13 +1106,14 @@ def test_incubator_belief_refusals():
         fba.Engine("gridworld", model=N.MODEL_BA_FACTORED, belief="incubator", size=3, sims=8, particles=8, resample_amount=2, threshold=0.5)
 
 
-@pytest.mark.parametrize("env", [{"FBA_NODE_VISITS": "1"}, {"FBA_NODE_WORDS": "16"}, {"FBA_DOUBLE_BUFFER": "1"}])
+@pytest.mark.parametrize("env", [{"FBA_NODE_VISITS": "1"}, {"FBA_NODE_WORDS": "16"}, {"FBA_DOUBLE_BUFFER": "1"}, {"FBA_SCRATCH_SLOTS": "2"}])
 def test_layout_knobs_do_not_change_results(env, monkeypatch):
     """The memory-layout choices C4 runs on -- tree nodes without a visits word (48 bytes), one record buffer per slot for
     history particles -- against their alternatives (the knobs the same-box A/B runs of DESIGN section 5a used): the same
     experiment, every trace field equal to the oracle's either way."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    eng, o = _pair("gridworld", N.MODEL_BA_FACTORED, "importance_sampling", 977, size=4, particles=130, sims=96, runs=3, episodes=2,
+    # (five slots: with a scratch pool of two, the resample and the reset work through three chunks, the last one partial)
+    eng, o = _pair("gridworld", N.MODEL_BA_FACTORED, "importance_sampling", 977, size=4, particles=130, sims=96, runs=5, episodes=2,
                    horizon=7, structure_prior=2)
     _assert_same_experiment(eng, o, ba=True)
