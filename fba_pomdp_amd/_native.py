@@ -12,12 +12,13 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB_PATH = os.environ.get("FBA_LIB") or os.path.join(HERE, "libfba_hip.so")   # (FBA_LIB: an instrumented build of the same sources, scripts/search_regions.py)
-SOURCES = [os.path.join(HERE, "csrc", f) for f in ("fba_kernels.hip", "fba_engine.hip")]
-HEADERS = [os.path.join(HERE, "csrc", f) for f in ("fba_device.h", "fba_state.h", "fba_kernels.h")] + [
+SOURCES = [os.path.join(HERE, "csrc", f) for f in ("fba_search.hip", "fba_kernels.hip", "fba_engine.hip")]
+HEADERS = [os.path.join(HERE, "csrc", f) for f in ("fba_device.h", "fba_state.h", "fba_kernels.h", "fba_kernels_common.h")] + [
     os.path.join(ROOT, "include", "fba_hip.h")]
+OBJ_DIR = os.path.join(HERE, "build")   # per-source objects (git-ignored): a change to one translation unit recompiles that one
 
 HIPCC_FLAGS = [
-    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     # the reference rounds a*b+c twice; contraction into FMA would break bit parity
     "-ffp-contract=off", "-fno-fast-math",
     "-Wall", "-Wno-unused-function",
@@ -112,24 +113,39 @@ EXPORTS = [
     "fba_abi_version", "fba_default_config", "fba_create", "fba_destroy", "fba_last_error",
     "fba_domain_sizes", "fba_counts_len", "fba_slots", "fba_particle_bytes", "fba_set_model_tabular", "fba_set_model_factored", "fba_log_bd_score", "fba_selftest_lgamma", "fba_get_prior", "fba_get_factored_layout",
     "fba_set_position", "fba_belief_init", "fba_belief_reset_domain_state", "fba_select_action",
-    "fba_belief_update", "fba_belief_get", "fba_belief_set", "fba_belief_get_fully_connected", "fba_belief_get_nested", "fba_belief_get_shadow", "fba_last_step_info",
+    "fba_belief_update", "fba_belief_get", "fba_belief_get_particle", "fba_belief_set", "fba_belief_get_fully_connected", "fba_belief_get_nested", "fba_belief_get_shadow", "fba_last_step_info",
     "fba_run_planning", "fba_run_bapomdp", "fba_run_ticks", "fba_get_returns", "fba_get_counters", "fba_get_return_sums",
     "fba_get_kernel_times", "fba_reset_kernel_times", "fba_trace_count", "fba_get_trace",
     "fba_selftest_ucb", "fba_stat_add", "fba_stat_var", "fba_stat_stder",
 ]
 
 
-def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU) -> fba_pomdp_amd/libfba_hip.so"""
-    deps = SOURCES + HEADERS
-    if (not force and os.path.exists(LIB_PATH)
-            and all(os.path.getmtime(d) <= os.path.getmtime(LIB_PATH) for d in deps)):
-        return LIB_PATH
-    cmd = ["hipcc"] + HIPCC_FLAGS + ["-I" + os.path.join(ROOT, "include")] + SOURCES + ["-o", LIB_PATH]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return LIB_PATH
+def build(force=False, verbose=False, extra_flags=(), lib_path=None, obj_tag=""):
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU) -> fba_pomdp_amd/libfba_hip.so.
+    One object per source, compiled side by side; an object is rebuilt when its source or any header is newer."""
+    lib_path = lib_path or LIB_PATH
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hdr_time = max(os.path.getmtime(h) for h in HEADERS)
+    jobs, objs = [], []
+    for src in SOURCES:
+        obj = os.path.join(OBJ_DIR, os.path.splitext(os.path.basename(src))[0] + obj_tag + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+            cmd = ["hipcc"] + HIPCC_FLAGS + list(extra_flags) + ["-I" + os.path.join(ROOT, "include"), "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in jobs:
+        if p.wait() != 0:
+            for _, q in jobs:
+                q.wait()
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    if jobs or not os.path.exists(lib_path) or any(os.path.getmtime(o) > os.path.getmtime(lib_path) for o in objs):
+        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib_path]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return lib_path
 
 
 CLI_PATH = os.path.join(HERE, "fba_experiment")
@@ -184,6 +200,8 @@ def load():
     L.fba_belief_update.argtypes = [vp, vp, vp, vp]
     L.fba_belief_get.argtypes = [vp, C.c_int32, vp, vp, vp]
     L.fba_belief_set.argtypes = [vp, C.c_int32, vp, vp, vp]
+    if not os.environ.get("FBA_LIB") or hasattr(L, "fba_belief_get_particle"):
+        L.fba_belief_get_particle.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp]
     L.fba_belief_get_fully_connected.argtypes = [vp, C.c_int32, vp, vp]
     if not os.environ.get("FBA_LIB") or hasattr(L, "fba_belief_get_nested"):   # (FBA_LIB may name an older build for an A/B run)
         L.fba_belief_get_nested.argtypes = [vp, C.c_int32, vp]

@@ -1614,6 +1614,13 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     CHK(dev_alloc(c, &c->d_n_active, 1));
     CHK(dev_alloc(c, &D.fault, 1));
     CHK(dev_alloc(c, &D.lazy_reset, E));
+    {   // lanes of the search grid in order of their slots' time-step (FBA_SEARCH_SORT=0 keeps slot e on lane e)
+        const char* so = std::getenv("FBA_SEARCH_SORT");
+        if (!(so && std::atoi(so) == 0) && E > SEARCH_BLOCK && !P.hist) {
+            CHK(dev_alloc(c, &D.search_perm, E));
+            CHK(dev_alloc(c, &D.sort_bins, 512));
+        }
+    }
     CHK(dev_alloc(c, &c->d_prior, P.Cs));
     CHK(dev_alloc(c, &c->d_prior_dense, std::max(c->dense_C, 1)));
     if (P.hist) {
@@ -1928,9 +1935,9 @@ static void hist_materialize(const fba_ctx* c, const uint32_t* rec, uint32_t cnt
     }
 }
 
-int fba_belief_get(fba_ctx* c, int32_t slot, int32_t* state, double* weight, float* counts)
+// particles [first, first + n) of slot `slot`'s filter, as the API speaks of particles (fp32 count tables whatever the record format)
+static int belief_get_range(fba_ctx* c, int32_t slot, int32_t first, int32_t n, int32_t* state, double* weight, float* counts)
 {
-    if (!c || slot < 0 || slot >= c->P.E) return FBA_EINVAL;
     const Problem& P = c->P;
     launch_materialize_reset(c->P, c->D, c->stream);  // a lazily reset rejection filter: write the states out first
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1939,15 +1946,15 @@ int fba_belief_get(fba_ctx* c, int32_t slot, int32_t* state, double* weight, flo
     const size_t pb = ((size_t)sel * P.E + slot) * (size_t)P.N;
     if (weight) {
         if (P.belief != FBA_BELIEF_IMPORTANCE) return fail(c, FBA_EINVAL, "the rejection filter is unweighted");
-        HIPCHK(c, hipMemcpy(weight, c->D.p_weight + pb, (size_t)P.N * 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(weight, c->D.p_weight + pb + first, (size_t)n * 8, hipMemcpyDeviceToHost));
     }
     if (state || (counts && (P.C || P.hist))) {
-        std::vector<float> tmp((size_t)P.N * P.Cs);
+        std::vector<float> tmp((size_t)n * P.Cs);
         const size_t rb = c->D.single_rec ? (size_t)slot * (size_t)P.N : pb;   // (history particles: one record buffer per slot)
-        HIPCHK(c, hipMemcpy(tmp.data(), c->D.p_rec + rb * P.Cs, tmp.size() * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(tmp.data(), c->D.p_rec + (rb + first) * P.Cs, tmp.size() * 4, hipMemcpyDeviceToHost));
         uint32_t hist_cnt = 0;
         if (P.hist) HIPCHK(c, hipMemcpy(&hist_cnt, c->D.hist_cnt + slot, 4, hipMemcpyDeviceToHost));
-        for (int i = 0; i < P.N; ++i) {
+        for (int i = 0; i < n; ++i) {
             const float* rec = tmp.data() + (size_t)i * P.Cs;
             if (state) std::memcpy(&state[i], &rec[P.C], 4);
             if (counts && P.ft_packed) {  // count = prior(cell, structure) + increments, then the structure word (PackedFtigerView)
@@ -1967,6 +1974,20 @@ int fba_belief_get(fba_ctx* c, int32_t slot, int32_t* state, double* weight, flo
         }
     }
     return FBA_OK;
+}
+
+int fba_belief_get(fba_ctx* c, int32_t slot, int32_t* state, double* weight, float* counts)
+{
+    if (!c || slot < 0 || slot >= c->P.E) return FBA_EINVAL;
+    return belief_get_range(c, slot, 0, c->P.N, state, weight, counts);
+}
+
+int fba_belief_get_particle(fba_ctx* c, int32_t slot, int32_t index, int32_t* state, double* weight, float* counts)
+{
+    if (!c || slot < 0 || slot >= c->P.E) return FBA_EINVAL;
+    if (index < 0 || index >= c->P.N) return fail(c, FBA_EINVAL, "particle %d out of range (the filter holds %d)", index, c->P.N);
+    if (c->P.nested) return fail(c, FBA_EINVAL, "the nested belief's particles are (model, state filter) pairs: fba_belief_get / fba_belief_get_nested");
+    return belief_get_range(c, slot, index, 1, state, weight, counts);
 }
 
 int fba_belief_get_fully_connected(fba_ctx* c, int32_t slot, int32_t* state, float* counts)
@@ -2202,6 +2223,16 @@ int fba_get_kernel_times(fba_ctx* c, fba_kernel_time* out)
         // weight and moves a record in and out (8 + 2 * 64)
         if (P.packed) out[FBA_K_BELIEF_IS].bytes = particles * (32 + Rt + Ro) + particles * (8 + 2 * (uint64_t)(P.Cs * 4));
     }
+    return FBA_OK;
+}
+
+// diagnostic (scripts/tick_probe.py; not part of include/fba_hip.h): every slot's simulated-step counter and time-step
+int fba_debug_slot_counters(fba_ctx* c, unsigned long long* sim_steps, int32_t* t)
+{
+    if (!c) return FBA_EINVAL;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (sim_steps) HIPCHK(c, hipMemcpy(sim_steps, c->D.sim_steps, (size_t)c->P.E * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (t) HIPCHK(c, hipMemcpy(t, c->D.t, (size_t)c->P.E * sizeof(int32_t), hipMemcpyDeviceToHost));
     return FBA_OK;
 }
 

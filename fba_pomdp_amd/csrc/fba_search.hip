@@ -1,0 +1,672 @@
+// fba_search.hip -- the tree-search kernels of the BA-POMCP engine (gfx950 / CDNA4, wave64).
+//
+//   search_kernel        POUCT / RBAPOUCT tree search, one lane per tree          (P1-P8)
+//   search_hist_kernel   the same search on history particles, four lanes per tree (BASELINE configs[3])
+//
+// The search is latency bound and gets its throughput from running one independent tree per lane (or quad), all
+// lanes executing the common "simulate one step" body together.  No dense contraction, no MFMA.
+#include <algorithm>
+#include <cstdlib>
+
+#include "fba_kernels_common.h"
+
+namespace fba {
+
+// ---------------------------------------------------------------------------------------------
+// search_kernel: one lane = one slot = one tree; `sims` simulations, sequential semantics.
+// POUCT::selectAction POUCT.cpp:63-129, RBAPOUCT::selectAction RBAPOUCT.cpp:67-153 (the root
+// particle's counts are read and never written: StepType::KeepCounts).
+// The recursion traverseActionNode / traverseChanceNode / rollout (POUCT.cpp:183-303) is unrolled
+// into a state machine whose every iteration performs exactly one simulator.step, so the 64
+// trees of a wave execute the expensive part (Philox + Dirichlet-row sampling) in lock-step.
+// LDS per lane: the path needed for the bottom-up back-up, [depth][lane], and -- when a particle
+// record fits SEARCH_STAGE_WORDS (STAGE) -- the root particle's whole count blob, [word][lane], fetched with
+// one burst of 16-byte loads per simulation so that no step waits on HBM for its Dirichlet rows.
+// ---------------------------------------------------------------------------------------------
+// FTIGER > 0: the simulator is the factored-tiger FBA-POMDP with FTIGER binary state features (expected
+// Dirichlet mode); its step is ftiger_step<FTIGER>, the layout restated as literals.
+// TIGER_POMDP: planning on the tiger POMDP itself (BASELINE configs[0]); the sizes and the domain are literals.
+__host__ __device__ __forceinline__ bool root_children_in_lds(const Problem& P, const DeviceState& D)
+{
+    return P.A * P.O <= ROOT_CHILDREN && D.max_nodes <= 32767;
+}
+
+// FTP: the factored-tiger records are packed (PackedFtigerView).
+#ifdef FBA_PROFILE_SEARCH
+// profiling build only (scripts/search_regions.py): shader-clock cycles a wave spends in each region of the search loop
+__device__ unsigned long long g_search_prof[8];
+#define PROF_MARK(r) { const long long now_ = clock64(); prof_[r] += now_ - prev_; prev_ = now_; }
+#else
+#define PROF_MARK(r)
+#endif
+template <bool STAGE, int AMAX, bool REG, int TIGER_TABLE, int MODEL, int FTIGER = 0, bool TIGER_POMDP = false, bool FTP = false>
+__global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceState D)
+{
+    if (TIGER_POMDP) {
+        P.S = 2; P.A = 3; P.O = 2; P.C = 0; P.Cs = 4; P.planner = FBA_PLANNER_POUCT;
+        if (P.domain != FBA_DOM_TIGER_CONTINUOUS) P.domain = FBA_DOM_TIGER_EPISODIC;
+        P.belief = P.belief == FBA_BELIEF_IMPORTANCE ? FBA_BELIEF_IMPORTANCE : FBA_BELIEF_REJECTION;
+        D.cn_off = 1; D.cq_off = 4; D.child_off = 10; D.node_words = 16; D.hash = nullptr;  // node layout of A = 3, O = 2 (fba_engine.hip)
+    }
+    // one instantiation per simulator: the launcher passes the model it read from P, so restating it
+    // here drops the other simulators' code (a plain-POMDP search carries every domain's step(),
+    // the Bayes-adaptive ones none of them) from this instantiation
+    P.model = MODEL;
+    if (FTIGER > 0) {  // sizes of factored tiger with FTIGER - 1 irrelevant features
+        P.S = 1 << FTIGER; P.A = 3; P.O = 2;
+        if (P.domain != FBA_DOM_FTIGER_CONTINUOUS) P.domain = FBA_DOM_FTIGER_EPISODIC;
+    }
+    // TIGER_TABLE: the launcher has checked that this is the tabular BA-POMDP over (episodic or
+    // continuous) tiger; restating its sizes as literals lets the compiler unroll the two-entry
+    // Dirichlet rows and fold every model / domain branch.  Same code, same results.
+    if (TIGER_TABLE) {
+        P.model = FBA_MODEL_BA_TABLE; P.planner = FBA_PLANNER_POUCT;
+        P.S = 2; P.A = 3; P.O = 2; P.phi_len = 12; P.C = 24; P.Cs = 32;
+        if (P.domain != FBA_DOM_TIGER_CONTINUOUS) P.domain = FBA_DOM_TIGER_EPISODIC;
+        P.belief = P.belief == FBA_BELIEF_IMPORTANCE ? FBA_BELIEF_IMPORTANCE : FBA_BELIEF_REJECTION;
+        D.cn_off = 1; D.cq_off = 4; D.child_off = 10; D.node_words = 16; D.hash = nullptr;  // node layout of A = 3, O = 2 (fba_engine.hip)
+        if (TIGER_TABLE == 2) { P.C = 12; P.Cs = 16; }  // packed particles (PackedView): 24 uint16 + state in 64 bytes
+    }
+    extern __shared__ double lds[];
+    __shared__ __attribute__((aligned(8))) float s_prior[TIGER_TABLE == 2 ? 24 : 2];
+    const int lane = threadIdx.x;
+    const int gid  = blockIdx.x * SEARCH_BLOCK + lane;
+    const int e    = (D.search_perm && gid < P.E) ? D.search_perm[gid] : gid;   // lanes grouped by their slots' time-step (sort_slots)
+    if (TIGER_TABLE == 2) {
+        if (lane < 24) s_prior[lane] = D.prior_dense[lane];
+        __syncthreads();
+    }
+    if (MODEL == FBA_MODEL_BA_FACTORED) {
+        // the factored model's description (which parents, how many values, where the rows start) is
+        // consulted several times per sampled feature: keep the part in use in LDS, at the end of
+        // this workgroup's allocation, instead of chasing it through global memory
+        const int depth_cap0 = P.max_depth > 0 ? P.max_depth : 1;
+        size_t words = (size_t)depth_cap0 * SEARCH_BLOCK * 2 + (STAGE ? (size_t)P.Cs * SEARCH_BLOCK : 0) +
+                       (root_children_in_lds(P, D) ? (size_t)P.A * P.O * SEARCH_BLOCK / 2 : 0);
+        words = (words + 3) & ~(size_t)3;  // 16-byte aligned
+        uint4* dst       = reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(lds) + words);
+        const uint4* src = reinterpret_cast<const uint4*>(P.fd);
+        for (int k = lane; k < (P.fd_bytes + 15) / 16; k += SEARCH_BLOCK) dst[k] = src[k];
+        __syncthreads();
+        P.fd = reinterpret_cast<const FDesc*>(dst);
+    }
+    if (e >= P.E || !D.active[e]) return;
+
+    const int depth_cap = P.max_depth > 0 ? P.max_depth : 1;
+    // Rewards on the path are kept as fp32: every reward of every domain here (and of the BA extensions) is a
+    // small integer or a multiple of 1/2, so the round trip through float is exact and the back-up still
+    // computes in fp64 -- and 4 bytes x depth x 64 lanes of LDS per wave buy one more resident wave per CU.
+    float* path_r       = reinterpret_cast<float*>(lds) + lane;                         // [depth][block]
+    int32_t* path_na    = reinterpret_cast<int32_t*>(path_r - lane + (size_t)depth_cap * SEARCH_BLOCK) + lane;
+    float* stage        = reinterpret_cast<float*>(path_na - lane + (size_t)depth_cap * SEARCH_BLOCK) + lane;  // [Cs][block]
+    // children of the root, [a*O + o][block], when there are at most ROOT_CHILDREN of them
+    // (node indices fit 16 bits up to 32 766 simulations; beyond that the root's children stay in its record)
+    const bool root_lds = root_children_in_lds(P, D);
+    int16_t* rootch     = reinterpret_cast<int16_t*>(stage - lane + (STAGE ? (size_t)P.Cs * SEARCH_BLOCK : 0)) + lane;
+
+    Rng g               = slot_rng(P, D, e);
+    const int hist_len  = D.t[e];
+    const int max_tree_depth = min(P.horizon - hist_len, P.max_depth);
+    const int W         = D.node_words;
+    int32_t* tree       = D.nodes + (size_t)e * D.max_nodes * W;
+    const float* prec   = D.p_rec + pbase(P, e, D.bufsel[e]) * (size_t)P.Cs;
+
+    // (the nested belief stores dense records only: never with the packed instantiations)
+    const bool nested = TIGER_TABLE != 2 && !TIGER_POMDP && !FTP && MODEL != FBA_MODEL_POMDP && P.nested != 0;
+    if (P.planner == FBA_PLANNER_RANDOM) {  // RandomPlanner::selectAction RandomPlanner.cpp:14-24
+        g.stream(FBA_PHASE_SEARCH, (uint32_t)P.sims);
+        int ns = 0;
+        const int src = nested ? nested_sample(P, D, e, g, ns) : belief_sample_uniform(P, D, g);
+        D.action[e]   = domain_random_action(P, g, nested ? ns : slot_lazy(D, e) ? lazy_state(P, D, e, src) : rec_state(prec + (size_t)src * P.Cs, P.C));
+        return;
+    }
+
+    // addLegalActions(belief.sample(), ...): the probe draw lives in its own stream (unit = sims)
+    // and its result is not needed -- legal actions do not depend on the state in these domains.
+    node_init(D, tree, P.A, P.O);
+    int n_nodes = 1, tree_depth = 0;
+    unsigned long long steps = 0;
+    // The root is on the path of every simulation: its visit counts and Q values live in registers
+    // for the whole search, log1p(root visits) is fetched when the visits change (never waited for
+    // on the critical path), and its child pointers sit in LDS.
+    int r_vis = 0, r_cn[AMAX];
+    double r_cq[AMAX];
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) { r_cn[a] = 0; r_cq[a] = 0.0; }
+    double root_L = D.log1p_tab[0];
+    if (root_lds)
+        for (int k = 0; k < P.A * P.O; ++k) rootch[k * SEARCH_BLOCK] = -1;
+    int4* tab      = hash_table(D, e);
+    const uint32_t epoch = D.hash ? hash_begin_search(D, e, tab, 0, 1) : 0;
+
+    const bool lazy = slot_lazy(D, e);  // particle states are still the episode's start-state draws (lazy_state)
+    // -P ts: TSPlanner / BATSPlanner (src/planners/ts/TSPlanner.cpp:16-29, bayes-adaptive/BATSPlanner.cpp:19-34) sample
+    // the belief once and plan on that point estimate, whose sample() draws nothing: every simulation starts
+    // from the same particle and its stream begins with the UCB tie-break.
+    int ts_src = -1, ts_state = 0;
+    if (P.planner == FBA_PLANNER_TS) {
+        g.stream(FBA_PHASE_SEARCH, (uint32_t)P.sims + 2u);
+        ts_src = nested ? nested_sample(P, D, e, g, ts_state) : belief_sample_uniform(P, D, g);
+    }
+    int sim = 0, mode = 0;  // 0 = start a simulation, 1 = in the tree, 2 = rollout
+    int s = 0, node = 0, dtg = 0, plen = 0, rdepth = 0;
+    const float* cnt = prec;
+    double rret = 0, rdisc = 1;
+#ifdef FBA_PROFILE_SEARCH
+    long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prev_ = clock64();
+#endif
+    while (true) {
+        PROF_MARK(6)
+        if (mode == 0) {
+            if (sim >= P.sims) break;
+            g.stream(FBA_PHASE_SEARCH, (uint32_t)sim);
+            int nest_state = ts_state;
+            const int src = ts_src >= 0 ? ts_src : (nested ? nested_sample(P, D, e, g, nest_state) : belief_sample_uniform(P, D, g));
+            cnt = prec + (size_t)src * P.Cs;
+            if (STAGE) {
+                const float4* rp = reinterpret_cast<const float4*>(cnt);
+                const int n4 = (P.C + 4) >> 2;  // counts and the state word; the padding behind them is not needed
+                // up to twelve 16-byte loads in flight before the first of them is waited for: with a trip count the compiler does
+                // not know, a load-then-store loop is one trip to memory per 16 bytes (C3: nine in a row, 42 % of the kernel)
+                constexpr int NB = TIGER_TABLE == 2 ? 4 : 12;   // (same-box A/B on C3, nine 16-byte pieces: 4 -> 385.9 ms per tick, 8 -> 374, 12 -> 365.5)
+                for (int k0 = 0; k0 < n4; k0 += NB) {
+                    float4 v[NB];
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) v[q] = rp[min(k0 + q, n4 - 1)];
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) {
+                        const int k = k0 + q;
+                        if (k < n4) {
+                            stage[(4 * k + 0) * SEARCH_BLOCK] = v[q].x;
+                            stage[(4 * k + 1) * SEARCH_BLOCK] = v[q].y;
+                            stage[(4 * k + 2) * SEARCH_BLOCK] = v[q].z;
+                            stage[(4 * k + 3) * SEARCH_BLOCK] = v[q].w;
+                        }
+                    }
+                }
+                s = __float_as_int(stage[P.C * SEARCH_BLOCK]);
+            } else {
+                s = rec_state(cnt, P.C);
+            }
+            if (lazy) s = lazy_state(P, D, e, src);
+            if (nested) s = nest_state;
+            node = 0; dtg = max_tree_depth; plen = 0; mode = 1;
+        }
+        PROF_MARK(0)
+        bool finish = false, do_step = true;
+        double delayed = 0;
+        int a = 0;
+        if (mode == 1) {  // traverseActionNode
+            tree_depth = max(tree_depth, max_tree_depth - dtg);
+            if (dtg == 0) { finish = true; do_step = false; }
+            else if (node == 0) a = ucb_pick<AMAX>(P, g, root_L, r_cn, r_cq, true);
+            else a = ucb_select<AMAX>(P, D, g, tree + (size_t)node * W, true);
+        } else {          // rollout: uniformly random action
+            a = domain_random_action(P, g, s);
+        }
+        PROF_MARK(1)
+        int o;
+        double r;
+        bool term;
+        if (do_step) {
+            if (FTIGER > 0 && STAGE && FTP)
+                term = ftiger_step_packed<(FTIGER > 0 ? FTIGER : 1)>(P, g, LdsView<SEARCH_BLOCK>{stage}, s, a, o, r, NoInc{});
+            else if (FTIGER > 0 && STAGE) term = ftiger_step<(FTIGER > 0 ? FTIGER : 1)>(P, g, LdsView<SEARCH_BLOCK>{stage}, s, a, o, r, NoInc{});
+            else if (FTIGER > 0) term = ftiger_step<(FTIGER > 0 ? FTIGER : 1)>(P, g, GlobalSearchView{cnt}, s, a, o, r, NoInc{});
+            else if (TIGER_TABLE == 2)
+                term = tiger_step_packed(P, g, [&](int w) { return __float_as_uint(stage[w * SEARCH_BLOCK]); }, s_prior, s, a, o, r, NoInc{});
+            else if (STAGE) term = sim_step<REG>(P, g, LdsView<SEARCH_BLOCK>{stage}, s, a, o, r, NoInc{});
+            else term = sim_step<REG>(P, g, GlobalSearchView{cnt}, s, a, o, r, NoInc{});
+            ++steps;
+#ifdef FBA_PROFILE_SEARCH
+        }
+        PROF_MARK(2)
+        if (do_step) {
+#endif
+            if (mode == 1) {  // traverseChanceNode
+                path_r[(size_t)plen * SEARCH_BLOCK]  = (float)r;
+                path_na[(size_t)plen * SEARCH_BLOCK] = (node << 5) | a  /* a < FBA_MAX_ACTIONS <= 32 */;
+                ++plen;
+                if (term) finish = true;
+                else {
+                    const bool at_root_lds = root_lds && node == 0;
+                    const int c = at_root_lds ? rootch[(a * P.O + o) * SEARCH_BLOCK] : child_get(P, D, tree, tab, epoch, node, a, o);
+                    if (c >= 0) { node = c; --dtg; }
+                    else {  // expand: new leaf, then rollout(depth_to_go - 1)
+                        // never write past the slot's records: beyond the host's node bound (fba_engine.hip; cannot happen
+                        // while that bound holds) the last record is reused and the overflow reported after the loop.  (A
+                        // `break` here instead cost the whole kernel 45 %: the loop lost its shape.)
+                        const int nn = min(n_nodes, D.max_nodes - 1);
+                        ++n_nodes;
+                        node_init(D, tree + (size_t)nn * W, P.A, P.O);
+                        if (at_root_lds) rootch[(a * P.O + o) * SEARCH_BLOCK] = (int16_t)nn;
+                        else child_set(P, D, tree, tab, epoch, node, a, o, nn);
+                        mode = 2; rdepth = dtg - 1; rret = 0; rdisc = 1;
+                        if (rdepth == 0) finish = true;
+                    }
+                }
+            } else {
+                rret += r * rdisc;
+                rdisc *= P.gamma;
+                --rdepth;
+                if (rdepth == 0 || term) { delayed = rret; finish = true; }
+            }
+        }
+        PROF_MARK(3)
+        if (finish) {
+            // back-up, leaf to root: ret = r + gamma * delayed; ChanceNode::addVisit(ret)
+            // (MCTSTreeNodes.cpp:8-12); ActionNode::addVisit() (:59-62)
+            // (the root is entry 0 of every path and no other entry: the loop runs over the nodes below it, the root's
+            // register copy is updated once behind it -- one code path per level instead of two)
+            double del = delayed;
+            for (int k = plen - 1; k >= 1; --k) {
+                const int na     = path_na[(size_t)k * SEARCH_BLOCK];
+                const double ret = (double)path_r[(size_t)k * SEARCH_BLOCK] + P.gamma * del;
+                const int act    = na & 31;
+                int32_t* rec = tree + (size_t)(na >> 5) * W;
+                double* q    = reinterpret_cast<double*>(rec + D.cq_off) + act;
+                int n;
+                if (P.A == 3) {  // {visits, n0, n1, n2} is one 16-byte word: one load, one store
+                    int4* hp = reinterpret_cast<int4*>(rec);
+                    int4 h   = *hp;
+                    n = act == 0 ? ++h.y : (act == 1 ? ++h.z : ++h.w);
+                    ++h.x;
+                    *hp = h;
+                } else {
+                    n = ++rec[D.cn_off + act];
+                    if (D.cn_off) ++rec[0];
+                }
+                *q += (ret - *q) / (double)n;
+                del = ret;
+            }
+            if (plen > 0) {
+                const double ret = (double)path_r[0] + P.gamma * del;
+                const int act    = path_na[0] & 31;
+                // register-array element `act`: select, ONE division, write back
+                int n = 0;
+                double q = 0.0;
+#pragma unroll
+                for (int a2 = 0; a2 < AMAX; ++a2)
+                    if (a2 == act) { n = r_cn[a2]; q = r_cq[a2]; }
+                ++n;
+                q += (ret - q) / (double)n;
+#pragma unroll
+                for (int a2 = 0; a2 < AMAX; ++a2)
+                    if (a2 == act) { r_cn[a2] = n; r_cq[a2] = q; }
+                ++r_vis;
+                root_L = D.log1p_tab[r_vis];
+            }
+            ++sim;
+            mode = 0;
+        }
+        PROF_MARK(4)
+#ifdef FBA_PROFILE_SEARCH
+        prof_[5] += 1;
+#endif
+    }
+#ifdef FBA_PROFILE_SEARCH
+    if (lane == 0)
+        for (int r = 0; r < 8; ++r) atomicAdd(&g_search_prof[r], (unsigned long long)prof_[r]);
+#endif
+    g.stream(FBA_PHASE_SEARCH, (uint32_t)P.sims + 1u);
+    if (n_nodes > D.max_nodes) atomicCAS(D.fault, 0, -(1 + e));  // -> FBA_ESTATE on the host
+    const int best = ucb_pick<AMAX>(P, g, 0.0, r_cn, r_cq, false);
+    D.action[e]    = best;
+    D.sim_steps[e] += steps;
+    fba_trace_rec& rec = D.cur[e];
+    rec.n_nodes    = n_nodes;
+    rec.tree_depth = tree_depth;
+#pragma unroll
+    for (int a = 0; a < FBA_MAX_ACTIONS; ++a) {
+        rec.root_n[a] = a < AMAX && a < P.A ? r_cn[a < AMAX ? a : 0] : 0;
+        rec.root_q[a] = a < AMAX && a < P.A ? r_cq[a < AMAX ? a : 0] : 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// search_hist_kernel: the same search (POUCT / RBAPOUCT::selectAction, state machine of search_kernel) for
+// history particles (fba_device.h) -- the gridworld FBA-POMDP of BASELINE configs[3].  A tree of 65 536
+// simulations costs megabytes of HBM, so a GPU holds tens of thousands of them, not the hundreds of thousands that
+// "one lane = one tree" needs to keep its SIMDs busy.  Here FOUR lanes share a tree: every lane carries the whole
+// search state and executes the tree logic redundantly (same addresses, same values: loads coalesce, stores
+// agree), and the simulator step -- where the time goes -- is split: lane q generates Philox block q of the
+// quad's eight draws, lane f < 3 scans the history for, fetches and samples the Dirichlet row of state /
+// observation feature f (gridworld_hist_step_quad).  Sixteen trees per wave, four times the waves per tree count;
+// same draws, same order, same results as search_kernel on dense records.
+// LDS per wave: path [depth][16], the root particle's record [2 + entries][16].
+// ---------------------------------------------------------------------------------------------
+constexpr int HIST_TREES = SEARCH_BLOCK / HIST_QUAD;
+template <int K>
+__global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, DeviceState D)
+{
+    constexpr int AMAX = 4;
+    P.model = FBA_MODEL_BA_FACTORED; P.domain = FBA_DOM_GRIDWORLD; P.A = 4; P.belief = FBA_BELIEF_IMPORTANCE;
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x, tl = lane >> 2;
+    const int e    = blockIdx.x * HIST_TREES + tl;
+    if (e >= P.E || !D.active[e]) return;  // (a quad leaves together)
+
+    const int depth_cap = P.max_depth > 0 ? P.max_depth : 1;
+    float* path_r    = reinterpret_cast<float*>(lds) + tl;                                                        // [depth][trees]
+    int32_t* path_na = reinterpret_cast<int32_t*>(path_r - tl + (size_t)depth_cap * HIST_TREES) + tl;
+    uint32_t* stage  = reinterpret_cast<uint32_t*>(path_na - tl + (size_t)depth_cap * HIST_TREES) + tl;           // [Cs][trees]
+
+    QuadRng g;
+    g.init(P.seed_lo, P.seed_hi, (uint32_t)D.run[e], (uint32_t)D.episode[e], (uint32_t)D.t[e], lane);
+    const int hist_len  = D.t[e];
+    const int max_tree_depth = min(P.horizon - hist_len, P.max_depth);
+    const int W         = D.node_words;
+    int32_t* tree       = D.nodes + (size_t)e * D.max_nodes * W;
+    const float* prec   = D.p_rec + rec_base(P, D, e, D.bufsel[e]) * (size_t)P.Cs;
+    const uint32_t hist_cnt = D.hist_cnt[e];  // entries of each action in every record of this slot, and where each group starts
+    const int hist_n        = hist_total(hist_cnt);
+    const uint32_t hist_off = (uint32_t)hist_offset(hist_cnt, 1) << 8 | (uint32_t)hist_offset(hist_cnt, 2) << 16 | (uint32_t)hist_offset(hist_cnt, 3) << 24;
+
+    if (P.planner == FBA_PLANNER_RANDOM) {  // RandomPlanner::selectAction RandomPlanner.cpp:14-24
+        g.stream(FBA_PHASE_SEARCH, (uint32_t)P.sims);
+        g.ensure(2);
+        (void)g.u01();                      // the belief sample: GridWorld::generateRandomAction does not look at the state
+        D.action[e] = g.slow_int(0, 4);
+        return;
+    }
+    node_init(D, tree, P.A, P.O);
+    int n_nodes = 1, tree_depth = 0;
+    unsigned long long steps = 0;
+    int r_vis = 0, r_cn[AMAX];
+    double r_cq[AMAX];
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) { r_cn[a] = 0; r_cq[a] = 0.0; }
+    double root_L = D.log1p_tab[0];
+    int4* tab      = hash_table(D, e);
+    const uint32_t epoch = hash_begin_search(D, e, tab, g.q, HIST_QUAD);
+
+    int ts_src = -1;
+    if (P.planner == FBA_PLANNER_TS) {  // TSPlanner / BATSPlanner: one belief sample, then the search from that particle
+        g.stream(FBA_PHASE_SEARCH, (uint32_t)P.sims + 2u);
+        g.ensure(1);
+        ts_src = uniform_weight_pick(D.uni_scan, P.N, g.u01() * D.uni_total, D.uni_total);
+    }
+    int sim = 0, mode = 0;  // 0 = start a simulation, 1 = in the tree, 2 = rollout
+    int node = 0, dtg = 0, plen = 0, rdepth = 0;
+    uint32_t sp = 0, hist_mask = 0;
+    double rret = 0, rdisc = 1;
+#ifdef FBA_PROFILE_SEARCH
+    long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prev_ = clock64();
+#endif
+    while (true) {
+        PROF_MARK(6)
+        if (mode == 0) {
+            if (sim >= P.sims) break;
+            g.stream(FBA_PHASE_SEARCH, (uint32_t)sim);
+            g.ensure(8);  // the root sample, the first action, six rows
+            const int src = ts_src >= 0 ? ts_src : uniform_weight_pick(D.uni_scan, P.N, g.u01() * D.uni_total, D.uni_total);
+            const uint4* rp = reinterpret_cast<const uint4*>(prec + (size_t)src * P.Cs);
+            const int n4 = (hist_n + 5) >> 2;  // state, structure bits, entries
+            for (int k0 = g.q; k0 < n4; k0 += 4 * HIST_QUAD) {   // (four loads in flight per lane, as in search_kernel)
+                uint4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = rp[min(k0 + q * HIST_QUAD, n4 - 1)];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int k = k0 + q * HIST_QUAD;
+                    if (k < n4) {
+                        stage[(4 * k + 0) * HIST_TREES] = v[q].x;
+                        stage[(4 * k + 1) * HIST_TREES] = v[q].y;
+                        stage[(4 * k + 2) * HIST_TREES] = v[q].z;
+                        stage[(4 * k + 3) * HIST_TREES] = v[q].w;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the other lanes' pieces (LDS operations of one wave complete in order)
+            hist_mask = stage[1 * HIST_TREES];
+            sp        = (hist_mask >> 16) & 0x3ffu;
+            node = 0; dtg = max_tree_depth; plen = 0; mode = 1;
+        }
+        PROF_MARK(0)
+        bool finish = false, do_step = true;
+        double delayed = 0;
+        int a = 0;
+        if (mode == 1 && dtg == 0) { finish = true; do_step = false; }
+        if (mode == 1) tree_depth = max(tree_depth, max_tree_depth - dtg);
+        int o = 0;
+        double r = 0;
+        bool term = false;
+        if (do_step) {
+            g.ensure(7);  // the action, six rows
+            if (mode == 1) {  // traverseActionNode
+                if (node == 0) a = ucb_pick<AMAX>(P, g, root_L, r_cn, r_cq, true);
+                else a = ucb_select<AMAX>(P, D, g, tree + (size_t)node * W, true);
+            } else {
+                a = g.slow_int(0, 4);  // GridWorld::generateRandomAction :220-226
+            }
+#ifdef FBA_PROFILE_SEARCH
+        }
+        PROF_MARK(1)
+        if (do_step) {
+#endif
+            term = gridworld_hist_step_quad<K, HIST_TREES>(P, g, stage + (size_t)(2 + ((hist_off >> (8 * a)) & 0xffu)) * HIST_TREES,
+                                                           hist_count(hist_cnt, a), hist_mask, sp, a, o, r);
+            ++steps;
+#ifdef FBA_PROFILE_SEARCH
+        }
+        PROF_MARK(2)
+        if (do_step) {
+#endif
+            if (mode == 1) {  // traverseChanceNode
+                path_r[(size_t)plen * HIST_TREES]  = (float)r;
+                path_na[(size_t)plen * HIST_TREES] = (node << 5) | a;
+                ++plen;
+                if (term) finish = true;
+                else {
+                    const int c = child_get(P, D, tree, tab, epoch, node, a, o);
+                    if (c >= 0) { node = c; --dtg; }
+                    else {  // expand: new leaf, then rollout(depth_to_go - 1)
+                        const int nn = min(n_nodes, D.max_nodes - 1);
+                        ++n_nodes;
+                        node_init(D, tree + (size_t)nn * W, P.A, P.O);
+                        child_set(P, D, tree, tab, epoch, node, a, o, nn);
+                        mode = 2; rdepth = dtg - 1; rret = 0; rdisc = 1;
+                        if (rdepth == 0) finish = true;
+                    }
+                }
+            } else {
+                rret += r * rdisc;
+                rdisc *= P.gamma;
+                --rdepth;
+                if (rdepth == 0 || term) { delayed = rret; finish = true; }
+            }
+        }
+        PROF_MARK(3)
+        if (finish) {  // back-up, leaf to root (MCTSTreeNodes.cpp:8-12, 59-62)
+            double del = delayed;
+            for (int k = plen - 1; k >= 0; --k) {
+                const int na     = path_na[(size_t)k * HIST_TREES];
+                const double ret = (double)path_r[(size_t)k * HIST_TREES] + P.gamma * del;
+                const int act    = na & 31;
+                if ((na >> 5) == 0) {
+                    int n = 0;
+                    double q = 0.0;
+#pragma unroll
+                    for (int a2 = 0; a2 < AMAX; ++a2)
+                        if (a2 == act) { n = r_cn[a2]; q = r_cq[a2]; }
+                    ++n;
+                    q += (ret - q) / (double)n;
+#pragma unroll
+                    for (int a2 = 0; a2 < AMAX; ++a2)
+                        if (a2 == act) { r_cn[a2] = n; r_cq[a2] = q; }
+                    ++r_vis;
+                    root_L = D.log1p_tab[r_vis];
+                } else {
+                    int32_t* rec = tree + (size_t)(na >> 5) * W;
+                    double* q    = reinterpret_cast<double*>(rec + D.cq_off) + act;
+                    const int n  = ++rec[D.cn_off + act];
+                    if (D.cn_off) ++rec[0];
+                    *q += (ret - *q) / (double)n;
+                }
+                del = ret;
+            }
+            ++sim;
+            mode = 0;
+        }
+        PROF_MARK(4)
+#ifdef FBA_PROFILE_SEARCH
+        prof_[5] += 1;
+#endif
+    }
+#ifdef FBA_PROFILE_SEARCH
+    if (lane == 0)
+        for (int r2 = 0; r2 < 8; ++r2) atomicAdd(&g_search_prof[r2], (unsigned long long)prof_[r2]);
+#endif
+    g.stream(FBA_PHASE_SEARCH, (uint32_t)P.sims + 1u);
+    g.ensure(1);
+    if (n_nodes > D.max_nodes) atomicCAS(D.fault, 0, -(1 + e));
+    const int best = ucb_pick<AMAX>(P, g, 0.0, r_cn, r_cq, false);
+    D.action[e]    = best;
+    if (g.q == 0) D.sim_steps[e] += steps;
+    fba_trace_rec& rec = D.cur[e];
+    rec.n_nodes    = n_nodes;
+    rec.tree_depth = tree_depth;
+#pragma unroll
+    for (int a = 0; a < FBA_MAX_ACTIONS; ++a) {
+        rec.root_n[a] = a < AMAX ? r_cn[a < AMAX ? a : 0] : 0;
+        rec.root_q[a] = a < AMAX ? r_cq[a < AMAX ? a : 0] : 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// sort_slots: search lanes in order of their slots' time-step.  A simulation is as deep as the slot's remaining horizon
+// lets it be (POUCT.cpp:80: max depth = min(horizon - history length, max depth)), every lane runs the same number of
+// simulations, and a wave lasts as long as its slowest lane: with slots of every time-step in every wave the lanes whose
+// trees are shallow sit idle for a third of the wave's iterations (bench workload: 2.26 simulated steps per simulation on
+// average, 3.2 at t = 0).  Which lane runs a slot changes nothing in what the slot computes.  Counting sort, three tiny
+// launches; the order inside a bin is whatever the atomics give.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t sort_key(const DeviceState& D, int e) { return D.active[e] ? (uint32_t)min(max(D.t[e], 0), 254) : 255u; }
+__global__ void __launch_bounds__(256) sort_count_kernel(Problem P, DeviceState D)
+{
+    __shared__ uint32_t s_bins[256];
+    s_bins[threadIdx.x] = 0;
+    __syncthreads();
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < P.E) atomicAdd(&s_bins[sort_key(D, e)], 1u);
+    __syncthreads();
+    if (s_bins[threadIdx.x]) atomicAdd(&D.sort_bins[threadIdx.x], s_bins[threadIdx.x]);
+}
+__global__ void __launch_bounds__(256) sort_offsets_kernel(DeviceState D)
+{
+    __shared__ uint32_t s_scan[256];
+    const uint32_t mine = D.sort_bins[threadIdx.x];
+    s_scan[threadIdx.x] = mine;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const uint32_t v = threadIdx.x >= (unsigned)d ? s_scan[threadIdx.x - d] : 0u;
+        __syncthreads();
+        s_scan[threadIdx.x] += v;
+        __syncthreads();
+    }
+    D.sort_bins[256 + threadIdx.x] = s_scan[threadIdx.x] - mine;   // where bin `threadIdx.x` starts
+    D.sort_bins[threadIdx.x]       = 0;                             // (ready for the next search)
+}
+__global__ void __launch_bounds__(256) sort_scatter_kernel(Problem P, DeviceState D)
+{
+    __shared__ uint32_t s_cnt[256], s_base[256];
+    s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    uint32_t key = 0, rank = 0;
+    if (e < P.E) {
+        key  = sort_key(D, e);
+        rank = atomicAdd(&s_cnt[key], 1u);
+    }
+    __syncthreads();
+    if (s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&D.sort_bins[256 + threadIdx.x], s_cnt[threadIdx.x]);
+    __syncthreads();
+    if (e < P.E) D.search_perm[s_base[key] + rank] = e;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host launcher
+// ---------------------------------------------------------------------------------------------
+void launch_search(const Problem& P, const DeviceState& D, hipStream_t st)
+{
+    const int depth_cap = P.max_depth > 0 ? P.max_depth : 1;
+    const bool stage = P.model != FBA_MODEL_POMDP && P.Cs <= SEARCH_STAGE_WORDS;
+    size_t lds = (size_t)depth_cap * SEARCH_BLOCK * (sizeof(float) + sizeof(int32_t)) +
+                 (stage ? (size_t)P.Cs * SEARCH_BLOCK * sizeof(float) : 0) +
+                 (root_children_in_lds(P, D) ? (size_t)P.A * P.O * SEARCH_BLOCK * sizeof(int16_t) : 0);
+    if (P.model == FBA_MODEL_BA_FACTORED) lds = ((lds + 15) & ~(size_t)15) + (((size_t)P.fd_bytes + 15) & ~(size_t)15);  // + the model description
+    static const size_t lds_pad = std::getenv("FBA_SEARCH_LDS_PAD") ? (size_t)std::atoi(std::getenv("FBA_SEARCH_LDS_PAD")) : 0;  // occupancy experiments
+    lds += lds_pad;
+    const dim3 grid(ceil_div(P.E, SEARCH_BLOCK)), block(SEARCH_BLOCK);
+    if (D.search_perm) {
+        hipLaunchKernelGGL(sort_count_kernel, dim3(ceil_div(P.E, 256)), dim3(256), 0, st, P, D);
+        hipLaunchKernelGGL(sort_offsets_kernel, dim3(1), dim3(256), 0, st, D);
+        hipLaunchKernelGGL(sort_scatter_kernel, dim3(ceil_div(P.E, 256)), dim3(256), 0, st, P, D);
+    }
+#define FBA_LAUNCH_SEARCH_M(STG, AM, MODEL)                                                                              \
+    do {                                                                                                                 \
+        if (P.dirichlet_regular && MODEL != FBA_MODEL_POMDP)                                                             \
+            hipLaunchKernelGGL((search_kernel<STG, AM, (MODEL != FBA_MODEL_POMDP), 0, MODEL>), grid, block, lds, st, P, D); \
+        else hipLaunchKernelGGL((search_kernel<STG, AM, false, 0, MODEL>), grid, block, lds, st, P, D);             \
+    } while (0)
+#define FBA_LAUNCH_SEARCH(STG, AM)                                                                  \
+    do {                                                                                            \
+        if (P.model == FBA_MODEL_BA_FACTORED) FBA_LAUNCH_SEARCH_M(STG, AM, FBA_MODEL_BA_FACTORED);  \
+        else if (P.model == FBA_MODEL_BA_TABLE) FBA_LAUNCH_SEARCH_M(STG, AM, FBA_MODEL_BA_TABLE);   \
+        else FBA_LAUNCH_SEARCH_M(false, AM, FBA_MODEL_POMDP);                                       \
+    } while (0)
+    if (P.hist) {  // history particles (gridworld FBA-POMDP): four lanes per tree
+        lds = (size_t)depth_cap * HIST_TREES * (sizeof(float) + sizeof(int32_t)) + (size_t)P.Cs * HIST_TREES * sizeof(float);
+        const dim3 qgrid(ceil_div(P.E, HIST_TREES));
+        if (P.hist_row <= 8) hipLaunchKernelGGL((search_hist_kernel<8>), qgrid, block, lds, st, P, D);
+        else if (P.hist_row <= 12) hipLaunchKernelGGL((search_hist_kernel<12>), qgrid, block, lds, st, P, D);
+        else hipLaunchKernelGGL((search_hist_kernel<16>), qgrid, block, lds, st, P, D);
+        return;
+    }
+    const bool tiger_table = P.model == FBA_MODEL_BA_TABLE && P.planner == FBA_PLANNER_POUCT && !P.dirichlet_regular && stage &&
+                             (P.domain == FBA_DOM_TIGER_EPISODIC || P.domain == FBA_DOM_TIGER_CONTINUOUS) && !D.hash;
+    if (tiger_table) {
+        if (P.packed) hipLaunchKernelGGL((search_kernel<true, 4, false, 2, FBA_MODEL_BA_TABLE>), grid, block, lds, st, P, D);
+        else hipLaunchKernelGGL((search_kernel<true, 4, false, 1, FBA_MODEL_BA_TABLE>), grid, block, lds, st, P, D);
+        return;
+    }
+    if (P.model == FBA_MODEL_POMDP && P.planner == FBA_PLANNER_POUCT && !D.hash &&
+        (P.domain == FBA_DOM_TIGER_EPISODIC || P.domain == FBA_DOM_TIGER_CONTINUOUS)) {
+        hipLaunchKernelGGL((search_kernel<false, 4, false, 0, FBA_MODEL_POMDP, 0, true>), grid, block, lds, st, P, D);
+        return;
+    }
+    if (P.model == FBA_MODEL_BA_FACTORED && (P.domain == FBA_DOM_FTIGER_EPISODIC || P.domain == FBA_DOM_FTIGER_CONTINUOUS) &&
+        !P.dirichlet_regular && P.planner == FBA_PLANNER_POUCT && !D.hash) {
+        const int FS = 31 - __builtin_clz((unsigned)P.S);  // S = 2^FS
+#define FBA_LAUNCH_FTIGER(FSV)                                                                                                    \
+    do {                                                                                                                          \
+        if (P.ft_packed) hipLaunchKernelGGL((search_kernel<true, 4, false, 0, FBA_MODEL_BA_FACTORED, FSV, false, true>), grid, block, lds, st, P, D); \
+        else if (stage) hipLaunchKernelGGL((search_kernel<true, 4, false, 0, FBA_MODEL_BA_FACTORED, FSV>), grid, block, lds, st, P, D); \
+        else hipLaunchKernelGGL((search_kernel<false, 4, false, 0, FBA_MODEL_BA_FACTORED, FSV>), grid, block, lds, st, P, D);      \
+        return;                                                                                                                   \
+    } while (0)
+        if (FS == 2) FBA_LAUNCH_FTIGER(2);
+        if (FS == 3) FBA_LAUNCH_FTIGER(3);
+        if (FS == 4) FBA_LAUNCH_FTIGER(4);
+#undef FBA_LAUNCH_FTIGER
+    }
+    if (P.A <= 4) { if (stage) FBA_LAUNCH_SEARCH(true, 4); else FBA_LAUNCH_SEARCH(false, 4); }
+    else if (P.A <= 8) { if (stage) FBA_LAUNCH_SEARCH(true, 8); else FBA_LAUNCH_SEARCH(false, 8); }
+    else if (P.A <= 16) { if (stage) FBA_LAUNCH_SEARCH(true, 16); else FBA_LAUNCH_SEARCH(false, 16); }
+    else FBA_LAUNCH_SEARCH_M(false, 24, FBA_MODEL_POMDP);  // agr (23 actions) is a POMDP-only domain
+#undef FBA_LAUNCH_SEARCH_M
+#undef FBA_LAUNCH_SEARCH
+}
+#ifdef FBA_PROFILE_SEARCH
+extern "C" int fba_debug_search_profile(unsigned long long* out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_search_prof), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) {
+        const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_search_prof), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
+}  // namespace fba

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FBA_ABI_VERSION 1
+#define FBA_ABI_VERSION 2   /* 2: fba_config.belief_option, fba_belief_get_particle; hosts check fba_abi_version() == FBA_ABI_VERSION before fba_create */
 #define FBA_MAX_ACTIONS 24
 
 /* domains: reference src/domains, selected by -D (DomainConf.hpp) */
@@ -250,6 +250,11 @@ int fba_belief_update(fba_ctx* ctx, const int32_t* action, const int32_t* obs, c
  * state[particles], weight[particles] (may be NULL), counts[particles * counts_len] (may be NULL) */
 int fba_belief_get(fba_ctx* ctx, int32_t slot, int32_t* state, double* weight, float* counts);
 int fba_belief_set(fba_ctx* ctx, int32_t slot, const int32_t* state, const double* weight, const float* counts);
+/* One particle of the filter -- what Belief::sample() (Belief.hpp:33) hands a HOST-side planner once the host has drawn the
+ * index (FlatFilter::sample FlatFilter.cpp:97-102: uniform; WeightedFilter::sample WeightedFilter.cpp:163-191: by weight):
+ * state[1], weight[1] (may be NULL; importance filters only), counts[counts_len] (may be NULL).  The adapters build the
+ * BAPOMDPState / FBAPOMDPState a reference planner borrows from it (RBAPOUCT.cpp:89-107). */
+int fba_belief_get_particle(fba_ctx* ctx, int32_t slot, int32_t index, int32_t* state, double* weight, float* counts);
 /* the second filter of the reinvigoration belief (ReinvigoratingRejectionSampling.hpp:
  * _fully_connected_belief) or of the cheating belief (CheatingReinvigoration.hpp:
  * _correct_structured_belief), for tests */

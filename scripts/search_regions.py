@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     from fba_pomdp_amd import _native as N
-    subprocess.check_call(["hipcc"] + N.HIPCC_FLAGS + ["-DFBA_PROFILE_SEARCH", "-I" + os.path.join(ROOT, "include")] + N.SOURCES + ["-o", PROF])
+    N.build(extra_flags=["-DFBA_PROFILE_SEARCH"], lib_path=PROF, obj_tag="_prof")
     print("built", PROF)
     sys.exit(0)
 

@@ -5,16 +5,26 @@
 // (action, observation) stream through the oracle and asks for the same actions.
 //
 //   drive_gpu <planning|bapomdp> <sims> <particles> <runs> <episodes> <horizon> <seed>
+//   drive_gpu <sample-planning|sample-bapomdp|sample-bapomdp-is|sample-fbapomdp> <draws> <particles> <runs> <episodes> <horizon> <seed>
+//       Belief::sample() of the hip beliefs under a HOST planner: the reference's RandomPlanner picks the actions from
+//       belief.sample(), and after every belief update `draws` samples are taken and each is looked up in the filter the
+//       engine holds (fba_belief_get): same state, and -- Bayes-adaptive -- the same counts read back through the reference's
+//       own BAPOMDPState / FBAPOMDPState accessors.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
+#include <vector>
 
 #include "easylogging++.h"
 
 #include "adapters.hpp"
+#include "domains/tiger/FactoredTiger.hpp"
 #include "domains/tiger/Tiger.hpp"
+#include "environment/Action.hpp"
+#include "environment/Observation.hpp"
+#include "planners/random/RandomPlanner.hpp"
 #include "environment/Discount.hpp"
 #include "environment/Environment.hpp"
 #include "environment/Horizon.hpp"
@@ -47,6 +57,186 @@ private:
 };
 }  // namespace
 
+// ---- Belief::sample() under a host planner -------------------------------------------------------------------------
+// the counts of a sampled BAState in the engine's blob order, read through the reference's own accessors
+static std::vector<float> counts_of(BAState const* ba, fba_ctx* ctx, int model)
+{
+    int32_t S, A, O;
+    fba_domain_sizes(ctx, &S, &A, &O);
+    std::vector<float> out;
+    if (model == FBA_MODEL_BA_TABLE) {
+        auto* st = const_cast<BAPOMDPState*>(dynamic_cast<BAPOMDPState const*>(ba));
+        if (!st) throw std::string("sample() of a tabular session is not a BAPOMDPState");
+        for (int s = 0; s < S; ++s)
+            for (int a = 0; a < A; ++a)
+                for (int ns = 0; ns < S; ++ns) {
+                    IndexState x(s), y(ns);
+                    IndexAction ia(a);
+                    out.push_back(st->model()->count(&x, &ia, &y));
+                }
+        for (int a = 0; a < A; ++a)
+            for (int ns = 0; ns < S; ++ns)
+                for (int o = 0; o < O; ++o) {
+                    IndexState y(ns);
+                    IndexAction ia(a);
+                    IndexObservation io(o);
+                    out.push_back(st->model()->count(&ia, &y, &io));
+                }
+        return out;
+    }
+    auto* st = const_cast<FBAPOMDPState*>(dynamic_cast<FBAPOMDPState const*>(ba));
+    if (!st) throw std::string("sample() of a factored session is not an FBAPOMDPState");
+    fba_factored_layout L;
+    fba_get_factored_layout(ctx, &L);
+    out.assign((size_t)L.n_counts, -1.f);   // cells of unused candidate-parent room stay -1 on both sides
+    for (int k = 0; k < L.n_nodes; ++k) {
+        bool const is_t = k < A * L.n_state_features;
+        int const a     = is_t ? k / L.n_state_features : (k - A * L.n_state_features) / L.n_obs_features;
+        int const f     = is_t ? k % L.n_state_features : (k - A * L.n_state_features) % L.n_obs_features;
+        IndexAction ia(a);
+        DBNNode& node = is_t ? st->model()->transitionNode(&ia, f) : st->model()->observationNode(&ia, f);
+        std::vector<int> const& parents = *node.parents();
+        std::vector<int> sizes;
+        for (int p : parents) sizes.push_back(L.state_feature_size[p]);
+        int rows = 1;
+        for (int sz : sizes) rows *= sz;
+        std::vector<int> pv(parents.size(), 0);
+        for (int r = 0; r < rows; ++r) {
+            int rem = r;
+            for (int j = (int)parents.size() - 1; j >= 0; --j) { pv[j] = rem % sizes[j]; rem /= sizes[j]; }
+            for (int v = 0; v < L.node[k].out; ++v) out[(size_t)(L.node[k].offset + r * L.node[k].out + v)] = node.count(pv, v);
+        }
+    }
+    return out;
+}
+
+// how many rows of each node a particle's parent set uses, to blank the unused room of the engine's max layout
+static void blank_unused(std::vector<float>& blob, fba_factored_layout const& L)
+{
+    std::vector<char> used((size_t)L.n_counts, 0);
+    for (int k = 0; k < L.n_nodes; ++k) {
+        fba_factored_node const& nd = L.node[k];
+        uint32_t mask = nd.fixed_mask;
+        if (nd.mask_word >= 0) std::memcpy(&mask, &blob[(size_t)(L.n_counts + nd.mask_word)], 4);
+        int rows = 1;
+        for (int j = 0; j < nd.n_candidates; ++j)
+            if ((mask >> j) & 1u) rows *= nd.candidate_size[j];
+        for (int c = 0; c < rows * nd.out; ++c) used[(size_t)(nd.offset + c)] = 1;
+    }
+    for (int c = 0; c < L.n_counts; ++c)
+        if (!used[(size_t)c]) blob[(size_t)c] = -1.f;
+}
+
+template <class BeliefT>
+static void check_samples(BeliefT& belief, fba_ctx* ctx, int model, int particles, int draws, bool weighted)
+{
+    int const C = fba_counts_len(ctx);
+    std::vector<int32_t> states((size_t)particles);
+    std::vector<double> weights((size_t)particles, 1.0);
+    std::vector<float> counts((size_t)particles * (size_t)(C > 0 ? C : 1));
+    if (fba_belief_get(ctx, 0, states.data(), weighted ? weights.data() : nullptr, C > 0 ? counts.data() : nullptr) != FBA_OK)
+        throw std::string(fba_last_error(ctx));
+    fba_factored_layout L;
+    if (model == FBA_MODEL_BA_FACTORED) {
+        fba_get_factored_layout(ctx, &L);
+        for (int i = 0; i < particles; ++i) {
+            std::vector<float> one(counts.begin() + (size_t)i * C, counts.begin() + (size_t)(i + 1) * C);
+            blank_unused(one, L);
+            std::copy(one.begin(), one.begin() + L.n_counts, counts.begin() + (size_t)i * C);
+        }
+    }
+    int32_t S, A, O;
+    fba_domain_sizes(ctx, &S, &A, &O);
+    std::vector<double> filter_hist((size_t)S, 0.0);
+    double total = 0;
+    for (int i = 0; i < particles; ++i) { filter_hist[(size_t)states[(size_t)i]] += weights[(size_t)i]; total += weights[(size_t)i]; }
+    std::vector<int> sample_hist((size_t)S, 0);
+    int matched = 0, swapped_back = 0;
+    for (int d = 0; d < draws; ++d) {
+        State const* smp = belief.sample();
+        int const s      = model == FBA_MODEL_POMDP ? smp->index() : static_cast<BAState const*>(smp)->_domain_state->index();
+        ++sample_hist[(size_t)s];
+        if (model == FBA_MODEL_POMDP) {
+            matched += filter_hist[(size_t)s] > 0;
+            continue;
+        }
+        auto const* ba = static_cast<BAState const*>(smp);
+        std::vector<float> const mine = counts_of(ba, ctx, model);
+        size_t const ncmp = model == FBA_MODEL_BA_FACTORED ? (size_t)L.n_counts : (size_t)C;
+        for (int i = 0; i < particles; ++i)
+            if (states[(size_t)i] == s && std::equal(mine.begin(), mine.begin() + ncmp, counts.begin() + (size_t)i * C)) { ++matched; break; }
+        // what RBAPOUCT does with the particle (RBAPOUCT.cpp:92-106): swap the domain state, simulate, put the old one back
+        State const* old = ba->_domain_state;
+        IndexState other((s + 1) % S);
+        const_cast<BAState*>(ba)->_domain_state = &other;
+        const_cast<BAState*>(ba)->_domain_state = old;
+        swapped_back += ba->_domain_state == old && old->index() == s;
+    }
+    std::printf("samples draws=%d matched=%d swapped_back=%d filter=", draws, matched, swapped_back);
+    for (int s = 0; s < S; ++s) std::printf("%s%.6f", s ? "," : "", filter_hist[(size_t)s] / total);
+    std::printf(" sampled=");
+    for (int s = 0; s < S; ++s) std::printf("%s%d", s ? "," : "", sample_hist[(size_t)s]);
+    std::printf("\n");
+}
+
+static int sample_mode(char const* mode, int draws, int particles, int runs, int episodes, int horizon, unsigned long long seed)
+{
+    bool const planning = std::strcmp(mode, "sample-planning") == 0, factored = std::strcmp(mode, "sample-fbapomdp") == 0;
+    bool const weighted = std::strcmp(mode, "sample-bapomdp-is") == 0;
+    fba_config cfg;
+    fba_default_config(&cfg);
+    cfg.domain    = factored ? FBA_DOM_FTIGER_EPISODIC : FBA_DOM_TIGER_EPISODIC;
+    cfg.size      = factored ? 2 : 0;
+    cfg.model     = planning ? FBA_MODEL_POMDP : (factored ? FBA_MODEL_BA_FACTORED : FBA_MODEL_BA_TABLE);
+    cfg.belief    = weighted ? FBA_BELIEF_IMPORTANCE : FBA_BELIEF_REJECTION;
+    cfg.structure_prior = factored ? FBA_SP_MATCH_UNIFORM : FBA_SP_NONE;
+    cfg.sims      = 16;
+    cfg.particles = particles;
+    cfg.horizon   = horizon;
+    cfg.episodes  = planning ? 1 : episodes;
+    cfg.runs      = runs;
+    cfg.seed      = seed;
+    domains::Tiger tiger(domains::Tiger::EPISODIC), tsim(domains::Tiger::EPISODIC);
+    domains::FactoredTiger ftiger(domains::FactoredTiger::EPISODIC, 2), fsim(domains::FactoredTiger::EPISODIC, 2);
+    Environment const& env = factored ? static_cast<Environment const&>(ftiger) : static_cast<Environment const&>(tiger);
+    POMDP const& sim       = factored ? static_cast<POMDP const&>(fsim) : static_cast<POMDP const&>(tsim);
+    auto session = std::make_shared<fba::HipSession>(cfg);
+    planners::RandomPlanner planner;   // the reference's own host planner: generateRandomAction(belief.sample())
+    if (planning) {
+        fba::HipParticleBelief belief(session);
+        for (int run = 0; run < runs; ++run) {
+            belief.initiate(sim);
+            check_samples(belief, session->ctx(), cfg.model, particles, draws, false);
+            auto const res = episode::run(planner, belief, env, sim, Horizon(horizon), Discount(.95));
+            std::printf("episode length %d\n", res.length);
+            check_samples(belief, session->ctx(), cfg.model, particles, draws, false);
+            belief.free(sim);
+        }
+        return 0;
+    }
+    fba::HipDomainStates states;   // BAPOMDP needs Boost: the mirror's domain states are index states the simulators here accept
+    states.make    = [](int i) -> State const* { return new IndexState(i); };
+    states.release = [](State const* st) { delete st; };
+    fba::HipBAParticleBelief belief(session, states);
+    alignas(16) static char never_used[64];
+    BAPOMDP const& no_bapomdp = *reinterpret_cast<BAPOMDP const*>(never_used);
+    // RandomPlanner over a Bayes-adaptive belief: the simulator it asks for a random action only looks at the index of
+    // the state it is handed (Tiger.cpp:21-25, FactoredTiger.cpp: generateRandomAction), and a BAState's index() is its
+    // domain state's (BAState.cpp) -- the BAPOMDP's own generateRandomAction forwards the same way (BAPOMDP.cpp:145-148)
+    for (int run = 0; run < runs; ++run) {
+        belief.initiate(sim);
+        check_samples(belief, session->ctx(), cfg.model, particles, draws, weighted);
+        for (int ep = 0; ep < episodes; ++ep) {
+            belief.resetDomainStateDistribution(no_bapomdp);
+            auto const res = episode::run(planner, belief, env, sim, Horizon(horizon), Discount(.95));
+            std::printf("episode length %d\n", res.length);
+            check_samples(belief, session->ctx(), cfg.model, particles, draws, weighted);
+        }
+        belief.free(sim);
+    }
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     if (argc < 8) {
@@ -60,6 +250,15 @@ int main(int argc, char** argv)
     rnd::initiate();
     { std::string seed_str("3"); rnd::seed(seed_str); }
 
+    if (std::strncmp(argv[1], "sample-", 7) == 0) {
+        try {
+            return sample_mode(argv[1], std::atoi(argv[2]), std::atoi(argv[3]), std::atoi(argv[4]), std::atoi(argv[5]), std::atoi(argv[6]),
+                               std::strtoull(argv[7], nullptr, 10));
+        } catch (std::string const& e) {
+            std::fprintf(stderr, "error: %s\n", e.c_str());
+            return 1;
+        }
+    }
     bool const ba = std::strcmp(argv[1], "bapomdp") == 0;
     int const runs = std::atoi(argv[4]), episodes = std::atoi(argv[5]), horizon = std::atoi(argv[6]);
     fba_config cfg;
@@ -90,7 +289,10 @@ int main(int argc, char** argv)
                 belief.free(sim);
             }
         } else {     // experiment::bapomdp::run (BAPOMDPExperiment.cpp:44-75); BAPOMDP itself needs Boost: the adapter ignores it
-            fba::HipBAParticleBelief belief(session);
+            fba::HipDomainStates states;
+            states.make    = [](int i) -> State const* { return new IndexState(i); };
+            states.release = [](State const* st) { delete st; };
+            fba::HipBAParticleBelief belief(session, states);
             alignas(16) static char never_used[64];
             BAPOMDP const& no_bapomdp = *reinterpret_cast<BAPOMDP const*>(never_used);
             for (int run = 0; run < runs; ++run) {

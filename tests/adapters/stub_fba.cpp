@@ -15,6 +15,18 @@ struct fba_ctx {
 static fba_ctx g_ctx;
 
 extern "C" {
+int fba_abi_version(void) { return FBA_ABI_VERSION; }
+int fba_domain_sizes(const fba_ctx*, int32_t* S, int32_t* A, int32_t* O) { *S = 2; *A = 3; *O = 2; return FBA_OK; }
+int fba_counts_len(const fba_ctx*) { return 24; }
+int fba_get_factored_layout(const fba_ctx*, fba_factored_layout*) { return FBA_EINVAL; }
+int fba_belief_get_particle(fba_ctx*, int32_t, int32_t index, int32_t* state, double* weight, float* counts)
+{
+    if (state) *state = index & 1;
+    if (weight) *weight = 1.0;
+    if (counts) for (int k = 0; k < 24; ++k) counts[k] = 100.f * (float)index + (float)k;   // particle `index`, cell k
+    std::printf("get_particle %d\n", index);
+    return FBA_OK;
+}
 void fba_default_config(fba_config* cfg) { std::memset(cfg, 0, sizeof *cfg); cfg->particles = 8; cfg->horizon = 4; }
 int fba_create(const fba_config* cfg, fba_ctx** out)
 {
@@ -49,9 +61,12 @@ int fba_belief_update(fba_ctx* c, const int32_t* action, const int32_t* obs, con
     std::printf("update run=%d episode=%d t=%d a=%d o=%d\n", c->run, c->episode, c->t, *action, *obs);
     return FBA_OK;
 }
-int fba_belief_get(fba_ctx* c, int32_t, int32_t* state, double*, float*)
+int fba_belief_get(fba_ctx* c, int32_t, int32_t* state, double* weight, float*)
 {
-    for (int i = 0; i < c->cfg.particles; ++i) state[i] = 1;
+    for (int i = 0; i < c->cfg.particles; ++i) {
+        if (state) state[i] = 1;
+        if (weight) weight[i] = 1.0;
+    }
     std::printf("get\n");
     return FBA_OK;
 }

@@ -66,3 +66,31 @@ def test_reference_episode_loop_drives_the_engine_through_the_adapters(mode, sim
                 n_steps += 1
             assert abs(ret - rec["ret"]) < 1e-9
     assert n_steps >= runs * episodes        # at least one real step per episode went through the GPU
+
+
+@pytest.mark.skipif(not os.path.exists(EXE), reason="oracle/_ref/adapters_drive_gpu is built only where /root/reference exists")
+@pytest.mark.parametrize("mode,particles", [("sample-planning", 64), ("sample-bapomdp", 48), ("sample-bapomdp-is", 48), ("sample-fbapomdp", 32)])
+def test_belief_sample_hands_a_host_planner_real_particles(mode, particles):
+    """Belief::sample() of the hip beliefs (Belief.hpp:33) under the reference's own RandomPlanner: every sample is a particle
+    of the filter the engine holds at that moment -- its state and, Bayes-adaptive, its learned counts read back through the
+    reference's BAPOMDPState / FBAPOMDPState accessors -- drawn with the filter's own distribution, and a planner may swap
+    the sample's domain state and put it back (RBAPOUCT.cpp:92-106)."""
+    draws = 400
+    r = subprocess.run([EXE, mode, str(draws), str(particles), "2", "3", "6", "99"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("samples ")]
+    assert len(lines) >= 2 * (1 + (1 if mode == "sample-planning" else 3))
+    seen_states = set()
+    for l in lines:
+        kv = dict(w.split("=") for w in l.split()[1:])
+        assert int(kv["matched"]) == draws, l          # every sample IS a particle of the device filter (state and counts)
+        if mode != "sample-planning":
+            assert int(kv["swapped_back"]) == draws, l
+        filt = [float(x) for x in kv["filter"].split(",")]
+        smp = [int(x) for x in kv["sampled"].split(",")]
+        assert sum(smp) == draws
+        for p, k in zip(filt, smp):                    # drawn with the filter's distribution (5 sigma of a binomial)
+            assert abs(k / draws - p) <= 5 * (p * (1 - p) / draws) ** 0.5 + 1e-12, l
+            if k:
+                seen_states.add(p)
+    assert len(seen_states) > 1                        # not a constant

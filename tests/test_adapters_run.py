@@ -20,9 +20,13 @@ def test_adapters_advance_run_episode_and_step(tmp_path):
     objs = [os.path.join(obj, p) for p in (
         "experiments/Episode.o", "domains/tiger/Tiger.o", "utils/random.o", "utils/index.o", "utils/distributions.o",
         "environment/Discount.o", "environment/History.o", "environment/Horizon.o", "environment/Return.o",
-        "environment/Reward.o", "environment/Terminal.o")]
+        "environment/Reward.o", "environment/Terminal.o",
+        # the state classes HipBAParticleBelief::sample() builds its host mirror from
+        "bayes-adaptive/states/BAState.o", "bayes-adaptive/states/table/BAPOMDPState.o", "bayes-adaptive/states/table/BAFlatModel.o",
+        "bayes-adaptive/states/factored/FBAPOMDPState.o", "bayes-adaptive/states/factored/BABNModel.o",
+        "bayes-adaptive/states/factored/DBNNode.o")]
     exe = str(tmp_path / "drive")
-    cmd = ["g++", "-std=c++11", "-O1", "-w", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "fba_pomdp_amd", "csrc", "host"),
+    cmd = ["g++", "-std=c++11", "-O1", "-w", "-DFBA_ADAPTERS_NO_BAPOMDP", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "fba_pomdp_amd", "csrc", "host"),
            "-I" + REF + "/src", "-I" + REF + "/includes", os.path.join(ROOT, "tests", "adapters", "drive.cpp"),
            os.path.join(ROOT, "tests", "adapters", "stub_fba.cpp")] + objs + ["-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -54,3 +58,15 @@ def test_adapters_advance_run_episode_and_step(tmp_path):
     assert len(set(pos(l) for l in calls if l.startswith("select"))) == 2 * 3 * 3   # no position is ever used twice
     # the belief's particle 0 is downloaded once per belief state, not once per sample()
     assert plan.count("get") <= plan.count("select")
+    # Belief::sample() of the Bayes-adaptive adapter: the particle the host drew, as a BAPOMDPState with THAT particle's counts
+    # (the stub's particle i holds 100 i + k in cell k, state i & 1) -- never a constant, never a prior sample
+    samples = [dict(kv.split("=") for kv in l.split()[1:]) for l in ba.splitlines() if l.startswith("sample ")]
+    assert len(samples) == 2 * 4
+    for smp in samples:
+        i = int(smp["particle"])
+        assert 0 <= i < 8
+        assert int(smp["state"]) == (i & 1)
+        assert float(smp["phi(1,2,1)"]) == 100 * i + 11 and float(smp["psi(2,1,1)"]) == 100 * i + 23
+    assert len({smp["particle"] for smp in samples}) > 1      # (uniform over 8 particles, 8 draws, fixed seed)
+    # a drawn particle is downloaded at most once per belief state (the adapters' own selectAction draws one to list the legal actions)
+    assert ba.count("get_particle") <= len(samples) + ba.count("select ")

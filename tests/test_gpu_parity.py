@@ -706,6 +706,38 @@ def test_prior_tables_equal_oracle():
         assert np.array_equal(eng.prior(), o.prior_counts())
 
 
+@pytest.mark.parametrize("dom", ["episodic-factored-tiger", "continuous-factored-tiger"])
+def test_factored_tiger_priors_have_the_reference_tests_known_answers(dom):
+    """/root/reference/test/domains/priors/TigerPriorTest.cpp:230-655 through the C-ABI: the flat prior (fba_get_prior), states
+    sampled from the factored prior with and without structure noise (fba_belief_init + fba_belief_get), the fully connected
+    and match-uniform structures -- the same checks tests/test_oracle_golden.py makes on the oracle."""
+    import prior_known_answers as K
+    for size in (1, 2, 3):
+        for n in K.NOISES:
+            eng = fba.Engine(dom, model=N.MODEL_BA_TABLE, size=size, noise=n, counts_total=K.TOTAL, particles=4, sims=4, slots=1)
+            assert (eng.S, eng.A, eng.O) == (2 << size, 3, 2)
+            K.check_flat(eng.prior(), size, n)
+            eng.close()
+            for sp in (0, 1):
+                eng = fba.Engine(dom, model=N.MODEL_BA_FACTORED, size=size, noise=n, counts_total=K.TOTAL, structure_prior=sp, particles=12,
+                                 sims=4, slots=1, seed=1000 + size)
+                eng.belief_init()
+                _, _, cnt = eng.belief_get(0)
+                masks = {K.check_factored(cnt[i], size, n, sp != 0) for i in range(12)}
+                assert (masks == {1}) if sp == 0 else (len(masks) > 1)
+                if sp == 0:
+                    K.check_factored(eng.prior(), size, n, False)
+                eng.close()
+        eng = fba.Engine(dom, model=N.MODEL_BA_FACTORED, size=size, structure_prior=2, particles=10, sims=4, slots=1, seed=5)
+        eng.belief_init()
+        assert all(K.factored_parts(c, size)[4] & 1 for c in eng.belief_get(0)[2])            # match-uniform: feature 0 is always a parent
+        eng.close()
+        eng = fba.Engine(dom, model=N.MODEL_BA_FACTORED, size=size, structure_prior=3, particles=3, sims=4, slots=1, seed=5)
+        eng.belief_init()
+        assert all(K.factored_parts(c, size)[4] == (2 << size) - 1 for c in eng.belief_get(0)[2])   # fully connected: every feature
+        eng.close()
+
+
 def test_per_step_interface_matches_oracle_calls():
     """Planner::selectAction / Belief::updateEstimation one call at a time (slots = 1)."""
     kw = dict(particles=128, sims=300)

@@ -9,18 +9,22 @@ from fba_pomdp_amd import _native as N
 
 
 def test_tiger_kernels_use_no_scratch(tmp_path):
-    out = tmp_path / "kernels.s"
-    src = os.path.join(N.HERE, "csrc", "fba_kernels.hip")
     flags = [f for f in N.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
-    subprocess.check_call(["hipcc"] + flags + ["-I" + os.path.join(N.ROOT, "include"), "-S", "--cuda-device-only", "-o", str(out), src],
-                          stderr=subprocess.DEVNULL)
-    meta = out.read_text()
-    meta = meta[meta.index("amdhsa.kernels:"):]
+    jobs = []
+    for base in ("fba_search", "fba_kernels"):   # the search kernels and the belief kernels are separate translation units
+        out = tmp_path / (base + ".s")
+        src = os.path.join(N.HERE, "csrc", base + ".hip")
+        jobs.append((out, subprocess.Popen(["hipcc"] + flags + ["-I" + os.path.join(N.ROOT, "include"), "-S", "--cuda-device-only", "-o", str(out), src],
+                                           stderr=subprocess.DEVNULL)))
     seen = {}
-    for blk in meta.split("  - .agpr_count")[1:]:
-        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
-        get = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1))
-        seen[name] = (get("private_segment_fixed_size"), get("vgpr_count"), get("vgpr_spill_count"))
+    for out, p in jobs:
+        assert p.wait() == 0
+        meta = out.read_text()
+        meta = meta[meta.index("amdhsa.kernels:"):]
+        for blk in meta.split("  - .agpr_count")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+            get = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1))
+            seen[name] = (get("private_segment_fixed_size"), get("vgpr_count"), get("vgpr_spill_count"))
     tiger = {n: v for n, v in seen.items()
              if re.search(r"search_kernelILb1ELi4ELb0ELi[12]ELi1E|reject_kernelILb0ELi[12]E|importance_kernelILb0ELi[12]E|reject_tiger_lds_kernel", n)}
     # dense (1) and packed (2) particle formats (the importance filter with its weights in HBM or in LDS) + the
