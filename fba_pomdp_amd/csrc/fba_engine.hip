@@ -58,6 +58,7 @@ struct fba_ctx {
     size_t returns_cap   = 0;
     bool started         = false;  // fba_run_ticks has set the slots up
     bool belief_ready    = false;
+    std::vector<uint32_t> packed_updates;  // per slot: fba_belief_update calls since fba_belief_init (packed records hold uint16 increments)
     // timing
     bool timing = true;
     std::vector<EventPair> pending;
@@ -105,6 +106,14 @@ int dev_alloc(fba_ctx* c, T** p, size_t n, bool zero = true)
     *p = static_cast<T*>(q);
     return FBA_OK;
 }
+
+// a device buffer that is freed on every way out of the function (the selftests return early through HIPCHK)
+template <typename T>
+struct ScratchBuf {
+    T* p = nullptr;
+    ~ScratchBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n * sizeof(T)); }
+};
 
 bool is_tiger(int d) { return d == FBA_DOM_TIGER_EPISODIC || d == FBA_DOM_TIGER_CONTINUOUS; }
 bool is_ftiger(int d) { return d == FBA_DOM_FTIGER_EPISODIC || d == FBA_DOM_FTIGER_CONTINUOUS; }
@@ -1614,13 +1623,6 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     CHK(dev_alloc(c, &c->d_n_active, 1));
     CHK(dev_alloc(c, &D.fault, 1));
     CHK(dev_alloc(c, &D.lazy_reset, E));
-    {   // lanes of the search grid in order of their slots' time-step (FBA_SEARCH_SORT=0 keeps slot e on lane e)
-        const char* so = std::getenv("FBA_SEARCH_SORT");
-        if (!(so && std::atoi(so) == 0) && E > SEARCH_BLOCK && !P.hist) {
-            CHK(dev_alloc(c, &D.search_perm, E));
-            CHK(dev_alloc(c, &D.sort_bins, 512));
-        }
-    }
     CHK(dev_alloc(c, &c->d_prior, P.Cs));
     CHK(dev_alloc(c, &c->d_prior_dense, std::max(c->dense_C, 1)));
     if (P.hist) {
@@ -1853,6 +1855,7 @@ int fba_belief_init(fba_ctx* c)
     if ((rc = timed(c, FBA_K_BELIEF_INIT, [&] { launch_init(c->P, c->D, c->stream); }))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->belief_ready = true;
+    c->packed_updates.assign((size_t)c->P.E, 0);
     return FBA_OK;
 }
 
@@ -1889,6 +1892,19 @@ int fba_belief_update(fba_ctx* c, const int32_t* action, const int32_t* obs, con
         if (active && !active[e]) continue;
         if (action[e] < 0 || action[e] >= c->P.A) return fail(c, FBA_EINVAL, "action %d out of range", action[e]);
         if (obs[e] < 0 || obs[e] >= c->P.O) return fail(c, FBA_EINVAL, "observation %d out of range", obs[e]);
+    }
+    if (c->P.packed || c->P.ft_packed) {
+        // a packed record counts a cell's "+1"s in 16 bits: the experiment loops cannot exceed that (episodes * horizon <= 65535 is
+        // part of the packing condition), a host driving the per-step interface can -- refuse instead of wrapping into the next cell
+        if (c->packed_updates.size() != (size_t)c->P.E) c->packed_updates.assign((size_t)c->P.E, 0);
+        for (int e = 0; e < c->P.E; ++e) {
+            if (active && !active[e]) continue;
+            if (c->packed_updates[e] >= 65535u)
+                return fail(c, FBA_ESTATE, "slot %d: more than 65535 belief updates since fba_belief_init, which packed particle records cannot count; "
+                            "create the context with FBA_DENSE_PARTICLES=1 in the environment to drive it beyond that", e);
+        }
+        for (int e = 0; e < c->P.E; ++e)
+            if (!active || active[e]) ++c->packed_updates[e];
     }
     int rc;
     HIPCHK(c, hipMemcpyAsync(c->D.action, action, (size_t)c->P.E * 4, hipMemcpyHostToDevice, c->stream));
@@ -2278,31 +2294,29 @@ int fba_get_trace(const fba_ctx* cc, fba_trace_rec* out, int32_t cap)
 int fba_selftest_ucb(fba_ctx* c, const double* L, const int32_t* n, int32_t count, double u, double* out)
 {
     if (!c || !L || !n || !out || count <= 0) return FBA_EINVAL;
-    double *dL = nullptr, *dout = nullptr;
-    int32_t* dn = nullptr;
-    HIPCHK(c, hipMalloc(&dL, (size_t)count * 8));
-    HIPCHK(c, hipMalloc(&dout, (size_t)count * 8));
-    HIPCHK(c, hipMalloc(&dn, (size_t)count * 4));
-    HIPCHK(c, hipMemcpy(dL, L, (size_t)count * 8, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(dn, n, (size_t)count * 4, hipMemcpyHostToDevice));
-    launch_selftest_ucb(dL, dn, count, u, dout, c->stream);
+    ScratchBuf<double> dL, dout;
+    ScratchBuf<int32_t> dn;
+    HIPCHK(c, dL.alloc((size_t)count));
+    HIPCHK(c, dout.alloc((size_t)count));
+    HIPCHK(c, dn.alloc((size_t)count));
+    HIPCHK(c, hipMemcpy(dL.p, L, (size_t)count * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dn.p, n, (size_t)count * 4, hipMemcpyHostToDevice));
+    launch_selftest_ucb(dL.p, dn.p, count, u, dout.p, c->stream);
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(out, dout, (size_t)count * 8, hipMemcpyDeviceToHost));
-    (void)hipFree(dL); (void)hipFree(dout); (void)hipFree(dn);
+    HIPCHK(c, hipMemcpy(out, dout.p, (size_t)count * 8, hipMemcpyDeviceToHost));
     return FBA_OK;
 }
 
 int fba_selftest_lgamma(fba_ctx* c, const double* x, int32_t count, double* out)
 {
     if (!c || !x || !out || count <= 0) return FBA_EINVAL;
-    double *dx = nullptr, *dout = nullptr;
-    HIPCHK(c, hipMalloc(&dx, (size_t)count * 8));
-    HIPCHK(c, hipMalloc(&dout, (size_t)count * 8));
-    HIPCHK(c, hipMemcpy(dx, x, (size_t)count * 8, hipMemcpyHostToDevice));
-    launch_selftest_lgamma(dx, count, dout, c->stream);
+    ScratchBuf<double> dx, dout;
+    HIPCHK(c, dx.alloc((size_t)count));
+    HIPCHK(c, dout.alloc((size_t)count));
+    HIPCHK(c, hipMemcpy(dx.p, x, (size_t)count * 8, hipMemcpyHostToDevice));
+    launch_selftest_lgamma(dx.p, count, dout.p, c->stream);
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(out, dout, (size_t)count * 8, hipMemcpyDeviceToHost));
-    (void)hipFree(dx); (void)hipFree(dout);
+    HIPCHK(c, hipMemcpy(out, dout.p, (size_t)count * 8, hipMemcpyDeviceToHost));
     return FBA_OK;
 }
 
@@ -2310,18 +2324,17 @@ int fba_log_bd_score(fba_ctx* c, const float* counts, const float* prior, double
 {
     if (!c || !counts || !prior || !out) return FBA_EINVAL;
     if (c->P.model != FBA_MODEL_BA_FACTORED) return fail(c, FBA_EINVAL, "fba_log_bd_score: not a factored model");
-    float *dc = nullptr, *dp = nullptr;
-    double* dout = nullptr;
-    const size_t n = (size_t)c->dense_C * 4;
-    HIPCHK(c, hipMalloc(&dc, n));
-    HIPCHK(c, hipMalloc(&dp, n));
-    HIPCHK(c, hipMalloc(&dout, 8));
-    HIPCHK(c, hipMemcpy(dc, counts, n, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(dp, prior, n, hipMemcpyHostToDevice));
-    launch_selftest_bd(c->P, dc, dp, dout, c->stream);
+    ScratchBuf<float> dc, dp;
+    ScratchBuf<double> dout;
+    const size_t n = (size_t)c->dense_C;
+    HIPCHK(c, dc.alloc(n));
+    HIPCHK(c, dp.alloc(n));
+    HIPCHK(c, dout.alloc(1));
+    HIPCHK(c, hipMemcpy(dc.p, counts, n * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dp.p, prior, n * 4, hipMemcpyHostToDevice));
+    launch_selftest_bd(c->P, dc.p, dp.p, dout.p, c->stream);
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(out, dout, 8, hipMemcpyDeviceToHost));
-    (void)hipFree(dc); (void)hipFree(dp); (void)hipFree(dout);
+    HIPCHK(c, hipMemcpy(out, dout.p, 8, hipMemcpyDeviceToHost));
     return FBA_OK;
 }
 

@@ -1961,11 +1961,14 @@ static void launch_importance_single(const Problem& P, const DeviceState& D, hip
     const int grid_e = D.single_rec ? std::min(D.scratch_slots, P.E - D.slot_base) : P.E;   // (single_rec: one chunk of slots per launch)
 #define FBA_LAUNCH_IS(...)                                                                                         \
     do {                                                                                                           \
-    static bool raised = false;                                                                                \
-    if (wl > 16384 && !raised) {                                                                               \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&importance_kernel<__VA_ARGS__>),              \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, IS_LDS_MAX_N * 12); \
-        raised = true;                                                                                         \
+    static unsigned long long raised = 0;   /* one bit per device: function attributes are per device */          \
+    int dev_ = 0;                                                                                              \
+    (void)hipGetDevice(&dev_);                                                                                 \
+    if (wl > 16384 && !((raised >> (dev_ & 63)) & 1ull)) {                                                      \
+        /* (a refused attribute leaves the bit clear and the launch below fails: the engine reads hipGetLastError after every tick / update) */ \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&importance_kernel<__VA_ARGS__>),                \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, IS_LDS_MAX_N * 12) == hipSuccess)  \
+            raised |= 1ull << (dev_ & 63);                                                                     \
     }                                                                                                          \
     hipLaunchKernelGGL((importance_kernel<__VA_ARGS__>), dim3(grid_e), dim3(IS_BLOCK), wl, st, P, D);          \
     } while (0)

@@ -213,9 +213,11 @@ __device__ __forceinline__ void child_set(const Problem& P, const DeviceState& D
 // POUCT::selectChanceNodeUCB (POUCT.cpp:138-181 = RBAPOUCT.cpp:162-205).
 // UCB(m, n) = u * sqrt(log1p(m) / n), DBL_MAX for n = 0 (POUCT.cpp:330-338); ties are collected in
 // action order and one slowRandomInt is ALWAYS drawn, also for a single candidate.
-// The node's statistics arrive in registers (cn / cq), L = log1p(visits).
+// The node's statistics arrive in registers (cn / cq); log1p_tab[visits] = log1p(visits) as the host's libm gives it (the
+// value the reference's table entry is built from) is only loaded where the exact fp64 comparison is needed.
 template <int AMAX, class RNG>
-__device__ __forceinline__ int ucb_pick(const Problem& P, RNG& g, double L, const int (&cn)[AMAX], const double (&cq)[AMAX], bool explore)
+__device__ __forceinline__ int ucb_pick(const Problem& P, RNG& g, const double* __restrict__ log1p_tab, int visits, const int (&cn)[AMAX],
+                                        const double (&cq)[AMAX], bool explore)
 {
     double best_q = -DBL_MAX;
     uint32_t mask = 0;
@@ -224,9 +226,10 @@ __device__ __forceinline__ int ucb_pick(const Problem& P, RNG& g, double L, cons
         // Fast paths that give the fp64 arg-max set exactly, without the fp64 divisions and square roots:
         //  * unvisited actions: q + DBL_MAX rounds to DBL_MAX for every finite q here, so they tie exactly and
         //    beat every visited action -- the candidate set is the set of unvisited actions;
-        //  * otherwise evaluate q + u sqrt(L / n) in fp32 (each operation within 1 ulp, so each value within
-        //    ~2^-21 of (|q| + bonus)); if one action leads by more than 1e-5 of the largest |q| + bonus -- twenty
-        //    times that error bound -- it is the unique fp64 maximum.  Anything closer falls through to fp64.
+        //  * otherwise evaluate q + u sqrt(L / n) in fp32, with L = log(1 + visits) from the hardware's log2 (1 ulp) -- no
+        //    trip to the table: each value lands within ~2^-20 of (|q| + bonus); if one action leads by more than 1e-5
+        //    of the largest |q| + bonus -- ten times that error bound -- it is the unique fp64 maximum.  Anything closer
+        //    falls through to fp64 and the table.  (A dependent table load per tree level was 6 % of the bench's search.)
         uint32_t unvisited = 0;
 #pragma unroll
         for (int a = 0; a < AMAX; ++a)
@@ -235,7 +238,7 @@ __device__ __forceinline__ int ucb_pick(const Problem& P, RNG& g, double L, cons
             mask    = unvisited;
             decided = true;
         } else {
-            const float Lf = (float)L, uf = (float)P.exploration;
+            const float Lf = __log2f((float)(visits + 1)) * 0.69314718f, uf = (float)P.exploration;
             float w[AMAX], top = -FLT_MAX, scale = 0.f;
 #pragma unroll
             for (int a = 0; a < AMAX; ++a) {
@@ -257,6 +260,7 @@ __device__ __forceinline__ int ucb_pick(const Problem& P, RNG& g, double L, cons
         }
     }
     if (!decided) {
+        const double L = explore ? log1p_tab[visits] : 0.0;
 #pragma unroll
         for (int a = 0; a < AMAX; ++a)
             if (a < P.A) {
@@ -306,7 +310,7 @@ __device__ __forceinline__ int ucb_select(const Problem& P, const DeviceState& D
             if (!D.cn_off) visits += cn[a];   // every back-up through the node adds one to exactly one of them (MCTSTreeNodes.cpp:8-12, 59-62)
         }
     }
-    return ucb_pick<AMAX>(P, g, explore ? D.log1p_tab[visits] : 0.0, cn, cq, explore);
+    return ucb_pick<AMAX>(P, g, D.log1p_tab, visits, cn, cq, explore);
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

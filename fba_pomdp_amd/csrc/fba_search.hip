@@ -32,6 +32,33 @@ __host__ __device__ __forceinline__ bool root_children_in_lds(const Problem& P, 
 }
 
 // FTP: the factored-tiger records are packed (PackedFtigerView).
+//
+// ETIGER: the episodic tiger family (tiger and factored tiger, POMDP or Bayes-adaptive simulator): A = 3, O = 2, and only
+// `listen` (action 2) continues -- opening a door ends the episode in the domain and in the BA extensions alike
+// (Tiger.cpp:75-79, TigerBAExtension.cpp:32-36, FactoredTigerBAExtension.cpp) -- so a node has at most two children and the
+// tree is a binary tree over the observations heard.  What a simulation costs this kernel is the 64-byte sectors it has
+// the memory system fetch (one more random sector per simulation is +45 ms on the bench), and the two
+// nodes below the root are on nearly every path; they live in LDS beside the path (18 words per lane: counts as uint16,
+// child indices as uint16, Q as fp64), never in HBM.  The path itself shrinks to 16 bits per level -- node index (12 bits:
+// the host bounds the tree at 2^(depth+1) + 1 nodes), action (2), and the reward as a code (-1 / 10 / -100: the only
+// rewards of these domains) -- which is what pays for the room.  Same draws, same arithmetic, same results.
+constexpr int ET_NODE_WORDS = 9;   // an LDS node: n0 | n1 << 16, n2, child0 | child1 << 16, q0, q1, q2 (two words each)
+__host__ __device__ __forceinline__ bool etiger_ok(const Problem& P, const DeviceState& D)
+{
+    return (P.domain == FBA_DOM_TIGER_EPISODIC || P.domain == FBA_DOM_FTIGER_EPISODIC) && P.A == 3 && P.O == 2 && P.sims <= 65535 &&
+           D.max_nodes <= 4093 && !D.hash && P.planner != FBA_PLANNER_RANDOM;
+}
+// 32-bit words of the dynamic LDS allocation of one search workgroup in front of the staged model description
+__host__ __device__ __forceinline__ size_t search_lds_words(const Problem& P, const DeviceState& D, bool stage, bool etiger)
+{
+    const int depth_cap = P.max_depth > 0 ? P.max_depth : 1;
+    if (etiger)
+        return (size_t)((depth_cap + 1) / 2) * SEARCH_BLOCK + (stage ? (size_t)P.Cs * SEARCH_BLOCK : 0) + (size_t)2 * ET_NODE_WORDS * SEARCH_BLOCK;
+    return (size_t)depth_cap * SEARCH_BLOCK * 2 + (stage ? (size_t)P.Cs * SEARCH_BLOCK : 0) +
+           (root_children_in_lds(P, D) ? (size_t)P.A * P.O * SEARCH_BLOCK / 2 : 0);
+}
+__device__ __forceinline__ int et_reward_code(double r) { return r == -1.0 ? 0 : (r == 10.0 ? 1 : 2); }
+__device__ __forceinline__ double et_reward(int code) { return code == 0 ? -1.0 : (code == 1 ? 10.0 : -100.0); }
 #ifdef FBA_PROFILE_SEARCH
 // profiling build only (scripts/search_regions.py): shader-clock cycles a wave spends in each region of the search loop
 __device__ unsigned long long g_search_prof[8];
@@ -39,7 +66,7 @@ __device__ unsigned long long g_search_prof[8];
 #else
 #define PROF_MARK(r)
 #endif
-template <bool STAGE, int AMAX, bool REG, int TIGER_TABLE, int MODEL, int FTIGER = 0, bool TIGER_POMDP = false, bool FTP = false>
+template <bool STAGE, int AMAX, bool REG, int TIGER_TABLE, int MODEL, int FTIGER = 0, bool TIGER_POMDP = false, bool FTP = false, bool ETIGER = false>
 __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceState D)
 {
     if (TIGER_POMDP) {
@@ -55,7 +82,9 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
     if (FTIGER > 0) {  // sizes of factored tiger with FTIGER - 1 irrelevant features
         P.S = 1 << FTIGER; P.A = 3; P.O = 2;
         if (P.domain != FBA_DOM_FTIGER_CONTINUOUS) P.domain = FBA_DOM_FTIGER_EPISODIC;
+        if (ETIGER) P.domain = FBA_DOM_FTIGER_EPISODIC;
     }
+    if (ETIGER) { P.A = 3; P.O = 2; }
     // TIGER_TABLE: the launcher has checked that this is the tabular BA-POMDP over (episodic or
     // continuous) tiger; restating its sizes as literals lets the compiler unroll the two-entry
     // Dirichlet rows and fold every model / domain branch.  Same code, same results.
@@ -67,11 +96,11 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
         D.cn_off = 1; D.cq_off = 4; D.child_off = 10; D.node_words = 16; D.hash = nullptr;  // node layout of A = 3, O = 2 (fba_engine.hip)
         if (TIGER_TABLE == 2) { P.C = 12; P.Cs = 16; }  // packed particles (PackedView): 24 uint16 + state in 64 bytes
     }
+    if (ETIGER && (TIGER_TABLE || TIGER_POMDP)) P.domain = FBA_DOM_TIGER_EPISODIC;
     extern __shared__ double lds[];
     __shared__ __attribute__((aligned(8))) float s_prior[TIGER_TABLE == 2 ? 24 : 2];
     const int lane = threadIdx.x;
-    const int gid  = blockIdx.x * SEARCH_BLOCK + lane;
-    const int e    = (D.search_perm && gid < P.E) ? D.search_perm[gid] : gid;   // lanes grouped by their slots' time-step (sort_slots)
+    const int e    = blockIdx.x * SEARCH_BLOCK + lane;
     if (TIGER_TABLE == 2) {
         if (lane < 24) s_prior[lane] = D.prior_dense[lane];
         __syncthreads();
@@ -80,9 +109,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
         // the factored model's description (which parents, how many values, where the rows start) is
         // consulted several times per sampled feature: keep the part in use in LDS, at the end of
         // this workgroup's allocation, instead of chasing it through global memory
-        const int depth_cap0 = P.max_depth > 0 ? P.max_depth : 1;
-        size_t words = (size_t)depth_cap0 * SEARCH_BLOCK * 2 + (STAGE ? (size_t)P.Cs * SEARCH_BLOCK : 0) +
-                       (root_children_in_lds(P, D) ? (size_t)P.A * P.O * SEARCH_BLOCK / 2 : 0);
+        size_t words = search_lds_words(P, D, STAGE, ETIGER);
         words = (words + 3) & ~(size_t)3;  // 16-byte aligned
         uint4* dst       = reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(lds) + words);
         const uint4* src = reinterpret_cast<const uint4*>(P.fd);
@@ -98,11 +125,16 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
     // computes in fp64 -- and 4 bytes x depth x 64 lanes of LDS per wave buy one more resident wave per CU.
     float* path_r       = reinterpret_cast<float*>(lds) + lane;                         // [depth][block]
     int32_t* path_na    = reinterpret_cast<int32_t*>(path_r - lane + (size_t)depth_cap * SEARCH_BLOCK) + lane;
-    float* stage        = reinterpret_cast<float*>(path_na - lane + (size_t)depth_cap * SEARCH_BLOCK) + lane;  // [Cs][block]
+    // ETIGER: the path is [depth][block] of uint16 {node (12 bits; at level 1: which of the two LDS nodes), action << 12, reward code << 14}
+    uint16_t* path16    = reinterpret_cast<uint16_t*>(lds) + lane;
+    float* stage        = ETIGER ? reinterpret_cast<float*>(lds) + (size_t)((depth_cap + 1) / 2) * SEARCH_BLOCK + lane
+                                 : reinterpret_cast<float*>(path_na - lane + (size_t)depth_cap * SEARCH_BLOCK) + lane;  // [Cs][block]
     // children of the root, [a*O + o][block], when there are at most ROOT_CHILDREN of them
     // (node indices fit 16 bits up to 32 766 simulations; beyond that the root's children stay in its record)
-    const bool root_lds = root_children_in_lds(P, D);
+    const bool root_lds = !ETIGER && root_children_in_lds(P, D);
     int16_t* rootch     = reinterpret_cast<int16_t*>(stage - lane + (STAGE ? (size_t)P.Cs * SEARCH_BLOCK : 0)) + lane;
+    // ETIGER: the two nodes below the root, [2][ET_NODE_WORDS][block]
+    uint32_t* l1        = reinterpret_cast<uint32_t*>(stage - lane + (STAGE ? (size_t)P.Cs * SEARCH_BLOCK : 0)) + lane;
 
     Rng g               = slot_rng(P, D, e);
     const int hist_len  = D.t[e];
@@ -127,15 +159,18 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
     int n_nodes = 1, tree_depth = 0;
     unsigned long long steps = 0;
     // The root is on the path of every simulation: its visit counts and Q values live in registers
-    // for the whole search, log1p(root visits) is fetched when the visits change (never waited for
-    // on the critical path), and its child pointers sit in LDS.
+    // for the whole search and its child pointers sit in LDS.
     int r_vis = 0, r_cn[AMAX];
     double r_cq[AMAX];
 #pragma unroll
     for (int a = 0; a < AMAX; ++a) { r_cn[a] = 0; r_cq[a] = 0.0; }
-    double root_L = D.log1p_tab[0];
     if (root_lds)
         for (int k = 0; k < P.A * P.O; ++k) rootch[k * SEARCH_BLOCK] = -1;
+    uint32_t l1_exists = 0;   // ETIGER: bit o = the root's child after (listen, o) has been created
+    // ETIGER: header and chosen Q of the path's nodes at levels 2 and 3 as this simulation's descent loaded them -- nothing
+    // else writes this tree, so the back-up need not fetch their sectors again (by then they have left the L2)
+    int4 cy_h2 = make_int4(0, 0, 0, 0), cy_h3 = make_int4(0, 0, 0, 0);
+    double cy_q2 = 0, cy_q3 = 0;
     int4* tab      = hash_table(D, e);
     const uint32_t epoch = D.hash ? hash_begin_search(D, e, tab, 0, 1) : 0;
 
@@ -199,7 +234,34 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
         if (mode == 1) {  // traverseActionNode
             tree_depth = max(tree_depth, max_tree_depth - dtg);
             if (dtg == 0) { finish = true; do_step = false; }
-            else if (node == 0) a = ucb_pick<AMAX>(P, g, root_L, r_cn, r_cq, true);
+            else if (ETIGER) {
+                // the node's statistics from where they live -- registers (root), LDS (the two nodes below it, node = -1 - o),
+                // HBM (the rest) -- then ONE selection for all lanes
+                int cn[AMAX], vis = r_vis;
+                double cq[AMAX];
+#pragma unroll
+                for (int a2 = 0; a2 < AMAX; ++a2) { cn[a2] = r_cn[a2]; cq[a2] = r_cq[a2]; }
+                if (node < 0) {
+                    const uint32_t* nd = l1 + (size_t)(-1 - node) * ET_NODE_WORDS * SEARCH_BLOCK;
+                    const uint32_t w0 = nd[0], w1 = nd[1 * SEARCH_BLOCK];
+                    cn[0] = (int)(w0 & 0xffffu); cn[1] = (int)(w0 >> 16); cn[2] = (int)(w1 & 0xffffu);
+#pragma unroll
+                    for (int a2 = 0; a2 < 3; ++a2)
+                        cq[a2] = __hiloint2double((int)nd[(4 + 2 * a2) * SEARCH_BLOCK], (int)nd[(3 + 2 * a2) * SEARCH_BLOCK]);
+                    vis = (cn[0] + cn[1]) + cn[2];
+                } else if (node > 0) {
+                    const int32_t* rec = tree + (size_t)node * W;
+                    const int4 h      = *reinterpret_cast<const int4*>(rec);
+                    const double2 q01 = *reinterpret_cast<const double2*>(rec + 4);
+                    const double q2   = *reinterpret_cast<const double*>(rec + 8);
+                    vis = h.x; cn[0] = h.y; cn[1] = h.z; cn[2] = h.w;
+                    cq[0] = q01.x; cq[1] = q01.y; cq[2] = q2;
+                }
+                a = ucb_pick<AMAX>(P, g, D.log1p_tab, vis, cn, cq, true);
+                if (plen == 2) { cy_h2 = make_int4(vis, cn[0], cn[1], cn[2]); cy_q2 = a == 0 ? cq[0] : (a == 1 ? cq[1] : cq[2]); }
+                if (plen == 3) { cy_h3 = make_int4(vis, cn[0], cn[1], cn[2]); cy_q3 = a == 0 ? cq[0] : (a == 1 ? cq[1] : cq[2]); }
+            }
+            else if (node == 0) a = ucb_pick<AMAX>(P, g, D.log1p_tab, r_vis, r_cn, r_cq, true);
             else a = ucb_select<AMAX>(P, D, g, tree + (size_t)node * W, true);
         } else {          // rollout: uniformly random action
             a = domain_random_action(P, g, s);
@@ -223,7 +285,41 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
         PROF_MARK(2)
         if (do_step) {
 #endif
-            if (mode == 1) {  // traverseChanceNode
+            if (ETIGER && mode == 1) {  // traverseChanceNode on the episodic tiger tree
+                path16[(size_t)plen * SEARCH_BLOCK] = (uint16_t)((node < 0 ? -1 - node : node) | (a << 12) | (et_reward_code(r) << 14));
+                ++plen;
+                if (term) finish = true;
+                else {   // (a continuing step is a `listen`: the child after observation o)
+                    int c = 0;   // 0 = none yet (the root is nobody's child)
+                    if (node == 0) c = ((l1_exists >> o) & 1u) ? -1 - o : 0;
+                    else if (node < 0) {
+                        const uint32_t w2 = l1[((size_t)(-1 - node) * ET_NODE_WORDS + 2) * SEARCH_BLOCK];
+                        c = (int)(o ? (w2 >> 16) : (w2 & 0xffffu));
+                    } else {
+                        c = tree[(size_t)node * W + D.child_off + 2 * 2 + o];
+                        c = c < 0 ? 0 : c;
+                    }
+                    if (c != 0) { node = c; --dtg; }
+                    else {  // expand: new leaf, then rollout(depth_to_go - 1)
+                        const int nn = min(n_nodes, D.max_nodes - 1);
+                        ++n_nodes;
+                        if (node == 0) {
+                            uint32_t* nd = l1 + (size_t)o * ET_NODE_WORDS * SEARCH_BLOCK;
+#pragma unroll
+                            for (int k = 0; k < ET_NODE_WORDS; ++k) nd[k * SEARCH_BLOCK] = 0;
+                            l1_exists |= 1u << o;
+                        } else {
+                            node_init(D, tree + (size_t)nn * W, P.A, P.O);
+                            if (node < 0) {
+                                uint32_t* w2 = l1 + ((size_t)(-1 - node) * ET_NODE_WORDS + 2) * SEARCH_BLOCK;
+                                *w2 = o ? ((*w2 & 0xffffu) | ((uint32_t)nn << 16)) : ((*w2 & 0xffff0000u) | (uint32_t)nn);
+                            } else tree[(size_t)node * W + D.child_off + 2 * 2 + o] = nn;
+                        }
+                        mode = 2; rdepth = dtg - 1; rret = 0; rdisc = 1;
+                        if (rdepth == 0) finish = true;
+                    }
+                }
+            } else if (mode == 1) {  // traverseChanceNode
                 path_r[(size_t)plen * SEARCH_BLOCK]  = (float)r;
                 path_na[(size_t)plen * SEARCH_BLOCK] = (node << 5) | a  /* a < FBA_MAX_ACTIONS <= 32 */;
                 ++plen;
@@ -259,11 +355,11 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
             // (the root is entry 0 of every path and no other entry: the loop runs over the nodes below it, the root's
             // register copy is updated once behind it -- one code path per level instead of two)
             double del = delayed;
-            for (int k = plen - 1; k >= 1; --k) {
-                const int na     = path_na[(size_t)k * SEARCH_BLOCK];
-                const double ret = (double)path_r[(size_t)k * SEARCH_BLOCK] + P.gamma * del;
-                const int act    = na & 31;
-                int32_t* rec = tree + (size_t)(na >> 5) * W;
+            for (int k = plen - 1; k >= (ETIGER ? 4 : 1); --k) {
+                const int na     = ETIGER ? (int)path16[(size_t)k * SEARCH_BLOCK] : path_na[(size_t)k * SEARCH_BLOCK];
+                const double ret = (ETIGER ? et_reward(na >> 14) : (double)path_r[(size_t)k * SEARCH_BLOCK]) + P.gamma * del;
+                const int act    = ETIGER ? ((na >> 12) & 3) : (na & 31);
+                int32_t* rec = tree + (size_t)(ETIGER ? (na & 0xfff) : (na >> 5)) * W;
                 double* q    = reinterpret_cast<double*>(rec + D.cq_off) + act;
                 int n;
                 if (P.A == 3) {  // {visits, n0, n1, n2} is one 16-byte word: one load, one store
@@ -279,9 +375,42 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
                 *q += (ret - *q) / (double)n;
                 del = ret;
             }
+            if (ETIGER) {   // levels 3 and 2: header and Q from the descent, two stores each, no load
+#pragma unroll
+                for (int lv = 3; lv >= 2; --lv)
+                    if (plen > lv) {
+                        const int na     = (int)path16[(size_t)lv * SEARCH_BLOCK];
+                        const double ret = et_reward(na >> 14) + P.gamma * del;
+                        const int act    = (na >> 12) & 3;
+                        int32_t* rec     = tree + (size_t)(na & 0xfff) * W;
+                        int4 h           = lv == 3 ? cy_h3 : cy_h2;
+                        const double q0  = lv == 3 ? cy_q3 : cy_q2;
+                        const int n      = act == 0 ? ++h.y : (act == 1 ? ++h.z : ++h.w);
+                        ++h.x;
+                        *reinterpret_cast<int4*>(rec) = h;
+                        reinterpret_cast<double*>(rec + D.cq_off)[act] = q0 + (ret - q0) / (double)n;
+                        del = ret;
+                    }
+            }
+            if (ETIGER && plen > 1) {   // the node below the root: in LDS
+                const int na     = (int)path16[1 * SEARCH_BLOCK];
+                const double ret = et_reward(na >> 14) + P.gamma * del;
+                const int act    = (na >> 12) & 3;
+                uint32_t* nd     = l1 + (size_t)(na & 0xfff) * ET_NODE_WORDS * SEARCH_BLOCK;
+                uint32_t* cw     = nd + (act >> 1) * SEARCH_BLOCK;   // n0 | n1 << 16, n2
+                const uint32_t w = *cw;
+                const int n      = (int)((act & 1) ? (w >> 16) : (w & 0xffffu)) + 1;
+                *cw              = (act & 1) ? ((w & 0xffffu) | ((uint32_t)n << 16)) : ((w & 0xffff0000u) | (uint32_t)n);
+                uint32_t* qw     = nd + (size_t)(3 + 2 * act) * SEARCH_BLOCK;
+                double q         = __hiloint2double((int)qw[SEARCH_BLOCK], (int)qw[0]);
+                q += (ret - q) / (double)n;
+                qw[0]            = (uint32_t)__double2loint(q);
+                qw[SEARCH_BLOCK] = (uint32_t)__double2hiint(q);
+                del = ret;
+            }
             if (plen > 0) {
-                const double ret = (double)path_r[0] + P.gamma * del;
-                const int act    = path_na[0] & 31;
+                const double ret = (ETIGER ? et_reward((int)path16[0] >> 14) : (double)path_r[0]) + P.gamma * del;
+                const int act    = ETIGER ? (((int)path16[0] >> 12) & 3) : (path_na[0] & 31);
                 // register-array element `act`: select, ONE division, write back
                 int n = 0;
                 double q = 0.0;
@@ -294,7 +423,6 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
                 for (int a2 = 0; a2 < AMAX; ++a2)
                     if (a2 == act) { r_cn[a2] = n; r_cq[a2] = q; }
                 ++r_vis;
-                root_L = D.log1p_tab[r_vis];
             }
             ++sim;
             mode = 0;
@@ -310,7 +438,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
 #endif
     g.stream(FBA_PHASE_SEARCH, (uint32_t)P.sims + 1u);
     if (n_nodes > D.max_nodes) atomicCAS(D.fault, 0, -(1 + e));  // -> FBA_ESTATE on the host
-    const int best = ucb_pick<AMAX>(P, g, 0.0, r_cn, r_cq, false);
+    const int best = ucb_pick<AMAX>(P, g, D.log1p_tab, 0, r_cn, r_cq, false);
     D.action[e]    = best;
     D.sim_steps[e] += steps;
     fba_trace_rec& rec = D.cur[e];
@@ -376,7 +504,6 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, De
     double r_cq[AMAX];
 #pragma unroll
     for (int a = 0; a < AMAX; ++a) { r_cn[a] = 0; r_cq[a] = 0.0; }
-    double root_L = D.log1p_tab[0];
     int4* tab      = hash_table(D, e);
     const uint32_t epoch = hash_begin_search(D, e, tab, g.q, HIST_QUAD);
 
@@ -434,7 +561,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, De
         if (do_step) {
             g.ensure(7);  // the action, six rows
             if (mode == 1) {  // traverseActionNode
-                if (node == 0) a = ucb_pick<AMAX>(P, g, root_L, r_cn, r_cq, true);
+                if (node == 0) a = ucb_pick<AMAX>(P, g, D.log1p_tab, r_vis, r_cn, r_cq, true);
                 else a = ucb_select<AMAX>(P, D, g, tree + (size_t)node * W, true);
             } else {
                 a = g.slow_int(0, 4);  // GridWorld::generateRandomAction :220-226
@@ -495,7 +622,6 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, De
                     for (int a2 = 0; a2 < AMAX; ++a2)
                         if (a2 == act) { r_cn[a2] = n; r_cq[a2] = q; }
                     ++r_vis;
-                    root_L = D.log1p_tab[r_vis];
                 } else {
                     int32_t* rec = tree + (size_t)(na >> 5) * W;
                     double* q    = reinterpret_cast<double*>(rec + D.cq_off) + act;
@@ -520,7 +646,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, De
     g.stream(FBA_PHASE_SEARCH, (uint32_t)P.sims + 1u);
     g.ensure(1);
     if (n_nodes > D.max_nodes) atomicCAS(D.fault, 0, -(1 + e));
-    const int best = ucb_pick<AMAX>(P, g, 0.0, r_cn, r_cq, false);
+    const int best = ucb_pick<AMAX>(P, g, D.log1p_tab, 0, r_cn, r_cq, false);
     D.action[e]    = best;
     if (g.q == 0) D.sim_steps[e] += steps;
     fba_trace_rec& rec = D.cur[e];
@@ -534,75 +660,29 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, De
 }
 
 // ---------------------------------------------------------------------------------------------
-// sort_slots: search lanes in order of their slots' time-step.  A simulation is as deep as the slot's remaining horizon
-// lets it be (POUCT.cpp:80: max depth = min(horizon - history length, max depth)), every lane runs the same number of
-// simulations, and a wave lasts as long as its slowest lane: with slots of every time-step in every wave the lanes whose
-// trees are shallow sit idle for a third of the wave's iterations (bench workload: 2.26 simulated steps per simulation on
-// average, 3.2 at t = 0).  Which lane runs a slot changes nothing in what the slot computes.  Counting sort, three tiny
-// launches; the order inside a bin is whatever the atomics give.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t sort_key(const DeviceState& D, int e) { return D.active[e] ? (uint32_t)min(max(D.t[e], 0), 254) : 255u; }
-__global__ void __launch_bounds__(256) sort_count_kernel(Problem P, DeviceState D)
-{
-    __shared__ uint32_t s_bins[256];
-    s_bins[threadIdx.x] = 0;
-    __syncthreads();
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e < P.E) atomicAdd(&s_bins[sort_key(D, e)], 1u);
-    __syncthreads();
-    if (s_bins[threadIdx.x]) atomicAdd(&D.sort_bins[threadIdx.x], s_bins[threadIdx.x]);
-}
-__global__ void __launch_bounds__(256) sort_offsets_kernel(DeviceState D)
-{
-    __shared__ uint32_t s_scan[256];
-    const uint32_t mine = D.sort_bins[threadIdx.x];
-    s_scan[threadIdx.x] = mine;
-    __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-        const uint32_t v = threadIdx.x >= (unsigned)d ? s_scan[threadIdx.x - d] : 0u;
-        __syncthreads();
-        s_scan[threadIdx.x] += v;
-        __syncthreads();
-    }
-    D.sort_bins[256 + threadIdx.x] = s_scan[threadIdx.x] - mine;   // where bin `threadIdx.x` starts
-    D.sort_bins[threadIdx.x]       = 0;                             // (ready for the next search)
-}
-__global__ void __launch_bounds__(256) sort_scatter_kernel(Problem P, DeviceState D)
-{
-    __shared__ uint32_t s_cnt[256], s_base[256];
-    s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    uint32_t key = 0, rank = 0;
-    if (e < P.E) {
-        key  = sort_key(D, e);
-        rank = atomicAdd(&s_cnt[key], 1u);
-    }
-    __syncthreads();
-    if (s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&D.sort_bins[256 + threadIdx.x], s_cnt[threadIdx.x]);
-    __syncthreads();
-    if (e < P.E) D.search_perm[s_base[key] + rank] = e;
-}
-
-// ---------------------------------------------------------------------------------------------
 // host launcher
 // ---------------------------------------------------------------------------------------------
 void launch_search(const Problem& P, const DeviceState& D, hipStream_t st)
 {
-    const int depth_cap = P.max_depth > 0 ? P.max_depth : 1;
     const bool stage = P.model != FBA_MODEL_POMDP && P.Cs <= SEARCH_STAGE_WORDS;
-    size_t lds = (size_t)depth_cap * SEARCH_BLOCK * (sizeof(float) + sizeof(int32_t)) +
-                 (stage ? (size_t)P.Cs * SEARCH_BLOCK * sizeof(float) : 0) +
-                 (root_children_in_lds(P, D) ? (size_t)P.A * P.O * SEARCH_BLOCK * sizeof(int16_t) : 0);
+    // the episodic tiger family on its own tree layout (ETIGER); FBA_NO_ETIGER=1 keeps the general layout, for A/B runs
+    static const bool no_etiger = std::getenv("FBA_NO_ETIGER") && std::atoi(std::getenv("FBA_NO_ETIGER")) != 0;
+    // (the instantiations that exist on that layout: the tabular tiger BA-POMDP, planning on tiger itself, packed factored tiger)
+    const bool tiger_table = P.model == FBA_MODEL_BA_TABLE && P.planner == FBA_PLANNER_POUCT && !P.dirichlet_regular && stage &&
+                             (P.domain == FBA_DOM_TIGER_EPISODIC || P.domain == FBA_DOM_TIGER_CONTINUOUS) && !D.hash;
+    const bool tiger_pomdp = P.model == FBA_MODEL_POMDP && P.planner == FBA_PLANNER_POUCT && !D.hash &&
+                             (P.domain == FBA_DOM_TIGER_EPISODIC || P.domain == FBA_DOM_TIGER_CONTINUOUS);
+    const int ft_fs        = P.S > 0 ? 31 - __builtin_clz((unsigned)P.S) : 0;  // factored tiger: S = 2^FS
+    const bool ftiger      = P.model == FBA_MODEL_BA_FACTORED && (P.domain == FBA_DOM_FTIGER_EPISODIC || P.domain == FBA_DOM_FTIGER_CONTINUOUS) &&
+                             !P.dirichlet_regular && P.planner == FBA_PLANNER_POUCT && !D.hash;
+    const bool et = !no_etiger && !P.hist && etiger_ok(P, D) &&
+                    (tiger_table || tiger_pomdp || (ftiger && P.ft_packed && ft_fs >= 2 && ft_fs <= 4));
+    size_t lds = search_lds_words(P, D, stage, et) * sizeof(uint32_t);
     if (P.model == FBA_MODEL_BA_FACTORED) lds = ((lds + 15) & ~(size_t)15) + (((size_t)P.fd_bytes + 15) & ~(size_t)15);  // + the model description
     static const size_t lds_pad = std::getenv("FBA_SEARCH_LDS_PAD") ? (size_t)std::atoi(std::getenv("FBA_SEARCH_LDS_PAD")) : 0;  // occupancy experiments
     lds += lds_pad;
+    const int depth_cap = P.max_depth > 0 ? P.max_depth : 1;
     const dim3 grid(ceil_div(P.E, SEARCH_BLOCK)), block(SEARCH_BLOCK);
-    if (D.search_perm) {
-        hipLaunchKernelGGL(sort_count_kernel, dim3(ceil_div(P.E, 256)), dim3(256), 0, st, P, D);
-        hipLaunchKernelGGL(sort_offsets_kernel, dim3(1), dim3(256), 0, st, D);
-        hipLaunchKernelGGL(sort_scatter_kernel, dim3(ceil_div(P.E, 256)), dim3(256), 0, st, P, D);
-    }
 #define FBA_LAUNCH_SEARCH_M(STG, AM, MODEL)                                                                              \
     do {                                                                                                                 \
         if (P.dirichlet_regular && MODEL != FBA_MODEL_POMDP)                                                             \
@@ -623,24 +703,24 @@ void launch_search(const Problem& P, const DeviceState& D, hipStream_t st)
         else hipLaunchKernelGGL((search_hist_kernel<16>), qgrid, block, lds, st, P, D);
         return;
     }
-    const bool tiger_table = P.model == FBA_MODEL_BA_TABLE && P.planner == FBA_PLANNER_POUCT && !P.dirichlet_regular && stage &&
-                             (P.domain == FBA_DOM_TIGER_EPISODIC || P.domain == FBA_DOM_TIGER_CONTINUOUS) && !D.hash;
     if (tiger_table) {
-        if (P.packed) hipLaunchKernelGGL((search_kernel<true, 4, false, 2, FBA_MODEL_BA_TABLE>), grid, block, lds, st, P, D);
+        if (P.packed && et) hipLaunchKernelGGL((search_kernel<true, 4, false, 2, FBA_MODEL_BA_TABLE, 0, false, false, true>), grid, block, lds, st, P, D);
+        else if (P.packed) hipLaunchKernelGGL((search_kernel<true, 4, false, 2, FBA_MODEL_BA_TABLE>), grid, block, lds, st, P, D);
+        else if (et) hipLaunchKernelGGL((search_kernel<true, 4, false, 1, FBA_MODEL_BA_TABLE, 0, false, false, true>), grid, block, lds, st, P, D);
         else hipLaunchKernelGGL((search_kernel<true, 4, false, 1, FBA_MODEL_BA_TABLE>), grid, block, lds, st, P, D);
         return;
     }
-    if (P.model == FBA_MODEL_POMDP && P.planner == FBA_PLANNER_POUCT && !D.hash &&
-        (P.domain == FBA_DOM_TIGER_EPISODIC || P.domain == FBA_DOM_TIGER_CONTINUOUS)) {
-        hipLaunchKernelGGL((search_kernel<false, 4, false, 0, FBA_MODEL_POMDP, 0, true>), grid, block, lds, st, P, D);
+    if (tiger_pomdp) {
+        if (et) hipLaunchKernelGGL((search_kernel<false, 4, false, 0, FBA_MODEL_POMDP, 0, true, false, true>), grid, block, lds, st, P, D);
+        else hipLaunchKernelGGL((search_kernel<false, 4, false, 0, FBA_MODEL_POMDP, 0, true>), grid, block, lds, st, P, D);
         return;
     }
-    if (P.model == FBA_MODEL_BA_FACTORED && (P.domain == FBA_DOM_FTIGER_EPISODIC || P.domain == FBA_DOM_FTIGER_CONTINUOUS) &&
-        !P.dirichlet_regular && P.planner == FBA_PLANNER_POUCT && !D.hash) {
-        const int FS = 31 - __builtin_clz((unsigned)P.S);  // S = 2^FS
+    if (ftiger) {
+        const int FS = ft_fs;
 #define FBA_LAUNCH_FTIGER(FSV)                                                                                                    \
     do {                                                                                                                          \
-        if (P.ft_packed) hipLaunchKernelGGL((search_kernel<true, 4, false, 0, FBA_MODEL_BA_FACTORED, FSV, false, true>), grid, block, lds, st, P, D); \
+        if (P.ft_packed && et) hipLaunchKernelGGL((search_kernel<true, 4, false, 0, FBA_MODEL_BA_FACTORED, FSV, false, true, true>), grid, block, lds, st, P, D); \
+        else if (P.ft_packed) hipLaunchKernelGGL((search_kernel<true, 4, false, 0, FBA_MODEL_BA_FACTORED, FSV, false, true>), grid, block, lds, st, P, D); \
         else if (stage) hipLaunchKernelGGL((search_kernel<true, 4, false, 0, FBA_MODEL_BA_FACTORED, FSV>), grid, block, lds, st, P, D); \
         else hipLaunchKernelGGL((search_kernel<false, 4, false, 0, FBA_MODEL_BA_FACTORED, FSV>), grid, block, lds, st, P, D);      \
         return;                                                                                                                   \

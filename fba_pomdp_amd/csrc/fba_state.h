@@ -105,11 +105,6 @@ struct DeviceState {
     int32_t hash_compact;  // 8-byte entries {epoch << 27 | code, child} instead (codes below 2^27): fba_kernels.hip child_get
     uint32_t* epoch;    // [E]
     const double* log1p_tab; // [sims + 1]
-    // search lanes grouped by remaining horizon: search_perm[g] = the slot that lane g of the search grid runs, slots in order of
-    // their time-step t (inactive ones last).  A tree's simulations are as long as its horizon allows, and a wave runs until its
-    // slowest lane is done, so waves of like slots waste fewer lane-iterations (fba_search.hip, sort_slots)
-    int32_t* search_perm;    // [E] or null (identity)
-    uint32_t* sort_bins;     // [2][256] scratch of the counting sort
     // --- outputs ---
     double* returns;    // [runs][episodes]
     int32_t* lengths;   // [runs][episodes]

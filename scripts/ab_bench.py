@@ -25,6 +25,6 @@ for r in range(rounds):
         p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"] + extra, env=e, capture_output=True, text=True, timeout=400)
         try:
             d = json.loads(p.stdout.strip().splitlines()[-1])
-            print(f"{name:24s} tick {d['ms_per_step']:8.2f} ms  search {d['search_kernel']['avg_ms']:8.2f}  belief {d['roofline']['avg_ms']:7.2f}  steps/s {d['value']:.4g}", flush=True)
+            print(f"{name:24s} tick {d['ms_per_step']:8.2f} ms  search {d['search_kernel']['avg_ms']:8.2f}  belief {d['roofline']['avg_ms']:7.2f}  steps/s {d['value']:.4g}  search steps/s {d['search_kernel']['steps_per_s']:.4g}", flush=True)
         except Exception:
             print(name, "FAILED", p.stderr[-800:], flush=True)

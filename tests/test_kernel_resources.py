@@ -27,9 +27,9 @@ def test_tiger_kernels_use_no_scratch(tmp_path):
             seen[name] = (get("private_segment_fixed_size"), get("vgpr_count"), get("vgpr_spill_count"))
     tiger = {n: v for n, v in seen.items()
              if re.search(r"search_kernelILb1ELi4ELb0ELi[12]ELi1E|reject_kernelILb0ELi[12]E|importance_kernelILb0ELi[12]E|reject_tiger_lds_kernel", n)}
-    # dense (1) and packed (2) particle formats (the importance filter with its weights in HBM or in LDS) + the
-    # LDS-resident packed rejection
-    assert len(tiger) == 9, sorted(seen)
+    # dense (1) and packed (2) particle formats (the search on the general tree layout and on the episodic tiger family's own;
+    # the importance filter with its weights in HBM or in LDS) + the LDS-resident packed rejection
+    assert len(tiger) == 11, sorted(seen)
     for name, (scratch, vgprs, spills) in tiger.items():
         assert scratch == 0 and spills == 0, (name, scratch, spills)
         # four waves per SIMD stay possible -- where LDS allows them: the search over DENSE tiger records (the bench's are
