@@ -333,17 +333,22 @@ def main():
                   "steps_per_launch": search.units / s_launches}
         sp, sp_src = search_traffic(args, w, eng.slots)
         if sp:
-            # the search is a latency / transaction-bound gather over node and particle records that are NOT cache resident at 262 144
-            # slots (51 GB of trees and filters): DESIGN.md section 5 -- SURVEY 8(d)'s "KB-scale, cache-resident" does not hold here
-            bps = sp["fetch_bytes_per_step_x2"] + sp["write_bytes_per_step"]
+            # the search is a gather over node and particle records that are NOT cache resident at 262 144 slots (trees + filters: 34 GB): SURVEY
+            # 8(d)'s "KB-scale, cache-resident" does not hold here.  What bounds it is the rate at which the memory system serves random 64-byte
+            # sectors (scripts/micro/randline: 48.7 G/s with every lane of 4 096 waves asking for its own), DESIGN.md section 5c.
+            bps = sp["fetch_bytes_per_step"] + sp["write_bytes_per_step"]
+            sectors = sp["fetch_sectors_64B_per_step"] * s_line["steps_per_s"]
             s_line.update({
                 "traffic": bps * s_line["steps_per_launch"], "traffic_source": sp_src,
-                "bytes_per_step": bps, "fetch_bytes_per_step_raw": sp["fetch_bytes_per_step_raw"], "write_bytes_per_step": sp["write_bytes_per_step"],
+                "bytes_per_step": bps, "fetch_bytes_per_step": sp["fetch_bytes_per_step"], "write_bytes_per_step": sp["write_bytes_per_step"],
                 "l2_misses_per_step": sp.get("l2_misses_per_step"), "algorithmic_bytes_per_step": sp["algorithmic_bytes_per_step"],
                 "frac_traffic": bps * s_line["steps_per_launch"] / 1e9 / (s_avg_ms / 1e3) / HBM_PEAK_GBS if s_avg_ms > 0 else None,
                 "frac_algorithmic": sp["algorithmic_bytes_per_step"] * s_line["steps_per_launch"] / 1e9 / (s_avg_ms / 1e3) / HBM_PEAK_GBS if s_avg_ms > 0 else None,
-                "traffic_note": "memory-side bytes per simulated step from the committed PMC passes of this command (FETCH_SIZE x 2: 128-byte lines "
-                                "tallied at 64 B, + WRITE_SIZE) x the steps of a timed launch; algorithmic = record bytes a step needs (DESIGN.md section 5)",
+                "random_sectors_per_s": sectors, "random_sector_ceiling_per_s": sp["random_sector_ceiling_G_per_s"] * 1e9,
+                "frac_sector_ceiling": sectors / (sp["random_sector_ceiling_G_per_s"] * 1e9),
+                "traffic_note": "memory-side bytes per simulated step from the committed PMC passes of this command (FETCH_SIZE, exact for random 16-byte "
+                                "loads per lane, + WRITE_SIZE) x the steps of a timed launch; algorithmic = record bytes a step needs (DESIGN.md section 5c); "
+                                "random_sectors_per_s = fetched 64-byte sectors per step x this run's search steps/s, against the micro-benchmark's ceiling",
             })
         out = {
             "metric": "simulated env steps/sec (belief+rollout)",

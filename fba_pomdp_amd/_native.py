@@ -25,6 +25,7 @@ HIPCC_FLAGS = [
 ]
 
 MAX_ACTIONS = 24
+TRACE_HIST_BINS = 64
 K_SEARCH, K_ENV, K_BELIEF_RS, K_BELIEF_IS, K_BELIEF_RESET, K_BELIEF_INIT, K_COUNT = range(7)
 KERNEL_NAMES = ["search_kernel", "env_kernel", "reject_kernel", "importance_kernel", "reset_kernel", "init_kernel"]
 
@@ -115,7 +116,7 @@ EXPORTS = [
     "fba_set_position", "fba_belief_init", "fba_belief_reset_domain_state", "fba_select_action",
     "fba_belief_update", "fba_belief_get", "fba_belief_get_particle", "fba_belief_set", "fba_belief_get_fully_connected", "fba_belief_get_nested", "fba_belief_get_shadow", "fba_last_step_info",
     "fba_run_planning", "fba_run_bapomdp", "fba_run_ticks", "fba_get_returns", "fba_get_counters", "fba_get_return_sums",
-    "fba_get_kernel_times", "fba_reset_kernel_times", "fba_trace_count", "fba_get_trace",
+    "fba_get_kernel_times", "fba_reset_kernel_times", "fba_trace_count", "fba_get_trace", "fba_get_trace_hist",
     "fba_selftest_ucb", "fba_stat_add", "fba_stat_var", "fba_stat_stder",
 ]
 
@@ -155,10 +156,10 @@ CLI_SOURCE = os.path.join(HERE, "csrc", "host", "fba_cli.cpp")
 def build_cli(force=False):
     """g++ the reference-compatible command line (planning / bapomdp / fbapomdp) against the C-ABI."""
     if (not force and os.path.exists(CLI_PATH)
-            and os.path.getmtime(CLI_SOURCE) <= os.path.getmtime(CLI_PATH)
+            and max(os.path.getmtime(CLI_SOURCE), os.path.getmtime(os.path.join(HERE, "csrc", "host", "conf_bridge.hpp"))) <= os.path.getmtime(CLI_PATH)
             and os.path.getmtime(LIB_PATH) <= os.path.getmtime(CLI_PATH)):
         return CLI_PATH
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), CLI_SOURCE,
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc", "host"), CLI_SOURCE,
                            "-L" + HERE, "-lfba_hip", "-Wl,-rpath,$ORIGIN", "-o", CLI_PATH])
     return CLI_PATH
 
@@ -217,6 +218,8 @@ def load():
     L.fba_reset_kernel_times.argtypes = [vp]
     L.fba_trace_count.argtypes = [vp]
     L.fba_get_trace.argtypes = [vp, vp, C.c_int32]
+    if not os.environ.get("FBA_LIB") or hasattr(L, "fba_get_trace_hist"):
+        L.fba_get_trace_hist.argtypes = [vp, vp, C.c_int32]
     L.fba_selftest_ucb.argtypes = [vp, vp, vp, C.c_int32, C.c_double, vp]
     L.fba_stat_add.argtypes = [P(Stat), C.c_double]
     L.fba_stat_var.restype = C.c_double

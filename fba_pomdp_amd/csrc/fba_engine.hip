@@ -963,6 +963,8 @@ int ensure_outputs(fba_ctx* c, int runs)
         if ((size_t)c->D.trace_cap < cap) {
             int rc;
             if ((rc = dev_alloc(c, &c->D.trace, cap))) return rc;
+            if (c->cfg.trace >= 2 && c->P.S <= FBA_TRACE_HIST_BINS && !c->P.nested)
+                if ((rc = dev_alloc(c, &c->D.trace_hist, cap * FBA_TRACE_HIST_BINS))) return rc;
             c->D.trace_cap = (int32_t)cap;
         }
         HIPCHK(c, hipMemsetAsync(c->D.trace_count, 0, sizeof(int32_t), c->stream));
@@ -2144,6 +2146,8 @@ int fba_run_ticks(fba_ctx* c, int32_t ticks)
             const size_t cap = std::min<size_t>((size_t)c->P.E * c->P.episodes * c->P.horizon, (size_t)1 << 22);
             if ((size_t)c->D.trace_cap < cap) {
                 if ((rc = dev_alloc(c, &c->D.trace, cap))) return rc;
+                if (c->cfg.trace >= 2 && c->P.S <= FBA_TRACE_HIST_BINS && !c->P.nested)
+                    if ((rc = dev_alloc(c, &c->D.trace_hist, cap * FBA_TRACE_HIST_BINS))) return rc;
                 c->D.trace_cap = (int32_t)cap;
             }
             HIPCHK(c, hipMemsetAsync(c->D.trace_count, 0, sizeof(int32_t), c->stream));
@@ -2288,6 +2292,30 @@ int fba_get_trace(const fba_ctx* cc, fba_trace_rec* out, int32_t cap)
         if (a.episode != b.episode) return a.episode < b.episode;
         return a.t < b.t;
     });
+    return n;
+}
+
+int fba_get_trace_hist(const fba_ctx* cc, uint32_t* out, int32_t cap)
+{
+    fba_ctx* c = const_cast<fba_ctx*>(cc);
+    if (!c || !out) return FBA_EINVAL;
+    if (!c->D.trace_hist) return fail(c, FBA_EINVAL, "no histograms were recorded: create the context with trace = 2 (domains of at most %d states)", FBA_TRACE_HIST_BINS);
+    const int n = std::min(fba_trace_count(c), cap);
+    if (n <= 0) return n;
+    std::vector<fba_trace_rec> tr((size_t)n);
+    std::vector<uint32_t> h((size_t)n * FBA_TRACE_HIST_BINS);
+    HIPCHK(c, hipMemcpy(tr.data(), c->D.trace, (size_t)n * sizeof(fba_trace_rec), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(h.data(), c->D.trace_hist, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::vector<int> order((size_t)n);
+    for (int i = 0; i < n; ++i) order[(size_t)i] = i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) {   // the order of fba_get_trace
+        if (tr[a].run != tr[b].run) return tr[a].run < tr[b].run;
+        if (tr[a].episode != tr[b].episode) return tr[a].episode < tr[b].episode;
+        return tr[a].t < tr[b].t;
+    });
+    for (int i = 0; i < n; ++i)
+        std::copy(h.begin() + (size_t)order[(size_t)i] * FBA_TRACE_HIST_BINS, h.begin() + (size_t)(order[(size_t)i] + 1) * FBA_TRACE_HIST_BINS,
+                  out + (size_t)i * FBA_TRACE_HIST_BINS);
     return n;
 }
 

@@ -1846,9 +1846,12 @@ __device__ uint64_t hist_hash_counts(const Problem& P, const uint32_t* rec, uint
 __global__ void __launch_bounds__(256) flush_kernel(Problem P, DeviceState D)
 {
     __shared__ unsigned long long s_sum;
+    __shared__ uint32_t s_hist[FBA_TRACE_HIST_BINS];
     const int e = blockIdx.x, tid = threadIdx.x;
     if (!D.trace_on || D.cur[e].belief_hash != 1) return;
     if (tid == 0) s_sum = 0;
+    if (tid < FBA_TRACE_HIST_BINS) s_hist[tid] = 0;
+    const bool hist_on = D.trace_hist != nullptr && !D.cur[e].terminal;   // (no belief update after a terminal step, Episode.cpp:47-50)
     __syncthreads();
     const size_t pb = pbase(P, e, D.bufsel[e]);
     const bool lazy = slot_lazy(D, e);
@@ -1856,6 +1859,7 @@ __global__ void __launch_bounds__(256) flush_kernel(Problem P, DeviceState D)
     for (int i = tid; i < P.N; i += 256) {
         const float* cnt = D.p_rec + (rec_base(P, D, e, D.bufsel[e]) + i) * (size_t)P.Cs;
         const int st = lazy ? lazy_state(P, D, e, i) : rec_state(cnt, P.C);
+        if (hist_on && (unsigned)st < (unsigned)FBA_TRACE_HIST_BINS) atomicAdd(&s_hist[st], 1u);
         uint64_t h = mix64((uint64_t)i * 0x9E3779B97F4A7C15ull + (uint64_t)(uint32_t)st);
         const double w = (P.belief == FBA_BELIEF_IMPORTANCE) ? D.p_weight[pb + i] : 0.0;
         h = mix64(h ^ (uint64_t)__double_as_longlong(w));
@@ -1888,6 +1892,12 @@ __global__ void __launch_bounds__(256) flush_kernel(Problem P, DeviceState D)
         D.cur[e].belief_hash = s_sum;
         const int idx = atomicAdd(D.trace_count, 1);
         if (idx < D.trace_cap) D.trace[idx] = D.cur[e];
+        s_sum = (unsigned long long)(unsigned)idx;
+    }
+    if (D.trace_hist) {
+        __syncthreads();
+        const size_t idx = (size_t)s_sum;
+        if (idx < (size_t)D.trace_cap && tid < FBA_TRACE_HIST_BINS) D.trace_hist[idx * FBA_TRACE_HIST_BINS + tid] = hist_on ? s_hist[tid] : 0u;
     }
 }
 

@@ -119,6 +119,7 @@ struct DeviceState {
     unsigned long long* upd_entries;   // [E] history particles: sum over updates of N * (entries per record before the update)
     fba_trace_rec* cur;  // [E] record being assembled for the current tick
     fba_trace_rec* trace; // [trace_cap]
+    uint32_t* trace_hist;  // [trace_cap][FBA_TRACE_HIST_BINS] or null: the filter's state histogram after the update of each record (cfg.trace = 2)
     int32_t* trace_count;
     int32_t trace_cap;
     int32_t trace_on;

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "fba_hip.h"
+#include "conf_bridge.hpp"
 
 namespace {
 
@@ -134,14 +135,9 @@ bool parse(int argc, char** argv, Options& o, std::string& err)
     return true;
 }
 
-// The reference seeds mt19937 from the characters of --seed; here they key Philox (FNV-1a).
-uint64_t seed_from(std::string const& s)
-{
-    if (s.empty()) return (uint64_t)std::time(nullptr);  // rnd::initiate(): time(nullptr)
-    uint64_t h = 1469598103934665603ull;
-    for (unsigned char ch : s) { h ^= ch; h *= 1099511628211ull; }
-    return h;
-}
+// The reference seeds mt19937 from the characters of --seed; here they key Philox (FNV-1a: conf_bridge.hpp, the function the
+// factory patch of INTEGRATION.md uses too).
+uint64_t seed_from(std::string const& s) { return fba::seed_from_string(s); }
 
 bool to_config(Options const& o, fba_config& c, std::string& err)
 {
@@ -205,16 +201,23 @@ bool to_config(Options const& o, fba_config& c, std::string& err)
     c.noise = o.noise; c.counts_total = o.counts_total;
     c.seed = seed_from(o.seed);
     c.slots = o.slots; c.device = o.device;
-    c.trace = o.verbose >= 2 ? 1 : 0;
+    c.trace = o.verbose >= 3 ? 2 : (o.verbose >= 2 ? 1 : 0);   // (2: with the filter's state histogram after every update)
     return true;
 }
 
-void print_trace(fba_ctx* ctx, int verbose, int A)
+void print_trace(fba_ctx* ctx, int verbose, int A, int particles)
 {
     const int n = fba_trace_count(ctx);
     if (n <= 0) return;
     std::vector<fba_trace_rec> tr((size_t)n);
     const int got = fba_get_trace(ctx, tr.data(), n);
+    // -v 3: FlatFilter::toString (FlatFilter.cpp:70-94) of the filter after every update (RejectionSampling.cpp:39,
+    // BARejectionSampling.cpp:46), for domains of at most FBA_TRACE_HIST_BINS states
+    std::vector<uint32_t> hist;
+    if (verbose >= 3) {
+        hist.resize((size_t)n * FBA_TRACE_HIST_BINS);
+        if (fba_get_trace_hist(ctx, hist.data(), n) != got) hist.clear();
+    }
     for (int i = 0; i < got; ++i) {
         const fba_trace_rec& r = tr[(size_t)i];
         if (r.t == 0) std::printf("V1: run %d, episode %d\n", r.run + 1, r.episode + 1);
@@ -225,6 +228,13 @@ void print_trace(fba_ctx* ctx, int verbose, int A)
         }
         std::printf("V2: T=%d\ta=%d\ts'=%d\to=%d\tr=%g\n", r.t, r.action, r.state, r.obs, r.reward);
         if (verbose >= 3 && r.update_count >= 0) std::printf("V3: performed %d loops for rejection sampling\n", r.update_count);
+        if (!hist.empty() && !r.terminal) {
+            std::printf("V3: Status of the filter after update:Particle filter contains:\n");
+            for (int st = 0; st < FBA_TRACE_HIST_BINS; ++st) {
+                const uint32_t k = hist[(size_t)i * FBA_TRACE_HIST_BINS + st];
+                if (k) std::printf("V3: \t(%d: %f(%u))\n", st, k / static_cast<double>(particles), k);
+            }
+        }
     }
 }
 
@@ -272,7 +282,7 @@ int main(int argc, char** argv)
     if (o.verbose >= 2) {
         int32_t S, A, O;
         fba_domain_sizes(ctx, &S, &A, &O);
-        print_trace(ctx, o.verbose, A);
+        print_trace(ctx, o.verbose, A, cfg.belief == FBA_BELIEF_POINT ? 1 : cfg.particles);
     }
     {
         std::ofstream f(o.output_file);

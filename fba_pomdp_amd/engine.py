@@ -117,6 +117,24 @@ class Engine:
             self._chk(n)
         return out[:n]
 
+    def trace_hist(self):
+        """trace = 2: the filter's state histogram after the belief update of every trace record, in the order of trace()."""
+        n = self.L.fba_trace_count(self.h)
+        out = np.zeros((max(n, 1), N.TRACE_HIST_BINS), np.uint32)
+        n = self.L.fba_get_trace_hist(self.h, out.ctypes.data, len(out))
+        if n < 0:
+            self._chk(n)
+        return out[:n]
+
+    def belief_get_particle(self, index, slot=0, weight=False):
+        """One particle of the filter (Belief::sample() for a host planner that has drawn the index): state, weight, counts."""
+        s = np.zeros(1, np.int32)
+        w = np.zeros(1, np.float64)
+        cnt = np.zeros(max(self.ncnt, 1), np.float32)
+        self._chk(self.L.fba_belief_get_particle(self.h, slot, index, s.ctypes.data, w.ctypes.data if weight else None,
+                                                 cnt.ctypes.data if self.ncnt else None))
+        return int(s[0]), float(w[0]), cnt[:self.ncnt]
+
     # ---- per-step interface
     def prior(self):
         out = np.zeros(self.ncnt, np.float32)

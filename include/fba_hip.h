@@ -117,7 +117,8 @@ typedef struct fba_config {
     int32_t run_offset;      /* global index of this ctx's first run (episode sharding)      */
     int32_t slots;           /* concurrent runs on the device; 0 => min(runs, auto)          */
     int32_t device;          /* HIP device ordinal                                           */
-    int32_t trace;           /* 1 => record one fba_trace_rec per real time-step             */
+    int32_t trace;           /* 1 => record one fba_trace_rec per real time-step; 2 => also the filter's state histogram
+                              * after every belief update (domains of at most FBA_TRACE_HIST_BINS states): fba_get_trace_hist */
     int32_t dirichlet_regular; /* --dirichlet_sampling_method regular (0 = expected, default);
                                 * bug-compatible with the reference's biased sampler (BAConf.hpp:22,
                                 * random.cpp:146-242) */
@@ -290,6 +291,12 @@ int fba_get_kernel_times(fba_ctx* ctx, fba_kernel_time* out /* [FBA_K_COUNT] */)
 int fba_reset_kernel_times(fba_ctx* ctx);
 int fba_trace_count(const fba_ctx* ctx);
 int fba_get_trace(const fba_ctx* ctx, fba_trace_rec* out, int32_t cap);
+/* cfg.trace = 2: hist[i][s] = how many particles of the filter held domain state s after the belief update of trace record i
+ * (the order of fba_get_trace) -- what FlatFilter::toString (src/beliefs/particle_filters/FlatFilter.cpp:70-94) prints at -v 3
+ * ("Status of rejection sampling filter after update", RejectionSampling.cpp:39, BARejectionSampling.cpp:46); all zero for a
+ * record without an update (terminal step).  out[cap][FBA_TRACE_HIST_BINS]. */
+#define FBA_TRACE_HIST_BINS 64
+int fba_get_trace_hist(const fba_ctx* ctx, uint32_t* out, int32_t cap);
 
 /* diagnostic: out[i] = u * sqrt(L[i] / n[i]) evaluated on the device, to check that the
  * engine's fp64 divide and square root round like the host's (they must, for UCB parity) */

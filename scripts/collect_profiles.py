@@ -1,5 +1,7 @@
-"""Turn gpurun_out/refresh/ (scripts/refresh_profiles.sh) into the committed profiles/ files."""
+"""Turn gpurun_out/refresh/ (scripts/refresh_profiles.sh) into the committed profiles/<tag>_* files.
+python scripts/collect_profiles.py [tag]      (default r03)"""
 import csv
+import glob
 import json
 import os
 import shutil
@@ -8,59 +10,192 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "refresh")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
-shutil.copy(os.path.join(SRC, "bench_default.json"), os.path.join(DST, f"{tag}_bench_default.json.log"))
-shutil.copy(os.path.join(SRC, "stats", "run_kernel_stats.csv"), os.path.join(DST, f"{tag}_bench_kernel_stats.csv"))
+
+def dst(name):
+    return os.path.join(DST, f"{tag}_{name}")
 
 
 def per_kernel(path, counter):
-    """KiB per launch, summed over the counter's instances (XCDs), per kernel name"""
+    """counter value per launch, summed over the counter's instances, per kernel name: {kernel: [v of launch 1, ...]}"""
     by = {}
     for row in csv.DictReader(open(path)):
         if row["Counter_Name"] != counter:
             continue
-        key = (row["Kernel_Name"], row["Dispatch_Id"])
+        key = (row["Kernel_Name"], int(row["Dispatch_Id"]))
         by[key] = by.get(key, 0.0) + float(row["Counter_Value"])
     out = {}
-    for (k, _), v in sorted(by.items(), key=lambda kv: int(kv[0][1])):
+    for (k, _), v in sorted(by.items(), key=lambda kv: kv[0][1]):
         out.setdefault(k, []).append(v)
     return out
 
 
-fetch = per_kernel(os.path.join(SRC, "fetch", "run_counter_collection.csv"), "FETCH_SIZE")
-write = per_kernel(os.path.join(SRC, "write", "run_counter_collection.csv"), "WRITE_SIZE")
-rk = [k for k in fetch if "reject_tiger_lds_kernel" in k or "reject_kernel" in k][0]
-# full launches only (the warm-up tick and the last, partly idle one move fewer bytes)
-f_full = max(fetch[rk]) * 1024.0
-w_full = max(write[rk]) * 1024.0
-# FETCH_SIZE calibrated on this kernel's two access shapes (profiles/r02_pmc_calibration.json, scripts/micro/pmc_calibrate.hip):
-# the parking pass touches every 64-byte record of the filter once -- known bytes, reported at 1 / park_factor of them --
-# and what the counter saw beyond that is the gather's 64-byte record reads, tallied at 64 B per 128-byte line moved (x 2)
-cal = json.load(open(os.path.join(DST, "r02_pmc_calibration.json")))
-park_factor = cal["factors"]["park_kernel"]["true_over_reported_fetch"]
-park_true = w_full  # slots x N x 64 B: the filter read once = the bytes written
-f_cal = park_true + 2.0 * max(f_full - park_true / park_factor, 0.0)
-doc = {
-    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline",
-    "config": "default bench workload, 262144 slots, packed particles (64 B records)",
-    "kernel": "reject_kernel",  # bench.py's name for the rejection update, whichever instantiation runs it
-    "kernel_instantiation": rk,
-    "fetch_bytes_per_launch_raw": f_full,
-    "write_bytes_per_launch": w_full,
-    "traffic_bytes_per_launch_raw": f_full + w_full,
-    "traffic_bytes_per_launch_fetch_x2": 2 * f_full + w_full,
-    "fetch_bytes_per_launch_calibrated": f_cal,
-    "traffic_bytes_per_launch_calibrated": f_cal + w_full,
-    "notes": [
-        "counter unit KiB (MI355X_MICROARCH.md, HBM / rocprofv3): values below are KiB per launch summed over instances; the per-launch figure used is the largest (a launch in which every slot updates)",
-        "WRITE_SIZE is exact on gfx950: 262144 slots x 4096 particles x 64 B = 68.72 GB is the minimum this kernel can write",
-        "FETCH_SIZE calibrated with scripts/micro/pmc_calibrate (profiles/r02_pmc_calibration.json): the parking pass (4-byte words of every 64-byte record) reports 1 / %.2f of its bytes, the gather (16 B x 4 lanes, random 64-byte records) is tallied at 64 B per 128-byte line moved; calibrated fetch = slots x N x 64 + 2 x (raw - slots x N x 64 / %.2f)" % (park_factor, park_factor),
-    ],
-    "per_launch_KiB": {k: {"fetch_KiB_per_launch": fetch.get(k, []), "write_KiB_per_launch": write.get(k, [])}
-                       for k in fetch if "search_kernel" in k or "reject_kernel" in k or "reject_tiger_lds_kernel" in k},
-}
-with open(os.path.join(DST, f"{tag}_pmc_fetch_write.json"), "w") as f:
-    json.dump(doc, f, indent=1)
-print(json.dumps({k: doc[k] for k in ("kernel_instantiation", "fetch_bytes_per_launch_raw", "write_bytes_per_launch", "traffic_bytes_per_launch_raw")}, indent=1))
-print(open(os.path.join(DST, f"{tag}_bench_kernel_stats.csv")).read()[:900])
+def last_json(path):
+    lines = [l for l in open(path).read().splitlines() if l.startswith("{")]
+    return json.loads(lines[-1]) if lines else None
+
+
+def find(d, sub):
+    ks = [k for k in d if sub in k]
+    return ks[0] if ks else None
+
+
+shutil.copy(os.path.join(SRC, "bench_default.json"), dst("bench_default.json.log"))
+shutil.copy(os.path.join(SRC, "stats", "run_kernel_stats.csv"), dst("bench_kernel_stats.csv"))
+if os.path.exists(os.path.join(SRC, "bench_importance.json")):
+    shutil.copy(os.path.join(SRC, "bench_importance.json"), dst("bench_importance_sampling.json.log"))
+with open(dst("other_configs.jsonl"), "w") as f:
+    for wl in ("c1", "c3", "c5"):
+        p = os.path.join(SRC, f"bench_{wl}.json")
+        if os.path.exists(p) and os.path.getsize(p):
+            f.write(open(p).read().strip() + "\n")
+
+fetch = per_kernel(os.path.join(SRC, "fetch", "run_counter_collection.csv"), "FETCH_SIZE")     # KiB
+write = per_kernel(os.path.join(SRC, "write", "run_counter_collection.csv"), "WRITE_SIZE")     # KiB
+KIB = 1024.0
+
+# ---- the random-sector micro-benchmark: what a counter reports for one random 64-byte record per lane, and the rate the part sustains
+rl = {}
+if os.path.exists(os.path.join(SRC, "randline.jsonl")):
+    shutil.copy(os.path.join(SRC, "randline.jsonl"), dst("randline.jsonl"))
+    rows = [json.loads(l) for l in open(os.path.join(SRC, "randline.jsonl")) if l.startswith("{")]
+    shapes = [r for r in rows if "shape" in r]
+    accesses = 4096 * 64 * 1024   # of the counter passes (iters 1024)
+    cnt = {}
+    for name, d, counter in (("fetch_B", "rl_fetch", "FETCH_SIZE"), ("write_B", "rl_write", "WRITE_SIZE"), ("rdreq", "rl_l2", "TCC_EA0_RDREQ_sum"),
+                             ("rdreq_32B", "rl_l2", "TCC_EA0_RDREQ_32B_sum"), ("l2_miss", "rl_l2", "TCC_MISS_sum"), ("l2_hit", "rl_l2", "TCC_HIT_sum")):
+        pk = per_kernel(os.path.join(SRC, d, "run_counter_collection.csv"), counter)
+        for k, v in pk.items():
+            # every shape runs a warm-up launch and a timed one: the timed one is the second
+            cnt.setdefault(k, {})[name] = v[-1] * (KIB if name.endswith("_B") else 1.0) / accesses
+    rl = {"shapes": shapes, "per_access_counters_of_one_XCD_instance_sum": cnt,
+          "note": "rocprofv3 sums the TCC counters it collects; on this box the per-access figures come out at 1/8 of the bytes a shape moves "
+                  "(one XCD's share): load16 reports 8.0 B of FETCH_SIZE per access = 64 B x 1/8, TCC_EA0_RDREQ 0.125 per access, no 32-byte "
+                  "requests.  So a random 16-byte load per lane costs ONE 64-byte read request at the fabric, and FETCH_SIZE counts it in full "
+                  "(the guide's x2 is for wide coalesced streams whose 128-byte requests are tallied at 64 B); a store into a record that is not "
+                  "resident fetches nothing (FETCH_SIZE 0) and writes 32 B."}
+    json.dump(rl, open(dst("randline_counters.json"), "w"), indent=1)
+    load16 = max(s["G_records_per_s"] for s in shapes if s["shape"] == "load16")
+else:
+    load16 = 48.7   # G random 64-byte sectors per second (profiles/r03_randline.jsonl)
+
+# ---- the search kernel: memory-side bytes, L2 requests and misses per simulated step
+sk = find(fetch, "search_kernel")
+line = last_json(os.path.join(SRC, "fetch.log"))
+if sk and line:
+    launches = len(fetch[sk])
+    steps = line["search_kernel"]["steps_per_launch"] * launches
+    l2 = {c: per_kernel(os.path.join(SRC, "l2", "run_counter_collection.csv"), c) for c in
+          ("TCC_MISS_sum", "TCC_HIT_sum", "TCP_TCC_READ_REQ_sum", "TCP_TCC_WRITE_REQ_sum")}
+    sq = {c: per_kernel(os.path.join(SRC, "sq", "run_counter_collection.csv"), c) for c in
+          ("SQ_INSTS_VALU", "SQ_INSTS_VMEM", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_BUSY_CYCLES")}
+    f_b, w_b = sum(fetch[sk]) * KIB, sum(write[find(write, "search_kernel")]) * KIB
+    doc = {
+        "command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE | TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCC_HIT_sum TCC_MISS_sum | SQ_*> "
+                   "--output-format csv -- python3 bench.py --steps 4 --warmup 0 --no-cpu-baseline   (one pass per counter group)",
+        "kernel": sk, "launches": launches, "simulated_steps_of_those_launches": steps,
+        "fetch_bytes_per_step": f_b / steps, "write_bytes_per_step": w_b / steps,
+        "fetch_sectors_64B_per_step": f_b / 64.0 / steps,
+        "l2_misses_per_step": sum(l2["TCC_MISS_sum"][find(l2["TCC_MISS_sum"], "search_kernel")]) / steps,
+        "l2_hits_per_step": sum(l2["TCC_HIT_sum"][find(l2["TCC_HIT_sum"], "search_kernel")]) / steps,
+        "l1_read_requests_per_step": sum(l2["TCP_TCC_READ_REQ_sum"][find(l2["TCP_TCC_READ_REQ_sum"], "search_kernel")]) / steps,
+        "l1_write_requests_per_step": sum(l2["TCP_TCC_WRITE_REQ_sum"][find(l2["TCP_TCC_WRITE_REQ_sum"], "search_kernel")]) / steps,
+        "valu_wave_instructions_per_64_steps": sum(sq["SQ_INSTS_VALU"][find(sq["SQ_INSTS_VALU"], "search_kernel")]) * 64.0 / steps,
+        "vmem_wave_instructions_per_64_steps": sum(sq["SQ_INSTS_VMEM"][find(sq["SQ_INSTS_VMEM"], "search_kernel")]) * 64.0 / steps,
+        "lds_wave_instructions_per_64_steps": sum(sq["SQ_INSTS_LDS"][find(sq["SQ_INSTS_LDS"], "search_kernel")]) * 64.0 / steps,
+        "sq_wait_any_over_wave_cycles": sum(sq["SQ_WAIT_ANY"][find(sq["SQ_WAIT_ANY"], "search_kernel")]) /
+                                        max(sum(sq["SQ_WAVE_CYCLES"][find(sq["SQ_WAVE_CYCLES"], "search_kernel")]), 1.0),
+        # what a simulated step needs of its records: per simulation one 64-byte particle record, per tree level below the two LDS-resident ones
+        # a 64-byte node record read and 24 bytes of it written back; at 0.44 simulations and ~0.2 such levels per step (DESIGN.md section 5c)
+        "algorithmic_bytes_per_step": 0.44 * 64.0 + 0.2 * (64.0 + 24.0),
+        "random_sector_ceiling_G_per_s": load16,
+        "fetch_calibration": "FETCH_SIZE is exact for this kernel's loads (random 16-byte loads per lane: one 64-byte request each, "
+                             "profiles/%s_randline_counters.json); no x2" % tag,
+        "per_launch_KiB": {"fetch": fetch[sk], "write": write[find(write, "search_kernel")]},
+    }
+    json.dump(doc, open(dst("pmc_search.json"), "w"), indent=1)
+    with open(dst("l2_counters.txt"), "w") as f:
+        f.write(f"# {doc['command']}: search kernel, one row per launch\n")
+        names = sorted(l2)
+        f.write("launch " + " ".join(f"{n:>22s}" for n in names) + "\n")
+        for i in range(launches):
+            f.write(f"{i:6d} " + " ".join(f"{l2[n][find(l2[n], 'search_kernel')][i]:22.4g}" for n in names) + "\n")
+    with open(dst("sq_counters.txt"), "w") as f:
+        f.write(f"# {doc['command']}: sums over the run's launches\n")
+        for kname in ("search_kernel", "reject_tiger_lds_kernel"):
+            f.write(f"# {kname}\n")
+            for n in sorted(sq):
+                k = find(sq[n], kname)
+                if k:
+                    f.write(f"{n:28s} {sum(sq[n][k]):.4g}  (launches {len(sq[n][k])})\n")
+    print("search:", {k: round(v, 3) for k, v in doc.items() if isinstance(v, float)})
+
+# ---- the rejection update (the bench's roofline kernel): a launch in which every slot updates
+rk = find(fetch, "reject_tiger_lds_kernel") or find(fetch, "reject_kernel")
+if rk:
+    f_full, w_full = max(fetch[rk]) * KIB, max(write[rk]) * KIB
+    cal = json.load(open(os.path.join(DST, "r02_pmc_calibration.json")))
+    park_factor = cal["factors"]["park_kernel"]["true_over_reported_fetch"]
+    park_true = w_full                       # slots x N x 64 B: the filter read once = the bytes written
+    gather_raw = max(f_full - park_true / park_factor, 0.0)
+    doc = {
+        "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py --steps 4 --warmup 0 --no-cpu-baseline",
+        "config": "default bench workload, 262144 slots, packed particles (64 B records)",
+        "kernel": "reject_kernel", "kernel_instantiation": rk,
+        "fetch_bytes_per_launch_raw": f_full, "write_bytes_per_launch": w_full, "traffic_bytes_per_launch_raw": f_full + w_full,
+        "fetch_bytes_per_launch_calibrated": park_true + gather_raw, "traffic_bytes_per_launch_calibrated": park_true + gather_raw + w_full,
+        "traffic_bytes_per_launch_upper_bound_r02_formula": park_true + 2.0 * gather_raw + w_full,
+        "notes": [
+            "counter unit KiB; per-launch figure = the largest launch (one in which every slot updates)",
+            "WRITE_SIZE is exact on gfx950: slots x N x 64 B is the minimum this kernel can write",
+            "FETCH_SIZE: the parking pass (4-byte words of every 64-byte record, records in order: a coalesced sweep) reports 1 / %.2f of its bytes "
+            "(profiles/r02_pmc_calibration.json); the gather's random 64-byte record reads are counted in full -- one 64-byte request per record, "
+            "profiles/%s_randline_counters.json -- which round 2 had doubled on the assumption that the memory side moves 128-byte lines "
+            "(kept as traffic_bytes_per_launch_upper_bound_r02_formula)" % (park_factor, tag),
+        ],
+    }
+    json.dump(doc, open(dst("pmc_fetch_write.json"), "w"), indent=1)
+    print("reject:", {k: v for k, v in doc.items() if k.startswith("traffic") or k.startswith("fetch_bytes")})
+
+# ---- the importance filter of the bench workload
+if os.path.exists(os.path.join(SRC, "is_fetch", "run_counter_collection.csv")):
+    fi = per_kernel(os.path.join(SRC, "is_fetch", "run_counter_collection.csv"), "FETCH_SIZE")
+    wi = per_kernel(os.path.join(SRC, "is_write", "run_counter_collection.csv"), "WRITE_SIZE")
+    ik = find(fi, "importance_kernel")
+    if ik:
+        f_full, w_full = max(fi[ik]) * KIB, max(wi[ik]) * KIB
+        doc = {
+            "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py --belief importance_sampling --steps 4 --warmup 0 --no-cpu-baseline",
+            "kernel": "importance_kernel", "kernel_instantiation": ik,
+            "fetch_bytes_per_launch_raw": f_full, "write_bytes_per_launch": w_full, "traffic_bytes_per_launch_raw": f_full + w_full,
+            # the update pass sweeps the filter's records and weights in order (wide coalesced loads: tallied at half, the guide's x2); the
+            # resample's gather reads random 64-byte records (counted in full).  The sweep is slots x N x (64 + 8) bytes.
+            "fetch_bytes_per_launch_calibrated": f_full + w_full / 2.0,
+            "traffic_bytes_per_launch_calibrated": f_full + w_full / 2.0 + w_full,
+            "notes": ["per-launch figure = the largest launch (every slot updates)",
+                      "calibrated = FETCH_SIZE + half the bytes written: the update pass sweeps the filter's records and weights in order (as many bytes as "
+                      "the kernel writes, N x 72 B per slot), a wide coalesced stream that FETCH_SIZE tallies at half; the resample's random record reads "
+                      "are counted in full (profiles/%s_randline_counters.json)" % tag],
+        }
+        json.dump(doc, open(dst("pmc_importance.json"), "w"), indent=1)
+        print("importance:", {k: v for k, v in doc.items() if k.startswith("traffic")})
+
+# ---- C5 shape
+if os.path.exists(os.path.join(SRC, "c5.json")) and os.path.getsize(os.path.join(SRC, "c5.json")):
+    c5 = last_json(os.path.join(SRC, "c5.json"))
+    fc = per_kernel(os.path.join(SRC, "c5_fetch", "run_counter_collection.csv"), "FETCH_SIZE")
+    wc = per_kernel(os.path.join(SRC, "c5_write", "run_counter_collection.csv"), "WRITE_SIZE")
+    upd = c5["updates"] + 1   # + the warm-up update
+    f_b = sum(sum(v) for k, v in fc.items() if "is_multi" in k or "scan_" in k or "chunk_totals" in k) * KIB / upd
+    w_b = sum(sum(v) for k, v in wc.items() if "is_multi" in k or "scan_" in k or "chunk_totals" in k) * KIB / upd
+    c5["pmc_fetch_bytes_per_update_raw"] = f_b
+    c5["pmc_write_bytes_per_update"] = w_b
+    c5["pmc_note"] = ("FETCH_SIZE / WRITE_SIZE of the multi-workgroup filter's kernels (is_multi_*, scan_*, chunk_totals), summed and divided by the updates of the "
+                      "run; the records are 3.5 KB and read as wide coalesced pieces, which FETCH_SIZE tallies at half (guide's x2)")
+    c5["pmc_traffic_per_update_fetch_x2"] = 2 * f_b + w_b
+    c5["frac_of_8TBs_on_pmc_traffic"] = (2 * f_b + w_b) / 1e9 / (c5["ms_per_update"] / 1e3) / 8000.0
+    json.dump(c5, open(dst("c5_importance_update.json"), "w"), indent=1)
+    shutil.copy(os.path.join(SRC, "c5_stats", "run_kernel_stats.csv"), dst("c5_kernel_stats.csv"))
+    print("c5:", c5["ms_per_update"], c5["frac_of_8TBs"], c5["frac_of_8TBs_on_pmc_traffic"])
+print(open(dst("bench_kernel_stats.csv")).read()[:700])

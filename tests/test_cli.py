@@ -123,3 +123,37 @@ def test_cli_structure_beliefs_of_round_two(cli, tmp_path):
                       (["planning", "-D", "episodic-tiger", "-B", "nested"], "legit state stimator")):
         r = subprocess.run([cli] + args, capture_output=True, text=True)
         assert r.returncode == 1 and msg in r.stderr, (args, r.stderr)
+
+
+@pytest.mark.gpu
+def test_cli_v3_prints_the_filter_histogram_after_every_update(cli):
+    """-v 3: FlatFilter::toString (FlatFilter.cpp:70-94) of the filter after every belief update (RejectionSampling.cpp:39,
+    BARejectionSampling.cpp:46): one line per state present, fraction and count; no block after a terminal step."""
+    r = subprocess.run([cli, "bapomdp", "-D", "episodic-tiger", "-s", "64", "--particle-amount", "40", "--runs", "3", "--episodes", "2",
+                        "--seed", "7", "-v", "3"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    h = 1469598103934665603
+    for ch in b"7":
+        h = ((h ^ ch) * 1099511628211) % 2 ** 64
+    eng = fba.Engine("episodic-tiger", model=N.MODEL_BA_TABLE, sims=64, particles=40, runs=3, episodes=2, seed=h, trace=2)
+    eng.run_bapomdp()
+    tr, hist = eng.trace(), eng.trace_hist()
+    assert len(tr) == len(hist) > 0
+    blocks, cur = [], None
+    for line in r.stdout.splitlines():
+        if line.startswith("V2: T="):
+            cur = {}
+            blocks.append(cur)
+        m = re.match(r"V3: \t\((\d+): ([0-9.]+)\((\d+)\)\)", line)
+        if m:
+            cur[int(m.group(1))] = (float(m.group(2)), int(m.group(3)))
+    assert len(blocks) == len(tr)
+    for rec, hrow, blk in zip(tr, hist, blocks):
+        want = {s: int(k) for s, k in enumerate(hrow) if k}
+        assert {s: k for s, (_, k) in blk.items()} == want
+        if rec["terminal"]:
+            assert not want
+        else:
+            assert sum(want.values()) == 40
+            assert all(abs(f - k / 40.0) < 1e-6 for f, k in blk.values())
+

@@ -738,6 +738,29 @@ def test_factored_tiger_priors_have_the_reference_tests_known_answers(dom):
         eng.close()
 
 
+@pytest.mark.parametrize("belief", ["rejection_sampling", "importance_sampling"])
+def test_trace_histograms_are_the_filters_states_after_each_update(belief):
+    """cfg.trace = 2: the state histogram recorded with every trace record equals the histogram of the states fba_belief_get
+    returns when the same run is replayed through the per-step interface (same streams, same filter)."""
+    kw = dict(model=N.MODEL_BA_TABLE, belief=belief, sims=48, particles=56, horizon=6, episodes=2, runs=1)
+    eng = fba.Engine("continuous-tiger", seed=77, slots=1, trace=2, **kw)
+    eng.run_bapomdp()
+    tr, hist = eng.trace(), eng.trace_hist()
+    assert len(tr) == len(hist) == 12
+    rep = fba.Engine("continuous-tiger", seed=77, slots=1, **kw)
+    rep.set_position(run=0, episode=0, t=0)
+    rep.belief_init()
+    for rec, hrow in zip(tr, hist):
+        if rec["t"] == 0:
+            rep.set_position(run=0, episode=int(rec["episode"]), t=0)
+            rep.belief_reset_domain_state()
+        rep.set_position(run=0, episode=int(rec["episode"]), t=int(rec["t"]))
+        assert rep.select_action(hist_len=int(rec["t"]))[0] == rec["action"]
+        rep.belief_update(int(rec["action"]), int(rec["obs"]))
+        s, _, _ = rep.belief_get(0)
+        assert np.array_equal(np.bincount(s, minlength=N.TRACE_HIST_BINS)[:N.TRACE_HIST_BINS], hrow)
+
+
 def test_per_step_interface_matches_oracle_calls():
     """Planner::selectAction / Belief::updateEstimation one call at a time (slots = 1)."""
     kw = dict(particles=128, sims=300)
