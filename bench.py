@@ -171,7 +171,19 @@ def spawn_ranks(args):
     sys.exit(rc)
 
 
-def open_collectives(dist, torch, rank, world, local_rank, shared):
+def rccl_probe(dist, torch, world):
+    """An RCCL group over all ranks that has carried one all-reduce (the communicator is built lazily: make it fail here if it will)."""
+    os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")     # a probe that cannot complete raises after the timeout instead of hanging
+    group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))   # nccl = RCCL on ROCm
+    probe = torch.ones(1, dtype=torch.float64, device="cuda")
+    dist.all_reduce(probe, group=group)
+    torch.cuda.synchronize()
+    if int(probe.item()) != world:
+        raise RuntimeError(f"probe all-reduce returned {probe.item()} for {world} ranks")
+    return group
+
+
+def open_collectives(dist, torch, rank, world, local_rank, shared, probe=rccl_probe):
     """The job's process groups.  Every rank first joins a gloo group (MASTER_ADDR / MASTER_PORT of the launcher): it carries the barriers
     and is where the ranks AGREE on the transport of the one data collective -- RCCL when every rank has its own GPU and every rank's
     probe all-reduce came back, gloo otherwise.  A rank never decides that alone: if some ranks fell back while others sat in an RCCL
@@ -182,13 +194,7 @@ def open_collectives(dist, torch, rank, world, local_rank, shared):
         return None, "cpu", "gloo (ranks share a GPU)"
     ok, err, group = 1, "", None
     try:
-        os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")     # a probe that cannot complete raises after the timeout instead of hanging
-        group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))   # nccl = RCCL on ROCm
-        probe = torch.ones(1, dtype=torch.float64, device="cuda")
-        dist.all_reduce(probe, group=group)                        # the communicator is built lazily: make it fail here if it will
-        torch.cuda.synchronize()
-        if int(probe.item()) != world:
-            raise RuntimeError(f"probe all-reduce returned {probe.item()} for {world} ranks")
+        group = probe(dist, torch, world)
     except Exception as e:   # the statistics reduce is 5 doubles: never lose a scaling run to the transport
         ok, err = 0, str(e).splitlines()[0][:200] if str(e) else type(e).__name__
         print(f"[bench] rank {rank}: RCCL probe failed ({err})", file=sys.stderr)

@@ -73,6 +73,46 @@ def test_two_ranks_reproduce_single_process_experiment():
     assert abs(pooled_var - np.var(list(ref.values()), ddof=1)) < 1e-9
 
 
+def _collective_worker(rank, world, port, q, fail_rank):
+    sys.path.insert(0, ROOT)
+    import bench
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+
+    def probe(dist_, torch_, world_):     # stands in for the RCCL probe: it works on every rank but `fail_rank`
+        if rank == fail_rank:
+            raise RuntimeError("simulated RCCL failure on this rank only")
+        return None
+
+    group, dev, how = bench.open_collectives(dist, torch, rank, world, rank, False, probe=probe)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, group=group)        # the data collective goes wherever the ranks agreed it goes: it must complete
+    q.put((rank, dev, how, float(t[0])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_rank", [1, -1])
+def test_ranks_agree_on_the_transport_before_the_data_collective(fail_rank):
+    """bench.py's ranks decide RCCL-or-gloo together (an all-reduce(MIN) of every rank's probe result over the gloo group):
+    when the probe fails on ONE rank, every rank reduces over gloo -- none is left waiting in an RCCL collective the other
+    never enters (round 2's fallback was decided per rank and could hang); when it fails nowhere, every rank reports rccl."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 300) + (7 if fail_rank < 0 else 0)
+    procs = [ctx.Process(target=_collective_worker, args=(r, 2, port, q, fail_rank)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [g[3] for g in got] == [3.0, 3.0]
+    if fail_rank >= 0:
+        assert all(g[1] == "cpu" and g[2].startswith("gloo (RCCL failed on at least one rank") for g in got)
+    else:
+        assert all(g[2] == "rccl" for g in got)
+
+
 @pytest.mark.gpu
 def test_bench_two_ranks_on_the_engine_equal_one_process():
     """`python bench.py --gpus 2` starts its own two worker processes (fresh processes, spawned before anything
@@ -109,3 +149,24 @@ def test_bench_two_ranks_on_the_engine_equal_one_process():
     assert round(line["value"] * line["ms_per_step"] * steps / 1e3) == one_steps
     assert line["returns"]["episodes"] == n
     assert abs(line["returns"]["mean"] - s1 / n) < 1e-9
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_scale_the_gridworld_workload():
+    """`python bench.py --gpus 2 --workload c4` is the command a scaling run needs: BASELINE configs[3] (episode-sharded FBA-POMDP
+    gridworld, history particles, importance sampling) on two ranks -- here with few slots, simulations and particles so that
+    it finishes in seconds; the line names the workload and both ranks' steps are in it."""
+    import json
+    import subprocess
+
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c4", "--steps", "2", "--warmup", "1", "--slots", "48",
+           "--sims", "512", "--particles", "256", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["workload_key"] == "c4" and line["config"]["slots_per_gpu"] == 48
+    assert "gridworld" in line["config"]["workload"] and line["roofline"]["kernel"] == "importance_kernel"
+    assert line["value"] > 0 and line["search_kernel"]["steps_per_launch"] >= 48 * 512         # (rank 0's own launches: at least one step per simulation)
+    assert line["returns"]["collective"] == "rccl" or line["returns"]["collective"].startswith("gloo")
+
