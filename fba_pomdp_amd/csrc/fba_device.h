@@ -35,26 +35,33 @@ struct Rng {
         c1   = unit;
         draw = 0;
     }
-    __device__ __forceinline__ uint64_t next64()
+    // Philox4x32-10 block `idx` of the current stream: draws 2 idx (words 0, 1) and 2 idx + 1 (words 2, 3)
+    __device__ __forceinline__ void block(uint32_t idx, uint32_t& w0, uint32_t& w1, uint32_t& w2, uint32_t& w3) const
     {
-        uint64_t r;
-        if ((draw & 1u) == 0) {
-            uint32_t x0 = draw >> 1, x1 = c1, x2 = c2, x3 = c3;
-            uint32_t a = k0, b = k1;
+        uint32_t x0 = idx, x1 = c1, x2 = c2, x3 = c3;
+        uint32_t a = k0, b = k1;
 #ifdef FBA_CHEAP_RNG   /* measurement builds only (scripts/search_regions.py): what the search would cost with a nearly free generator */
 #define FBA_PHILOX_ROUNDS 5
 #else
 #define FBA_PHILOX_ROUNDS 10
 #endif
 #pragma unroll
-            for (int i = 0; i < FBA_PHILOX_ROUNDS; ++i) {
-                const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)x0, p1 = (uint64_t)0xCD9E8D57u * (uint64_t)x2;  // one 32x32->64 multiply each
-                const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-                uint32_t n0 = hi1 ^ x1 ^ a, n2 = hi0 ^ x3 ^ b;
-                x0 = n0; x1 = lo1; x2 = n2; x3 = lo0;
-                a += 0x9E3779B9u;
-                b += 0xBB67AE85u;
-            }
+        for (int i = 0; i < FBA_PHILOX_ROUNDS; ++i) {
+            const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)x0, p1 = (uint64_t)0xCD9E8D57u * (uint64_t)x2;  // one 32x32->64 multiply each
+            const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+            uint32_t n0 = hi1 ^ x1 ^ a, n2 = hi0 ^ x3 ^ b;
+            x0 = n0; x1 = lo1; x2 = n2; x3 = lo0;
+            a += 0x9E3779B9u;
+            b += 0xBB67AE85u;
+        }
+        w0 = x0; w1 = x1; w2 = x2; w3 = x3;
+    }
+    __device__ __forceinline__ uint64_t next64()
+    {
+        uint64_t r;
+        if ((draw & 1u) == 0) {
+            uint32_t x0, x1, x2, x3;
+            block(draw >> 1, x0, x1, x2, x3);
             r       = ((uint64_t)x1 << 32) | x0;
             keep_lo = x2;
             keep_hi = x3;
@@ -170,8 +177,8 @@ struct PackedFtigerView {
 // ---------------------------------------------------------------------------------------------
 
 // sampleFromMult<float const>: CDF accumulated in float, compared with a double threshold.
-template <class View>
-__device__ __forceinline__ int sample_from_mult_f(Rng& g, const View& row, int off, int n, double total)
+template <class RNG, class View>
+__device__ __forceinline__ int sample_from_mult_f(RNG& g, const View& row, int off, int n, double total)
 {
     const double p = g.u01() * total;
     float sum      = row.at(off);
@@ -324,6 +331,7 @@ struct Problem {
     int32_t hist_cap;
     int32_t gw_N, gw_G;          // gridworld: N, number of goals (copies of GridDesc's, as kernel arguments)
     uint32_t gw_goalcell[4];     // gridworld: x*N + y of goal g, 8 bits each
+    int32_t search_budget;  // > 0: search_hist_kernel stops at the first simulation boundary behind this many loop iterations and parks the search (fba_hip.h)
     int32_t hist_row;   // the longest Dirichlet row of the model (max(N, G)): picks the row width the kernels are instantiated for
     const float* hist_base;  // the prior count table every particle starts from (max layout, x / y nodes without the goal parent)
     const float* hist_alt;   // [A][2][N*N*G*N]: the x / y transition nodes as a particle with the goal as their third parent starts them
@@ -433,7 +441,8 @@ __device__ __forceinline__ int domain_start(const Problem& P, Rng& g)
 }
 
 // Tiger::generateRandomAction (Tiger.cpp:21-25), FactoredTiger::generateRandomAction
-__device__ __forceinline__ int domain_random_action(const Problem& P, Rng& g, int /*s*/)
+template <class RNG>
+__device__ __forceinline__ int domain_random_action(const Problem& P, RNG& g, int /*s*/)
 {
     if (dom_is_grid(P.domain)) return g.slow_int(0, 4);  // GridWorld::generateRandomAction :220-226
     if (dom_is_coffee(P.domain)) return g.boolean() ? 1 : 0;  // CoffeeProblem::generateRandomAction :27-34
@@ -442,7 +451,8 @@ __device__ __forceinline__ int domain_random_action(const Problem& P, Rng& g, in
 
 // True dynamics: Tiger::step (Tiger.cpp:40-82), FactoredTiger::step (FactoredTiger.cpp:77-122).
 // Note the draw order when opening a door: observation coin first, then the next state.
-__device__ __forceinline__ bool domain_step(const Problem& P, Rng& g, int& s, int a, int& o, double& r)
+template <class RNG>
+__device__ __forceinline__ bool domain_step(const Problem& P, RNG& g, int& s, int a, int& o, double& r)
 {
     const int d = P.domain;
     if (dom_is_agr(d)) {  // AGR::step :247-305, no draws: state = (2n+1)(goal+n) + pos+n; help(-n..n) = 0..2n, work, observe
@@ -1521,8 +1531,8 @@ __device__ __forceinline__ bool sim_step(const Problem& P, Rng& g, const View& c
 // step have two cells and start at an even cell -- T(s, a, .) at 6s + 2a, O(a, s', .) at 12 + 4a + 2s' -- so a row is ONE
 // word of the record (its two uint16 increment counts) plus the two prior values beside it in the prior table (one
 // 8-byte read).  `word(w)` = word w of the record.  Same draws, same sums, same results as sim_step through PackedView.
-template <class WordFn, class Sink>
-__device__ __forceinline__ bool tiger_step_packed(const Problem& P, Rng& g, const WordFn& word, const float* prior, int& s, int a, int& o, double& r,
+template <class RNG, class WordFn, class Sink>
+__device__ __forceinline__ bool tiger_step_packed(const Problem& P, RNG& g, const WordFn& word, const float* prior, int& s, int a, int& o, double& r,
                                                   const Sink& inc)
 {
     const int t_off = s * 6 + a * 2;

@@ -998,7 +998,9 @@ int run_experiment(fba_ctx* c, fba_stat* stats)
     const int runs = c->cfg.runs, E = c->P.E, eps = c->P.episodes;
     if ((rc = ensure_outputs(c, runs))) return rc;
     if ((rc = start_experiment(c, runs))) return rc;
-    const long long max_ticks = (long long)((runs + E - 1) / E) * eps * c->P.horizon + 2;
+    long long max_ticks = (long long)((runs + E - 1) / E) * eps * c->P.horizon + 2;
+    if (c->P.search_budget > 0)   // budgeted launches: a real step takes as many launches as its search needs (<= horizon iterations per simulation)
+        max_ticks *= ((long long)c->P.sims * c->P.horizon) / c->P.search_budget + 2;
     for (long long k = 0; k < max_ticks; ++k) {
         if ((rc = tick(c))) return rc;
         int32_t n_active = 0;
@@ -1625,6 +1627,18 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     CHK(dev_alloc(c, &c->d_n_active, 1));
     CHK(dev_alloc(c, &D.fault, 1));
     CHK(dev_alloc(c, &D.lazy_reset, E));
+    P.search_budget = (P.hist && cfg->search_budget > 0) ? cfg->search_budget : 0;   // (only search_hist_kernel parks and resumes)
+    if (P.search_budget > 0) {
+        CHK(dev_alloc(c, &D.s_sim, E));
+        CHK(dev_alloc(c, &D.s_nodes, E));
+        CHK(dev_alloc(c, &D.s_depth, E));
+        CHK(dev_alloc(c, &D.search_done, E));
+        if (D.single_rec) {   // the chunked belief launches run over compacted lists of the slots that have work (fba_state.h)
+            CHK(dev_alloc(c, &D.slot_list, E));
+            CHK(dev_alloc(c, &D.scratch_idx, E));
+            CHK(dev_alloc(c, &D.list_count, 1));
+        }
+    }
     CHK(dev_alloc(c, &c->d_prior, P.Cs));
     CHK(dev_alloc(c, &c->d_prior_dense, std::max(c->dense_C, 1)));
     if (P.hist) {
@@ -1880,7 +1894,13 @@ int fba_select_action(fba_ctx* c, const int32_t* hist_len, const uint8_t* active
     int rc;
     if (hist_len) HIPCHK(c, hipMemcpyAsync(c->D.t, hist_len, (size_t)c->P.E * 4, hipMemcpyHostToDevice, c->stream));
     if ((rc = set_flags(c, c->D.active, active, 1))) return rc;
-    if ((rc = timed(c, FBA_K_SEARCH, [&] { launch_search(c->P, c->D, c->stream); }))) return rc;
+    {   // Planner::selectAction returns a finished search: whole searches in one launch, whatever the context's search_budget
+        Problem Pw = c->P;
+        DeviceState Dw = c->D;
+        Pw.search_budget = 0;
+        Dw.search_done   = nullptr;
+        if ((rc = timed(c, FBA_K_SEARCH, [&] { launch_search(Pw, Dw, c->stream); }))) return rc;
+    }
     HIPCHK(c, hipMemcpyAsync(action, c->D.action, (size_t)c->P.E * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return check_fault(c);
@@ -2154,6 +2174,21 @@ int fba_run_ticks(fba_ctx* c, int32_t ticks)
         }
         if ((rc = start_experiment(c, -1))) return rc;
         c->started = true;
+    }
+    if (c->P.search_budget > 0) {
+        // slots advance on their own: "ticks" real steps per slot on average = launches until the slots have together made
+        // ticks x slots of them (a launch = one budget of search iterations + the step and belief update of the slots that finished)
+        int rc2 = FBA_OK;
+        const uint64_t base   = sum_counter(c, c->D.env_steps, c->P.E, &rc2);
+        const uint64_t target = (uint64_t)ticks * (uint64_t)c->P.E;
+        const long long bound = ((long long)ticks + 2) * (((long long)c->P.sims * c->P.horizon) / c->P.search_budget + 2);
+        for (long long k = 0; k < bound && !rc2; ++k) {
+            if (sum_counter(c, c->D.env_steps, c->P.E, &rc2) - base >= target) break;   // (synchronises: the launches of the last round are done)
+            if ((rc = tick(c))) return rc;
+        }
+        if (rc2) return rc2;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return check_fault(c);
     }
     for (int k = 0; k < ticks; ++k)
         if ((rc = tick(c))) return rc;

@@ -56,6 +56,10 @@ __global__ void env_kernel(Problem P, DeviceState D, int32_t* n_active)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= P.E || !D.active[e]) return;
+    if (D.search_done) {   // budgeted searches: only the slots whose search has just finished take their step
+        if (!D.search_done[e]) return;
+        D.search_done[e] = 0;
+    }
     Rng g = slot_rng(P, D, e);
     g.stream(FBA_PHASE_ENV, 0);
     const int a = D.action[e];
@@ -1187,7 +1191,7 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
     __shared__ double s_carry[IS_MAX_CHUNKS + 2];
     __shared__ int32_t s_src[IS_BLOCK], s_inc[HIST ? 1 : (TIGER_TABLE ? 2 : MAXINC) * IS_BLOCK];
     extern __shared__ double s_w[];  // WLDS: [N] weights, then normalised weights, then their inclusive prefix sums
-    const int e = blockIdx.x + D.slot_base, tid = threadIdx.x;
+    const int e = chunk_slot(D, blockIdx.x), tid = threadIdx.x;
     if (!D.need_update[e]) return;
     if (TIGER_TABLE == 2) {
         if (tid < 24) s_prior[tid] = D.prior_dense[tid];
@@ -1666,7 +1670,7 @@ __global__ void __launch_bounds__(256) init_kernel(Problem P, DeviceState D, int
 __global__ void __launch_bounds__(256) reset_kernel(Problem P, DeviceState D, int fc)
 {
     __shared__ int32_t s_src[256], s_ns[256];
-    const int e = blockIdx.y + D.slot_base, tid = threadIdx.x;
+    const int e = chunk_slot(D, blockIdx.y), tid = threadIdx.x;
     if (D.need_reset[e] != 1) return;
     const int i_lo = blockIdx.x * PARTICLE_TILE, i_hi = min(P.N, i_lo + PARTICLE_TILE);
     if (i_lo >= P.N) return;
@@ -1922,10 +1926,10 @@ __global__ void selftest_ucb_kernel(const double* L, const int32_t* n, int count
 // DeviceState::single_rec: the filter a resample / reset has built in the scratch pool becomes the slot's filter
 __global__ void __launch_bounds__(256) copy_back_kernel(Problem P, DeviceState D)
 {
-    const int e = blockIdx.y + D.slot_base;
+    const int e = chunk_slot(D, blockIdx.y);
     if (!D.copy_pending[e]) return;
     const size_t n4 = (size_t)P.N * (size_t)(P.Cs / 4);
-    const float4* src = reinterpret_cast<const float4*>(D.rec_scratch + (size_t)(e - D.slot_base) * (size_t)P.N * (size_t)P.Cs);
+    const float4* src = reinterpret_cast<const float4*>(D.rec_scratch + (size_t)scratch_place(D, e) * (size_t)P.N * (size_t)P.Cs);
     float4* dst       = reinterpret_cast<float4*>(D.p_rec + (size_t)e * (size_t)P.N * (size_t)P.Cs);
     const size_t per  = (n4 + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = lo + per < n4 ? lo + per : n4;
     for (size_t k = lo + threadIdx.x; k < hi; k += 4 * 256) {
@@ -1968,7 +1972,8 @@ static void launch_importance_single(const Problem& P, const DeviceState& D, hip
     // weights and prefix sums of a slot in LDS while its workgroup works on them (8 bytes per particle)
     const bool wlds = P.N <= IS_LDS_MAX_N && !P.dirichlet_regular;
     const size_t wl = wlds ? (size_t)P.N * (sizeof(double) + ((tiger_table && P.packed) ? 4 : 0)) : 0;  // (packed tiger: + pending updates and sources, 16 bits each)
-    const int grid_e = D.single_rec ? std::min(D.scratch_slots, P.E - D.slot_base) : P.E;   // (single_rec: one chunk of slots per launch)
+    const int grid_e = D.use_list ? D.scratch_slots /* (set to the chunk's count by the caller) */
+                                  : (D.single_rec ? std::min(D.scratch_slots, P.E - D.slot_base) : P.E);   // (single_rec: one chunk of slots per launch)
 #define FBA_LAUNCH_IS(...)                                                                                         \
     do {                                                                                                           \
     static unsigned long long raised = 0;   /* one bit per device: function attributes are per device */          \
@@ -1989,10 +1994,38 @@ static void launch_importance_single(const Problem& P, const DeviceState& D, hip
     else { if (wlds) FBA_LAUNCH_IS(false, 0, false, true); else FBA_LAUNCH_IS(false, 0, false, false); }
 #undef FBA_LAUNCH_IS
 }
+// the slots whose flag (need_update / need_reset == 1) is set, compacted; a listed slot's scratch place is its position in its chunk
+__global__ void __launch_bounds__(256) build_slot_list_kernel(Problem P, DeviceState D, const uint8_t* flag)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= P.E || flag[e] != 1) return;
+    const int pos      = atomicAdd(D.list_count, 1);
+    D.slot_list[pos]   = e;
+    D.scratch_idx[e]   = pos % D.scratch_slots;
+}
 // DeviceState::single_rec: the slots in chunks of as many as the scratch pool holds -- gather into the pool, copy back, next chunk
 template <class F>
-static void for_each_chunk(const Problem& P, const DeviceState& D, hipStream_t st, F launch)
+static void for_each_chunk(const Problem& P, const DeviceState& D, hipStream_t st, F launch, const uint8_t* flag = nullptr)
 {
+    if (D.slot_list && flag) {
+        // budgeted searches: few slots have work, anywhere among all of them -- chunks of the compacted list instead of E / scratch_slots
+        // nearly empty launches (C4: 32 of them took 35 ms per round for a handful of updates).  The count is read on the host.
+        (void)hipMemsetAsync(D.list_count, 0, sizeof(int32_t), st);
+        hipLaunchKernelGGL(build_slot_list_kernel, dim3(ceil_div(P.E, 256)), dim3(256), 0, st, P, D, flag);
+        int32_t n = 0;
+        (void)hipMemcpyAsync(&n, D.list_count, sizeof n, hipMemcpyDeviceToHost, st);
+        (void)hipStreamSynchronize(st);
+        for (int i0 = 0; i0 < n; i0 += D.scratch_slots) {
+            DeviceState Dc = D;
+            Dc.slot_base   = i0;
+            Dc.use_list    = 1;
+            const int cnt  = std::min(D.scratch_slots, n - i0);
+            launch(Dc, cnt);
+            hipLaunchKernelGGL(copy_back_kernel, dim3(16, cnt), dim3(256), 0, st, P, Dc);
+        }
+        if (n > 0) (void)hipMemsetAsync(D.copy_pending, 0, (size_t)P.E, st);
+        return;
+    }
     for (int e0 = 0; e0 < P.E; e0 += D.scratch_slots) {
         DeviceState Dc = D;
         Dc.slot_base   = e0;
@@ -2050,7 +2083,13 @@ void launch_belief_update(const Problem& P, const DeviceState& D, hipStream_t st
         else hipLaunchKernelGGL((reject_kernel<false, 0>), dim3(P.E), dim3(REJECT_BLOCK), 0, st, P, D, 1);
     }
     if (!D.is_multi) {
-        if (D.single_rec) for_each_chunk(P, D, st, [&](const DeviceState& Dc, int) { launch_importance_single(P, Dc, st); });
+        if (D.single_rec)
+            for_each_chunk(P, D, st, [&](const DeviceState& Dc, int cnt) {
+                if (!Dc.use_list) { launch_importance_single(P, Dc, st); return; }
+                DeviceState Dl   = Dc;           // (list mode: the launch's grid is the chunk's count; scratch places were fixed against
+                Dl.scratch_slots = cnt;          //  the pool's size when the list was built)
+                launch_importance_single(P, Dl, st);
+            }, D.need_update);
         else launch_importance_single(P, D, st);
         if (P.cheat) hipLaunchKernelGGL(cheat_kernel, dim3(P.E), dim3(256), 0, st, P, D);
         if (P.mh) hipLaunchKernelGGL(mh_kernel, dim3(ceil_div(P.E, 64)), dim3(64), 0, st, P, D);
@@ -2094,7 +2133,7 @@ void launch_reset(const Problem& P, const DeviceState& D, hipStream_t st)
     if (D.single_rec)
         for_each_chunk(P, D, st, [&](const DeviceState& Dc, int cnt) {
             hipLaunchKernelGGL(reset_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), cnt), dim3(256), 0, st, P, Dc, 0);
-        });
+        }, D.need_reset);
     else hipLaunchKernelGGL(reset_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), P.E), dim3(256), 0, st, P, D, 0);
     if (P.reinvig || P.cheat || P.incub) hipLaunchKernelGGL(reset_kernel, dim3(ceil_div(P.N, PARTICLE_TILE), P.E), dim3(256), 0, st, P, D, 1);
     if (P.incub) {  // StructureIncubatorSampling::resetDomainStateDistribution (:46-61): the shadow filter too, in place

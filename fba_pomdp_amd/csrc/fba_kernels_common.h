@@ -24,9 +24,12 @@ __device__ __forceinline__ Rng slot_rng(const Problem& P, const DeviceState& D, 
 __device__ __forceinline__ size_t pbase(const Problem& P, int e, int buf) { return ((size_t)buf * P.E + e) * (size_t)P.N; }
 // first record of slot e's current filter / of the filter a resample or reset is building (DeviceState::single_rec)
 __device__ __forceinline__ size_t rec_base(const Problem& P, const DeviceState& D, int e, int buf) { return D.single_rec ? (size_t)e * (size_t)P.N : pbase(P, e, buf); }
+// the slot block `b` of a chunked launch works on: the b-th of the chunk, or of the compacted list (DeviceState::use_list)
+__device__ __forceinline__ int chunk_slot(const DeviceState& D, int b) { return D.use_list ? D.slot_list[D.slot_base + b] : D.slot_base + b; }
+__device__ __forceinline__ int scratch_place(const DeviceState& D, int e) { return D.use_list ? D.scratch_idx[e] : e - D.slot_base; }
 __device__ __forceinline__ float* rec_dst(const Problem& P, const DeviceState& D, int e, int other)
 {
-    return D.single_rec ? D.rec_scratch + (size_t)(e - D.slot_base) * (size_t)P.N * (size_t)P.Cs : D.p_rec + pbase(P, e, other) * (size_t)P.Cs;
+    return D.single_rec ? D.rec_scratch + (size_t)scratch_place(D, e) * (size_t)P.N * (size_t)P.Cs : D.p_rec + pbase(P, e, other) * (size_t)P.Cs;
 }
 
 // particle record accessors (layout: fba_state.h)
@@ -104,7 +107,8 @@ __device__ __forceinline__ int uniform_weight_pick(const double* __restrict__ in
 }
 
 // Belief::sample() of a freshly initiated / resampled filter (all weights 1/N)
-__device__ __forceinline__ int belief_sample_uniform(const Problem& P, const DeviceState& D, Rng& g)
+template <class RNG>
+__device__ __forceinline__ int belief_sample_uniform(const Problem& P, const DeviceState& D, RNG& g)
 {
     if (P.belief == FBA_BELIEF_REJECTION) return P.point ? 0 : g.uniform_int(P.N);  // FlatFilter.cpp:97-102; PointEstimation::sample :30-34
     return uniform_weight_pick(D.uni_scan, P.N, g.u01() * D.uni_total, D.uni_total);

@@ -475,9 +475,14 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, De
     if (e >= P.E || !D.active[e]) return;  // (a quad leaves together)
 
     const int depth_cap = P.max_depth > 0 ? P.max_depth : 1;
-    float* path_r    = reinterpret_cast<float*>(lds) + tl;                                                        // [depth][trees]
+    // the chosen action's count and Q of every node on the path as the descent loaded them: the back-up needs no load (a trip to
+    // memory per level, twenty in a row at t = 0), only its two stores -- nothing else writes this tree
+    double* path_q   = lds + tl;                                                                                  // [depth][trees]
+    int32_t* path_n  = reinterpret_cast<int32_t*>(path_q - tl + (size_t)depth_cap * HIST_TREES) + tl;
+    float* path_r    = reinterpret_cast<float*>(path_n - tl + (size_t)depth_cap * HIST_TREES) + tl;
     int32_t* path_na = reinterpret_cast<int32_t*>(path_r - tl + (size_t)depth_cap * HIST_TREES) + tl;
     uint32_t* stage  = reinterpret_cast<uint32_t*>(path_na - tl + (size_t)depth_cap * HIST_TREES) + tl;           // [Cs][trees]
+    const bool carry = D.cn_off == 0;   // (the 48-byte record of hashed trees with four actions: {n0..n3}, {q0..q3}; others reload)
 
     QuadRng g;
     g.init(P.seed_lo, P.seed_hi, (uint32_t)D.run[e], (uint32_t)D.episode[e], (uint32_t)D.t[e], lane);
@@ -495,25 +500,40 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, De
         g.ensure(2);
         (void)g.u01();                      // the belief sample: GridWorld::generateRandomAction does not look at the state
         D.action[e] = g.slow_int(0, 4);
+        if (P.search_budget > 0) D.search_done[e] = 1;
         return;
     }
-    node_init(D, tree, P.A, P.O);
+    // budgeted launches (Problem::search_budget): a search parked by an earlier launch is taken up where it stopped -- its tree and
+    // hash table are where it left them, the root's statistics come back from the root's record
+    const int budget  = P.search_budget;
+    int sim           = budget > 0 ? D.s_sim[e] : 0;
+    const bool resume = sim > 0;
     int n_nodes = 1, tree_depth = 0;
     unsigned long long steps = 0;
     int r_vis = 0, r_cn[AMAX];
     double r_cq[AMAX];
 #pragma unroll
     for (int a = 0; a < AMAX; ++a) { r_cn[a] = 0; r_cq[a] = 0.0; }
-    int4* tab      = hash_table(D, e);
-    const uint32_t epoch = hash_begin_search(D, e, tab, g.q, HIST_QUAD);
-
+    int4* tab = hash_table(D, e);
+    uint32_t epoch;
+    if (!resume) {
+        node_init(D, tree, P.A, P.O);
+        epoch = hash_begin_search(D, e, tab, g.q, HIST_QUAD);
+    } else {
+        n_nodes    = D.s_nodes[e];
+        tree_depth = D.s_depth[e];
+        epoch      = D.epoch[e];
+        const double* rq = reinterpret_cast<const double*>(tree + D.cq_off);
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a) { r_cn[a] = tree[D.cn_off + a]; r_cq[a] = rq[a]; r_vis += r_cn[a]; }
+    }
     int ts_src = -1;
     if (P.planner == FBA_PLANNER_TS) {  // TSPlanner / BATSPlanner: one belief sample, then the search from that particle
         g.stream(FBA_PHASE_SEARCH, (uint32_t)P.sims + 2u);
         g.ensure(1);
         ts_src = uniform_weight_pick(D.uni_scan, P.N, g.u01() * D.uni_total, D.uni_total);
     }
-    int sim = 0, mode = 0;  // 0 = start a simulation, 1 = in the tree, 2 = rollout
+    int mode = 0, iter = 0;  // 0 = start a simulation, 1 = in the tree, 2 = rollout
     int node = 0, dtg = 0, plen = 0, rdepth = 0;
     uint32_t sp = 0, hist_mask = 0;
     double rret = 0, rdisc = 1;
@@ -524,6 +544,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, De
         PROF_MARK(6)
         if (mode == 0) {
             if (sim >= P.sims) break;
+            if (budget > 0 && iter >= budget) break;   // out of iterations at a simulation boundary: park the search (below)
             g.stream(FBA_PHASE_SEARCH, (uint32_t)sim);
             g.ensure(8);  // the root sample, the first action, six rows
             const int src = ts_src >= 0 ? ts_src : uniform_weight_pick(D.uni_scan, P.N, g.u01() * D.uni_total, D.uni_total);
@@ -562,7 +583,17 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, De
             g.ensure(7);  // the action, six rows
             if (mode == 1) {  // traverseActionNode
                 if (node == 0) a = ucb_pick<AMAX>(P, g, D.log1p_tab, r_vis, r_cn, r_cq, true);
-                else a = ucb_select<AMAX>(P, D, g, tree + (size_t)node * W, true);
+                else if (carry) {
+                    const int32_t* rec = tree + (size_t)node * W;
+                    const int4 h      = *reinterpret_cast<const int4*>(rec);
+                    const double2 q01 = *reinterpret_cast<const double2*>(rec + 4);
+                    const double2 q23 = *reinterpret_cast<const double2*>(rec + 8);
+                    const int cn[AMAX]    = {h.x, h.y, h.z, h.w};
+                    const double cq[AMAX] = {q01.x, q01.y, q23.x, q23.y};
+                    a = ucb_pick<AMAX>(P, g, D.log1p_tab, ((h.x + h.y) + h.z) + h.w, cn, cq, true);
+                    path_n[(size_t)plen * HIST_TREES] = a == 0 ? h.x : (a == 1 ? h.y : (a == 2 ? h.z : h.w));
+                    path_q[(size_t)plen * HIST_TREES] = a == 0 ? q01.x : (a == 1 ? q01.y : (a == 2 ? q23.x : q23.y));
+                } else a = ucb_select<AMAX>(P, D, g, tree + (size_t)node * W, true);
             } else {
                 a = g.slow_int(0, 4);  // GridWorld::generateRandomAction :220-226
             }
@@ -622,6 +653,12 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, De
                     for (int a2 = 0; a2 < AMAX; ++a2)
                         if (a2 == act) { r_cn[a2] = n; r_cq[a2] = q; }
                     ++r_vis;
+                } else if (carry) {
+                    int32_t* rec    = tree + (size_t)(na >> 5) * W;
+                    const int n     = path_n[(size_t)k * HIST_TREES] + 1;
+                    const double q0 = path_q[(size_t)k * HIST_TREES];
+                    rec[act] = n;
+                    reinterpret_cast<double*>(rec + D.cq_off)[act] = q0 + (ret - q0) / (double)n;
                 } else {
                     int32_t* rec = tree + (size_t)(na >> 5) * W;
                     double* q    = reinterpret_cast<double*>(rec + D.cq_off) + act;
@@ -635,6 +672,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, De
             mode = 0;
         }
         PROF_MARK(4)
+        ++iter;
 #ifdef FBA_PROFILE_SEARCH
         prof_[5] += 1;
 #endif
@@ -643,6 +681,18 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, De
     if (lane == 0)
         for (int r2 = 0; r2 < 8; ++r2) atomicAdd(&g_search_prof[r2], (unsigned long long)prof_[r2]);
 #endif
+    if (sim < P.sims) {   // parked: the four lanes of the quad hold the same values and store them to the same places
+        double* rq = reinterpret_cast<double*>(tree + D.cq_off);
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a) { tree[D.cn_off + a] = r_cn[a]; rq[a] = r_cq[a]; }
+        if (D.cn_off) tree[0] = r_vis;
+        D.s_sim[e]   = sim;
+        D.s_nodes[e] = n_nodes;
+        D.s_depth[e] = tree_depth;
+        if (g.q == 0) D.sim_steps[e] += steps;
+        return;   // (search_done[e] stays 0: env_kernel leaves the slot alone)
+    }
+    if (budget > 0) { D.s_sim[e] = 0; D.search_done[e] = 1; }
     g.stream(FBA_PHASE_SEARCH, (uint32_t)P.sims + 1u);
     g.ensure(1);
     if (n_nodes > D.max_nodes) atomicCAS(D.fault, 0, -(1 + e));
@@ -696,7 +746,7 @@ void launch_search(const Problem& P, const DeviceState& D, hipStream_t st)
         else FBA_LAUNCH_SEARCH_M(false, AM, FBA_MODEL_POMDP);                                       \
     } while (0)
     if (P.hist) {  // history particles (gridworld FBA-POMDP): four lanes per tree
-        lds = (size_t)depth_cap * HIST_TREES * (sizeof(float) + sizeof(int32_t)) + (size_t)P.Cs * HIST_TREES * sizeof(float);
+        lds = (size_t)depth_cap * HIST_TREES * (sizeof(double) + sizeof(int32_t) + sizeof(float) + sizeof(int32_t)) + (size_t)P.Cs * HIST_TREES * sizeof(float);
         const dim3 qgrid(ceil_div(P.E, HIST_TREES));
         if (P.hist_row <= 8) hipLaunchKernelGGL((search_hist_kernel<8>), qgrid, block, lds, st, P, D);
         else if (P.hist_row <= 12) hipLaunchKernelGGL((search_hist_kernel<12>), qgrid, block, lds, st, P, D);

@@ -67,6 +67,12 @@ struct DeviceState {
     int32_t single_rec;       // 1: p_rec holds one buffer per slot (records only; weights stay double-buffered)
     int32_t slot_base;        // first slot of the chunk a chunked launch works on
     int32_t scratch_slots;
+    // budgeted searches: only a few slots need a belief update or a reset per launch, scattered over all of them -- the chunked launches
+    // then run over a compacted list of those slots (block b of a launch works on slot slot_list[slot_base + b], scratch place b)
+    int32_t* slot_list;       // [E] or null
+    int32_t* list_count;      // [1]
+    int32_t* scratch_idx;     // [E] the scratch place of a listed slot
+    int32_t use_list;         // 1 in the DeviceState of a launch over the list
     // incubator belief (StructureIncubatorSampling.cpp): the weighted shadow filter, laid out like p_rec / p_weight / bufsel
     float* p_rec_sh;         // [2][E][N][Cs]
     double* p_weight_sh;     // [2][E][N]
@@ -105,6 +111,12 @@ struct DeviceState {
     int32_t hash_compact;  // 8-byte entries {epoch << 27 | code, child} instead (codes below 2^27): fba_kernels.hip child_get
     uint32_t* epoch;    // [E]
     const double* log1p_tab; // [sims + 1]
+    // budgeted searches (Problem::search_budget > 0): a search that ran out of iterations is parked -- the root's statistics in its
+    // node record, the rest here -- and resumed by the next launch
+    int32_t* s_sim;       // [E] simulations done by the parked search (0 = none parked: the next launch starts a search)
+    int32_t* s_nodes;     // [E] nodes created so far
+    int32_t* s_depth;     // [E] deepest level reached so far
+    uint8_t* search_done; // [E] or null: the slot's search finished in the last launch (env_kernel steps those slots only)
     // --- outputs ---
     double* returns;    // [runs][episodes]
     int32_t* lengths;   // [runs][episodes]

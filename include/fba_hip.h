@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FBA_ABI_VERSION 2   /* 2: fba_config.belief_option, fba_belief_get_particle; hosts check fba_abi_version() == FBA_ABI_VERSION before fba_create */
+#define FBA_ABI_VERSION 2   /* 2: fba_config.belief_option and .search_budget, fba_belief_get_particle, fba_get_trace_hist; hosts check fba_abi_version() == FBA_ABI_VERSION before fba_create */
 #define FBA_MAX_ACTIONS 24
 
 /* domains: reference src/domains, selected by -D (DomainConf.hpp) */
@@ -126,6 +126,12 @@ typedef struct fba_config {
                               * belief / copied per cheat by the cheating belief (BeliefConf.cpp:17-21) */
     double threshold;        /* --threshold: log likelihood below which the cheating belief cheats (< 0) */
     int32_t belief_option;   /* --belief-option: mh-within-gibbs 0 = state histories by message passing (default), 1 = "rs" */
+    int32_t search_budget;   /* history-particle searches (gridworld FBA-POMDP, importance filter): iterations of the search loop per launch.
+                              * 0 = a launch runs every slot's whole search (lock-step ticks: a tick lasts as long as its deepest tree);
+                              * > 0 = a launch stops at the first simulation boundary behind that many iterations, unfinished searches
+                              * are parked in their trees and resumed by the next launch, and slots whose search is done take their
+                              * real step and belief update meanwhile -- slots advance on their own, results are the same
+                              * (Episode.cpp:39-55 and BAPOMDPExperiment.cpp:44-75 never couple two runs) */
 } fba_config;
 
 /* One record per real time-step: the information the reference prints at -v 2 / -v 3

@@ -761,6 +761,54 @@ def test_trace_histograms_are_the_filters_states_after_each_update(belief):
         assert np.array_equal(np.bincount(s, minlength=N.TRACE_HIST_BINS)[:N.TRACE_HIST_BINS], hrow)
 
 
+@pytest.mark.parametrize("size,budget", [(3, 1), (3, 37), (5, 250), (5, 1000000)])
+def test_budgeted_searches_give_the_results_of_whole_searches(size, budget):
+    """fba_config.search_budget: a launch stops every history-particle search at the first simulation boundary behind `budget`
+    loop iterations, parks it in its tree and the next launch resumes it, while slots whose search is done take their real step
+    and belief update -- slots advance on their own.  Runs never interact (BAPOMDPExperiment.cpp:44-75), so every trace record
+    (actions, root statistics, tree sizes, weights, the checksum over every particle), every statistic and every counter must
+    be those of lock-step ticks, whatever the budget (1: a launch per simulation)."""
+    kw = dict(model=N.MODEL_BA_FACTORED, belief="importance_sampling", size=size, sims=96, particles=64, structure_prior=2, horizon=7,
+              episodes=2, runs=7, slots=4, seed=606 + size, trace=1)
+    out = []
+    for b in (0, budget):
+        eng = fba.Engine("gridworld", search_budget=b, **kw)
+        assert eng.particle_bytes < 4096           # history particles: the records search_hist_kernel reads
+        stats = eng.run_bapomdp()
+        c = eng.counters()
+        out.append((eng.trace(), [(s.count, s.mean, s.m2) for s in stats], (c.sim_steps, c.belief_steps, c.env_steps), eng.returns()))
+        eng.close()
+    (t0, s0, c0, r0), (t1, s1, c1, r1) = out
+    assert len(t0) == len(t1) > 14 and s0 == s1 and c0 == c1
+    for name in t0.dtype.names:
+        assert np.array_equal(t0[name], t1[name]), name
+    assert np.array_equal(r0[0], r1[0]) and np.array_equal(r0[1], r1[1])
+
+
+def test_budgeted_throughput_driver_makes_the_steps_it_is_asked_for():
+    """fba_run_ticks with a search budget: launches until the slots have together made ticks x slots real steps; every record it
+    traces is a record the lock-step driver traces too."""
+    kw = dict(model=N.MODEL_BA_FACTORED, belief="importance_sampling", size=3, sims=128, particles=48, structure_prior=2, horizon=8,
+              episodes=2, runs=1 << 20, slots=24, seed=909, trace=1)
+    lock = fba.Engine("gridworld", **kw)
+    lock.run_ticks(8)
+    ref = {(int(r["run"]), int(r["episode"]), int(r["t"])): r for r in lock.trace()}
+    eng = fba.Engine("gridworld", search_budget=200, **kw)
+    eng.run_ticks(3)
+    c = eng.counters()
+    assert c.env_steps >= 3 * 24
+    tr = eng.trace()
+    assert len(tr) == c.env_steps
+    seen = 0
+    for r in tr:
+        key = (int(r["run"]), int(r["episode"]), int(r["t"]))
+        if key in ref:     # (a slot of the budgeted engine may be a step or two ahead of eight lock-step ticks: those are not compared)
+            seen += 1
+            for name in tr.dtype.names:
+                assert np.array_equal(r[name], ref[key][name]), (key, name)
+    assert seen >= 3 * 24 - 24
+
+
 def test_per_step_interface_matches_oracle_calls():
     """Planner::selectAction / Belief::updateEstimation one call at a time (slots = 1)."""
     kw = dict(particles=128, sims=300)
