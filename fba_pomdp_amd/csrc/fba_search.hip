@@ -483,6 +483,16 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, De
     int32_t* path_na = reinterpret_cast<int32_t*>(path_r - tl + (size_t)depth_cap * HIST_TREES) + tl;
     uint32_t* stage  = reinterpret_cast<uint32_t*>(path_na - tl + (size_t)depth_cap * HIST_TREES) + tl;           // [Cs][trees]
     const bool carry = D.cn_off == 0;   // (the 48-byte record of hashed trees with four actions: {n0..n3}, {q0..q3}; others reload)
+    // Child speculation.  A tree level costs two dependent trips to memory: the node's statistics, then -- once the step has produced
+    // the observation -- the hash probe for the child.  The upper 16 bits of a node's count words (a node below the root has fewer than
+    // 65 536 visits) remember the child each action led to last time; its statistics are requested right after the action is chosen,
+    // so they are on their way while the step is computed and the probe answers.  The probe still decides: a wrong guess costs a
+    // wasted request, never a result.  (child index = hint + 2; hint + 2 == the node itself = none; the root's hints live in registers.)
+    const bool spec = carry && D.max_nodes <= 65538 && P.sims <= 65536;
+    int pf_node = -1;
+    int4 pf_h = make_int4(0, 0, 0, 0);
+    double2 pf_q01 = make_double2(0, 0), pf_q23 = make_double2(0, 0);
+    int r_hint[AMAX] = {0, 0, 0, 0};   // the root's: child index, 0 = none
 
     QuadRng g;
     g.init(P.seed_lo, P.seed_hi, (uint32_t)D.run[e], (uint32_t)D.episode[e], (uint32_t)D.t[e], lane);
@@ -582,18 +592,42 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, De
         if (do_step) {
             g.ensure(7);  // the action, six rows
             if (mode == 1) {  // traverseActionNode
-                if (node == 0) a = ucb_pick<AMAX>(P, g, D.log1p_tab, r_vis, r_cn, r_cq, true);
-                else if (carry) {
+                int guess = 0;   // spec: the child this (node, action) led to last time, 0 = none
+                if (node == 0) {
+                    a = ucb_pick<AMAX>(P, g, D.log1p_tab, r_vis, r_cn, r_cq, true);
+                    if (spec) {
+                        guess = a == 0 ? r_hint[0] : (a == 1 ? r_hint[1] : (a == 2 ? r_hint[2] : r_hint[3]));
+                        if (guess >= min(n_nodes, D.max_nodes)) guess = 0;
+                    }
+                } else if (carry) {
                     const int32_t* rec = tree + (size_t)node * W;
-                    const int4 h      = *reinterpret_cast<const int4*>(rec);
-                    const double2 q01 = *reinterpret_cast<const double2*>(rec + 4);
-                    const double2 q23 = *reinterpret_cast<const double2*>(rec + 8);
-                    const int cn[AMAX]    = {h.x, h.y, h.z, h.w};
+                    int4 h;
+                    double2 q01, q23;
+                    if (spec && node == pf_node) { h = pf_h; q01 = pf_q01; q23 = pf_q23; }   // requested a level ago
+                    else {
+                        h   = *reinterpret_cast<const int4*>(rec);
+                        q01 = *reinterpret_cast<const double2*>(rec + 4);
+                        q23 = *reinterpret_cast<const double2*>(rec + 8);
+                    }
+                    const int m = spec ? 0xffff : -1;
+                    const int cn[AMAX]    = {h.x & m, h.y & m, h.z & m, h.w & m};
                     const double cq[AMAX] = {q01.x, q01.y, q23.x, q23.y};
-                    a = ucb_pick<AMAX>(P, g, D.log1p_tab, ((h.x + h.y) + h.z) + h.w, cn, cq, true);
-                    path_n[(size_t)plen * HIST_TREES] = a == 0 ? h.x : (a == 1 ? h.y : (a == 2 ? h.z : h.w));
+                    a = ucb_pick<AMAX>(P, g, D.log1p_tab, ((cn[0] + cn[1]) + cn[2]) + cn[3], cn, cq, true);
+                    const int word = a == 0 ? h.x : (a == 1 ? h.y : (a == 2 ? h.z : h.w));
+                    path_n[(size_t)plen * HIST_TREES] = word;   // (spec: count | hint << 16)
                     path_q[(size_t)plen * HIST_TREES] = a == 0 ? q01.x : (a == 1 ? q01.y : (a == 2 ? q23.x : q23.y));
+                    if (spec) {
+                        guess = (int)((uint32_t)word >> 16) + 2;
+                        if (guess == node || guess >= min(n_nodes, D.max_nodes)) guess = 0;   // none (node 1's "itself" does not fit the encoding), or not a node
+                    }
                 } else a = ucb_select<AMAX>(P, D, g, tree + (size_t)node * W, true);
+                if (spec && guess > 0) {   // the likely child's statistics, on their way while the step is computed
+                    const int32_t* crec = tree + (size_t)guess * W;
+                    pf_h    = *reinterpret_cast<const int4*>(crec);
+                    pf_q01  = *reinterpret_cast<const double2*>(crec + 4);
+                    pf_q23  = *reinterpret_cast<const double2*>(crec + 8);
+                    pf_node = guess;
+                } else pf_node = -1;
             } else {
                 a = g.slow_int(0, 4);  // GridWorld::generateRandomAction :220-226
             }
@@ -617,11 +651,28 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, De
                 if (term) finish = true;
                 else {
                     const int c = child_get(P, D, tree, tab, epoch, node, a, o);
+                    const int nn = min(n_nodes, D.max_nodes - 1);   // (the node an expansion creates)
+                    if (spec) {   // remember where (node, a) led: the root's hint in its register, a node's in the word the back-up stores
+                        const int to = c >= 0 ? c : nn;
+                        if (node == 0) {
+#pragma unroll
+                            for (int a2 = 0; a2 < AMAX; ++a2)
+                                if (a2 == a) r_hint[a2] = to;
+                        } else {
+                            int32_t* pw = path_n + (size_t)(plen - 1) * HIST_TREES;
+                            *pw = (*pw & 0xffff) | (int)((uint32_t)((to - 2) & 0xffff) << 16);
+                        }
+                    }
                     if (c >= 0) { node = c; --dtg; }
                     else {  // expand: new leaf, then rollout(depth_to_go - 1)
-                        const int nn = min(n_nodes, D.max_nodes - 1);
                         ++n_nodes;
-                        node_init(D, tree + (size_t)nn * W, P.A, P.O);
+                        if (spec) {   // counts 0, no child remembered (hint + 2 == the node itself), Q 0
+                            int32_t* nrec = tree + (size_t)nn * W;
+                            const int none = (int)((uint32_t)((nn - 2) & 0xffff) << 16);
+                            *reinterpret_cast<int4*>(nrec)        = make_int4(none, none, none, none);
+                            *reinterpret_cast<double2*>(nrec + 4) = make_double2(0.0, 0.0);
+                            *reinterpret_cast<double2*>(nrec + 8) = make_double2(0.0, 0.0);
+                        } else node_init(D, tree + (size_t)nn * W, P.A, P.O);
                         child_set(P, D, tree, tab, epoch, node, a, o, nn);
                         mode = 2; rdepth = dtg - 1; rret = 0; rdisc = 1;
                         if (rdepth == 0) finish = true;
@@ -655,9 +706,10 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, De
                     ++r_vis;
                 } else if (carry) {
                     int32_t* rec    = tree + (size_t)(na >> 5) * W;
-                    const int n     = path_n[(size_t)k * HIST_TREES] + 1;
+                    const int word  = path_n[(size_t)k * HIST_TREES];
+                    const int n     = (spec ? (word & 0xffff) : word) + 1;
                     const double q0 = path_q[(size_t)k * HIST_TREES];
-                    rec[act] = n;
+                    rec[act] = spec ? ((word & (int)0xffff0000) | n) : n;
                     reinterpret_cast<double*>(rec + D.cq_off)[act] = q0 + (ret - q0) / (double)n;
                 } else {
                     int32_t* rec = tree + (size_t)(na >> 5) * W;
