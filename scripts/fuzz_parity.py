@@ -85,6 +85,8 @@ def draw(rng):
             kw["dirichlet_regular"] = 1
     if rng.random() < 0.15:
         kw["planner"] = rng.choice(["random", "ts"])
+    if domain == "gridworld" and model == N.MODEL_BA_FACTORED and belief == "importance_sampling" and rng.random() < 0.6:
+        kw["search_budget"] = rng.choice([1, 9, 60, 400])   # engine only: budgeted launches must give the results of whole searches
     return domain, model, belief, slots, kw
 
 
@@ -93,6 +95,7 @@ def one(domain, model, belief, slots, kw, seed):
     planner = kw.pop("planner", "po-uct")
     eng = fba.Engine(domain, model=model, belief=belief, planner=planner, seed=seed, slots=slots, trace=1, **kw)
     okw = dict(kw)
+    okw.pop("search_budget", None)     # (a schedule of the engine, not a parameter of the algorithm)
     if domain == "centered-collision-avoidance":
         okw["ca_centered"] = 1
     o = orc.Oracle(domain=DOM[domain], model=model, belief=N.BELIEF_NAMES[belief], planner=N.PLANNER_NAMES[planner],

@@ -632,6 +632,47 @@ def test_packed_tiger_particles_equal_dense_ones(belief, monkeypatch):
     assert eng.particle_bytes == 128
 
 
+def test_packed_rejection_update_carries_every_cell_of_its_particles(monkeypatch):
+    """reject_tiger_lds_kernel runs its attempts against an LDS copy of the rows the update's action can read; everything else a
+    particle holds must still travel with it: particles whose open-door cells carry increments (fba_belief_set) and an update
+    after a door (fba_belief_update with an open action: only a host can ask for it) must come out as on fp32 records."""
+    kw = dict(model=N.MODEL_BA_TABLE, particles=200, sims=8, slots=1, seed=5)
+    engines = []
+    for dense in (False, True):
+        if dense:
+            monkeypatch.setenv("FBA_DENSE_PARTICLES", "1")
+        eng = fba.Engine("episodic-tiger", **kw)
+        monkeypatch.delenv("FBA_DENSE_PARTICLES", raising=False)
+        eng.belief_init()
+        eng.belief_reset_domain_state()
+        engines.append(eng)
+    packed, dense = engines
+    assert packed.particle_bytes == 64 and dense.particle_bytes == 128
+
+    def same():
+        (s, _, c), (s2, _, c2) = packed.belief_get(0), dense.belief_get(0)
+        assert np.array_equal(s, s2) and np.array_equal(c, c2)
+        return s, c
+    for eng in engines:                    # a listen update on pristine particles
+        eng.set_position(run=0, episode=0, t=0)
+        eng.belief_update(2, 1)
+    s, c = same()
+    assert np.any(c[:, 20:24] != c[0, 20:24][None, :]) or np.any(c[:, 20:24] != dense.prior()[20:24][None, :])   # listen cells were bumped
+    c = c.copy()
+    c[::2, 0] += 3                          # T(0, open-left, 0) of every other particle
+    c[1::3, 13] += 2                        # O(open-left, 0, 1)
+    for eng in engines:
+        eng.belief_set(0, state=s, counts=c)
+        eng.set_position(run=0, episode=0, t=1)
+        eng.belief_update(2, 0)             # listen again, on particles that differ outside the listen cells
+    s, c2 = same()
+    assert np.any(c2[:, 0] != c2[0, 0]) and np.any(c2[:, 13] != c2[0, 13])     # the door increments travelled with their particles
+    for eng in engines:
+        eng.set_position(run=0, episode=0, t=2)
+        eng.belief_update(0, 1)             # an update after opening a door (only a host can ask for it)
+    same()
+
+
 @pytest.mark.parametrize("planner,sims", [("po-uct", 300), ("ts", 120)])
 def test_planning_agr(planner, sims):
     """planning -D agr (AGR.cpp, AGR(10)): 441 states, 23 actions (search_kernel<.., 24, ..>), 22 observations,
