@@ -665,94 +665,147 @@ __global__ void __launch_bounds__(256) cheat_kernel(Problem P, DeviceState D)
 // structure (computePriorModel, FactoredTigerPriors.cpp:293-321), posterior counts along a sampled state history
 // (computePosteriorCounts :397-436), LogBDScore, accept if log(u) < score difference -- inside a Gibbs loop that
 // re-samples the state history (msgSampleStateHistory :96-213 or rejectionSampleStateHistory :38-94) after every
-// accepted model.  The chain is sequential by definition and this belief is a research variant, so ONE lane runs
-// one slot's chain, all draws from stream (REINVIG, 0); slots run side by side.  Factored tiger.
+// accepted model.
+// One WAVE runs one slot's chain.  The chain is sequential by definition (every accept decides what the next proposal is
+// conditioned on), so all 64 lanes carry the same Rng and walk the same control flow -- the draws (stream (REINVIG, 0)) and
+// every floating-point sum keep the order of a one-lane chain, which is the checker's -- and share out the work BETWEEN
+// two draws: record copies, the nodes of computePriorModel, the per-node increments along the history, the (a, s) rows of
+// flattenT/O, the states of a message, the lgamma terms of LogBDScore (evaluated side by side, then added up in CPT
+// order).  The chain's scratch (three count blobs, T and O, messages, the state sequence) lives in LDS when it fits in
+// 64 KB, in HBM otherwise; a block is one wave, so MH_SYNC costs a wait, not a rendezvous.
 // ---------------------------------------------------------------------------------------------
+constexpr int MH_TERMS    = 1024;                                             // doubles: LogBDScore terms evaluated side by side
+constexpr int MH_LDS_HEAD = MH_TERMS * 8 + 2 * MH_MAXVAR * 4 + 64 * 4;        // terms, two structures, terms per lane
+#define MH_SYNC() __syncthreads()
 struct MhScratch {
     float *prior, *model, *fresh, *T, *O;
     double *msg, *probs;
     int32_t* seq;
+    double* terms;
+    uint32_t *masks, *nmasks;
+    int32_t* nterm;
+    int stride;  // longest Dirichlet row + 1
 };
-__device__ __forceinline__ MhScratch mh_scratch(const Problem& P, const DeviceState& D, int e)
+__device__ __forceinline__ MhScratch mh_scratch(const Problem& P, float* base, char* head)
 {
     MhScratch m;
-    float* base = D.mh_scratch + (size_t)e * D.mh_scratch_words;
     m.prior = base; m.model = base + P.Cs; m.fresh = base + 2 * P.Cs;
     m.T = base + 3 * P.Cs;
     m.O = m.T + P.S * P.A * P.S;
     m.msg   = reinterpret_cast<double*>(base + ((3 * P.Cs + P.S * P.A * P.S + P.A * P.S * P.O + 1) & ~1));
     m.probs = m.msg + (size_t)(P.horizon + 1) * P.S;
     m.seq   = reinterpret_cast<int32_t*>(m.probs + P.S);
+    m.terms  = reinterpret_cast<double*>(head);
+    m.masks  = reinterpret_cast<uint32_t*>(head + MH_TERMS * 8);
+    m.nmasks = m.masks + MH_MAXVAR;
+    m.nterm  = reinterpret_cast<int32_t*>(m.nmasks + MH_MAXVAR);
+    int longest = 1;
+    for (int j = 0; j < P.A * (P.fd->FS + P.fd->FO); ++j) longest = max(longest, P.fd->nodes[j].out);
+    m.stride = longest + 1;
     return m;
 }
-// BABNModel::incrementCountsOf (BABNModel.cpp:354-382; observation rows at the OLD state's parent values, App. A #6)
-__device__ void mh_increment(const Problem& P, float* cnt, int s, int a, int o, int ns, float amount)
+__device__ __forceinline__ void mh_copy(float* dst, const float* src, int n, int lane)
+{
+    for (int k = lane; k < n; k += 64) dst[k] = src[k];
+}
+// BABNModel::incrementCountsOf (BABNModel.cpp:354-382; observation rows at the OLD state's parent values, App. A #6), the
+// count of ONE node: k < FS the transition node of state feature k, else the observation node of feature k - FS
+__device__ __forceinline__ void mh_increment_node(const Problem& P, float* cnt, int k, uint64_t fv, uint64_t nf, uint64_t of, int a, float amount)
+{
+    const FDesc* fd = P.fd;
+    const GlobalView v{cnt};
+    const bool tr   = k < fd->FS;
+    const FNode& nd = tr ? fd->nodes[a * fd->FS + k] : fd->nodes[P.A * fd->FS + a * fd->FO + (k - fd->FS)];
+    cnt[node_row(fd, nd, node_mask(fd, nd, v), fv) + (tr ? feat(nf, k) : feat(of, k - fd->FS))] += amount;
+}
+// (the whole step from one lane: the nested belief's filters)
+__device__ __forceinline__ void fact_increment(const Problem& P, float* cnt, int s, int a, int o, int ns, float amount)
 {
     const FDesc* fd   = P.fd;
-    const GlobalView v{cnt};
     const uint64_t fv = pack_features(s, fd->Sstep, fd->FS), nf = pack_features(ns, fd->Sstep, fd->FS), of = pack_features(o, fd->Ostep, fd->FO);
-    for (int f = 0; f < fd->FS; ++f) {
-        const FNode& nd = fd->nodes[a * fd->FS + f];
-        cnt[node_row(fd, nd, node_mask(fd, nd, v), fv) + feat(nf, f)] += amount;
-    }
-    for (int f = 0; f < fd->FO; ++f) {
-        const FNode& nd = fd->nodes[P.A * fd->FS + a * fd->FO + f];
-        cnt[node_row(fd, nd, node_mask(fd, nd, v), fv) + feat(of, f)] += amount;
-    }
+    for (int k = 0; k < fd->FS + fd->FO; ++k) mh_increment_node(P, cnt, k, fv, nf, of, a, amount);
+}
+// (every lane of the wave calls; a lane per node)
+__device__ __forceinline__ void mh_increment(const Problem& P, float* cnt, int s, int a, int o, int ns, float amount, int lane)
+{
+    const FDesc* fd   = P.fd;
+    const uint64_t fv = pack_features(s, fd->Sstep, fd->FS), nf = pack_features(ns, fd->Sstep, fd->FS), of = pack_features(o, fd->Ostep, fd->FO);
+    MH_SYNC();
+    for (int k = lane; k < fd->FS + fd->FO; k += 64) mh_increment_node(P, cnt, k, fv, nf, of, a, amount);
+    MH_SYNC();
 }
 // FBAPOMDPPrior::computePriorModel(structure): factored tiger (FactoredTigerPriors.cpp:293-321) = the prior with the listen
 // observation node set for its parent set; collision avoidance (CollisionAvoidancePriors.cpp:490-526) = the prior with every
-// obstacle's transition node, per action, set for its parent set
-__device__ void mh_compute_prior(const Problem& P, const DeviceState& D, const uint32_t* masks, float* out)
+// obstacle's transition node, per action, set for its parent set.  A lane per node.
+__device__ void mh_compute_prior(const Problem& P, const DeviceState& D, const uint32_t* masks, float* out, int lane)
 {
-    for (int k = 0; k < P.C; ++k) out[k] = D.prior[k];
+    MH_SYNC();
+    mh_copy(out, D.prior, P.C, lane);
+    MH_SYNC();
     if (dom_is_sys(P.domain)) {  // SysAdminFactoredPrior::computePriorModel (:98-127): every transition node anew
         const int N = P.sys->N;
-        for (int a = 0; a < P.A; ++a)
-            for (int f = 0; f < N; ++f) sys_fill_node(P, out, a, f, masks[a * N + f]);
+        for (int i = lane; i < P.A * N; i += 64) sys_fill_node(P, out, i / N, i % N, masks[i]);
     } else if (dom_is_grid(P.domain)) {  // GridWorldFactBAPrior::computePriorModel (GridWorldBAPriors.cpp:227-254)
-        for (int a = 0; a < P.A; ++a)
-            for (int f = 0; f < 2; ++f)
-                if (masks[P.fd->nodes[a * 3 + f].var] == 7u) gw_fill_xy_node_with_goal(P, out, a, f);
+        for (int i = lane; i < P.A * 2; i += 64)
+            if (masks[P.fd->nodes[(i >> 1) * 3 + (i & 1)].var] == 7u) gw_fill_xy_node_with_goal(P, out, i >> 1, i & 1);
     } else if (dom_is_ca(P.domain)) {
         const int n = P.ca->n;
-        for (int f = 2; f < P.fd->FS; ++f)
-            for (int a = 0; a < P.A; ++a) ca_fill_obstacle_node(P, out, a, f, masks[a * n + (f - 2)]);
-    } else {
+        for (int i = lane; i < n * P.A; i += 64) ca_fill_obstacle_node(P, out, i % P.A, 2 + i / P.A, masks[(i % P.A) * n + i / P.A]);
+    } else if (lane == 0) {
         ftiger_set_observation_model(P, out, masks[0]);
     }
+    MH_SYNC();
 }
 // FBAPOMDP::mutate: FactoredTigerFactoredPrior::mutate (FactoredTigerPriors.cpp:351-381) flips a random edge
 // (BABNModel.cpp:16-31) of O[listen][0]; CollisionAvoidanceFactoredPrior::mutate (CollisionAvoidancePriors.cpp:455-488)
 // draws an action and an obstacle, then flips a random edge of that transition node
-__device__ void mh_mutate(const Problem& P, Rng& g, uint32_t* masks)
+__device__ void mh_mutate(const Problem& P, Rng& g, uint32_t* masks, int lane)
 {
+    int word;
+    uint32_t bit;
     if (dom_is_sys(P.domain)) {  // SysAdminFactoredPrior::mutate (:47-55): computer, action (g++ evaluates the second subscript first), then the edge
         const int mc = g.uniform_int(P.sys->N), ma = g.uniform_int(P.A);
-        masks[ma * P.sys->N + mc] ^= 1u << g.slow_int(0, P.fd->FS);
+        word = ma * P.sys->N + mc;
+        bit  = 1u << g.slow_int(0, P.fd->FS);
     } else if (dom_is_grid(P.domain)) {  // GridWorldFactBAPrior::mutate (GridWorldBAPriors.cpp:200-225): an action, the x or the y node, the goal edge toggled
         const int a = g.slow_int(0, P.A);
         const int f = g.slow_int(0, 2);
-        masks[P.fd->nodes[a * 3 + f].var] ^= 4u;
+        word = P.fd->nodes[a * 3 + f].var;
+        bit  = 4u;
     } else if (dom_is_ca(P.domain)) {
         const int n  = P.ca->n;
         const int a  = g.uniform_int(P.A);
         const int ob = g.uniform_int(n);
-        masks[a * n + ob] ^= 1u << g.slow_int(0, P.fd->FS);
+        word = a * n + ob;
+        bit  = 1u << g.slow_int(0, P.fd->FS);
     } else {
-        masks[0] ^= 1u << g.slow_int(0, P.fd->FS);
+        word = 0;
+        bit  = 1u << g.slow_int(0, P.fd->FS);
     }
+    MH_SYNC();
+    if (lane == 0) masks[word] ^= bit;
+    MH_SYNC();
 }
-__device__ void mh_posterior(const Problem& P, const DeviceState& D, int e, const float* prior, const int32_t* seq, float* out)
+// computePosteriorCounts (MHwithinGibbs.cpp:397-436): the prior plus one count per node and step of the history, a lane per node
+__device__ void mh_posterior(const Problem& P, const DeviceState& D, int e, const float* prior, const int32_t* seq, float* out, int lane)
 {
-    for (int k = 0; k < P.C; ++k) out[k] = prior[k];
+    const FDesc* fd = P.fd;
+    MH_SYNC();
+    mh_copy(out, prior, P.C, lane);
+    MH_SYNC();
     const int16_t *ha = D.mh_a + (size_t)e * P.episodes * P.horizon, *ho = D.mh_o + (size_t)e * P.episodes * P.horizon;
     const int32_t* len = D.mh_ep_len + (size_t)e * (P.episodes + 1);
-    int k = 0, h = 0;
-    for (int ep = 0; ep < D.mh_n_ep[e]; ++ep) {
-        for (int t = 0; t < len[ep]; ++t, ++h, ++k) mh_increment(P, out, seq[k], ha[h], ho[h], seq[k + 1], 1.0f);
-        ++k;
+    const int n_ep = D.mh_n_ep[e];
+    for (int node = lane; node < fd->FS + fd->FO; node += 64) {
+        int k = 0, h = 0;
+        for (int ep = 0; ep < n_ep; ++ep) {
+            for (int t = 0; t < len[ep]; ++t, ++h, ++k)
+                mh_increment_node(P, out, node, pack_features(seq[k], fd->Sstep, fd->FS), pack_features(seq[k + 1], fd->Sstep, fd->FS),
+                                  pack_features(ho[h], fd->Ostep, fd->FO), ha[h], 1.0f);
+            ++k;
+        }
     }
+    MH_SYNC();
 }
 // expectedMult (random.cpp:257-279): float sum, float division, all-zero if the sum underflows
 __device__ __forceinline__ void mh_expected(const float* row, int n, float* out)
@@ -761,37 +814,39 @@ __device__ __forceinline__ void mh_expected(const float* row, int n, float* out)
     for (int i = 1; i < n; ++i) sum += row[i];
     for (int i = 0; i < n; ++i) out[i] = ((double)sum <= 1e-300) ? 0.f : row[i] / sum;
 }
-// BABNModel::flattenT / flattenO (BABNModel.cpp:89-181)
-__device__ void mh_flatten(const Problem& P, const float* model, float* T, float* O)
+// BABNModel::flattenT / flattenO (BABNModel.cpp:89-181), a lane per (action, state)
+__device__ void mh_flatten(const Problem& P, const float* model, float* T, float* O, int lane)
 {
     const FDesc* fd = P.fd;
     const GlobalView v{model};
     const int S = P.S, A = P.A, NO = P.O;
-    for (int a = 0; a < A; ++a)
-        for (int s = 0; s < S; ++s) {
-            float ex[MAXF][MAXROW];
-            const uint64_t fv = pack_features(s, fd->Sstep, fd->FS);
-            for (int f = 0; f < fd->FS; ++f) {
-                const FNode& nd = fd->nodes[a * fd->FS + f];
-                mh_expected(model + node_row(fd, nd, node_mask(fd, nd, v), fv), nd.out, ex[f]);
-            }
-            for (int ns = 0; ns < S; ++ns) {
-                const uint64_t nf = pack_features(ns, fd->Sstep, fd->FS);
-                float p = 1;
-                for (int f = 0; f < fd->FS; ++f) p *= ex[f][feat(nf, f)];
-                T[((size_t)s * A + a) * S + ns] = p;
-            }
-            for (int f = 0; f < fd->FO; ++f) {  // (s plays the new state here)
-                const FNode& nd = fd->nodes[A * fd->FS + a * fd->FO + f];
-                mh_expected(model + node_row(fd, nd, node_mask(fd, nd, v), fv), nd.out, ex[f]);
-            }
-            for (int o = 0; o < NO; ++o) {
-                const uint64_t of = pack_features(o, fd->Ostep, fd->FO);
-                float p = 1;
-                for (int f = 0; f < fd->FO; ++f) p *= ex[f][feat(of, f)];
-                O[((size_t)a * S + s) * NO + o] = p;
-            }
+    MH_SYNC();
+    for (int i = lane; i < A * S; i += 64) {
+        const int a = i / S, s = i % S;
+        float ex[MAXF][MAXROW];
+        const uint64_t fv = pack_features(s, fd->Sstep, fd->FS);
+        for (int f = 0; f < fd->FS; ++f) {
+            const FNode& nd = fd->nodes[a * fd->FS + f];
+            mh_expected(model + node_row(fd, nd, node_mask(fd, nd, v), fv), nd.out, ex[f]);
         }
+        for (int ns = 0; ns < S; ++ns) {
+            const uint64_t nf = pack_features(ns, fd->Sstep, fd->FS);
+            float p = 1;
+            for (int f = 0; f < fd->FS; ++f) p *= ex[f][feat(nf, f)];
+            T[((size_t)s * A + a) * S + ns] = p;
+        }
+        for (int f = 0; f < fd->FO; ++f) {  // (s plays the new state here)
+            const FNode& nd = fd->nodes[A * fd->FS + a * fd->FO + f];
+            mh_expected(model + node_row(fd, nd, node_mask(fd, nd, v), fv), nd.out, ex[f]);
+        }
+        for (int o = 0; o < NO; ++o) {
+            const uint64_t of = pack_features(o, fd->Ostep, fd->FO);
+            float p = 1;
+            for (int f = 0; f < fd->FO; ++f) p *= ex[f][feat(of, f)];
+            O[((size_t)a * S + s) * NO + o] = p;
+        }
+    }
+    MH_SYNC();
 }
 // rnd::sample::Dir::sampleFromMult<double> (random.hpp:93-115)
 __device__ __forceinline__ int mh_sample_d(Rng& g, const double* m, int n, double total)
@@ -804,76 +859,142 @@ __device__ __forceinline__ int mh_sample_d(Rng& g, const double* m, int n, doubl
     }
     return n - 1;
 }
-__device__ bool mh_sample_history(const Problem& P, const DeviceState& D, int e, Rng& g, const MhScratch& m, const float* model)
+__device__ bool mh_sample_history(const Problem& P, const DeviceState& D, int e, Rng& g, const MhScratch& m, const float* model, int lane)
 {
     const int S = P.S, A = P.A, NO = P.O;
     const int16_t *ha = D.mh_a + (size_t)e * P.episodes * P.horizon, *ho = D.mh_o + (size_t)e * P.episodes * P.horizon;
     const int32_t* len = D.mh_ep_len + (size_t)e * (P.episodes + 1);
+    const int n_ep = D.mh_n_ep[e];
     int k = 0, h0 = 0;
-    if (P.mh == 2) {  // rejectionSampleStateHistory
-        for (int ep = 0; ep < D.mh_n_ep[e]; ++ep) {
+    if (P.mh == 2) {  // rejectionSampleStateHistory: one draw decides the next, the wave walks it as one
+        MH_SYNC();
+        for (int ep = 0; ep < n_ep; ++ep) {
             const int L = len[ep];
             bool ok = false;
             for (int tries = 0; !ok; ++tries) {
                 if (tries >= (1 << 22)) return false;
                 int s = domain_start(P, g);
-                m.seq[k] = s;
+                if (lane == 0) m.seq[k] = s;
                 ok = true;
                 for (int t = 0; t < L; ++t) {
                     int so;
                     double r;
                     fact_step<false>(P, g, GlobalView{model}, s, ha[h0 + t], so, r, NoInc{});
                     if (so != ho[h0 + t]) { ok = false; break; }
-                    m.seq[k + 1 + t] = s;
+                    if (lane == 0) m.seq[k + 1 + t] = s;
                 }
             }
             k += L + 1;
             h0 += L;
         }
+        MH_SYNC();
         return true;
     }
-    // msgSampleStateHistory
-    mh_flatten(P, model, m.T, m.O);
+    // msgSampleStateHistory: a lane per state of a message; the normalising sums run over the states in order
+    mh_flatten(P, model, m.T, m.O, lane);
     const float init = 1.0f / (float)S;
     const float prior_p = (float)((double)init / (double)(init * (float)S));  // categoricalDistr(size, init)::prob (distributions.cpp:12-35)
-    for (int ep = 0; ep < D.mh_n_ep[e]; ++ep) {
+    for (int ep = 0; ep < n_ep; ++ep) {
         const int L = len[ep];
         const int16_t *ea = ha + h0, *eo = ho + h0;
-        for (int st = 0; st < S; ++st) m.msg[(size_t)L * S + st] = (double)m.O[((size_t)ea[L - 1] * S + st) * NO + eo[L - 1]];
+        for (int st = lane; st < S; st += 64) m.msg[(size_t)L * S + st] = (double)m.O[((size_t)ea[L - 1] * S + st) * NO + eo[L - 1]];
+        MH_SYNC();
         for (int step = L - 1; step >= 0; --step) {
             const int a = ea[step];
-            double tot = 0;
-            for (int st = 0; st < S; ++st) {
+            for (int st = lane; st < S; st += 64) {
                 double acc = 0.0;
                 for (int ns = 0; ns < S; ++ns) acc = acc + (double)m.T[((size_t)st * A + a) * S + ns] * m.msg[(size_t)(step + 1) * S + ns];
                 if (step != 0) acc *= (double)m.O[((size_t)ea[step - 1] * S + st) * NO + eo[step - 1]];
                 else acc *= (double)prior_p;
                 m.msg[(size_t)step * S + st] = acc;
-                tot += acc;
             }
-            for (int st = 0; st < S; ++st) m.msg[(size_t)step * S + st] = m.msg[(size_t)step * S + st] / tot;
+            MH_SYNC();
+            double tot = 0;
+            for (int st = 0; st < S; ++st) tot += m.msg[(size_t)step * S + st];
+            MH_SYNC();
+            for (int st = lane; st < S; st += 64) m.msg[(size_t)step * S + st] = m.msg[(size_t)step * S + st] / tot;
+            MH_SYNC();
         }
         int st = mh_sample_d(g, m.msg, S, 1);
-        m.seq[k++] = st;
+        if (lane == 0) m.seq[k] = st;
+        ++k;
         for (int step = 0; step < L; ++step) {
+            MH_SYNC();
+            for (int ns = lane; ns < S; ns += 64) m.probs[ns] = (double)m.T[((size_t)st * A + ea[step]) * S + ns] * m.msg[(size_t)(step + 1) * S + ns];
+            MH_SYNC();
             double tot = 0;
-            for (int ns = 0; ns < S; ++ns) {
-                m.probs[ns] = (double)m.T[((size_t)st * A + ea[step]) * S + ns] * m.msg[(size_t)(step + 1) * S + ns];
-                tot += m.probs[ns];
-            }
+            for (int ns = 0; ns < S; ++ns) tot += m.probs[ns];
             st = mh_sample_d(g, m.probs, S, tot);
-            m.seq[k++] = st;
+            if (lane == 0) m.seq[k] = st;
+            ++k;
         }
         h0 += L;
     }
+    MH_SYNC();
     return true;
 }
-__global__ void __launch_bounds__(64) mh_kernel(Problem P, DeviceState D)
+// BABNModel::LogBDScore (log_bd_score, fba_device.h): the lgamma terms of up to 64 Dirichlet rows at a time, a lane per row,
+// then ONE running sum over them in CPT order -- the order, and so the double, of the one-lane score
+template <class View>
+__device__ double mh_log_bd_score(const Problem& P, const View& cnt, const View& prior, const MhScratch& m, int lane)
 {
-    const int e = blockIdx.x * 64 + threadIdx.x;
-    if (e >= P.E || !D.cheat_pending[e]) return;
+    const FDesc* fd = P.fd;
+    const int per = fd->FS + fd->FO, nn = P.A * per, W = min(64, MH_TERMS / m.stride);
+    MH_SYNC();
+    if (W < 2) return log_bd_score(P, cnt, prior);  // rows too long to share out
+    const auto node_of = [&](int j) -> const FNode& {
+        const int a = j / per, k = j % per;
+        return k < fd->FS ? fd->nodes[a * fd->FS + k] : fd->nodes[P.A * fd->FS + a * fd->FO + (k - fd->FS)];
+    };
+    const auto rows_of = [&](const FNode& nd) {
+        const uint32_t mask = node_mask(fd, nd, cnt);
+        int rows = 1;
+        for (int j = 0; j < nd.nmax; ++j)
+            if ((mask >> j) & 1u) rows *= nd.psz[j];
+        return rows;
+    };
+    double bd = 0;
+    int node = 0, row = 0;
+    while (node < nn) {
+        int filled = 0, my_node = -1, my_row = 0;
+        while (filled < W && node < nn) {  // hand the next rows out, across node boundaries
+            const int rows = rows_of(node_of(node)), take = min(W - filled, rows - row);
+            if (lane >= filled && lane < filled + take) { my_node = node; my_row = row + (lane - filled); }
+            filled += take;
+            row += take;
+            if (row == rows) { ++node; row = 0; }
+        }
+        if (my_node >= 0) {
+            const FNode& nd = node_of(my_node);
+            double* t  = m.terms + lane * m.stride;
+            double tot = 0, ptot = 0;
+            for (int v = 0; v < nd.out; ++v) {
+                const float x = cnt.at(nd.off + my_row * nd.out + v), y = prior.at(nd.off + my_row * nd.out + v);
+                tot += (double)x;
+                ptot += (double)y;
+                t[v] = log_gamma((double)x) - log_gamma((double)y);
+            }
+            t[nd.out]     = log_gamma(ptot) - log_gamma(tot);
+            m.nterm[lane] = nd.out + 1;
+        }
+        MH_SYNC();
+        for (int l = 0; l < filled; ++l) {
+            const double* t = m.terms + l * m.stride;
+            const int n     = m.nterm[l];
+            for (int v = 0; v < n; ++v) bd += t[v];
+        }
+        MH_SYNC();
+    }
+    return bd;
+}
+__global__ void __launch_bounds__(64) mh_kernel(Problem P, DeviceState D, int scratch_in_lds)
+{
+    extern __shared__ __align__(16) char mh_lds[];
+    const int e = blockIdx.x, lane = threadIdx.x;
+    if (!D.cheat_pending[e]) return;
+    MH_SYNC();  // (every lane has read the flag)
     D.cheat_pending[e] = 0;
-    // history.back().add(a, o); log likelihood
+    // history.back().add(a, o); log likelihood.  (Every lane stores the same values: each then reads what it wrote.)
     int16_t *ha = D.mh_a + (size_t)e * P.episodes * P.horizon, *ho = D.mh_o + (size_t)e * P.episodes * P.horizon;
     int32_t* len = D.mh_ep_len + (size_t)e * (P.episodes + 1);
     const int n_ep = D.mh_n_ep[e];
@@ -883,17 +1004,21 @@ __global__ void __launch_bounds__(64) mh_kernel(Problem P, DeviceState D)
         atomicCAS(D.fault, 0, 0x40000000 + e);
         return;
     }
+    const int len_last = len[n_ep - 1];
+    const double ll    = D.lik[e] + det_log(D.cur[e].weight_total);
+    MH_SYNC();
     ha[h] = (int16_t)D.action[e];
     ho[h] = (int16_t)D.obs[e];
-    len[n_ep - 1] += 1;
-    const double ll = D.lik[e] + det_log(D.cur[e].weight_total);
-    D.lik[e] = ll;
+    len[n_ep - 1] = len_last + 1;
+    D.lik[e]      = ll;
     if (!(ll < D.lik[P.E])) return;
+    __threadfence_block();
+    MH_SYNC();
 
     // reinvigorate
     for (int ep = 0; ep < n_ep; ++ep) nseq += len[ep] + 1;
     const FDesc* fd = P.fd;
-    const MhScratch m = mh_scratch(P, D, e);
+    const MhScratch m = mh_scratch(P, scratch_in_lds ? reinterpret_cast<float*>(mh_lds + MH_LDS_HEAD) : D.mh_scratch + (size_t)e * D.mh_scratch_words, mh_lds);
     const int cur = D.bufsel[e], N = P.N;
     const float* old_recs = D.p_rec + pbase(P, e, cur) * (size_t)P.Cs;
     float* new_recs       = D.p_rec + pbase(P, e, cur ^ 1) * (size_t)P.Cs;
@@ -902,7 +1027,7 @@ __global__ void __launch_bounds__(64) mh_kernel(Problem P, DeviceState D)
     g.stream(FBA_PHASE_REINVIG, 0);
     const double w1 = 1.0 / (double)N;
     const int nvar  = fd->nvar;
-    uint32_t masks[MH_MAXVAR], nmasks[MH_MAXVAR];
+    uint32_t *masks = m.masks, *nmasks = m.nmasks;
     int made = 0;
     bool ok  = true;
     if (P.mh == 3) {
@@ -914,11 +1039,13 @@ __global__ void __launch_bounds__(64) mh_kernel(Problem P, DeviceState D)
         for (int iters = 0; made < N; ++iters) {
             if (iters >= (1 << 24)) { ok = false; break; }
             const float* src = old_recs + (size_t)uniform_weight_pick(D.uni_scan, N, g.u01() * D.uni_total, D.uni_total) * P.Cs;  // old_belief.sample()->model()
-            for (int v = 0; v < nvar; ++v) masks[v] = __float_as_uint(src[fd->ncounts + v]);
-            mh_compute_prior(P, D, masks, m.prior);        // sampled_prior_model
-            if (!g.boolean()) mh_mutate(P, g, masks);      // the same structure half of the time
-            mh_compute_prior(P, D, masks, m.model);        // new_prior_model
-            for (int k = 0; k < P.C; ++k) m.fresh[k] = m.model[k];
+            MH_SYNC();
+            for (int v = lane; v < nvar; v += 64) masks[v] = __float_as_uint(src[fd->ncounts + v]);
+            mh_compute_prior(P, D, masks, m.prior, lane);        // sampled_prior_model
+            if (!g.boolean()) mh_mutate(P, g, masks, lane);      // the same structure half of the time
+            mh_compute_prior(P, D, masks, m.model, lane);        // new_prior_model
+            mh_copy(m.fresh, m.model, P.C, lane);
+            MH_SYNC();
             int last = 0, h0 = 0;
             for (int ep = 0; ok && ep < n_ep; ++ep) {
                 const int L = len[ep];
@@ -932,52 +1059,58 @@ __global__ void __launch_bounds__(64) mh_kernel(Problem P, DeviceState D)
                         fact_step<false>(P, g, GlobalView{m.fresh}, s, ca[h0 + t], so, r, NoInc{});
                         last = s;
                         if (so != co[h0 + t]) break;
-                        mh_increment(P, m.fresh, from, ca[h0 + t], so, s, 1.0f);
-                        m.seq[2 * t] = from; m.seq[2 * t + 1] = s;
+                        if (lane == 0) { m.seq[2 * t] = from; m.seq[2 * t + 1] = s; }
+                        mh_increment(P, m.fresh, from, ca[h0 + t], so, s, 1.0f, lane);
                     }
                     if (t == L) break;
-                    for (int u = 0; u < t; ++u) mh_increment(P, m.fresh, m.seq[2 * u], ca[h0 + u], co[h0 + u], m.seq[2 * u + 1], -1.0f);
+                    for (int u = 0; u < t; ++u) mh_increment(P, m.fresh, m.seq[2 * u], ca[h0 + u], co[h0 + u], m.seq[2 * u + 1], -1.0f, lane);
                 }
                 h0 += L;
             }
             if (!ok) break;
-            const double old_score = log_bd_score(P, GlobalView{src}, GlobalView{m.prior});
-            const double new_score = log_bd_score(P, GlobalView{m.fresh}, GlobalView{m.model});
+            const double old_score = mh_log_bd_score(P, GlobalView{src}, GlobalView{m.prior}, m, lane);
+            const double new_score = mh_log_bd_score(P, GlobalView{m.fresh}, GlobalView{m.model}, m, lane);
             if (det_log(g.u01()) < (new_score - old_score)) {
                 float* dst = new_recs + (size_t)made * P.Cs;
-                for (int k = 0; k < P.C; ++k) dst[k] = m.fresh[k];
-                rec_set_state(dst, P.C, last);
-                new_w[made] = w1;
+                mh_copy(dst, m.fresh, P.C, lane);
+                if (lane == 0) {
+                    rec_set_state(dst, P.C, last);
+                    new_w[made] = w1;
+                }
                 ++made;
             }
         }
     } else {
         {
             const float* src = old_recs + (size_t)uniform_weight_pick(D.uni_scan, N, g.u01() * D.uni_total, D.uni_total) * P.Cs;  // old_belief.sample()->model()
-            for (int k = 0; k < P.C; ++k) m.model[k] = src[k];
+            mh_copy(m.model, src, P.C, lane);
+            MH_SYNC();
         }
-        ok = mh_sample_history(P, D, e, g, m, m.model);
-        for (int v = 0; v < nvar; ++v) masks[v] = __float_as_uint(m.model[fd->ncounts + v]);
-        mh_compute_prior(P, D, masks, m.prior);
-        mh_posterior(P, D, e, m.prior, m.seq, m.model);
-        double score = log_bd_score(P, GlobalView{m.model}, GlobalView{m.prior});
+        ok = mh_sample_history(P, D, e, g, m, m.model, lane);
+        for (int v = lane; v < nvar; v += 64) masks[v] = __float_as_uint(m.model[fd->ncounts + v]);
+        mh_compute_prior(P, D, masks, m.prior, lane);
+        mh_posterior(P, D, e, m.prior, m.seq, m.model, lane);
+        double score = mh_log_bd_score(P, GlobalView{m.model}, GlobalView{m.prior}, m, lane);
         for (int iters = 0; ok && made < N; ++iters) {
             if (iters >= (1 << 24)) { ok = false; break; }
-            for (int v = 0; v < nvar; ++v) nmasks[v] = masks[v];
-            mh_mutate(P, g, nmasks);
-            mh_compute_prior(P, D, nmasks, m.prior);
-            mh_posterior(P, D, e, m.prior, m.seq, m.fresh);
-            const double new_score = log_bd_score(P, GlobalView{m.fresh}, GlobalView{m.prior});
+            MH_SYNC();
+            for (int v = lane; v < nvar; v += 64) nmasks[v] = masks[v];
+            mh_mutate(P, g, nmasks, lane);
+            mh_compute_prior(P, D, nmasks, m.prior, lane);
+            mh_posterior(P, D, e, m.prior, m.seq, m.fresh, lane);
+            const double new_score = mh_log_bd_score(P, GlobalView{m.fresh}, GlobalView{m.prior}, m, lane);
             if (det_log(g.u01()) < (new_score - score)) {
                 float* dst = new_recs + (size_t)made * P.Cs;
-                for (int k = 0; k < P.C; ++k) dst[k] = m.fresh[k];
-                rec_set_state(dst, P.C, m.seq[nseq - 1]);
-                new_w[made] = w1;
+                mh_copy(dst, m.fresh, P.C, lane);
+                if (lane == 0) {
+                    rec_set_state(dst, P.C, m.seq[nseq - 1]);
+                    new_w[made] = w1;
+                }
                 ++made;
-                ok = mh_sample_history(P, D, e, g, m, m.model);   // (from the model of the LAST accepted structure, as the reference does)
-                mh_posterior(P, D, e, m.prior, m.seq, m.model);
-                for (int v = 0; v < nvar; ++v) masks[v] = nmasks[v];
-                score = log_bd_score(P, GlobalView{m.model}, GlobalView{m.prior});
+                ok = mh_sample_history(P, D, e, g, m, m.model, lane);   // (from the model of the LAST accepted structure, as the reference does)
+                mh_posterior(P, D, e, m.prior, m.seq, m.model, lane);
+                for (int v = lane; v < nvar; v += 64) masks[v] = nmasks[v];
+                score = mh_log_bd_score(P, GlobalView{m.model}, GlobalView{m.prior}, m, lane);
             }
         }
     }
@@ -985,6 +1118,7 @@ __global__ void __launch_bounds__(64) mh_kernel(Problem P, DeviceState D)
         atomicCAS(D.fault, 0, 0x20000000 + e);
         return;
     }
+    MH_SYNC();
     D.bufsel[e] = cur ^ 1;
     D.lik[e]    = 0.0;
 }
@@ -1135,7 +1269,7 @@ __global__ void __launch_bounds__(256) nested_update_kernel(Problem P, DeviceSta
             ++count;
             if (so == o) {
                 fresh[acc++] = s;
-                if (P.model == FBA_MODEL_BA_FACTORED) mh_increment(P, rec, old, a, o, s, amount);
+                if (P.model == FBA_MODEL_BA_FACTORED) fact_increment(P, rec, old, a, o, s, amount);
                 else {  // BAFlatModel::incrementCountsOf (BAFlatModel.cpp:130-139)
                     rec[old * P.A * P.S + a * P.S + s] += amount;
                     rec[P.phi_len + a * P.S * P.O + s * P.O + o] += amount;
@@ -2092,7 +2226,11 @@ void launch_belief_update(const Problem& P, const DeviceState& D, hipStream_t st
             }, D.need_update);
         else launch_importance_single(P, D, st);
         if (P.cheat) hipLaunchKernelGGL(cheat_kernel, dim3(P.E), dim3(256), 0, st, P, D);
-        if (P.mh) hipLaunchKernelGGL(mh_kernel, dim3(ceil_div(P.E, 64)), dim3(64), 0, st, P, D);
+        if (P.mh) {  // a wave per slot; the chain's scratch in LDS when it fits
+            const size_t scratch = (size_t)D.mh_scratch_words * 4;
+            const int in_lds     = MH_LDS_HEAD + scratch <= 64 * 1024;
+            hipLaunchKernelGGL(mh_kernel, dim3(P.E), dim3(64), MH_LDS_HEAD + (in_lds ? scratch : 0), st, P, D, in_lds);
+        }
         return;
     }
     const int nchunks = (P.N + 255) / 256;

@@ -1,5 +1,5 @@
 """Randomised differential test: engine (HIP) against the oracle (Philox, device arithmetic) over random
-valid configurations -- domains x simulators x beliefs x sizes x modes.  python scripts/fuzz_parity.py [n] [seed]"""
+valid configurations -- domains x simulators x beliefs x sizes x modes.  python scripts/fuzz_parity.py [n] [seed] [belief-name filter]"""
 import os, sys, random, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -122,12 +122,14 @@ def one(domain, model, belief, slots, kw, seed):
     eng.close()
 
 
-def run(n, seed, verbose=True):
-    """(mismatches, refused) over n random configurations"""
+def run(n, seed, verbose=True, only=""):
+    """(mismatches, refused) over n random configurations (only: those whose belief's name contains it)"""
     rng = random.Random(seed)
     bad = skipped = 0
     for i in range(n):
         cfg = draw(rng)
+        while only not in cfg[2]:
+            cfg = draw(rng)
         if verbose:
             print(i, cfg[0], cfg[1], cfg[2], cfg[3], cfg[4], flush=True)
         try:
@@ -146,6 +148,6 @@ def run(n, seed, verbose=True):
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-    bad, skipped = run(n, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    bad, skipped = run(n, int(sys.argv[2]) if len(sys.argv) > 2 else 1, only=sys.argv[3] if len(sys.argv) > 3 else "")
     print(f"{n} configurations: {bad} mismatches, {skipped} refused", flush=True)
     sys.exit(1 if bad else 0)
