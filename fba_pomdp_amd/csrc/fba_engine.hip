@@ -1594,7 +1594,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
             return FBA_EINVAL;
         }
         D.mh_scratch_words = (int32_t)((words + 3) & ~(size_t)3);
-        CHK(dev_alloc(c, &D.mh_scratch, (size_t)E * D.mh_scratch_words));
+        if (!mh_scratch_in_lds(D.mh_scratch_words)) CHK(dev_alloc(c, &D.mh_scratch, (size_t)E * D.mh_scratch_words));  // (else the chain's scratch is LDS)
         const double thr = cfg->threshold;
         HIPC(hipMemcpy(D.lik + E, &thr, sizeof thr, hipMemcpyHostToDevice));
     }

@@ -17,7 +17,10 @@ constexpr int IS_BLOCK      = 512;   // one workgroup per slot in the importance
 constexpr int PARTICLE_TILE = 4096;  // particles one workgroup initialises / resets
 constexpr int CARRY_TILE    = 2048;  // chunk totals staged in LDS per step of the carry chain
 constexpr int IS_MAX_CHUNKS = 256;   // 256-element scan chunks per slot => N <= 65536
-constexpr int MH_MAXVAR = 128;  // structure words of one particle the MH beliefs carry in registers
+constexpr int MH_MAXVAR = 128;  // structure words of one particle the MH beliefs' chains handle
+constexpr int MH_TERMS  = 1024; // doubles: LogBDScore terms one chain evaluates side by side
+constexpr int MH_LDS_HEAD = MH_TERMS * 8 + 2 * MH_MAXVAR * 4 + 64 * 4;  // those terms, two structures, terms per lane
+inline bool mh_scratch_in_lds(int scratch_words) { return MH_LDS_HEAD + (size_t)scratch_words * 4 <= 64 * 1024; }  // else [E][words] in HBM
 constexpr int IS_LDS_MAX_N  = 8192;  // importance filters up to this many particles keep their weights and prefix sums in LDS (64 KB)
 
 void launch_search(const Problem& P, const DeviceState& D, hipStream_t st);

@@ -674,8 +674,6 @@ __global__ void __launch_bounds__(256) cheat_kernel(Problem P, DeviceState D)
 // order).  The chain's scratch (three count blobs, T and O, messages, the state sequence) lives in LDS when it fits in
 // 64 KB, in HBM otherwise; a block is one wave, so MH_SYNC costs a wait, not a rendezvous.
 // ---------------------------------------------------------------------------------------------
-constexpr int MH_TERMS    = 1024;                                             // doubles: LogBDScore terms evaluated side by side
-constexpr int MH_LDS_HEAD = MH_TERMS * 8 + 2 * MH_MAXVAR * 4 + 64 * 4;        // terms, two structures, terms per lane
 #define MH_SYNC() __syncthreads()
 struct MhScratch {
     float *prior, *model, *fresh, *T, *O;
@@ -2227,9 +2225,8 @@ void launch_belief_update(const Problem& P, const DeviceState& D, hipStream_t st
         else launch_importance_single(P, D, st);
         if (P.cheat) hipLaunchKernelGGL(cheat_kernel, dim3(P.E), dim3(256), 0, st, P, D);
         if (P.mh) {  // a wave per slot; the chain's scratch in LDS when it fits
-            const size_t scratch = (size_t)D.mh_scratch_words * 4;
-            const int in_lds     = MH_LDS_HEAD + scratch <= 64 * 1024;
-            hipLaunchKernelGGL(mh_kernel, dim3(P.E), dim3(64), MH_LDS_HEAD + (in_lds ? scratch : 0), st, P, D, in_lds);
+            const int in_lds = mh_scratch_in_lds(D.mh_scratch_words);
+            hipLaunchKernelGGL(mh_kernel, dim3(P.E), dim3(64), MH_LDS_HEAD + (in_lds ? (size_t)D.mh_scratch_words * 4 : 0), st, P, D, in_lds);
         }
         return;
     }
