@@ -330,7 +330,8 @@ struct Problem {
                         // 4-byte entry per real step over the shared prior tables (HistView below); C = 0 then, hist_cap entries per record
     int32_t hist_cap;
     int32_t gw_N, gw_G;          // gridworld: N, number of goals (copies of GridDesc's, as kernel arguments)
-    uint32_t gw_goalcell[4];     // gridworld: x*N + y of goal g, 8 bits each
+    uint32_t gw_goalcell0, gw_goalcell1, gw_goalcell2, gw_goalcell3;  // gridworld: x*N + y of goal g, 8 bits each, four goals per word (scalars, not an
+                                                                      // array: an indexed member pins the whole by-value struct to scratch memory)
     int32_t search_budget;  // > 0: search_hist_kernel stops at the first simulation boundary behind this many loop iterations and parks the search (fba_hip.h)
     int32_t hist_row;   // the longest Dirichlet row of the model (max(N, G)): picks the row width the kernels are instantiated for
     const float* hist_base;  // the prior count table every particle starts from (max layout, x / y nodes without the goal parent)
@@ -1245,7 +1246,10 @@ struct HistRow {
 __device__ __forceinline__ double u01_of(uint64_t w) { return (double)(w >> 11) * (1.0 / 9007199254740992.0); }  // rnd::uniform_rand01 of one draw
 __device__ __forceinline__ bool gridworld_on_goal(const Problem& P, int cell, int gl)
 {
-    const uint32_t w = gl < 8 ? (gl < 4 ? P.gw_goalcell[0] : P.gw_goalcell[1]) : (gl < 12 ? P.gw_goalcell[2] : P.gw_goalcell[3]);
+    // (every word is read, none chosen by address: a choice between two members' addresses keeps the whole by-value Problem in
+    //  scratch memory, and each of its fields then costs a trip to memory where it is used)
+    const int q      = gl >> 2;
+    const uint32_t w = (q == 0 ? P.gw_goalcell0 : 0u) | (q == 1 ? P.gw_goalcell1 : 0u) | (q == 2 ? P.gw_goalcell2 : 0u) | (q == 3 ? P.gw_goalcell3 : 0u);
     return ((w >> (8 * (gl & 3))) & 0xffu) == (uint32_t)cell;
 }
 __device__ __forceinline__ uint32_t gridworld_pack_state(const Problem& P, int s)

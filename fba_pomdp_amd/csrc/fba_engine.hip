@@ -1405,9 +1405,10 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
             P.hist_cap = cap;
             P.hist_row = std::max(c->gdesc.N, c->gdesc.G);
             P.gw_N = c->gdesc.N; P.gw_G = c->gdesc.G;
-            for (int k = 0; k < 4; ++k) P.gw_goalcell[k] = 0;
+            uint32_t cells[4] = {0, 0, 0, 0};
             for (int gq = 0; gq < c->gdesc.G; ++gq)
-                P.gw_goalcell[gq >> 2] |= (uint32_t)(c->gdesc.goal[gq][0] * c->gdesc.N + c->gdesc.goal[gq][1]) << (8 * (gq & 3));
+                cells[gq >> 2] |= (uint32_t)(c->gdesc.goal[gq][0] * c->gdesc.N + c->gdesc.goal[gq][1]) << (8 * (gq & 3));
+            P.gw_goalcell0 = cells[0]; P.gw_goalcell1 = cells[1]; P.gw_goalcell2 = cells[2]; P.gw_goalcell3 = cells[3];
             P.C        = 0;  // word 0 = state, word 1 = structure bits, words 2.. = entries
         }
     }

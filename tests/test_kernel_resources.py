@@ -36,6 +36,12 @@ def test_tiger_kernels_use_no_scratch(tmp_path):
         # packed) stages 8 KB per wave and holds 11 waves per CU whatever its registers, so three per SIMD (<= 168) cost nothing
         dense_search = re.search(r"search_kernelILb1ELi4ELb0ELi1ELi1E", name) is not None
         assert vgprs <= (168 if dense_search else 128), (name, vgprs)
+    # the history-particle search (C4) indexes nothing inside the by-value Problem: a choice between two members' addresses once
+    # kept the whole struct in scratch memory, one trip to memory per field use, and cost a third of its throughput
+    hist = {n: v for n, v in seen.items() if "search_hist_kernel" in n}
+    assert len(hist) == 3, sorted(seen)
+    for name, (scratch, vgprs, spills) in hist.items():
+        assert scratch == 0 and spills == 0 and vgprs <= 256, (name, scratch, vgprs, spills)
     regular = re.compile(r"search_kernelILb[01]ELi\d+ELb1E|(reject|importance)_kernelILb1E|is_multi_step_kernelILb1E")
     for name, (scratch, vgprs, spills) in seen.items():
         if not regular.search(name):              # (the `regular` Dirichlet instantiations carry the gamma sampler)
