@@ -46,7 +46,7 @@ shutil.copy(os.path.join(SRC, "stats", "run_kernel_stats.csv"), dst("bench_kerne
 if os.path.exists(os.path.join(SRC, "bench_importance.json")):
     shutil.copy(os.path.join(SRC, "bench_importance.json"), dst("bench_importance_sampling.json.log"))
 with open(dst("other_configs.jsonl"), "w") as f:
-    for wl in ("c1", "c3", "c5"):
+    for wl in ("c1", "c3", "c4", "c5"):
         p = os.path.join(SRC, f"bench_{wl}.json")
         if os.path.exists(p) and os.path.getsize(p):
             f.write(open(p).read().strip() + "\n")

@@ -37,7 +37,7 @@ if [ -x $R/scripts/micro/randline ]; then
 fi
 echo "[refresh] randline done"
 # the other BASELINE configs through the same bench.py
-for wl in c1 c3 c5; do
+for wl in c1 c3 c4 c5; do
   timeout -k 10 400 $B --workload $wl --steps 4 --warmup 1 > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err || echo "[refresh] $wl failed"
 done
 cat $OUT/bench_default.json
