@@ -337,7 +337,7 @@ def main():
         min_traffic = k.units * 2.0 * rec_b     # every written particle read once, written once
         s_launches = max(int(search.launches), 1)
         s_avg_ms = search.ms / s_launches
-        s_line = {"avg_ms": s_avg_ms, "steps_per_s": search.units / (search.ms / 1e3) if search.ms > 0 else 0.0,
+        s_line = {"avg_ms": s_avg_ms, "share_of_timed_region": search.ms / (1e3 * dt_max), "steps_per_s": search.units / (search.ms / 1e3) if search.ms > 0 else 0.0,
                   "steps_per_launch": search.units / s_launches}
         sp, sp_src = search_traffic(args, w, eng.slots)
         if sp:
@@ -387,6 +387,7 @@ def main():
                 "frac_traffic": (traffic / 1e9) / (k.ms / launches / 1e3) / HBM_PEAK_GBS if traffic and k.ms > 0 else None,
                 "frac_min_traffic": (min_traffic / 1e9) / (k.ms / 1e3) / HBM_PEAK_GBS if k.ms > 0 else None,
                 "launches": int(k.launches), "avg_ms": k.ms / max(int(k.launches), 1),
+                "share_of_timed_region": k.ms / (1e3 * dt_max),   # (this rank's launches over the timed wall time: what the kernel weighs in `value`)
                 "algorithmic_bytes_per_launch": k.bytes / max(int(k.launches), 1),
                 "algorithmic_basis": basis,
                 "particle_bytes_in_hbm": eng.particle_bytes, "survey_dense_formula_GBs": dense_equiv,

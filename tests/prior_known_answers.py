@@ -65,3 +65,70 @@ def check_factored(blob, size, noise, structure_noise):
         assert np.array_equal(o_listen[:4], np.array([acc(noise), inacc(noise), inacc(noise), acc(noise)], np.float32))
         assert not o_listen[4:].any()                         # numParams() == 4: nothing beyond the four cells in use
     return mask
+
+
+# ---- collision avoidance: /root/reference/test/domains/priors/CollisionAvoidancePriorTests.cpp --------------------------------
+CA_DOWN, CA_STAY, CA_UP = 0, 1, 2      # CollisionAvoidance.hpp: MOVE_DOWN, STAY, MOVE_UP
+BLOCK_MOVE_PROB = .5                   # CollisionAvoidance.hpp (the probability that an obstacle stays where it is)
+
+
+def check_ca_flat(counts, W, H):
+    """the table prior with one obstacle and no noise (:15-131): transitionExpectation(state, STAY) -- expectedMult of the row, float
+    sum and float division -- is EXACTLY .5 for the obstacle staying and .25 for each neighbour row, .75 / .25 at the two edges,
+    whatever counts_total (the reference draws it from 3..19); state index = (x H + y) H + obstacle row"""
+    S, A = W * H * H, 3
+    phi = np.asarray(counts, np.float32)[:S * A * S].reshape(S, A, S)
+    st = lambda x, y, b: (x * H + y) * H + b
+
+    def expectation(s):
+        row = phi[s, CA_STAY]
+        total = np.float32(0)
+        for v in row:                       # expectedMult (random.cpp:257-279): a float running sum
+            total = np.float32(total + v)
+        return row / total
+    for x in range(1, W):
+        for y in range(1, H):
+            for b in range(1, H - 1):                                                                    # :52-79
+                e = expectation(st(x, y, b))
+                assert e[st(x - 1, y, b)] == BLOCK_MOVE_PROB
+                assert e[st(x - 1, y, b + 1)] == (1 - BLOCK_MOVE_PROB) / 2 and e[st(x - 1, y, b - 1)] == (1 - BLOCK_MOVE_PROB) / 2
+            e = expectation(st(x, y, 0))                                                                 # :81-102
+            assert e[st(x - 1, y, 1)] == (1 - BLOCK_MOVE_PROB) / 2 and e[st(x - 1, y, 0)] == (1 + BLOCK_MOVE_PROB) / 2
+            e = expectation(st(x, y, H - 1))                                                             # :104-127
+            assert e[st(x - 1, y, H - 2)] == (1 - BLOCK_MOVE_PROB) / 2 and e[st(x - 1, y, H - 1)] == (1 + BLOCK_MOVE_PROB) / 2
+
+
+def ca_factored_rows(blob, W, H, n):
+    """row(a, f, v): the Dirichlet row of transition node (a, f) at value v of its one parent, normalised -- the blob of the prior with
+    the correct graph (no structure prior: every transition node has itself as its only parent, its rows are all it stores)"""
+    FS = 2 + n
+    sizes = [W, H] + [H] * n
+    b = np.asarray(blob, np.float32)
+
+    def row(a, f, v):
+        off = 0
+        for aa in range(3):
+            for ff in range(FS):
+                if (aa, ff) == (a, f):
+                    r = b[off + v * sizes[f]: off + (v + 1) * sizes[f]]
+                    return r / r.sum()
+                off += sizes[ff] * sizes[ff]
+    return row
+
+
+def check_ca_factored(blob, W, H, n, approx):
+    """the factored prior, no noise (:215-340): obstacle rows expect {.25, .5, .25} in the middle and {.75, .25} at the edges, the agent
+    always moves one column, its row follows the action and stops at the walls"""
+    row = ca_factored_rows(blob, W, H, n)
+    for a in range(3):
+        for f in range(2, 2 + n):
+            for pos in range(1, H - 1):                                                                  # :243-262
+                e = row(a, f, pos)
+                assert e[pos] == approx(BLOCK_MOVE_PROB) and e[pos + 1] == approx(BLOCK_MOVE_PROB * .5) and e[pos - 1] == approx(BLOCK_MOVE_PROB * .5)
+            assert row(a, f, 0)[0] == approx(.5 * (1 + BLOCK_MOVE_PROB)) and row(a, f, 0)[1] == approx(.5 * (1 - BLOCK_MOVE_PROB))          # :264-279
+            assert row(a, f, H - 1)[H - 1] == approx(.5 * (1 + BLOCK_MOVE_PROB)) and row(a, f, H - 1)[H - 2] == approx(.5 * (1 - BLOCK_MOVE_PROB))
+        for x in range(1, W):
+            assert row(a, 0, x)[x - 1] == 1.0                                                            # :296-301
+    for y in range(1, H - 1):                                                                            # :307-323
+        assert row(CA_UP, 1, y)[y + 1] == 1.0 and row(CA_STAY, 1, y)[y] == 1.0 and row(CA_DOWN, 1, y)[y - 1] == 1.0
+    assert row(CA_UP, 1, H - 1)[H - 1] == 1.0 and row(CA_DOWN, 1, 0)[0] == 1.0                           # :325-329

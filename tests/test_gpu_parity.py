@@ -779,6 +779,22 @@ def test_factored_tiger_priors_have_the_reference_tests_known_answers(dom):
         eng.close()
 
 
+def test_collision_avoidance_priors_have_the_reference_tests_known_answers():
+    """/root/reference/test/domains/priors/CollisionAvoidancePriorTests.cpp:15-131 (table prior) and :215-340 (factored prior) through
+    the C-ABI (fba_get_prior) -- the checks tests/test_oracle_golden.py makes on the oracle."""
+    import prior_known_answers as K
+    for total in (3.0, 10.0, 19.0):
+        eng = fba.Engine("random-collision-avoidance", model=N.MODEL_BA_TABLE, width=5, height=7, size=1, counts_total=total, noise=0.0,
+                         particles=4, sims=4, slots=1)
+        assert (eng.S, eng.A, eng.O) == (5 * 7 * 7, 3, 7)
+        K.check_ca_flat(eng.prior(), 5, 7)
+        eng.close()
+    eng = fba.Engine("random-collision-avoidance", model=N.MODEL_BA_FACTORED, width=4, height=7, size=2, counts_total=1000.0, noise=0.0,
+                     particles=4, sims=4, slots=1)
+    K.check_ca_factored(eng.prior(), 4, 7, 2, pytest.approx)
+    eng.close()
+
+
 @pytest.mark.parametrize("belief", ["rejection_sampling", "importance_sampling"])
 def test_trace_histograms_are_the_filters_states_after_each_update(belief):
     """cfg.trace = 2: the state histogram recorded with every trace record equals the histogram of the states fba_belief_get
