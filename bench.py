@@ -41,7 +41,7 @@ WORKLOADS = {
                slots=None, cpu=dict(runs=4, episodes=500)),
     "c3": dict(name="configs[2]: episodic-factored-tiger FBA-POMDP (--size 3), factored Dirichlet prior (match-uniform), 16384 sims/step, 4096 particles",
                domain="episodic-factored-tiger", model=2, belief="rejection_sampling", size=3, structure_prior=2, sims=16384, particles=4096,
-               horizon=10, episodes=64, slots=147456, cpu=dict(runs=4, episodes=60, sims=2048, particles=1024)),
+               horizon=10, episodes=64, slots=163840, cpu=dict(runs=4, episodes=60, sims=2048, particles=1024)),   # (ten search waves per CU: what LDS holds)
     "c4": dict(name="configs[3]: gridworld (--size 7) FBA-POMDP, 65536 sims/step, 16384 particles, importance sampling, episode-sharded",
                domain="gridworld", model=2, belief="importance_sampling", size=7, structure_prior=2, sims=65536, particles=16384,
                horizon=20, episodes=2, slots=32768, search_budget=16384, cpu=dict(runs=8, episodes=1, sims=2048, particles=1024)),

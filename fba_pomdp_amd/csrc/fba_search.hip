@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_kernel(Problem P, DeviceS
         if (lane < 24) s_prior[lane] = D.prior_dense[lane];
         __syncthreads();
     }
-    if (MODEL == FBA_MODEL_BA_FACTORED) {
+    if (MODEL == FBA_MODEL_BA_FACTORED && FTIGER == 0) {  // (the factored-tiger instantiations carry their layout as constants)
         // the factored model's description (which parents, how many values, where the rows start) is
         // consulted several times per sampled feature: keep the part in use in LDS, at the end of
         // this workgroup's allocation, instead of chasing it through global memory
@@ -780,7 +780,9 @@ void launch_search(const Problem& P, const DeviceState& D, hipStream_t st)
     const bool et = !no_etiger && !P.hist && etiger_ok(P, D) &&
                     (tiger_table || tiger_pomdp || (ftiger && P.ft_packed && ft_fs >= 2 && ft_fs <= 4));
     size_t lds = search_lds_words(P, D, stage, et) * sizeof(uint32_t);
-    if (P.model == FBA_MODEL_BA_FACTORED) lds = ((lds + 15) & ~(size_t)15) + (((size_t)P.fd_bytes + 15) & ~(size_t)15);  // + the model description
+    if (P.model == FBA_MODEL_BA_FACTORED && !(ftiger && ft_fs >= 2 && ft_fs <= 4))
+        lds = ((lds + 15) & ~(size_t)15) + (((size_t)P.fd_bytes + 15) & ~(size_t)15);  // + the model description (not the factored-tiger instantiations: 0.9 KB
+                                                                                        //   that kept C3 at nine waves per CU where ten fit)
     static const size_t lds_pad = std::getenv("FBA_SEARCH_LDS_PAD") ? (size_t)std::atoi(std::getenv("FBA_SEARCH_LDS_PAD")) : 0;  // occupancy experiments
     lds += lds_pad;
     const int depth_cap = P.max_depth > 0 ? P.max_depth : 1;

@@ -21,7 +21,7 @@ CONFIGS = {
                particles=4096, structure_prior=2, horizon=10, slots=32768, ticks=3),
     # fbapomdp -D gridworld --size 7, 65536 sims, 16384 particles, importance sampling
     "c3x2": dict(domain="episodic-factored-tiger", model=N.MODEL_BA_FACTORED, belief="rejection_sampling", size=3, sims=16384,
-                 particles=4096, structure_prior=2, horizon=10, slots=147456, ticks=2),   # 9 search waves per CU: what LDS holds (packed records: 17 KB per wave)
+                 particles=4096, structure_prior=2, horizon=10, slots=163840, ticks=2),   # 10 search waves per CU: what LDS holds (packed records: 15 KB per wave)
     "c3half": dict(domain="episodic-factored-tiger", model=N.MODEL_BA_FACTORED, belief="rejection_sampling", size=3, sims=16384,
                    particles=4096, structure_prior=2, horizon=10, slots=16384, ticks=2),
     # (two episodes per run: a history particle holds episodes * (horizon + 1) entries, fba_device.h)
