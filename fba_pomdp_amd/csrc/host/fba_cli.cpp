@@ -205,36 +205,65 @@ bool to_config(Options const& o, fba_config& c, std::string& err)
     return true;
 }
 
-void print_trace(fba_ctx* ctx, int verbose, int A, int particles)
+// -v 1 / 2 / 3 in the reference's own format, "V%vlevel: %fbase\t%msg" (ArgumentParser.cpp:16-20), from the trace the engine kept:
+//   V1  run / episode                                       BAPOMDPExperiment.cpp:56, PlanningExperiment.cpp:41
+//   V2  the real step, the end of an episode                 Episode.cpp:44, :58
+//   V3  po-uct's pick and root statistics                    POUCT.cpp:94-100, RBAPOUCT.cpp:118-124 (ChanceNode::toString, MCTSTreeNodes.cpp:24-28)
+//       the rejection update's loops, the filter behind it   RejectionSampling.hpp:68; (BA)RejectionSampling.cpp:39 / :46 + FlatFilter::toString (FlatFilter.cpp:70-94)
+//       the importance update's total weight                 ImportanceSampler.hpp:56
+// States, actions and observations are printed as the index elements they are here, "(i)" (IndexedElements.hpp:25) -- the reference's
+// gridworld / collision-avoidance types describe themselves in words.  The runs of an experiment execute side by side; their records
+// are printed run by run, episode by episode.
+void print_trace(fba_ctx* ctx, const Options& o, const fba_config& cfg, int A)
 {
     const int n = fba_trace_count(ctx);
     if (n <= 0) return;
     std::vector<fba_trace_rec> tr((size_t)n);
     const int got = fba_get_trace(ctx, tr.data(), n);
-    // -v 3: FlatFilter::toString (FlatFilter.cpp:70-94) of the filter after every update (RejectionSampling.cpp:39,
-    // BARejectionSampling.cpp:46), for domains of at most FBA_TRACE_HIST_BINS states
-    std::vector<uint32_t> hist;
+    const int verbose = o.verbose;
+    const bool planning = o.mode == "planning", pouct = cfg.planner == FBA_PLANNER_POUCT;
+    const int particles = cfg.belief == FBA_BELIEF_POINT ? 1 : cfg.particles;
+    const char* planner_file = planning ? "POUCT.cpp" : "RBAPOUCT.cpp";
+    std::vector<uint32_t> hist;   // the filter's state histogram after every update (domains of at most FBA_TRACE_HIST_BINS states)
     if (verbose >= 3) {
         hist.resize((size_t)n * FBA_TRACE_HIST_BINS);
         if (fba_get_trace_hist(ctx, hist.data(), n) != got) hist.clear();
     }
+    double ret = 0, disc = 1;
     for (int i = 0; i < got; ++i) {
         const fba_trace_rec& r = tr[(size_t)i];
-        if (r.t == 0) std::printf("V1: run %d, episode %d\n", r.run + 1, r.episode + 1);
-        if (verbose >= 3) {
-            std::printf("V3: po-uct tree of depth=%d and %d action nodes; Action stats:", r.tree_depth, r.n_nodes);
-            for (int a = 0; a < A; ++a) std::printf(" (a=%d, q=%f, n=%d)", a, r.root_q[a], r.root_n[a]);
-            std::printf("\n");
+        if (r.t == 0) {
+            if (planning) std::printf("V1: PlanningExperiment.cpp\trun %d/%d\n", r.run + 1, cfg.runs);
+            else std::printf("V1: BAPOMDPExperiment.cpp\trun %d/%d, episode %d/%d\n", r.run + 1, cfg.runs, r.episode + 1, cfg.episodes);
+            ret = 0; disc = 1;
         }
-        std::printf("V2: T=%d\ta=%d\ts'=%d\to=%d\tr=%g\n", r.t, r.action, r.state, r.obs, r.reward);
-        if (verbose >= 3 && r.update_count >= 0) std::printf("V3: performed %d loops for rejection sampling\n", r.update_count);
-        if (!hist.empty() && !r.terminal) {
-            std::printf("V3: Status of the filter after update:Particle filter contains:\n");
-            for (int st = 0; st < FBA_TRACE_HIST_BINS; ++st) {
-                const uint32_t k = hist[(size_t)i * FBA_TRACE_HIST_BINS + st];
-                if (k) std::printf("V3: \t(%d: %f(%u))\n", st, k / static_cast<double>(particles), k);
+        if (verbose >= 3 && pouct) {
+            const int a = r.action;
+            std::printf("V3: %s\tpo-uct picked node (a=(%d), q=%f, n=%d) at tree of depth=%d and %d action nodes\n", planner_file, a,
+                        r.root_q[a], r.root_n[a], r.tree_depth, r.n_nodes);
+            std::printf("V3: %s\tAction stats:\n", planner_file);
+            for (int k = 0; k < A; ++k) std::printf("V3: %s\t\t(a=(%d), q=%f, n=%d)\n", planner_file, k, r.root_q[k], r.root_n[k]);
+        }
+        std::printf("V2: Episode.cpp\tT=%d\ta=(%d)\ts'=(%d)\to=(%d)\tr=%g\n", r.t, r.action, r.state, r.obs, r.reward);
+        ret += r.reward * disc;
+        disc *= cfg.discount;
+        if (verbose >= 3 && !r.terminal) {
+            if (r.update_count >= 0) {
+                std::printf("V3: RejectionSampling.hpp\tperformed %d loops for rejection sampling for %d samples\n", r.update_count, particles);
+                if (!hist.empty()) {   // one message of several lines, as the reference's
+                    std::printf("V3: %s\tStatus of rejection sampling filter after update:Particle filter contains:\n",
+                                planning ? "RejectionSampling.cpp" : "BARejectionSampling.cpp");
+                    for (int st = 0; st < FBA_TRACE_HIST_BINS; ++st) {
+                        const uint32_t k = hist[(size_t)i * FBA_TRACE_HIST_BINS + st];
+                        if (k) std::printf("\t((%d): %f(%u))\n", st, k / static_cast<double>(particles), k);
+                    }
+                }
+            } else if (cfg.belief == FBA_BELIEF_IMPORTANCE) {
+                std::printf("V3: ImportanceSampler.hpp\tacquired total weight of %g after updating %d particles\n", r.weight_total, particles);
             }
         }
+        const bool last = i + 1 == got || tr[(size_t)i + 1].t == 0;
+        if (last) std::printf("V2: Episode.cpp\tEnd of episode at s=(%d) with return=%g\n", r.state, ret);
     }
 }
 
@@ -282,7 +311,7 @@ int main(int argc, char** argv)
     if (o.verbose >= 2) {
         int32_t S, A, O;
         fba_domain_sizes(ctx, &S, &A, &O);
-        print_trace(ctx, o.verbose, A, cfg.belief == FBA_BELIEF_POINT ? 1 : cfg.particles);
+        print_trace(ctx, o, cfg, A);
     }
     {
         std::ofstream f(o.output_file);

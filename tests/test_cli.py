@@ -51,9 +51,17 @@ def test_cli_planning_result_file_matches_library(cli, tmp_path):
     st = eng.run_planning()
     assert count == 50 and float("%g" % st.mean) == mean and float("%g" % st.var) == var and float("%g" % st.stder) == stder
     assert dur > 0
-    steps = [l for l in r.stdout.splitlines() if l.startswith("V2: T=")]
+    # the reference's verbose format, "V%vlevel: %fbase\t%msg" (ArgumentParser.cpp:16-20), and Episode.cpp:44's message; index
+    # elements print as "(i)" (IndexedElements.hpp:25)
+    steps = [l for l in r.stdout.splitlines() if l.startswith("V2: Episode.cpp\tT=")]
     assert len(steps) == eng.counters().env_steps
-    assert re.match(r"V2: T=0\ta=\d\ts'=\d\to=\d\tr=-?\d+", steps[0])
+    assert re.fullmatch(r"V2: Episode\.cpp\tT=0\ta=\(\d\)\ts'=\(\d\)\to=\(\d\)\tr=-?\d+", steps[0])
+    out_lines = r.stdout.splitlines()
+    assert sum(l.startswith("V1: PlanningExperiment.cpp\trun ") for l in out_lines) == 50 and "V1: PlanningExperiment.cpp\trun 50/50" in out_lines
+    ends = [l for l in out_lines if l.startswith("V2: Episode.cpp\tEnd of episode at s=(")]
+    assert len(ends) == 50                                      # Episode.cpp:58, one per run
+    rets, _ = eng.returns()
+    assert sorted(float(l.rsplit("=", 1)[1]) for l in ends) == pytest.approx(sorted(float("%g" % x) for x in rets.ravel()))
 
 
 @pytest.mark.gpu
@@ -141,13 +149,25 @@ def test_cli_v3_prints_the_filter_histogram_after_every_update(cli):
     assert len(tr) == len(hist) > 0
     blocks, cur = [], None
     for line in r.stdout.splitlines():
-        if line.startswith("V2: T="):
+        if line.startswith("V2: Episode.cpp\tT="):
             cur = {}
             blocks.append(cur)
-        m = re.match(r"V3: \t\((\d+): ([0-9.]+)\((\d+)\)\)", line)
+        m = re.fullmatch(r"\t\(\((\d+)\): ([0-9.]+)\((\d+)\)\)", line)     # FlatFilter::toString: "\t(" + state + ": " + fraction + "(" + count + "))"
         if m:
             cur[int(m.group(1))] = (float(m.group(2)), int(m.group(3)))
     assert len(blocks) == len(tr)
+    lines = r.stdout.splitlines()
+    assert sum(l == "V3: BARejectionSampling.cpp\tStatus of rejection sampling filter after update:Particle filter contains:" for l in lines) \
+        == sum(1 for rec in tr if not rec["terminal"])
+    loops = [int(re.fullmatch(r"V3: RejectionSampling\.hpp\tperformed (\d+) loops for rejection sampling for 40 samples", l).group(1))
+             for l in lines if l.startswith("V3: RejectionSampling.hpp")]
+    assert loops == [int(rec["update_count"]) for rec in tr if not rec["terminal"]]
+    picks = [l for l in lines if l.startswith("V3: RBAPOUCT.cpp\tpo-uct picked node (a=(")]
+    assert len(picks) == len(tr)
+    m = re.fullmatch(r"V3: RBAPOUCT\.cpp\tpo-uct picked node \(a=\((\d)\), q=(-?[0-9.]+), n=(\d+)\) at tree of depth=(\d+) and (\d+) action nodes", picks[0])
+    assert m and (int(m.group(1)), int(m.group(3)), int(m.group(4)), int(m.group(5))) == \
+        (int(tr[0]["action"]), int(tr[0]["root_n"][tr[0]["action"]]), int(tr[0]["tree_depth"]), int(tr[0]["n_nodes"]))
+    assert sum(l == "V3: RBAPOUCT.cpp\tAction stats:" for l in lines) == len(tr)
     for rec, hrow, blk in zip(tr, hist, blocks):
         want = {s: int(k) for s, k in enumerate(hrow) if k}
         assert {s: k for s, (_, k) in blk.items()} == want
