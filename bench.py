@@ -151,28 +151,48 @@ def search_traffic(args, w, slots):
     return committed_profile("pmc_search.json")
 
 
-def spawn_ranks(args):
+def spawn_ranks(n, argv=None, poll=0.1, grace=5.0, out=sys.stderr):
     """`python bench.py --gpus N` without a launcher: this process starts N fresh workers (RANK / LOCAL_RANK /
-    WORLD_SIZE / MASTER_* in their environment, as torch.distributed.run would) BEFORE anything here touches a GPU,
-    waits for them and leaves with the worst exit code.  Rank 0 prints the JSON line on the inherited stdout."""
+    WORLD_SIZE / MASTER_* in their environment, as torch.distributed.run would) BEFORE anything here touches a GPU
+    and polls them.  The first worker that exits non-zero ends the job: its siblings -- which would otherwise sit in the
+    gloo rendezvous or in a barrier until its 600-s timeout -- are terminated (killed after `grace` seconds) and the exit
+    code is that worker's.  Rank 0 prints the JSON line on the inherited stdout.  Returns the job's exit code."""
     import socket
     import subprocess
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+    argv = argv if argv is not None else [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    live = {}
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
-    sys.exit(rc)
+        live[r] = subprocess.Popen(argv, env=env)
+    rc, deadline = 0, None
+    while live:
+        for r, p in list(live.items()):
+            code = p.poll()
+            if code is None:
+                continue
+            del live[r]
+            if code != 0 and rc == 0:
+                rc = abs(code) if abs(code) < 256 else 1
+                print(f"[bench] rank {r} exited with code {code}: terminating the other {len(live)} rank(s)", file=out, flush=True)
+                for q in live.values():
+                    q.terminate()
+                deadline = time.monotonic() + grace
+        if deadline is not None and live and time.monotonic() > deadline:
+            for q in live.values():
+                q.kill()
+            deadline = time.monotonic() + 3600.0
+        if live:
+            time.sleep(poll)
+    return rc
 
 
 def rccl_probe(dist, torch, world):
-    """An RCCL group over all ranks that has carried one all-reduce (the communicator is built lazily: make it fail here if it will)."""
+    """An RCCL group over all ranks that has carried one all-reduce of ones (the communicator is built lazily: make it fail here if it
+    will), and the sum that all-reduce returned = the number of ranks RCCL saw."""
     os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")     # a probe that cannot complete raises after the timeout instead of hanging
     group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))   # nccl = RCCL on ROCm
     probe = torch.ones(1, dtype=torch.float64, device="cuda")
@@ -180,31 +200,50 @@ def rccl_probe(dist, torch, world):
     torch.cuda.synchronize()
     if int(probe.item()) != world:
         raise RuntimeError(f"probe all-reduce returned {probe.item()} for {world} ranks")
-    return group
+    return group, int(probe.item())
 
 
 def open_collectives(dist, torch, rank, world, local_rank, shared, probe=rccl_probe):
     """The job's process groups.  Every rank first joins a gloo group (MASTER_ADDR / MASTER_PORT of the launcher): it carries the barriers
     and is where the ranks AGREE on the transport of the one data collective -- RCCL when every rank has its own GPU and every rank's
     probe all-reduce came back, gloo otherwise.  A rank never decides that alone: if some ranks fell back while others sat in an RCCL
-    collective, the job would hang.  Returns (group for the statistics reduce or None = the gloo default group, its device, description)."""
+    collective, the job would hang.  Returns (group for the statistics reduce or None = the gloo default group, its device, description,
+    the number of ranks the RCCL probe's all-reduce counted or None)."""
     dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
     if shared:   # RCCL needs one GPU per rank ("Duplicate GPU detected"): the five doubles go over gloo, and the line says so
         print(f"[bench] rank {rank}: ranks share GPU {local_rank} -> statistics reduce over gloo", file=sys.stderr)
-        return None, "cpu", "gloo (ranks share a GPU)"
-    ok, err, group = 1, "", None
+        return None, "cpu", "gloo (ranks share a GPU)", None
+    ok, err, group, seen = 1, "", None, None
     try:
-        group = probe(dist, torch, world)
+        group, seen = probe(dist, torch, world)
     except Exception as e:   # the statistics reduce is 5 doubles: never lose a scaling run to the transport
         ok, err = 0, str(e).splitlines()[0][:200] if str(e) else type(e).__name__
         print(f"[bench] rank {rank}: RCCL probe failed ({err})", file=sys.stderr)
     agreed = torch.tensor([ok], dtype=torch.int32)
     dist.all_reduce(agreed, op=dist.ReduceOp.MIN)                  # over gloo: every rank learns whether EVERY rank's RCCL works
     if int(agreed.item()) == 1:
-        return group, "cuda", "rccl"
+        return group, "cuda", "rccl", seen
     if rank == 0:
         print("[bench] not every rank's RCCL probe succeeded: all ranks reduce over gloo", file=sys.stderr)
-    return None, "cpu", "gloo (RCCL failed on at least one rank" + (f": {err}" if err else "") + ")"
+    return None, "cpu", "gloo (RCCL failed on at least one rank" + (f": {err}" if err else "") + ")", None
+
+
+def agree_on_slots(dist, torch, slots):
+    """After the per-rank out-of-memory step-down the ranks may hold different slot counts; weak scaling means the SAME work per GPU, so every
+    rank takes the smallest (all-reduce MIN over the gloo group)."""
+    t = torch.tensor([slots], dtype=torch.int64)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item())
+
+
+def gather_per_rank(dist, torch, world, values):
+    """[values of rank 0, values of rank 1, ...] over the gloo group (a few doubles per rank, for the JSON line)."""
+    mine = torch.tensor(values, dtype=torch.float64)
+    if world == 1:
+        return [mine.tolist()]
+    parts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    return [p.tolist() for p in parts]
 
 
 def main():
@@ -237,7 +276,7 @@ def main():
         return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        spawn_ranks(args)   # does not return
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -253,9 +292,9 @@ def main():
     shared = world > ndev or args.all_ranks_on_device is not None
     local_rank = args.all_ranks_on_device if args.all_ranks_on_device is not None else local_rank % ndev
     torch.cuda.set_device(local_rank)
-    group, red_dev, collective = None, "cpu", None
+    group, red_dev, collective, rccl_ranks = None, "cpu", None, None
     if world > 1:
-        group, red_dev, collective = open_collectives(dist, torch, rank, world, local_rank, shared)
+        group, red_dev, collective, rccl_ranks = open_collectives(dist, torch, rank, world, local_rank, shared)
 
     import fba_pomdp_amd as fba
     w = workload_of(args)
@@ -263,17 +302,27 @@ def main():
         w["slots"] = 64 * 16 * torch.cuda.get_device_properties(local_rank).multi_processor_count
     per_rank = w["slots"]
     slots = per_rank
+
+    def make_engine(n):
+        return fba.Engine(w["domain"], runs=1 << 30, slots=n, run_offset=rank * per_rank, seed=20261003, device=local_rank,
+                          **{k: w[k] for k in ENGINE_KEYS if k in w})
     while True:  # step down if this GPU cannot give the memory right now (c2: 0.66 MB per slot, 172 GB)
         try:
-            eng = fba.Engine(w["domain"], runs=1 << 30, slots=slots, run_offset=rank * per_rank, seed=20261003, device=local_rank,
-                             **{k: w[k] for k in ENGINE_KEYS if k in w})
+            eng = make_engine(slots)
             break
         except fba.FbaError as e:
             if "out of memory" not in str(e) or slots <= 1:
                 raise
             nxt = next((v for v in (245760, 196608, 163840, 131072) if v < slots), (slots * 7) // 8 if slots > 8 else slots // 2)
-            print(f"[bench] {slots} slots do not fit ({e}); retrying with {nxt}", file=sys.stderr)
+            print(f"[bench] rank {rank}: {slots} slots do not fit ({e}); retrying with {nxt}", file=sys.stderr)
             slots = nxt
+    if world > 1:   # weak scaling = the same work on every GPU: all ranks run the smallest count any of them could allocate
+        agreed = agree_on_slots(dist, torch, slots)
+        if agreed != slots:
+            print(f"[bench] rank {rank}: {slots} slots here, {agreed} on the tightest rank -> {agreed}", file=sys.stderr)
+            eng.close()
+            slots = agreed
+            eng = make_engine(slots)
 
     def barrier():
         torch.cuda.synchronize()
@@ -302,6 +351,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=group)
     tot = tot.cpu().tolist()
     dt_max = float(tmax.cpu()[0])
+    per_rank_rows = gather_per_rank(dist, torch, world, [float(steps), dt, float(eng.slots)])
 
     if rank == 0:
         kname = "reject_kernel" if w["belief"] == "rejection_sampling" else "importance_kernel"
@@ -395,7 +445,9 @@ def main():
             "search_kernel": s_line,
             "returns": {"episodes": n_ep, "mean": tot[3] / n_ep if n_ep else None,
                         "var": (tot[4] - tot[3] ** 2 / n_ep) / (n_ep - 1) if n_ep > 1 else None,
-                        "collective": collective},
+                        "collective": collective, "rccl_ranks": rccl_ranks},
+            # what every rank did in the timed region (gathered over gloo): simulated steps, its own wall seconds, its slots
+            "per_rank": {"steps": [r[0] for r in per_rank_rows], "seconds": [r[1] for r in per_rank_rows], "slots": [int(r[2]) for r in per_rank_rows]},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)

@@ -877,6 +877,7 @@ int timed(fba_ctx* c, int kind, F&& launch)
 {
     if (!c->timing) {
         launch();
+        if (const hipError_t le = launch_take_error(); le != hipSuccess) return fail(c, FBA_EHIP, "inside a kernel launch sequence: %s", hipGetErrorString(le));
         return FBA_OK;
     }
     if (c->pending.size() >= 2048) {
@@ -896,6 +897,7 @@ int timed(fba_ctx* c, int kind, F&& launch)
     launch();
     HIPCHK(c, hipEventRecord(p.b, c->stream));
     c->pending.push_back(p);
+    if (const hipError_t le = launch_take_error(); le != hipSuccess) return fail(c, FBA_EHIP, "inside a kernel launch sequence: %s", hipGetErrorString(le));
     return FBA_OK;
 }
 
@@ -972,9 +974,23 @@ int ensure_outputs(fba_ctx* c, int runs)
     return FBA_OK;
 }
 
+// Budgeted searches park their state per slot (s_sim / s_nodes / s_depth, fba_state.h).  Whatever re-positions the slots -- a new
+// experiment, fba_belief_init, fba_set_position -- makes a parked search stale: the next launch must start a search, not resume one.
+int clear_parked_searches(fba_ctx* c)
+{
+    if (!c->D.s_sim) return FBA_OK;
+    const size_t E = (size_t)c->P.E;
+    HIPCHK(c, hipMemsetAsync(c->D.s_sim, 0, E * sizeof *c->D.s_sim, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->D.s_nodes, 0, E * sizeof *c->D.s_nodes, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->D.s_depth, 0, E * sizeof *c->D.s_depth, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->D.search_done, 0, E * sizeof *c->D.search_done, c->stream));
+    return FBA_OK;
+}
+
 int start_experiment(fba_ctx* c, int runs_total)
 {
     int rc;
+    if ((rc = clear_parked_searches(c))) return rc;
     c->D.runs_total = runs_total;
     c->D.run_offset = c->cfg.run_offset;
     const int32_t n_active = runs_total < 0 ? c->P.E : std::min(c->P.E, runs_total);
@@ -999,8 +1015,8 @@ int run_experiment(fba_ctx* c, fba_stat* stats)
     if ((rc = ensure_outputs(c, runs))) return rc;
     if ((rc = start_experiment(c, runs))) return rc;
     long long max_ticks = (long long)((runs + E - 1) / E) * eps * c->P.horizon + 2;
-    if (c->P.search_budget > 0)   // budgeted launches: a real step takes as many launches as its search needs (<= horizon iterations per simulation)
-        max_ticks *= ((long long)c->P.sims * c->P.horizon) / c->P.search_budget + 2;
+    if (c->P.search_budget > 0)   // budgeted launches: a real step takes as many launches as its search needs (<= horizon + 1 iterations per simulation)
+        max_ticks *= ((long long)c->P.sims * (c->P.horizon + 1)) / c->P.search_budget + 2;
     for (long long k = 0; k < max_ticks; ++k) {
         if ((rc = tick(c))) return rc;
         int32_t n_active = 0;
@@ -1856,6 +1872,8 @@ int fba_set_position(fba_ctx* c, const int32_t* run, const int32_t* episode, con
 {
     if (!c) return FBA_EINVAL;
     const size_t n = (size_t)c->P.E * 4;
+    int rc;
+    if ((rc = clear_parked_searches(c))) return rc;
     if (run || episode) launch_materialize_reset(c->P, c->D, c->stream);  // a pending lazy reset belongs to the old (run, episode)
     if (run) HIPCHK(c, hipMemcpyAsync(c->D.run, run, n, hipMemcpyHostToDevice, c->stream));
     if (episode) HIPCHK(c, hipMemcpyAsync(c->D.episode, episode, n, hipMemcpyHostToDevice, c->stream));
@@ -1868,6 +1886,7 @@ int fba_belief_init(fba_ctx* c)
 {
     if (!c) return FBA_EINVAL;
     int rc;
+    if ((rc = clear_parked_searches(c))) return rc;
     if ((rc = set_flags(c, c->D.need_init, nullptr, 1))) return rc;
     if ((rc = timed(c, FBA_K_BELIEF_INIT, [&] { launch_init(c->P, c->D, c->stream); }))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2182,14 +2201,25 @@ int fba_run_ticks(fba_ctx* c, int32_t ticks)
         int rc2 = FBA_OK;
         const uint64_t base   = sum_counter(c, c->D.env_steps, c->P.E, &rc2);
         const uint64_t target = (uint64_t)ticks * (uint64_t)c->P.E;
-        const long long bound = ((long long)ticks + 2) * (((long long)c->P.sims * c->P.horizon) / c->P.search_budget + 2);
+        // (a simulation takes at most horizon + 1 loop iterations: the last one finishes it when depth-to-go is 0)
+        const long long bound = ((long long)ticks + 2) * (((long long)c->P.sims * (c->P.horizon + 1)) / c->P.search_budget + 2);
+        uint64_t made = 0;
         for (long long k = 0; k < bound && !rc2; ++k) {
-            if (sum_counter(c, c->D.env_steps, c->P.E, &rc2) - base >= target) break;   // (synchronises: the launches of the last round are done)
+            made = sum_counter(c, c->D.env_steps, c->P.E, &rc2) - base;   // (synchronises: the launches of the last round are done)
+            if (made >= target) break;
             if ((rc = tick(c))) return rc;
         }
         if (rc2) return rc2;
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        return check_fault(c);
+        if ((rc = check_fault(c))) return rc;
+        if (made < target) {
+            made = sum_counter(c, c->D.env_steps, c->P.E, &rc2) - base;
+            if (rc2) return rc2;
+            if (made < target)
+                return fail(c, FBA_ESTATE, "budgeted run_ticks: %llu of %llu real steps made after %lld launches", (unsigned long long)made,
+                            (unsigned long long)target, bound);
+        }
+        return FBA_OK;
     }
     for (int k = 0; k < ticks; ++k)
         if ((rc = tick(c))) return rc;

@@ -35,6 +35,7 @@ void launch_flush(const Problem& P, const DeviceState& D, hipStream_t st);
 void launch_selftest_lgamma(const double* x, int count, double* out, hipStream_t st);
 void launch_selftest_bd(const Problem& P, const float* cnt, const float* prior, double* out, hipStream_t st);
 void launch_selftest_ucb(const double* L, const int32_t* n, int count, double u, double* out, hipStream_t st);
+hipError_t launch_take_error();   // a HIP error a launch_* function met on its way (and clears it); hipSuccess if none
 void launch_uniform_scan(int n, double* w_tmp, double* out, double* total, double* ctot, hipStream_t st);
 
 }  // namespace fba

@@ -2135,6 +2135,14 @@ __global__ void __launch_bounds__(256) build_slot_list_kernel(Problem P, DeviceS
     D.slot_list[pos]   = e;
     D.scratch_idx[e]   = pos % D.scratch_slots;
 }
+// a HIP error met inside a launch_* function that has no status to return (the engine's timed() asks after every launch)
+static thread_local hipError_t g_launch_err = hipSuccess;
+hipError_t launch_take_error()
+{
+    const hipError_t e = g_launch_err;
+    g_launch_err = hipSuccess;
+    return e;
+}
 // DeviceState::single_rec: the slots in chunks of as many as the scratch pool holds -- gather into the pool, copy back, next chunk
 template <class F>
 static void for_each_chunk(const Problem& P, const DeviceState& D, hipStream_t st, F launch, const uint8_t* flag = nullptr)
@@ -2142,11 +2150,15 @@ static void for_each_chunk(const Problem& P, const DeviceState& D, hipStream_t s
     if (D.slot_list && flag) {
         // budgeted searches: few slots have work, anywhere among all of them -- chunks of the compacted list instead of E / scratch_slots
         // nearly empty launches (C4: 32 of them took 35 ms per round for a handful of updates).  The count is read on the host.
-        (void)hipMemsetAsync(D.list_count, 0, sizeof(int32_t), st);
+        hipError_t he = hipMemsetAsync(D.list_count, 0, sizeof(int32_t), st);
         hipLaunchKernelGGL(build_slot_list_kernel, dim3(ceil_div(P.E, 256)), dim3(256), 0, st, P, D, flag);
         int32_t n = 0;
-        (void)hipMemcpyAsync(&n, D.list_count, sizeof n, hipMemcpyDeviceToHost, st);
-        (void)hipStreamSynchronize(st);
+        if (he == hipSuccess) he = hipMemcpyAsync(&n, D.list_count, sizeof n, hipMemcpyDeviceToHost, st);
+        if (he == hipSuccess) he = hipStreamSynchronize(st);
+        if (he != hipSuccess) {   // the count is unknown: nothing was launched, the request flags stay set -- the engine must hear of it (timed())
+            g_launch_err = he;
+            return;
+        }
         for (int i0 = 0; i0 < n; i0 += D.scratch_slots) {
             DeviceState Dc = D;
             Dc.slot_base   = i0;

@@ -744,7 +744,8 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, De
         if (g.q == 0) D.sim_steps[e] += steps;
         return;   // (search_done[e] stays 0: env_kernel leaves the slot alone)
     }
-    if (budget > 0) { D.s_sim[e] = 0; D.search_done[e] = 1; }
+    if (D.s_sim) D.s_sim[e] = 0;   // (also after a whole search run on a budgeted context, fba_select_action: what was parked for this slot is stale)
+    if (budget > 0) D.search_done[e] = 1;
     g.stream(FBA_PHASE_SEARCH, (uint32_t)P.sims + 1u);
     g.ensure(1);
     if (n_nodes > D.max_nodes) atomicCAS(D.fault, 0, -(1 + e));

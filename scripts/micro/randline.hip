@@ -7,6 +7,10 @@
 //   store24   a 16-byte and an 8-byte store into one random record                (a back-up's header + Q)
 //   rmw       16-byte + 8-byte load, then 16-byte + 8-byte store, same record     (a back-up as the search does it)
 //   near64    load64 where each lane's records come from its own 4 KB window      (a lane's small tree: lines recur)
+//   pair64    lanes 2k and 2k+1 load 16 bytes of the two 64-byte halves of ONE random 128-byte line: if the memory side moves
+//             128-byte lines, records/s = 2 x load16; if it moves 64-byte sectors, records/s = load16
+//   line128   one lane loads 16 bytes of BOTH halves of its own random 128-byte line (two records per access pair)
+//   far2x64   one lane loads 16 bytes of two UNRELATED random 64-byte records (the control for line128: same requests, no shared line)
 // Per-lane "dep" accesses are issued with `fly` of them in flight (independent addresses).
 // Usage (GPU box):  hipcc --offload-arch=gfx950 -O3 randline.hip -o randline && ./randline [GiB] [iters]
 //   rocprofv3 --kernel-trace --pmc FETCH_SIZE ... -- ./randline ; --pmc WRITE_SIZE ; --pmc TCC_HIT_sum TCC_MISS_sum
@@ -38,7 +42,12 @@ __global__ void __launch_bounds__(64) shape_kernel(uint4* buf, uint32_t rec_mask
 #pragma unroll
         for (int f = 0; f < FLY; ++f) {
             const uint32_t h = mix((gid * 0x9e3779b9u) ^ mix((uint32_t)(it + f) * 0x85ebca6bu + seed));
-            const uint32_t rec = MODE == 5 ? (window | (h & 63u)) : (h & rec_mask);
+            uint32_t rec = MODE == 5 ? (window | (h & 63u)) : (h & rec_mask);
+            if (MODE == 6) {   // the pair of lanes shares the hash of the even lane; each takes its own half of the 128-byte line
+                const uint32_t hp = mix(((gid & ~1u) * 0x9e3779b9u) ^ mix((uint32_t)(it + f) * 0x85ebca6bu + seed));
+                rec = ((hp & rec_mask) & ~1u) | (gid & 1u);
+            }
+            if (MODE == 7) rec &= ~1u;
             p[f] = buf + (size_t)rec * 4;
         }
         if (MODE == 0) {
@@ -46,6 +55,23 @@ __global__ void __launch_bounds__(64) shape_kernel(uint4* buf, uint32_t rec_mask
             for (int f = 0; f < FLY; ++f) v[f][0] = p[f][0];
 #pragma unroll
             for (int f = 0; f < FLY; ++f) acc ^= v[f][0].x;
+        } else if (MODE == 6) {
+#pragma unroll
+            for (int f = 0; f < FLY; ++f) v[f][0] = p[f][0];
+#pragma unroll
+            for (int f = 0; f < FLY; ++f) acc ^= v[f][0].x;
+        } else if (MODE == 7 || MODE == 8) {
+#pragma unroll
+            for (int f = 0; f < FLY; ++f) {
+                v[f][0] = p[f][0];
+                if (MODE == 7) v[f][1] = p[f][4];   // the other 64-byte half of the same 128-byte line
+                else {
+                    const uint32_t h2 = mix((gid * 0x85ebca6bu) ^ mix((uint32_t)(it + f) * 0x9e3779b9u + seed + 77u));
+                    v[f][1] = buf[(size_t)(h2 & rec_mask) * 4];
+                }
+            }
+#pragma unroll
+            for (int f = 0; f < FLY; ++f) acc ^= v[f][0].x ^ v[f][1].y;
         } else if (MODE == 1 || MODE == 5) {
 #pragma unroll
             for (int f = 0; f < FLY; ++f)
@@ -129,5 +155,11 @@ int main(int argc, char** argv)
     run<4, 2>("rmw", buf, mask, iters, sink, waves, 48);
     run<5, 1>("near64", buf, mask, iters, sink, waves, 64);
     run<5, 2>("near64", buf, mask, iters, sink, waves, 64);
+    run<6, 1>("pair64", buf, mask, iters, sink, waves, 16);
+    run<6, 4>("pair64", buf, mask, iters, sink, waves, 16);
+    run<7, 1>("line128", buf, mask, iters, sink, waves, 32);
+    run<7, 2>("line128", buf, mask, iters, sink, waves, 32);
+    run<8, 1>("far2x64", buf, mask, iters, sink, waves, 32);
+    run<8, 2>("far2x64", buf, mask, iters, sink, waves, 32);
     return 0;
 }

@@ -866,6 +866,38 @@ def test_budgeted_throughput_driver_makes_the_steps_it_is_asked_for():
     assert seen >= 3 * 24 - 24
 
 
+def test_an_experiment_after_run_ticks_on_a_budgeted_context_starts_fresh_searches():
+    """A budgeted context that was driven by fba_run_ticks holds parked searches (s_sim > 0 for most slots).  An experiment started
+    on it afterwards re-positions every slot, so its first launch must START searches; resuming the parked ones would apply the old
+    run's root statistics, node count and hash epoch to the new run.  Same for the per-step interface: fba_select_action returns whole
+    searches and leaves nothing parked.  Compared with a context that never ran anything else."""
+    kw = dict(model=N.MODEL_BA_FACTORED, belief="importance_sampling", size=3, sims=96, particles=64, structure_prior=2, horizon=7,
+              episodes=2, runs=9, slots=6, seed=4711, trace=1, search_budget=53)
+    fresh = fba.Engine("gridworld", **kw)
+    want_stats = [(s.count, s.mean, s.m2) for s in fresh.run_bapomdp()]
+    want = fresh.trace()
+    fresh.close()
+    eng = fba.Engine("gridworld", **kw)
+    eng.run_ticks(2)                       # leaves searches parked in the middle of their simulations
+    got_stats = [(s.count, s.mean, s.m2) for s in eng.run_bapomdp()]
+    got = eng.trace()
+    assert got_stats == want_stats and len(got) == len(want)
+    for name in want.dtype.names:
+        assert np.array_equal(got[name], want[name]), name
+    # the per-step interface after parked searches: select_action on re-initiated beliefs equals a fresh context's
+    eng.run_ticks(1)
+    outs = []
+    for e in (eng, fba.Engine("gridworld", **kw)):
+        e.set_position(run=3, episode=0, t=0)
+        e.belief_init()
+        e.belief_reset_domain_state()
+        a = e.select_action(hist_len=0)
+        outs.append((np.array(a), e.last_step_info()))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    for name in ("n_nodes", "tree_depth", "root_n", "root_q"):
+        assert np.array_equal(outs[0][1][name], outs[1][1][name]), name
+
+
 def test_per_step_interface_matches_oracle_calls():
     """Planner::selectAction / Belief::updateEstimation one call at a time (slots = 1)."""
     kw = dict(particles=128, sims=300)

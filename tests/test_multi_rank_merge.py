@@ -81,12 +81,15 @@ def _collective_worker(rank, world, port, q, fail_rank):
     def probe(dist_, torch_, world_):     # stands in for the RCCL probe: it works on every rank but `fail_rank`
         if rank == fail_rank:
             raise RuntimeError("simulated RCCL failure on this rank only")
-        return None
+        return None, world_
 
-    group, dev, how = bench.open_collectives(dist, torch, rank, world, rank, False, probe=probe)
+    group, dev, how, seen = bench.open_collectives(dist, torch, rank, world, rank, False, probe=probe)
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, group=group)        # the data collective goes wherever the ranks agreed it goes: it must complete
-    q.put((rank, dev, how, float(t[0])))
+    # the out-of-memory step-down is per rank: the ranks then agree on the smallest count, and the line carries every rank's figures
+    slots = bench.agree_on_slots(dist, torch, 1000 - 100 * rank)
+    rows = bench.gather_per_rank(dist, torch, world, [10.0 * (rank + 1), 0.5 + rank, float(slots)])
+    q.put((rank, dev, how, float(t[0]), seen, slots, rows))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -108,9 +111,46 @@ def test_ranks_agree_on_the_transport_before_the_data_collective(fail_rank):
         assert p.exitcode == 0
     assert [g[3] for g in got] == [3.0, 3.0]
     if fail_rank >= 0:
-        assert all(g[1] == "cpu" and g[2].startswith("gloo (RCCL failed on at least one rank") for g in got)
+        assert all(g[1] == "cpu" and g[2].startswith("gloo (RCCL failed on at least one rank") and g[4] is None for g in got)
     else:
-        assert all(g[2] == "rccl" for g in got)
+        assert all(g[2] == "rccl" and g[4] == 2 for g in got)     # returns.rccl_ranks: the count the probe's all-reduce returned
+    assert all(g[5] == 900 for g in got)                           # rank 0 could hold 1000 slots, rank 1 900: both run 900
+    assert all(g[6] == [[10.0, 0.5, 900.0], [20.0, 1.5, 900.0]] for g in got)
+
+
+def test_the_launcher_ends_the_job_when_one_rank_dies_at_start_up(tmp_path):
+    """`bench.py --gpus 8` without a launcher: rank 3 exits at once (as a rank whose fba_create fails would); its seven siblings sit in
+    the gloo rendezvous, which waits 600 s for the missing rank.  spawn_ranks must notice the first non-zero exit, terminate the
+    siblings and return that exit code -- within seconds, not after the rendezvous timeout (merge_result_files.py:60-78 pools
+    per-process results; a job that lost a rank has nothing to pool)."""
+    import time
+
+    sys.path.insert(0, ROOT)
+    import bench
+    worker = tmp_path / "worker.py"
+    worker.write_text(
+        "import os, sys, datetime\n"
+        "rank = int(os.environ['RANK'])\n"
+        "if rank == 3:\n"
+        "    sys.exit(7)\n"
+        "import torch.distributed as dist\n"
+        "dist.init_process_group('gloo', rank=rank, world_size=int(os.environ['WORLD_SIZE']), timeout=datetime.timedelta(seconds=600))\n"
+        "dist.barrier()\n")
+    t0 = time.monotonic()
+    with open(tmp_path / "launcher.err", "w") as err:
+        rc = bench.spawn_ranks(8, argv=[sys.executable, str(worker)], out=err)
+    took = time.monotonic() - t0
+    assert rc == 7
+    assert took < 60, took
+    assert "rank 3 exited with code 7" in (tmp_path / "launcher.err").read_text()
+
+
+def test_the_launcher_returns_zero_when_every_rank_succeeds(tmp_path):
+    sys.path.insert(0, ROOT)
+    import bench
+    worker = tmp_path / "ok.py"
+    worker.write_text("import os, sys\nsys.exit(0)\n")
+    assert bench.spawn_ranks(4, argv=[sys.executable, str(worker)]) == 0
 
 
 @pytest.mark.gpu
