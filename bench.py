@@ -44,7 +44,7 @@ WORKLOADS = {
                horizon=10, episodes=64, slots=163840, cpu=dict(runs=4, episodes=60, sims=2048, particles=1024)),   # (ten search waves per CU: what LDS holds)
     "c4": dict(name="configs[3]: gridworld (--size 7) FBA-POMDP, 65536 sims/step, 16384 particles, importance sampling, episode-sharded",
                domain="gridworld", model=2, belief="importance_sampling", size=7, structure_prior=2, sims=65536, particles=16384,
-               horizon=20, episodes=2, slots=32768, search_budget=16384, cpu=dict(runs=8, episodes=1, sims=2048, particles=1024)),
+               horizon=20, episodes=2, slots=32768, search_budget=16384, tree_buckets=65536, cpu=dict(runs=8, episodes=1, sims=2048, particles=1024)),
     "c5": dict(name="configs[4]: collision avoidance 7x7, 2 obstacles (largest factored domain), 10^6 particles per belief, "
                     "importance-weighted update + resample",
                domain="random-collision-avoidance", model=2, belief="importance_sampling", size=2, width=7, height=7, sims=16,
@@ -52,13 +52,13 @@ WORKLOADS = {
 }
 ORC_DOMAIN = {"episodic-tiger": "DOM_TIGER_EPISODIC", "episodic-factored-tiger": "DOM_FTIGER_EPISODIC", "gridworld": "DOM_GRIDWORLD",
               "random-collision-avoidance": "DOM_COLLISION_AVOID"}
-ENGINE_KEYS = ("model", "belief", "size", "width", "height", "structure_prior", "sims", "particles", "horizon", "episodes", "search_budget")
+ENGINE_KEYS = ("model", "belief", "size", "width", "height", "structure_prior", "sims", "particles", "horizon", "episodes", "search_budget", "tree_buckets")
 
 
 def workload_of(args):
     """The workload dictionary with the command line's overrides (--sims / --particles / --horizon / --belief / --slots)."""
     w = dict(WORKLOADS[args.workload])
-    for k in ("sims", "particles", "horizon", "belief", "slots", "search_budget"):
+    for k in ("sims", "particles", "horizon", "belief", "slots", "search_budget", "tree_buckets"):
         if getattr(args, k) is not None:
             w[k] = getattr(args, k)
     return w
@@ -262,6 +262,8 @@ def main():
     ap.add_argument("--belief", default=None, choices=["rejection_sampling", "importance_sampling"])
     ap.add_argument("--search-budget", type=int, default=None,
                     help="c4: iterations of the search loop per launch (slots advance on their own; 0 = lock-step ticks); default: the workload's")
+    ap.add_argument("--tree-buckets", type=int, default=None,
+                    help="c4: 64-byte node buckets per slot's search tree (fba_config.tree_buckets; 0 = 2 * (sims + 2), which no search can fill); default: the workload's")
     ap.add_argument("--cpu-cores", type=int, default=16,
                     help="processes of the CPU baseline (a 1-GPU box's CPU share is 16 cores, whatever the affinity mask says)")
     ap.add_argument("--cpu-runs", type=int, default=None)
@@ -425,7 +427,7 @@ def main():
                 "workload": f"{w['name']}; {w['belief']}, H={w['horizon']}" +
                             (f" [overridden: {w['sims']} sims, {w['particles']} particles]" if (args.sims or args.particles) else ""),
                 "workload_key": args.workload, "slots_per_gpu": eng.slots, "parallelism": f"episode-sharded x{world}",
-                "search_budget": w.get("search_budget", 0),
+                "search_budget": w.get("search_budget", 0), "tree_buckets": w.get("tree_buckets", 0),
             },
             "roofline": {
                 "bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -63,6 +63,7 @@ class Config(C.Structure):
         ("seed", C.c_uint64), ("run_offset", C.c_int32), ("slots", C.c_int32),
         ("device", C.c_int32), ("trace", C.c_int32), ("dirichlet_regular", C.c_int32),
         ("resample_amount", C.c_int32), ("threshold", C.c_double), ("belief_option", C.c_int32), ("search_budget", C.c_int32),
+        ("tree_buckets", C.c_int32),
     ]
 
 

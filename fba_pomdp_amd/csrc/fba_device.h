@@ -1407,9 +1407,10 @@ __device__ __forceinline__ int quad_bcast(int addr0, int from, int v) { return _
 // Lane f < 3 of the quad owns state / observation feature f (lane 3 repeats lane 2's work): one history pass,
 // one row, one sampling chain per lane and phase instead of three.  Draws 0..2 of the phase go to features 0..2
 // as in the one-lane form.  `list` = the root particle's n_list entries of action a, staged as [j * STRIDE].
+// `otab` = the observation tables (HistLayout::obase0 onwards: A * ostride floats), in HBM or the search kernel's LDS copy.
 template <int K, int STRIDE>
 __device__ __forceinline__ bool gridworld_hist_step_quad(const Problem& P, QuadRng& g, const uint32_t* list, int n_list, uint32_t mask, uint32_t& sp,
-                                                         int a, int& o, double& r)
+                                                         int a, int& o, double& r, const float* otab)
 {
     const HistLayout L(P.gw_N, P.gw_G, 4);
     const int N = L.N, G = L.G;
@@ -1432,7 +1433,7 @@ __device__ __forceinline__ bool gridworld_hist_step_quad(const Problem& P, QuadR
     row.add(n, cnt);
     const int nv = row.sample(u01_of(g.at(g.draw + (uint32_t)f)), n);
     const int nx = quad_bcast(g.addr0, 0, nv), ny = quad_bcast(g.addr0, 1, nv), ng = quad_bcast(g.addr0, 2, nv);
-    row.fetch(P.hist_base + L.o_row(a, f, nv));
+    row.fetch(otab + (L.o_row(a, f, nv) - L.obase0));
     cnt = RowCount{0, 0};
     for (int j = 0; j < n_list; ++j) {
         const uint32_t e = list[j * STRIDE];

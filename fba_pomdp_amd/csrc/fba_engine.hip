@@ -933,6 +933,9 @@ int check_fault(fba_ctx* c)
     if (f >= 0x40000000)
         return fail(c, FBA_ESTATE, "slot %d: more belief updates in one run than the %d (episodes * horizon) a history particle was "
                     "sized for; create the context with FBA_DENSE_PARTICLES=1 in the environment to drive it beyond that", f - 0x40000000, c->P.hist_cap);
+    if (f < 0 && c->D.bkt)
+        return fail(c, FBA_ESTATE, "the search tree of slot %d outgrew its table of %d buckets (fba_config.tree_buckets; 0 = 2 * (sims + 2), which no search can fill)",
+                    -f - 1, 2 * c->D.bkt_lines);
     if (f < 0) return fail(c, FBA_ESTATE, "the search tree of slot %d needed more than the %d node records it has", -f - 1, c->D.max_nodes);
     return fail(c, FBA_ESTATE, "rejection sampling in slot %d accepted fewer than %d particles in %d attempts: no particle of the filter "
                 "can produce the observation (the reference loops forever in RejectionSampling.hpp:26-72 here)", f - 1, c->P.N, REJECT_MAX_ATTEMPTS);
@@ -1501,8 +1504,35 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         }
     }
 
+    // History-particle searches keep their tree in one table of 64-byte buckets (search_hist2_kernel, fba_state.h) where its keys fit:
+    // (parent bucket, action, observation) in 28 bits, counts below the root in 16.  FBA_HIST_TREE=records keeps node records + hash table
+    // (search_hist_kernel), for A/B runs and for what does not fit.
+    D.bkt = nullptr; D.bkt_lines = 0; D.s_root = nullptr;
+    size_t bkt_lines = 0;
+    const bool force_records = std::getenv("FBA_HIST_TREE") && !std::strcmp(std::getenv("FBA_HIST_TREE"), "records");
+    if (P.hist && P.sims <= 65536 && !force_records) {
+        long long buckets = cfg->tree_buckets > 0 ? cfg->tree_buckets : 2ll * (P.sims + 2);
+        buckets = std::max(buckets, 8ll);
+        const long long fit = (1ll << 28) / (4ll * P.O) - 2;   // ((buckets * 4 + 3) * O + O - 1 < 2^28: the root's "bucket" is index `buckets`)
+        if (cfg->tree_buckets <= 0 || buckets <= fit) {
+            buckets   = std::min(buckets, fit);
+            bkt_lines = (size_t)((buckets + 1) / 2);
+        }
+    }
+    if (cfg->tree_buckets < 0 || (cfg->tree_buckets > 0 && !bkt_lines && P.hist && !force_records)) {
+        fail(nullptr, FBA_EINVAL, "tree_buckets = %d: not a size this context's search can use (history-particle searches of at most 65536 "
+             "simulations, keys of 28 bits)", cfg->tree_buckets);
+        fba_destroy(c);
+        return FBA_EINVAL;
+    }
+    if (bkt_lines) {   // no node records, no separate hash table
+        D.max_nodes = P.sims + 2;
+        hcap = 0;
+    }
+
     // slots
-    const size_t per_slot = (size_t)P.N * (2 * 8 + 8 + 4 * (MAXINC + 1) + ((P.reinvig || P.cheat) ? 4 : (P.incub ? 6 : (P.hist ? 1 : 2))) * (size_t)P.Cs * 4) + (size_t)D.max_nodes * D.node_words * 4 + (size_t)hcap * hash_entry + 1024;
+    const size_t per_slot = (size_t)P.N * (2 * 8 + 8 + 4 * (MAXINC + 1) + ((P.reinvig || P.cheat) ? 4 : (P.incub ? 6 : (P.hist ? 1 : 2))) * (size_t)P.Cs * 4) +
+                            (bkt_lines ? bkt_lines * 128 : (size_t)D.max_nodes * D.node_words * 4 + (size_t)hcap * hash_entry) + 1024;
     int E = cfg->slots;
     if (E <= 0) {
         size_t free_b = 0, total_b = 0;
@@ -1627,10 +1657,17 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         const double thr = cfg->threshold;
         HIPC(hipMemcpy(D.lik + E, &thr, sizeof thr, hipMemcpyHostToDevice));
     }
-    CHK(dev_alloc(c, &D.nodes, (size_t)E * D.max_nodes * D.node_words, false));
-    if (hashed) {
-        CHK(dev_alloc(c, &D.hash, (size_t)E * hcap * hash_entry / 16));
+    if (bkt_lines) {
+        D.bkt_lines = (int32_t)bkt_lines;
+        CHK(dev_alloc(c, &D.bkt, (size_t)E * bkt_lines * 8));   // (zeroed: key 0 carries epoch 0, which no search uses)
         CHK(dev_alloc(c, &D.epoch, E));
+        CHK(dev_alloc(c, &D.nodes, 16));
+    } else {
+        CHK(dev_alloc(c, &D.nodes, (size_t)E * D.max_nodes * D.node_words, false));
+        if (hashed) {
+            CHK(dev_alloc(c, &D.hash, (size_t)E * hcap * hash_entry / 16));
+            CHK(dev_alloc(c, &D.epoch, E));
+        }
     }
     CHK(dev_alloc(c, &D.sim_steps, E));
     CHK(dev_alloc(c, &D.belief_steps, E));
@@ -1650,6 +1687,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         CHK(dev_alloc(c, &D.s_nodes, E));
         CHK(dev_alloc(c, &D.s_depth, E));
         CHK(dev_alloc(c, &D.search_done, E));
+        if (D.bkt) CHK(dev_alloc(c, &D.s_root, (size_t)6 * E));
         if (D.single_rec) {   // the chunked belief launches run over compacted lists of the slots that have work (fba_state.h)
             CHK(dev_alloc(c, &D.slot_list, E));
             CHK(dev_alloc(c, &D.scratch_idx, E));

@@ -637,7 +637,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, De
         if (do_step) {
 #endif
             term = gridworld_hist_step_quad<K, HIST_TREES>(P, g, stage + (size_t)(2 + ((hist_off >> (8 * a)) & 0xffu)) * HIST_TREES,
-                                                           hist_count(hist_cnt, a), hist_mask, sp, a, o, r);
+                                                           hist_count(hist_cnt, a), hist_mask, sp, a, o, r, P.hist_base + HistLayout(P.gw_N, P.gw_G, 4).obase0);
             ++steps;
 #ifdef FBA_PROFILE_SEARCH
         }
@@ -763,6 +763,373 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, De
 }
 
 // ---------------------------------------------------------------------------------------------
+// search_hist2_kernel: the history-particle search on a tree whose node IS its hash bucket, with every trip to HBM asked for one
+// loop iteration before it is needed.
+//
+// What bounded search_hist_kernel was the chain of dependent trips a tree level makes -- the node's
+// statistics, the two Dirichlet-row fetches of the step, then the hash probe for the child -- at two waves per SIMD, with the sixteen
+// trees of a wave in different phases, so that nearly every iteration of the wave waited for all of them.  Here:
+//   * DeviceState::bkt: one open-addressing table per slot, 64-byte buckets, two to a 128-byte line (the unit the memory side moves:
+//     profiles/r04_randline_counters.json).  A bucket is a node -- key = (parent bucket, action, observation) | epoch << 28, the four
+//     action counts as uint16, the four Q values -- so the probe for the child of (node, a, o) returns the child's statistics: one trip
+//     per level where there were two.  Three quarters of a gridworld tree's nodes are created and never reached again (measured on the
+//     CPU restatement: 48 000 of 65 537 at the BASELINE size); they have no statistics to keep and live as 4-byte keys in the last 16 bytes
+//     of the buckets (eight per line), found by the same one-line probe.  A node gets a bucket when it is reached a second time.
+//     Probing is linear over lines; a probe ends at the first line with a free bucket (nodes) / a free key slot (keys), nothing is ever
+//     deleted, the epoch in the key makes the table empty for the next search.
+//   * The line of the child is requested right after the step that produced the observation and consumed at the top of the NEXT
+//     iteration: the wave executes a whole iteration of the other trees' work in between.  The four lanes of a quad each load a quarter
+//     of the line (lane q: piece q of both buckets; lane 3 the eight keys) and exchange what is needed by DPP.  The next simulation's
+//     root particle is requested when the current one finishes, the same way.
+//   * The observation tables of the prior (3.7 KB) sit in LDS: the second of a step's two dependent row fetches never leaves the CU.
+//   * A filter of 2^k uniformly weighted particles is sampled in closed form (its prefix sums are exact multiples of 2^-k).
+// Same streams, same draws, same arithmetic as search_hist_kernel: every trace field is bit-equal.
+// ---------------------------------------------------------------------------------------------
+constexpr int H2_PF = 3;   // 16-byte pieces per lane the prefetch registers hold (a root particle of up to 12 pieces = 46 entries; more are fetched in place)
+
+template <int LANE>
+__device__ __forceinline__ uint32_t quad_get(uint32_t v)   // the value lane LANE of this quad holds (all four lanes of a quad are always active together)
+{
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, LANE * 0x55, 0xf, 0xf, true);
+}
+template <int LANE>
+__device__ __forceinline__ double quad_get_f64(uint32_t lo, uint32_t hi)
+{
+    return __hiloint2double((int)quad_get<LANE>(hi), (int)quad_get<LANE>(lo));
+}
+__device__ __forceinline__ uint32_t h2_home_line(uint32_t code, uint32_t nlines) { return __umulhi(child_hash((uint64_t)code), nlines); }
+
+template <int K>
+__global__ void __launch_bounds__(SEARCH_BLOCK) search_hist2_kernel(Problem P, DeviceState D)
+{
+    constexpr int AMAX = 4;
+    P.model = FBA_MODEL_BA_FACTORED; P.domain = FBA_DOM_GRIDWORLD; P.A = 4; P.belief = FBA_BELIEF_IMPORTANCE;
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x, tl = lane >> 2;
+    const int depth_cap = P.max_depth > 0 ? P.max_depth : 1;
+    double* path_q   = lds + tl;                                                                                  // [depth][trees]: the chosen action's Q as the descent saw it
+    int32_t* path_n  = reinterpret_cast<int32_t*>(path_q - tl + (size_t)depth_cap * HIST_TREES) + tl;            // ... and its count
+    float* path_r    = reinterpret_cast<float*>(path_n - tl + (size_t)depth_cap * HIST_TREES) + tl;
+    int32_t* path_na = reinterpret_cast<int32_t*>(path_r - tl + (size_t)depth_cap * HIST_TREES) + tl;            // bucket << 5 | action
+    uint32_t* stage  = reinterpret_cast<uint32_t*>(path_na - tl + (size_t)depth_cap * HIST_TREES) + tl;           // [Cs][trees]
+    float* otab      = reinterpret_cast<float*>(stage - tl + (size_t)P.Cs * HIST_TREES);                          // the prior's observation tables
+    const HistLayout HL(P.gw_N, P.gw_G, 4);
+    {   // every lane of the wave, before any quad leaves
+        const float4* src = reinterpret_cast<const float4*>(P.hist_base + HL.obase0);
+        float4* dst       = reinterpret_cast<float4*>(otab);
+        for (int i = lane; i < HL.ostride; i += SEARCH_BLOCK) dst[i] = src[i];   // 4 actions x ostride floats = ostride float4
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    const int e = blockIdx.x * HIST_TREES + tl;
+    if (e >= P.E || !D.active[e]) return;  // (a quad leaves together)
+
+    QuadRng g;
+    g.init(P.seed_lo, P.seed_hi, (uint32_t)D.run[e], (uint32_t)D.episode[e], (uint32_t)D.t[e], lane);
+    const int hist_len  = D.t[e];
+    const int max_tree_depth = min(P.horizon - hist_len, P.max_depth);
+    const float* prec   = D.p_rec + rec_base(P, D, e, D.bufsel[e]) * (size_t)P.Cs;
+    const uint32_t hist_cnt = D.hist_cnt[e];
+    const int hist_n        = hist_total(hist_cnt);
+    const int n4            = (hist_n + 5) >> 2;  // 16-byte pieces of a record: state, structure bits, entries
+    const uint32_t hist_off = (uint32_t)hist_offset(hist_cnt, 1) << 8 | (uint32_t)hist_offset(hist_cnt, 2) << 16 | (uint32_t)hist_offset(hist_cnt, 3) << 24;
+    const bool uni_exact    = (P.N & (P.N - 1)) == 0 && D.uni_total == 1.0;   // N = 2^k: the prefix sums of the weights 1/N are the exact values (i + 1) / N
+
+    if (P.planner == FBA_PLANNER_RANDOM) {  // RandomPlanner::selectAction RandomPlanner.cpp:14-24
+        g.stream(FBA_PHASE_SEARCH, (uint32_t)P.sims);
+        g.ensure(2);
+        (void)g.u01();                      // the belief sample: GridWorld::generateRandomAction does not look at the state
+        D.action[e] = g.slow_int(0, 4);
+        if (P.search_budget > 0) D.search_done[e] = 1;
+        return;
+    }
+    const uint32_t nlines = (uint32_t)D.bkt_lines;
+    uint4* tab            = D.bkt + (size_t)e * nlines * 8;
+    uint32_t* tabw        = reinterpret_cast<uint32_t*>(tab);
+    const int ROOT        = (int)(nlines * 2u);   // the root has no bucket: its statistics live in registers
+    const int budget      = P.search_budget;
+    int sim               = budget > 0 ? D.s_sim[e] : 0;
+    const bool resume     = sim > 0;
+    int n_nodes = 1, tree_depth = 0;
+    unsigned long long steps = 0;
+    int r_vis = 0, r_cn[AMAX];
+    double r_cq[AMAX];
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) { r_cn[a] = 0; r_cq[a] = 0.0; }
+    uint32_t epoch;
+    if (!resume) {
+        epoch = D.epoch[e] + 1;
+        if (epoch > 15u) {   // the four bits of the key are used up: empty the table (once in fifteen searches)
+            for (uint32_t k = (uint32_t)g.q; k < nlines * 8u; k += HIST_QUAD) tab[k] = make_uint4(0, 0, 0, 0);
+            epoch = 1;
+        }
+        D.epoch[e] = epoch;
+    } else {
+        n_nodes    = D.s_nodes[e];
+        tree_depth = D.s_depth[e];
+        epoch      = D.epoch[e];
+        const int32_t* rn = reinterpret_cast<const int32_t*>(D.s_root + (size_t)e * 6);
+        const double* rq  = D.s_root + (size_t)e * 6 + 2;
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a) { r_cn[a] = rn[a]; r_cq[a] = rq[a]; r_vis += r_cn[a]; }
+    }
+    const uint32_t ekey = epoch << 28;
+    int ts_src = -1;
+    if (P.planner == FBA_PLANNER_TS) {  // TSPlanner / BATSPlanner: one belief sample, then the search from that particle
+        g.stream(FBA_PHASE_SEARCH, (uint32_t)P.sims + 2u);
+        g.ensure(1);
+        ts_src = uniform_weight_pick(D.uni_scan, P.N, g.u01() * D.uni_total, D.uni_total);
+    }
+    int mode = 0, iter = 0;  // 0 = start a simulation, 1 = in the tree, 2 = rollout
+    int node = ROOT, dtg = 0, plen = 0, rdepth = 0, cur_src = 0;
+    uint32_t sp = 0, hist_mask = 0;
+    double rret = 0, rdisc = 1;
+    bool have_particle = false, pend = false, broken = false;
+    uint32_t pk = 0, pline = 0;          // the child being looked up: its key, its home line
+    uint4 pf[H2_PF];                     // this lane's share of what was requested an iteration ago: a line of the table, or a root particle
+#pragma unroll
+    for (int j = 0; j < H2_PF; ++j) pf[j] = make_uint4(0, 0, 0, 0);
+
+    // the root particle of simulation `sim`: Belief::sample() on its stream, and this lane's pieces of the record on their way
+    auto request_particle = [&]() {
+        g.stream(FBA_PHASE_SEARCH, (uint32_t)sim);
+        g.ensure(8);  // the root sample, the first action, six rows
+        if (ts_src >= 0) cur_src = ts_src;
+        else {
+            const double u = g.u01();
+            if (uni_exact) cur_src = max((int)ceil(u * (double)P.N) - 1, 0);   // the largest i with i / N < u (WeightedFilter.cpp:163-191 on exact prefix sums)
+            else cur_src = uniform_weight_pick(D.uni_scan, P.N, u * D.uni_total, D.uni_total);
+        }
+        const uint4* rp = reinterpret_cast<const uint4*>(prec + (size_t)cur_src * P.Cs);
+#pragma unroll
+        for (int j = 0; j < H2_PF; ++j) pf[j] = rp[min(g.q + HIST_QUAD * j, n4 - 1)];
+    };
+
+    while (true) {
+        int cn[AMAX] = {0, 0, 0, 0};          // the current node's statistics (below the root), set where the node is entered
+        double cq[AMAX] = {0.0, 0.0, 0.0, 0.0};
+        bool finish = false, do_step = true;
+        double delayed = 0;
+        if (mode == 0) {
+            if (sim >= P.sims) break;
+            if (budget > 0 && iter >= budget) break;   // out of iterations at a simulation boundary: park the search (below)
+            if (!have_particle) request_particle();
+            have_particle = false;
+#pragma unroll
+            for (int j = 0; j < H2_PF; ++j) {
+                const int k = g.q + HIST_QUAD * j;
+                if (k < n4) {
+                    stage[(4 * k + 0) * HIST_TREES] = pf[j].x;
+                    stage[(4 * k + 1) * HIST_TREES] = pf[j].y;
+                    stage[(4 * k + 2) * HIST_TREES] = pf[j].z;
+                    stage[(4 * k + 3) * HIST_TREES] = pf[j].w;
+                }
+            }
+            if (n4 > HIST_QUAD * H2_PF) {   // (records of more than 46 entries: the rest in place)
+                const uint4* rp = reinterpret_cast<const uint4*>(prec + (size_t)cur_src * P.Cs);
+                for (int k = g.q + HIST_QUAD * H2_PF; k < n4; k += HIST_QUAD) {
+                    const uint4 v = rp[k];
+                    stage[(4 * k + 0) * HIST_TREES] = v.x;
+                    stage[(4 * k + 1) * HIST_TREES] = v.y;
+                    stage[(4 * k + 2) * HIST_TREES] = v.z;
+                    stage[(4 * k + 3) * HIST_TREES] = v.w;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the other lanes' pieces (LDS operations of one wave complete in order)
+            hist_mask = stage[1 * HIST_TREES];
+            sp        = (hist_mask >> 16) & 0x3ffu;
+            node = ROOT; dtg = max_tree_depth; plen = 0; mode = 1; pend = false;
+        } else if (mode == 1 && pend) {
+            // traverseChanceNode's child lookup (POUCT.cpp:224-246), answered by the line requested an iteration ago
+            pend = false;
+            const uint32_t k0 = quad_get<0>(pf[0].x), k1 = quad_get<0>(pf[1].x);
+            const bool v0 = (k0 >> 28) == epoch, v1 = (k1 >> 28) == epoch;
+            uint32_t lm = 0, lf = 8;   // lane 3 holds the line's eight keys: is pk among them, and the first free place
+            {
+                const uint32_t w[8] = {pf[0].x, pf[0].y, pf[0].z, pf[0].w, pf[1].x, pf[1].y, pf[1].z, pf[1].w};
+#pragma unroll
+                for (int j = 7; j >= 0; --j) {
+                    lm |= (w[j] == pk) ? 1u : 0u;
+                    lf = ((w[j] >> 28) != epoch) ? (uint32_t)j : lf;
+                }
+            }
+            lm = quad_get<3>(lm);
+            lf = quad_get<3>(lf);
+            int hit = (k0 == pk) ? 0 : ((k1 == pk) ? 1 : -1);          // the child has a bucket in its home line
+            int bucket = (int)(pline * 2u) + max(hit, 0);
+            bool is_leaf = false, have_stats = hit >= 0;
+            int free_bucket = (!v0) ? (int)(pline * 2u) : ((!v1) ? (int)(pline * 2u) + 1 : -1);
+            int free_key    = lf < 8u ? (int)((pline * 2u + (lf >> 2)) * 16u + 12u + (lf & 3u)) : -1;   // word index in the table
+            if (hit < 0) {
+                const bool nodes_done = free_bucket >= 0;              // a free bucket ends the probe for a node
+                const bool keys_done  = lm != 0u || free_key >= 0;     // a match or a free place ends the probe for a key
+                is_leaf = lm != 0u;
+                if (!(nodes_done && keys_done)) {
+                    // the home line is full of other nodes or other keys: walk on, line by line (a few per cent of the lookups at load 1/2)
+                    bool need_n = !nodes_done, need_k = !keys_done;
+                    uint32_t line = pline;
+                    for (uint32_t n = 1; n < nlines && (need_n || need_k); ++n) {
+                        line = line + 1u == nlines ? 0u : line + 1u;
+                        const uint4* lp = tab + (size_t)line * 8;
+                        const uint32_t c0 = lp[0].x, c1 = lp[4].x;
+                        const uint4 ka = lp[3], kb = lp[7];
+                        if (need_n) {
+                            if (c0 == pk || c1 == pk) { hit = c0 == pk ? 0 : 1; bucket = (int)(line * 2u) + hit; need_n = false; need_k = false; is_leaf = false; }
+                            else if ((c0 >> 28) != epoch || (c1 >> 28) != epoch) { free_bucket = (int)(line * 2u) + ((c0 >> 28) != epoch ? 0 : 1); need_n = false; }
+                        }
+                        if (need_k) {
+                            const uint32_t w[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
+                            int fj = 8;
+                            bool m = false;
+#pragma unroll
+                            for (int j = 7; j >= 0; --j) {
+                                m  = m || w[j] == pk;
+                                fj = ((w[j] >> 28) != epoch) ? j : fj;
+                            }
+                            if (m) { is_leaf = true; need_k = false; }
+                            else if (fj < 8) { free_key = (int)((line * 2u + ((uint32_t)fj >> 2)) * 16u + 12u + ((uint32_t)fj & 3u)); need_k = false; }
+                        }
+                    }
+                    if (need_n || need_k) { atomicCAS(D.fault, 0, -(1 + e)); broken = true; }   // the table is full (DeviceState::bkt_lines too small for this tree)
+                }
+            }
+            if (hit >= 0) {          // traverseActionNode of an existing node with statistics
+                if (have_stats) {
+                    const uint4 mine = hit ? pf[1] : pf[0];   // this lane's piece of the bucket
+                    const uint32_t c01 = quad_get<0>(mine.y), c23 = quad_get<0>(mine.z);
+                    cn[0] = (int)(c01 & 0xffffu); cn[1] = (int)(c01 >> 16); cn[2] = (int)(c23 & 0xffffu); cn[3] = (int)(c23 >> 16);
+                    cq[0] = quad_get_f64<1>(mine.x, mine.y); cq[1] = quad_get_f64<1>(mine.z, mine.w);
+                    cq[2] = quad_get_f64<2>(mine.x, mine.y); cq[3] = quad_get_f64<2>(mine.z, mine.w);
+                } else {             // found further down the probe sequence: fetch it now
+                    const uint4* bp   = tab + (size_t)bucket * 4;
+                    const uint4 h     = bp[0];
+                    const double2 q01 = *reinterpret_cast<const double2*>(bp + 1);
+                    const double2 q23 = *reinterpret_cast<const double2*>(bp + 2);
+                    cn[0] = (int)(h.y & 0xffffu); cn[1] = (int)(h.y >> 16); cn[2] = (int)(h.z & 0xffffu); cn[3] = (int)(h.z >> 16);
+                    cq[0] = q01.x; cq[1] = q01.y; cq[2] = q23.x; cq[3] = q23.y;
+                }
+                node = bucket; --dtg;
+            } else if (broken) {
+                finish = true; do_step = false; plen = 0; sim = P.sims;   // (the host reports the fault; leave the loop)
+            } else if (is_leaf) {    // a node that exists and was never reached again: all its statistics are zero; it gets a bucket now
+                if (free_bucket < 0) { atomicCAS(D.fault, 0, -(1 + e)); broken = true; finish = true; do_step = false; plen = 0; sim = P.sims; }
+                else {
+                    uint4* bp = tab + (size_t)free_bucket * 4;
+                    if (g.q < 3) bp[g.q] = make_uint4(g.q == 0 ? pk : 0u, 0u, 0u, 0u);   // key + counts, Q's; the bucket's four keys stay
+                    node = free_bucket; --dtg;
+                }
+            } else {                 // no such child: create it, then rollout(depth_to_go - 1)  (POUCT.cpp:236-244)
+                if (free_key < 0) { atomicCAS(D.fault, 0, -(1 + e)); broken = true; finish = true; do_step = false; plen = 0; sim = P.sims; }
+                else {
+                    tabw[free_key] = pk;
+                    ++n_nodes;
+                    mode = 2; rdepth = dtg - 1; rret = 0; rdisc = 1;
+                    if (rdepth == 0) { finish = true; do_step = false; }
+                }
+            }
+        }
+        if (mode == 1 && dtg == 0 && !finish) { finish = true; do_step = false; }
+        if (mode == 1) tree_depth = max(tree_depth, max_tree_depth - dtg);
+        int a = 0, o = 0;
+        double r = 0;
+        bool term = false;
+        if (do_step) {
+            g.ensure(7);  // the action, six rows
+            if (mode == 1) {  // traverseActionNode
+                if (node == ROOT) a = ucb_pick<AMAX>(P, g, D.log1p_tab, r_vis, r_cn, r_cq, true);
+                else {
+                    a = ucb_pick<AMAX>(P, g, D.log1p_tab, ((cn[0] + cn[1]) + cn[2]) + cn[3], cn, cq, true);
+                    path_n[(size_t)plen * HIST_TREES] = a == 0 ? cn[0] : (a == 1 ? cn[1] : (a == 2 ? cn[2] : cn[3]));
+                    path_q[(size_t)plen * HIST_TREES] = a == 0 ? cq[0] : (a == 1 ? cq[1] : (a == 2 ? cq[2] : cq[3]));
+                }
+            } else {
+                a = g.slow_int(0, 4);  // GridWorld::generateRandomAction :220-226
+            }
+            term = gridworld_hist_step_quad<K, HIST_TREES>(P, g, stage + (size_t)(2 + ((hist_off >> (8 * a)) & 0xffu)) * HIST_TREES,
+                                                           hist_count(hist_cnt, a), hist_mask, sp, a, o, r, otab);
+            ++steps;
+            if (mode == 1) {  // traverseChanceNode
+                path_r[(size_t)plen * HIST_TREES]  = (float)r;
+                path_na[(size_t)plen * HIST_TREES] = (node << 5) | a;
+                ++plen;
+                if (term) finish = true;
+                else {   // ask for the child's line; it is looked at when this loop comes round again
+                    const uint32_t code = ((uint32_t)node * 4u + (uint32_t)a) * (uint32_t)P.O + (uint32_t)o;
+                    pk    = ekey | code;
+                    pline = h2_home_line(code, nlines);
+                    const uint4* lp = tab + (size_t)pline * 8;
+                    pf[0] = lp[g.q];
+                    pf[1] = lp[4 + g.q];
+                    pend  = true;
+                }
+            } else {
+                rret += r * rdisc;
+                rdisc *= P.gamma;
+                --rdepth;
+                if (rdepth == 0 || term) { delayed = rret; finish = true; }
+            }
+        }
+        if (finish) {  // back-up, leaf to root (MCTSTreeNodes.cpp:8-12, 59-62): two stores per level, the loads were the descent's
+            double del = delayed;
+            for (int k = plen - 1; k >= 0; --k) {
+                const int na     = path_na[(size_t)k * HIST_TREES];
+                const double ret = (double)path_r[(size_t)k * HIST_TREES] + P.gamma * del;
+                const int act    = na & 31;
+                if ((na >> 5) == ROOT) {
+                    int n = 0;
+                    double q = 0.0;
+#pragma unroll
+                    for (int a2 = 0; a2 < AMAX; ++a2)
+                        if (a2 == act) { n = r_cn[a2]; q = r_cq[a2]; }
+                    ++n;
+                    q += (ret - q) / (double)n;
+#pragma unroll
+                    for (int a2 = 0; a2 < AMAX; ++a2)
+                        if (a2 == act) { r_cn[a2] = n; r_cq[a2] = q; }
+                    ++r_vis;
+                } else {
+                    uint32_t* bw    = tabw + (size_t)(na >> 5) * 16;
+                    const int n     = path_n[(size_t)k * HIST_TREES] + 1;
+                    const double q0 = path_q[(size_t)k * HIST_TREES];
+                    reinterpret_cast<uint16_t*>(bw + 1)[act] = (uint16_t)n;
+                    reinterpret_cast<double*>(bw + 4)[act]   = q0 + (ret - q0) / (double)n;
+                }
+                del = ret;
+            }
+            if (!broken) ++sim;
+            mode = 0; pend = false;
+            if (sim < P.sims) { request_particle(); have_particle = true; }
+        }
+        ++iter;
+    }
+    if (sim < P.sims) {   // parked: the four lanes of the quad hold the same values and store them to the same places
+        int32_t* rn = reinterpret_cast<int32_t*>(D.s_root + (size_t)e * 6);
+        double* rq  = D.s_root + (size_t)e * 6 + 2;
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a) { rn[a] = r_cn[a]; rq[a] = r_cq[a]; }
+        D.s_sim[e]   = sim;
+        D.s_nodes[e] = n_nodes;
+        D.s_depth[e] = tree_depth;
+        if (g.q == 0) D.sim_steps[e] += steps;
+        return;   // (search_done[e] stays 0: env_kernel leaves the slot alone)
+    }
+    if (D.s_sim) D.s_sim[e] = 0;
+    if (budget > 0) D.search_done[e] = 1;
+    g.stream(FBA_PHASE_SEARCH, (uint32_t)P.sims + 1u);
+    g.ensure(1);
+    const int best = ucb_pick<AMAX>(P, g, D.log1p_tab, 0, r_cn, r_cq, false);
+    D.action[e]    = best;
+    if (g.q == 0) D.sim_steps[e] += steps;
+    fba_trace_rec& rec = D.cur[e];
+    rec.n_nodes    = n_nodes;
+    rec.tree_depth = tree_depth;
+#pragma unroll
+    for (int a = 0; a < FBA_MAX_ACTIONS; ++a) {
+        rec.root_n[a] = a < AMAX ? r_cn[a < AMAX ? a : 0] : 0;
+        rec.root_q[a] = a < AMAX ? r_cq[a < AMAX ? a : 0] : 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host launcher
 // ---------------------------------------------------------------------------------------------
 void launch_search(const Problem& P, const DeviceState& D, hipStream_t st)
@@ -803,6 +1170,13 @@ void launch_search(const Problem& P, const DeviceState& D, hipStream_t st)
     if (P.hist) {  // history particles (gridworld FBA-POMDP): four lanes per tree
         lds = (size_t)depth_cap * HIST_TREES * (sizeof(double) + sizeof(int32_t) + sizeof(float) + sizeof(int32_t)) + (size_t)P.Cs * HIST_TREES * sizeof(float);
         const dim3 qgrid(ceil_div(P.E, HIST_TREES));
+        if (D.bkt) {   // the tree as one table of buckets, trips to memory requested an iteration ahead
+            lds += (size_t)4 * HistLayout(P.gw_N, P.gw_G, 4).ostride * sizeof(float);   // the prior's observation tables
+            if (P.hist_row <= 8) hipLaunchKernelGGL((search_hist2_kernel<8>), qgrid, block, lds, st, P, D);
+            else if (P.hist_row <= 12) hipLaunchKernelGGL((search_hist2_kernel<12>), qgrid, block, lds, st, P, D);
+            else hipLaunchKernelGGL((search_hist2_kernel<16>), qgrid, block, lds, st, P, D);
+            return;
+        }
         if (P.hist_row <= 8) hipLaunchKernelGGL((search_hist_kernel<8>), qgrid, block, lds, st, P, D);
         else if (P.hist_row <= 12) hipLaunchKernelGGL((search_hist_kernel<12>), qgrid, block, lds, st, P, D);
         else hipLaunchKernelGGL((search_hist_kernel<16>), qgrid, block, lds, st, P, D);

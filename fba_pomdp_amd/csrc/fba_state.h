@@ -111,6 +111,13 @@ struct DeviceState {
     int32_t hash_compact;  // 8-byte entries {epoch << 27 | code, child} instead (codes below 2^27): fba_kernels.hip child_get
     uint32_t* epoch;    // [E]
     const double* log1p_tab; // [sims + 1]
+    // history-particle searches (search_hist2_kernel): the tree of a slot is ONE open-addressing table of 64-byte buckets, two to a 128-byte
+    // line, keyed by (parent bucket, action, observation) | epoch << 28.  A bucket IS a node: {key, n0 | n1 << 16, n2 | n3 << 16, -},
+    // {q0, q1}, {q2, q3}, and four 4-byte keys of nodes that exist but were never visited again (three quarters of a tree's nodes: they
+    // have no statistics to keep).  The probe for a child returns its statistics in the same line: one trip to memory per tree level.
+    uint4* bkt;           // [E][bkt_lines][8] or null (the node records + hash table above serve the search instead)
+    int32_t bkt_lines;    // 128-byte lines per slot (buckets / 2)
+    double* s_root;       // [E][6] budgeted searches: the parked root's {n0..n3} (as int32) and {q0..q3}
     // budgeted searches (Problem::search_budget > 0): a search that ran out of iterations is parked -- the root's statistics in its
     // node record, the rest here -- and resumed by the next launch
     int32_t* s_sim;       // [E] simulations done by the parked search (0 = none parked: the next launch starts a search)

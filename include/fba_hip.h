@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FBA_ABI_VERSION 2   /* 2: fba_config.belief_option and .search_budget, fba_belief_get_particle, fba_get_trace_hist; hosts check fba_abi_version() == FBA_ABI_VERSION before fba_create */
+#define FBA_ABI_VERSION 3   /* 3: fba_config.tree_buckets; 2: fba_config.belief_option and .search_budget, fba_belief_get_particle, fba_get_trace_hist; hosts check fba_abi_version() == FBA_ABI_VERSION before fba_create */
 #define FBA_MAX_ACTIONS 24
 
 /* domains: reference src/domains, selected by -D (DomainConf.hpp) */
@@ -132,6 +132,11 @@ typedef struct fba_config {
                               * are parked in their trees and resumed by the next launch, and slots whose search is done take their
                               * real step and belief update meanwhile -- slots advance on their own, results are the same
                               * (Episode.cpp:39-55 and BAPOMDPExperiment.cpp:44-75 never couple two runs) */
+    int32_t tree_buckets;    /* history-particle searches: 64-byte node buckets per slot's tree (the reference's tree is heap-allocated and
+                              * unbounded: MCTSTreeNodes.hpp:39-108).  0 = 2 * (sims + 2), which no search can fill -- 8.4 MB per slot at 65 536
+                              * simulations.  A gridworld tree gives a bucket only to the nodes it reaches a second time (a quarter of them at
+                              * the BASELINE size), so a throughput run that wants more slots per GB passes less here; a search that does outgrow
+                              * its table stops with FBA_ESTATE and a message, never with a wrong result */
 } fba_config;
 
 /* One record per real time-step: the information the reference prints at -v 2 / -v 3

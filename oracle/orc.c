@@ -2927,6 +2927,17 @@ static int32_t select_action(orc_ctx* c, int hist_len, orc_trace_rec* rec)
         st.cnt = c->P[src].cnt;
         traverse_action(c, root, &st, c->tr.max_tree_depth);
     }
+    if (getenv("ORC_TREE_STATS")) { /* diagnostic: how many nodes were ever revisited, and how the visits spread (sizing of tree records) */
+        int32_t k, v0 = 0, v1 = 0, v2_7 = 0, v8 = 0;
+        long long sumv = 0;
+        for (k = 1; k < c->tr.n_nodes; ++k) {
+            int32_t v = c->tr.visits[k];
+            sumv += v;
+            if (v == 0) v0++; else if (v == 1) v1++; else if (v < 8) v2_7++; else v8++;
+        }
+        fprintf(stderr, "tree_stats t=%d nodes=%d never_revisited=%d once=%d 2to7=%d ge8=%d levels_below_root_per_sim=%.3f depth=%d\n", hist_len,
+                c->tr.n_nodes, v0, v1, v2_7, v8, (double)sumv / n, c->tr.tree_depth);
+    }
     orc_rng_stream(&c->rng, ORC_PH_SEARCH, (uint32_t)n + 1);
     best = select_chance_ucb(c, root, 0);
     if (rec) {

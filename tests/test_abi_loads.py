@@ -25,7 +25,7 @@ def test_exports_every_declared_symbol(lib):
     assert declared == set(N.EXPORTS), (declared ^ set(N.EXPORTS))
     for sym in declared:
         assert hasattr(lib, sym), f"libfba_hip.so does not export {sym}"
-    assert lib.fba_abi_version() == 2   # 2: fba_config.belief_option, fba_belief_get_particle
+    assert lib.fba_abi_version() == 3   # 3: fba_config.tree_buckets; 2: fba_config.belief_option, fba_belief_get_particle
 
 
 def test_default_config_matches_reference_cli_defaults(lib):

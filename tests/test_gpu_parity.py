@@ -842,6 +842,46 @@ def test_budgeted_searches_give_the_results_of_whole_searches(size, budget):
     assert np.array_equal(r0[0], r1[0]) and np.array_equal(r0[1], r1[1])
 
 
+@pytest.mark.parametrize("size,sims,buckets,budget", [(3, 128, 128, 0), (3, 200, 0, 0), (5, 160, 160, 0), (5, 300, 0, 37), (7, 256, 256, 0), (4, 128, 130, 11)])
+def test_the_bucket_tree_gives_the_results_of_node_records(size, sims, buckets, budget, monkeypatch):
+    """search_hist2_kernel keeps a slot's tree in one open-addressing table of 64-byte buckets -- a node IS its bucket, keyed by (parent
+    bucket, action, observation); nodes never reached again are 4-byte keys in the buckets' spare words -- and asks for every line an
+    iteration before it looks at it.  None of that may show in a result: every trace field (actions, root statistics, node counts, tree
+    depths, the belief checksum), statistic and counter equals search_hist_kernel's on node records + hash table (FBA_HIST_TREE=records),
+    with the default table (2 * (sims + 2) buckets, never full) and with one of `sims` buckets, which a dense little gridworld fills to the
+    brim: most lookups then walk past their home line (the probe sequences of nodes and of keys end at different lines)."""
+    kw = dict(model=N.MODEL_BA_FACTORED, belief="importance_sampling", size=size, sims=sims, particles=64, structure_prior=2, horizon=7,
+              episodes=2, runs=9, slots=5, seed=1300 + size, trace=1, search_budget=budget)
+    out = []
+    for records in (True, False):
+        if records:
+            monkeypatch.setenv("FBA_HIST_TREE", "records")
+        else:
+            monkeypatch.delenv("FBA_HIST_TREE")
+        eng = fba.Engine("gridworld", tree_buckets=0 if records else buckets, **kw)
+        assert eng.particle_bytes < 4096
+        stats = eng.run_bapomdp()
+        c = eng.counters()
+        out.append((eng.trace(), [(s.count, s.mean, s.m2) for s in stats], (c.sim_steps, c.belief_steps, c.env_steps), eng.returns()))
+        eng.close()
+    (t0, s0, c0, r0), (t1, s1, c1, r1) = out
+    assert len(t0) == len(t1) > 14 and s0 == s1 and c0 == c1
+    for name in t0.dtype.names:
+        assert np.array_equal(t0[name], t1[name]), name
+    assert np.array_equal(r0[0], r1[0]) and np.array_equal(r0[1], r1[1])
+
+
+def test_a_bucket_tree_that_is_too_small_stops_the_experiment_loudly():
+    """fba_config.tree_buckets below what a search needs: FBA_ESTATE with the knob's name, never a wrong action."""
+    eng = fba.Engine("gridworld", model=N.MODEL_BA_FACTORED, belief="importance_sampling", size=3, sims=512, particles=64, structure_prior=2,
+                     horizon=7, episodes=1, runs=4, slots=4, seed=5, tree_buckets=8)
+    with pytest.raises(fba.FbaError, match="tree_buckets"):
+        eng.run_bapomdp()
+    with pytest.raises(ValueError, match="tree_buckets"):
+        fba.Engine("gridworld", model=N.MODEL_BA_FACTORED, belief="importance_sampling", size=3, sims=512, particles=64, structure_prior=2,
+                   horizon=7, episodes=1, runs=4, slots=4, seed=5, tree_buckets=-3)
+
+
 def test_budgeted_throughput_driver_makes_the_steps_it_is_asked_for():
     """fba_run_ticks with a search budget: launches until the slots have together made ticks x slots real steps; every record it
     traces is a record the lock-step driver traces too."""

@@ -42,6 +42,10 @@ def test_tiger_kernels_use_no_scratch(tmp_path):
     assert len(hist) == 3, sorted(seen)
     for name, (scratch, vgprs, spills) in hist.items():
         assert scratch == 0 and spills == 0 and vgprs <= 256, (name, scratch, vgprs, spills)
+    hist2 = {n: v for n, v in seen.items() if "search_hist2_kernel" in n}   # the same search on the bucket table, lines requested an iteration ahead
+    assert len(hist2) == 3, sorted(seen)
+    for name, (scratch, vgprs, spills) in hist2.items():
+        assert scratch == 0 and spills == 0 and vgprs <= 256, (name, scratch, vgprs, spills)
     regular = re.compile(r"search_kernelILb[01]ELi\d+ELb1E|(reject|importance)_kernelILb1E|is_multi_step_kernelILb1E")
     for name, (scratch, vgprs, spills) in seen.items():
         if not regular.search(name):              # (the `regular` Dirichlet instantiations carry the gamma sampler)
