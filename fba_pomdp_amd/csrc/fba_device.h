@@ -336,6 +336,12 @@ struct Problem {
     int32_t hist_row;   // the longest Dirichlet row of the model (max(N, G)): picks the row width the kernels are instantiated for
     const float* hist_base;  // the prior count table every particle starts from (max layout, x / y nodes without the goal parent)
     const float* hist_alt;   // [A][2][N*N*G*N]: the x / y transition nodes as a particle with the goal as their third parent starts them
+    // The same rows once more, deduplicated (a gridworld prior has a few dozen distinct Dirichlet rows among its ten thousand): one byte per
+    // row slot (HistRowIds numbering) + the distinct rows, hist_row rounded up to 4 floats each -- 13 KB at N = 7, which the search keeps in LDS
+    // so that no simulated step waits for a row.  Null when the prior has more than 256 distinct rows.
+    const uint8_t* hist_lds;    // [hist_rid_bytes] row ids, then [hist_distinct][K] floats
+    int32_t hist_rid_bytes;     // multiple of 16
+    int32_t hist_distinct;
     int32_t S, A, O;
     int32_t N;          // particles per slot
     int32_t C;          // floats per particle count blob
@@ -1178,6 +1184,38 @@ struct HistLayout {
     __host__ __device__ int o_row(int a, int f, int v) const { return obase0 + a * ostride + (f == 2 ? 2 * ON + v * GS : f * ON + v * NS); }
 };
 
+// row slots of the deduplicated tables (Problem::hist_lds): per action the x, y and goal transition rows (N*N*G slots each; an x / y node
+// without the goal parent uses the first N*N), then per action and x / y node the rows with the goal parent, then the observation rows
+struct HistRowIds {
+    int N, G, RR, ALT0, OB0, total;
+    __host__ __device__ HistRowIds(int n, int g, int a) : N(n), G(g)
+    {
+        RR = N * N * G; ALT0 = a * 3 * RR; OB0 = ALT0 + a * 2 * RR; total = OB0 + a * (2 * N + G);
+    }
+    __host__ __device__ int t(int a, int f, bool with_goal, int cell, int gl) const
+    {
+        if (f < 2 && with_goal) return ALT0 + (a * 2 + f) * RR + cell * G + gl;
+        return a * 3 * RR + f * RR + (f == 2 ? cell * G + gl : cell);
+    }
+    __host__ __device__ int o(int a, int f, int v) const { return OB0 + a * (2 * N + G) + (f == 2 ? 2 * N + v : f * N + v); }
+};
+// where a step's Dirichlet rows come from: the padded tables in HBM (L2-resident), the same with the observation tables in LDS, or the
+// deduplicated rows in LDS
+struct HistRowsGlobal {
+    const float* base; const float* alt; const float* otab; HistLayout L;
+    __device__ __forceinline__ const float* t(int a, int f, bool with_goal, int cell, int gl) const
+    {
+        return f < 2 && with_goal ? alt + L.alt_row(a, f, cell, gl) : base + L.t_row(a, f, with_goal, cell, gl);
+    }
+    __device__ __forceinline__ const float* o(int a, int f, int v) const { return otab + (L.o_row(a, f, v) - L.obase0); }
+};
+template <int K>
+struct HistRowsLds {
+    const uint8_t* rid; const float* rows; HistRowIds I;
+    __device__ __forceinline__ const float* t(int a, int f, bool with_goal, int cell, int gl) const { return rows + (int)rid[I.t(a, f, with_goal, cell, gl)] * K; }
+    __device__ __forceinline__ const float* o(int a, int f, int v) const { return rows + (int)rid[I.o(a, f, v)] * K; }
+};
+
 // increments per cell of one row (at most 16 cells), 8 bits each
 struct RowCount {
     uint64_t lo, hi;
@@ -1189,6 +1227,28 @@ struct RowCount {
     }
     __device__ __forceinline__ float at(int i) const { return (float)(uint32_t)(((i < 8 ? lo >> (8 * i) : hi >> (8 * (i - 8)))) & 0xffull); }
 };
+
+// the same with 6 bits per cell in one word: at most 10 cells, at most 63 increments per cell (records of at most 63 entries)
+struct RowCount6 {
+    uint64_t v;
+    __device__ __forceinline__ void add(bool hit, int cell) { v += (uint64_t)(hit ? 1u : 0u) << (6 * cell); }
+    __device__ __forceinline__ float at(int i) const { return (float)(uint32_t)((v >> ((6 * i) & 63)) & 63ull); }
+};
+// quad-wide sum by DPP (all four lanes of a quad are active together): every lane ends with the total.  No field of a RowCount6 can carry
+// into its neighbour (the four lanes' counts of one cell add up to at most 63), so the 64-bit sum is a plain one.
+template <int CTRL>
+__device__ __forceinline__ uint64_t quad_perm_u64(uint64_t x)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)x, CTRL, 0xf, 0xf, true);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(x >> 32), CTRL, 0xf, 0xf, true);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t quad_sum_u64(uint64_t x)
+{
+    x += quad_perm_u64<0xB1>(x);   // lanes 1 0 3 2
+    x += quad_perm_u64<0x4E>(x);   // lanes 2 3 0 1
+    return x;
+}
 
 struct GlobalEntries {
     const uint32_t* p;
@@ -1209,7 +1269,8 @@ struct HistRow {
             r[4 * i] = v.x; r[4 * i + 1] = v.y; r[4 * i + 2] = v.z; r[4 * i + 3] = v.w;
         }
     }
-    __device__ __forceinline__ void add(int n, const RowCount& c)
+    template <class COUNTS>
+    __device__ __forceinline__ void add(int n, const COUNTS& c)
     {
 #pragma unroll
         for (int i = 0; i < K; ++i) r[i] = i < n ? r[i] + c.at(i) : 0.f;
@@ -1224,11 +1285,14 @@ struct HistRow {
         for (int i = 1; i < K; ++i)
             if (i < n) total += (double)r[i];
         const double p = u * total;
+        // "p < (double)sum" for a float sum is "sum > pf" with pf the largest float <= p (p >= 0): the comparisons stay in fp32
+        float pf = (float)p;
+        if ((double)pf > p) pf = __uint_as_float(__float_as_uint(pf) - 1u);
         float sum = r[0];
         int pick  = 0;
 #pragma unroll
         for (int i = 1; i < K; ++i) {
-            pick += (i < n && !(p < (double)sum)) ? 1 : 0;
+            pick += (i < n && !(sum > pf)) ? 1 : 0;
             sum += r[i];
         }
         return pick;
@@ -1407,10 +1471,14 @@ __device__ __forceinline__ int quad_bcast(int addr0, int from, int v) { return _
 // Lane f < 3 of the quad owns state / observation feature f (lane 3 repeats lane 2's work): one history pass,
 // one row, one sampling chain per lane and phase instead of three.  Draws 0..2 of the phase go to features 0..2
 // as in the one-lane form.  `list` = the root particle's n_list entries of action a, staged as [j * STRIDE].
-// `otab` = the observation tables (HistLayout::obase0 onwards: A * ostride floats), in HBM or the search kernel's LDS copy.
-template <int K, int STRIDE>
+// `rows` = where the Dirichlet rows come from (HistRowsGlobal / HistRowsLds).
+// SPLIT: the passes over the record's entries are what a step costs once histories have grown (twenty vector instructions per entry
+// and pass when every lane walks all of them for its own feature).  With SPLIT lane q walks entries q, q + 4, ... and counts for all three
+// features -- 6-bit counters, one 64-bit word per feature -- and a DPP sum over the quad hands every lane the totals: a quarter of the
+// entries per lane.  Same counts, so the same rows; needs records of at most 63 entries (else the lanes walk as before).
+template <int K, int STRIDE, bool SPLIT = false, class ROWS>
 __device__ __forceinline__ bool gridworld_hist_step_quad(const Problem& P, QuadRng& g, const uint32_t* list, int n_list, uint32_t mask, uint32_t& sp,
-                                                         int a, int& o, double& r, const float* otab)
+                                                         int a, int& o, double& r, const ROWS& rows)
 {
     const HistLayout L(P.gw_N, P.gw_G, 4);
     const int N = L.N, G = L.G;
@@ -1420,26 +1488,51 @@ __device__ __forceinline__ bool gridworld_hist_step_quad(const Problem& P, QuadR
     const bool with_goal = f == 2 || ((mask >> (2 * a + f)) & 1u);
     const int shift = 3 * f;
     const uint32_t fmask = f == 2 ? 15u : 7u;
+    const bool split = SPLIT && P.hist_cap <= 63;
     HistRow<K> row;
-    row.fetch(f < 2 && with_goal ? P.hist_alt + L.alt_row(a, f, cell, gl) : P.hist_base + L.t_row(a, f, with_goal, cell, gl));
-    RowCount cnt{0, 0};
-    {
+    row.fetch(rows.t(a, f, with_goal, cell, gl));
+    if (split) {
+        const bool mx = (mask >> (2 * a)) & 1u, my = (mask >> (2 * a + 1)) & 1u;
+        RowCount6 cx{0}, cy{0}, cg{0};
+        for (int j = g.q; j < n_list; j += HIST_QUAD) {
+            const uint32_t e = list[j * STRIDE];
+            const bool hit_xy = ((e ^ sp) & 0x3fu) == 0, hit_g = ((e ^ sp) & 0x3ffu) == 0;
+            cx.add(mx ? hit_g : hit_xy, (int)((e >> 10) & 7u));
+            cy.add(my ? hit_g : hit_xy, (int)((e >> 13) & 7u));
+            cg.add(hit_g, (int)((e >> 16) & 15u));
+        }
+        const uint64_t sx = quad_sum_u64(cx.v), sy = quad_sum_u64(cy.v), sg = quad_sum_u64(cg.v);   // (every lane executes every DPP sum)
+        row.add(n, RowCount6{f == 0 ? sx : (f == 1 ? sy : sg)});
+    } else {
+        RowCount cnt{0, 0};
         const uint32_t keep = with_goal ? 0x3ffu : 0x3fu;
         for (int j = 0; j < n_list; ++j) {
             const uint32_t e = list[j * STRIDE];
             cnt.add(((e ^ sp) & keep) == 0, (int)((e >> (10 + shift)) & fmask));
         }
+        row.add(n, cnt);
     }
-    row.add(n, cnt);
     const int nv = row.sample(u01_of(g.at(g.draw + (uint32_t)f)), n);
     const int nx = quad_bcast(g.addr0, 0, nv), ny = quad_bcast(g.addr0, 1, nv), ng = quad_bcast(g.addr0, 2, nv);
-    row.fetch(otab + (L.o_row(a, f, nv) - L.obase0));
-    cnt = RowCount{0, 0};
-    for (int j = 0; j < n_list; ++j) {
-        const uint32_t e = list[j * STRIDE];
-        cnt.add(((e >> shift) & fmask) == (uint32_t)nv, (int)((e >> (20 + shift)) & fmask));
+    row.fetch(rows.o(a, f, nv));
+    if (split) {
+        RowCount6 ox{0}, oy{0}, og{0};
+        for (int j = g.q; j < n_list; j += HIST_QUAD) {
+            const uint32_t e = list[j * STRIDE];
+            ox.add((int)(e & 7u) == nx, (int)((e >> 20) & 7u));
+            oy.add((int)((e >> 3) & 7u) == ny, (int)((e >> 23) & 7u));
+            og.add((int)((e >> 6) & 15u) == ng, (int)((e >> 26) & 15u));
+        }
+        const uint64_t sx = quad_sum_u64(ox.v), sy = quad_sum_u64(oy.v), sg = quad_sum_u64(og.v);
+        row.add(n, RowCount6{f == 0 ? sx : (f == 1 ? sy : sg)});
+    } else {
+        RowCount cnt{0, 0};
+        for (int j = 0; j < n_list; ++j) {
+            const uint32_t e = list[j * STRIDE];
+            cnt.add(((e >> shift) & fmask) == (uint32_t)nv, (int)((e >> (20 + shift)) & fmask));
+        }
+        row.add(n, cnt);
     }
-    row.add(n, cnt);
     const int ov = row.sample(u01_of(g.at(g.draw + 3u + (uint32_t)f)), n);
     g.draw += 6;
     const int vx = quad_bcast(g.addr0, 0, ov), vy = quad_bcast(g.addr0, 1, ov), vg = quad_bcast(g.addr0, 2, ov);

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <map>
 #include <queue>
 #include <vector>
 
@@ -43,6 +44,7 @@ struct fba_ctx {
     std::vector<float> prior_alt;    // history particles: the x / y transition nodes with the goal as third parent, [A][2][N*N*G*N]
     float* d_hist_base   = nullptr;  // ... and both tables on the device, rows padded to 16 bytes (HistLayout)
     float* d_hist_alt    = nullptr;
+    uint8_t* d_hist_lds  = nullptr;  // ... and deduplicated: row ids + distinct rows (Problem::hist_lds)
     FDesc fdesc{};          // host copy of the factored model description
     FDesc* d_fdesc       = nullptr;
     GridDesc gdesc{};
@@ -843,6 +845,50 @@ int upload_prior(fba_ctx* c)
         }
         HIPCHK(c, hipMemcpyAsync(c->d_hist_base, base.data(), base.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->d_hist_alt, alt.data(), alt.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        {
+            // the same rows deduplicated (Problem::hist_lds): a row slot -> one byte, the distinct rows K floats each
+            const HistRowIds I(N, G, A);
+            const int K = c->P.hist_row <= 8 ? 8 : (c->P.hist_row <= 12 ? 12 : 16);
+            const int rid_bytes = (I.total + 15) & ~15;
+            std::vector<uint8_t> blob((size_t)rid_bytes, 0);
+            std::vector<float> rows;
+            std::map<std::vector<uint32_t>, int> ids;
+            bool fits = true;
+            auto put = [&](int slot, const float* src, int n) {
+                std::vector<uint32_t> key((size_t)K, 0u);
+                for (int i = 0; i < n; ++i) std::memcpy(&key[i], &src[i], 4);
+                auto it = ids.find(key);
+                if (it == ids.end()) {
+                    if (ids.size() >= 256) { fits = false; return; }
+                    it = ids.emplace(key, (int)ids.size()).first;
+                    for (int i = 0; i < K; ++i) { float f; std::memcpy(&f, &key[i], 4); rows.push_back(f); }
+                }
+                blob[(size_t)slot] = (uint8_t)it->second;
+            };
+            for (int a = 0; a < A && fits; ++a) {
+                for (int f = 0; f < 2; ++f)
+                    for (int cell = 0; cell < N * N; ++cell) put(I.t(a, f, false, cell, 0), &base[(size_t)L.t_row(a, f, false, cell, 0)], N);
+                for (int cell = 0; cell < N * N; ++cell)
+                    for (int gl = 0; gl < G; ++gl) {
+                        put(I.t(a, 2, true, cell, gl), &base[(size_t)L.t_row(a, 2, true, cell, gl)], G);
+                        for (int f = 0; f < 2; ++f) put(I.t(a, f, true, cell, gl), &alt[(size_t)L.alt_row(a, f, cell, gl)], N);
+                    }
+                for (int f = 0; f < 3; ++f)
+                    for (int v = 0; v < (f == 2 ? G : N); ++v) put(I.o(a, f, v), &base[(size_t)L.o_row(a, f, v)], f == 2 ? G : N);
+            }
+            if (fits) {
+                const size_t nb = blob.size();
+                blob.resize(nb + rows.size() * sizeof(float));
+                std::memcpy(blob.data() + nb, rows.data(), rows.size() * sizeof(float));
+                HIPCHK(c, hipMemcpyAsync(c->d_hist_lds, blob.data(), blob.size(), hipMemcpyHostToDevice, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));   // (blob is a local)
+                c->P.hist_lds       = c->d_hist_lds;
+                c->P.hist_rid_bytes = rid_bytes;
+                c->P.hist_distinct  = (int)ids.size();
+            } else {
+                c->P.hist_lds = nullptr; c->P.hist_rid_bytes = 0; c->P.hist_distinct = 0;
+            }
+        }
         HIPCHK(c, hipStreamSynchronize(c->stream));
     } else if (c->P.packed) {  // records start as "no increments yet"; the table itself goes beside them
         if (!packable_prior(c->prior))
@@ -1413,6 +1459,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     // the run fits the record (one entry per belief update), the grid fits 3-bit coordinates and prior + j is exact in
     // fp32 for every count a run can reach (so a row read through the entries is bit for bit the dense row).
     P.hist = 0; P.hist_cap = 0; P.hist_row = 0; P.hist_base = nullptr; P.hist_alt = nullptr;
+    P.hist_lds = nullptr; P.hist_rid_bytes = 0; P.hist_distinct = 0;
     if (cfg->model == FBA_MODEL_BA_FACTORED && cfg->domain == FBA_DOM_GRIDWORLD && cfg->belief == FBA_BELIEF_IMPORTANCE &&
         !cfg->dirichlet_regular && cfg->particles <= IS_MAX_CHUNKS * 256 && !std::getenv("FBA_IS_MULTI_MIN") &&
         !std::getenv("FBA_DENSE_PARTICLES") && (long long)cfg->episodes * cfg->horizon <= HIST_MAX_CAP && cfg->size <= HIST_MAX_N) {
@@ -1700,6 +1747,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         const HistLayout L(c->gdesc.N, c->gdesc.G, P.A);
         CHK(dev_alloc(c, &c->d_hist_base, (size_t)L.total + 16));   // (+16: a row fetch may run up to a row width past the last row)
         CHK(dev_alloc(c, &c->d_hist_alt, (size_t)L.alt_total + 16));
+        CHK(dev_alloc(c, &c->d_hist_lds, (size_t)HistRowIds(c->gdesc.N, c->gdesc.G, P.A).total + 16 + 256 * 16 * sizeof(float)));
         P.hist_base = c->d_hist_base;
         P.hist_alt  = c->d_hist_alt;
     }

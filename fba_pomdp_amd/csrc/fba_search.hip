@@ -7,6 +7,7 @@
 // lanes executing the common "simulate one step" body together.  No dense contraction, no MFMA.
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 #include "fba_kernels_common.h"
 
@@ -637,7 +638,8 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, De
         if (do_step) {
 #endif
             term = gridworld_hist_step_quad<K, HIST_TREES>(P, g, stage + (size_t)(2 + ((hist_off >> (8 * a)) & 0xffu)) * HIST_TREES,
-                                                           hist_count(hist_cnt, a), hist_mask, sp, a, o, r, P.hist_base + HistLayout(P.gw_N, P.gw_G, 4).obase0);
+                                                           hist_count(hist_cnt, a), hist_mask, sp, a, o, r,
+                                                           HistRowsGlobal{P.hist_base, P.hist_alt, P.hist_base + HistLayout(P.gw_N, P.gw_G, 4).obase0, HistLayout(P.gw_N, P.gw_G, 4)});
             ++steps;
 #ifdef FBA_PROFILE_SEARCH
         }
@@ -799,28 +801,50 @@ __device__ __forceinline__ double quad_get_f64(uint32_t lo, uint32_t hi)
 }
 __device__ __forceinline__ uint32_t h2_home_line(uint32_t code, uint32_t nlines) { return __umulhi(child_hash((uint64_t)code), nlines); }
 
-template <int K>
-__global__ void __launch_bounds__(SEARCH_BLOCK) search_hist2_kernel(Problem P, DeviceState D)
+#ifndef FBA_HIST2_WAVES
+#define FBA_HIST2_WAVES 2   // waves per SIMD the register allocation aims at (3: at most 168 VGPRs)
+#endif
+// LROWS: every Dirichlet row of the prior comes from LDS (Problem::hist_lds: row ids + the distinct rows, shared by the H2_WAVES waves of a
+// workgroup); otherwise the transition rows come from the padded tables in HBM and only the observation tables sit in LDS.
+constexpr int H2_WAVES = 4;                                   // waves per workgroup
+constexpr int H2_BLOCK = H2_WAVES * 64;
+__host__ __device__ __forceinline__ size_t h2_shared_bytes(const Problem& P, bool lrows)
+{
+    const int K = P.hist_row <= 8 ? 8 : (P.hist_row <= 12 ? 12 : 16);
+    return lrows ? (size_t)P.hist_rid_bytes + (size_t)P.hist_distinct * K * sizeof(float) : (size_t)4 * HistLayout(P.gw_N, P.gw_G, 4).ostride * sizeof(float);
+}
+__host__ __device__ __forceinline__ size_t h2_wave_bytes(const Problem& P)
+{
+    const int depth_cap = P.max_depth > 0 ? P.max_depth : 1;
+    return (size_t)depth_cap * HIST_TREES * (sizeof(double) + sizeof(int32_t) + sizeof(float) + sizeof(int32_t)) +
+           (size_t)(P.Cs > 2 * depth_cap ? P.Cs : 2 * depth_cap) * HIST_TREES * sizeof(float);
+}
+template <int K, bool LROWS>
+__global__ void __launch_bounds__(H2_BLOCK) __attribute__((amdgpu_waves_per_eu(FBA_HIST2_WAVES, FBA_HIST2_WAVES))) search_hist2_kernel(Problem P, DeviceState D)
 {
     constexpr int AMAX = 4;
     P.model = FBA_MODEL_BA_FACTORED; P.domain = FBA_DOM_GRIDWORLD; P.A = 4; P.belief = FBA_BELIEF_IMPORTANCE;
-    extern __shared__ double lds[];
-    const int lane = threadIdx.x, tl = lane >> 2;
+    extern __shared__ double lds_all[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tl = lane >> 2;
     const int depth_cap = P.max_depth > 0 ? P.max_depth : 1;
+    const size_t shared_bytes = h2_shared_bytes(P, LROWS);
+    double* lds = reinterpret_cast<double*>(reinterpret_cast<char*>(lds_all) + shared_bytes + (size_t)wave * h2_wave_bytes(P));   // this wave's paths and staging area
     double* path_q   = lds + tl;                                                                                  // [depth][trees]: the chosen action's Q as the descent saw it
     int32_t* path_n  = reinterpret_cast<int32_t*>(path_q - tl + (size_t)depth_cap * HIST_TREES) + tl;            // ... and its count
     float* path_r    = reinterpret_cast<float*>(path_n - tl + (size_t)depth_cap * HIST_TREES) + tl;
     int32_t* path_na = reinterpret_cast<int32_t*>(path_r - tl + (size_t)depth_cap * HIST_TREES) + tl;            // bucket << 5 | action
     uint32_t* stage  = reinterpret_cast<uint32_t*>(path_na - tl + (size_t)depth_cap * HIST_TREES) + tl;           // [Cs][trees]
-    float* otab      = reinterpret_cast<float*>(stage - tl + (size_t)P.Cs * HIST_TREES);                          // the prior's observation tables
+                                                                                                                  // (stage also holds the back-up's returns: two words per level)
     const HistLayout HL(P.gw_N, P.gw_G, 4);
-    {   // every lane of the wave, before any quad leaves
-        const float4* src = reinterpret_cast<const float4*>(P.hist_base + HL.obase0);
-        float4* dst       = reinterpret_cast<float4*>(otab);
-        for (int i = lane; i < HL.ostride; i += SEARCH_BLOCK) dst[i] = src[i];   // 4 actions x ostride floats = ostride float4
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    {   // the workgroup's shared tables: every thread, before any quad leaves
+        const uint4* src = LROWS ? reinterpret_cast<const uint4*>(P.hist_lds) : reinterpret_cast<const uint4*>(P.hist_base + HL.obase0);
+        uint4* dst       = reinterpret_cast<uint4*>(lds_all);
+        for (int i = threadIdx.x; i < (int)(shared_bytes / 16); i += (int)blockDim.x) dst[i] = src[i];
+        __syncthreads();
     }
-    const int e = blockIdx.x * HIST_TREES + tl;
+    const uint8_t* s_rid = reinterpret_cast<const uint8_t*>(lds_all);
+    const float* s_rows  = reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds_all) + (LROWS ? P.hist_rid_bytes : 0));
+    const int e = (blockIdx.x * (int)(blockDim.x >> 6) + wave) * HIST_TREES + tl;   // (the launcher picks 4, 2 or 1 waves per workgroup: what 64 KB of LDS hold)
     if (e >= P.E || !D.active[e]) return;  // (a quad leaves together)
 
     QuadRng g;
@@ -890,9 +914,8 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist2_kernel(Problem P, D
     for (int j = 0; j < H2_PF; ++j) pf[j] = make_uint4(0, 0, 0, 0);
 
     // the root particle of simulation `sim`: Belief::sample() on its stream, and this lane's pieces of the record on their way
+    // (its stream is set and eight draws -- the root sample, the first action, six rows -- are ensured by the caller)
     auto request_particle = [&]() {
-        g.stream(FBA_PHASE_SEARCH, (uint32_t)sim);
-        g.ensure(8);  // the root sample, the first action, six rows
         if (ts_src >= 0) cur_src = ts_src;
         else {
             const double u = g.u01();
@@ -904,7 +927,11 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist2_kernel(Problem P, D
         for (int j = 0; j < H2_PF; ++j) pf[j] = rp[min(g.q + HIST_QUAD * j, n4 - 1)];
     };
 
+#ifdef FBA_PROFILE_SEARCH
+    long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prev_ = clock64();
+#endif
     while (true) {
+        PROF_MARK(6)
         int cn[AMAX] = {0, 0, 0, 0};          // the current node's statistics (below the root), set where the node is entered
         double cq[AMAX] = {0.0, 0.0, 0.0, 0.0};
         bool finish = false, do_step = true;
@@ -912,7 +939,11 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist2_kernel(Problem P, D
         if (mode == 0) {
             if (sim >= P.sims) break;
             if (budget > 0 && iter >= budget) break;   // out of iterations at a simulation boundary: park the search (below)
-            if (!have_particle) request_particle();
+            if (!have_particle) {   // the launch's first simulation (later ones are asked for when their predecessor finishes)
+                g.stream(FBA_PHASE_SEARCH, (uint32_t)sim);
+                g.ensure(8);
+                request_particle();
+            }
             have_particle = false;
 #pragma unroll
             for (int j = 0; j < H2_PF; ++j) {
@@ -1027,26 +1058,47 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist2_kernel(Problem P, D
                 }
             }
         }
+        PROF_MARK(0)
         if (mode == 1 && dtg == 0 && !finish) { finish = true; do_step = false; }
         if (mode == 1) tree_depth = max(tree_depth, max_tree_depth - dtg);
         int a = 0, o = 0;
         double r = 0;
         bool term = false;
         if (do_step) {
-            g.ensure(7);  // the action, six rows
+            // (the action's draw and the six rows': ensured at the end of the previous iteration)
             if (mode == 1) {  // traverseActionNode
-                if (node == ROOT) a = ucb_pick<AMAX>(P, g, D.log1p_tab, r_vis, r_cn, r_cq, true);
-                else {
-                    a = ucb_pick<AMAX>(P, g, D.log1p_tab, ((cn[0] + cn[1]) + cn[2]) + cn[3], cn, cq, true);
-                    path_n[(size_t)plen * HIST_TREES] = a == 0 ? cn[0] : (a == 1 ? cn[1] : (a == 2 ? cn[2] : cn[3]));
-                    path_q[(size_t)plen * HIST_TREES] = a == 0 ? cq[0] : (a == 1 ? cq[1] : (a == 2 ? cq[2] : cq[3]));
+                // one selectChanceNodeUCB for the wave, on the root's registers or the bucket's values (two inlined copies would run one after the other)
+                const bool at_root = node == ROOT;
+                int vis = 0;
+#pragma unroll
+                for (int a2 = 0; a2 < AMAX; ++a2) {
+                    cn[a2] = at_root ? r_cn[a2] : cn[a2];
+                    cq[a2] = at_root ? r_cq[a2] : cq[a2];
+                    vis += cn[a2];    // (ActionNode::_visit_count is the sum of its chance nodes' counts: every back-up through the node adds one to exactly one of them)
                 }
+                a = ucb_pick<AMAX>(P, g, D.log1p_tab, at_root ? r_vis : vis, cn, cq, true);
+                path_n[(size_t)plen * HIST_TREES] = a == 0 ? cn[0] : (a == 1 ? cn[1] : (a == 2 ? cn[2] : cn[3]));   // (unused at the root: its back-up works on the registers)
+                path_q[(size_t)plen * HIST_TREES] = a == 0 ? cq[0] : (a == 1 ? cq[1] : (a == 2 ? cq[2] : cq[3]));
             } else {
                 a = g.slow_int(0, 4);  // GridWorld::generateRandomAction :220-226
             }
-            term = gridworld_hist_step_quad<K, HIST_TREES>(P, g, stage + (size_t)(2 + ((hist_off >> (8 * a)) & 0xffu)) * HIST_TREES,
-                                                           hist_count(hist_cnt, a), hist_mask, sp, a, o, r, otab);
+#ifdef FBA_PROFILE_SEARCH
+        }
+        PROF_MARK(1)
+        if (do_step) {
+#endif
+            if (LROWS)
+                term = gridworld_hist_step_quad<K, HIST_TREES, true>(P, g, stage + (size_t)(2 + ((hist_off >> (8 * a)) & 0xffu)) * HIST_TREES, hist_count(hist_cnt, a),
+                                                                     hist_mask, sp, a, o, r, HistRowsLds<K>{s_rid, s_rows, HistRowIds(P.gw_N, P.gw_G, 4)});
+            else
+                term = gridworld_hist_step_quad<K, HIST_TREES, true>(P, g, stage + (size_t)(2 + ((hist_off >> (8 * a)) & 0xffu)) * HIST_TREES, hist_count(hist_cnt, a),
+                                                                     hist_mask, sp, a, o, r, HistRowsGlobal{P.hist_base, P.hist_alt, s_rows, HL});
             ++steps;
+#ifdef FBA_PROFILE_SEARCH
+        }
+        PROF_MARK(2)
+        if (do_step) {
+#endif
             if (mode == 1) {  // traverseChanceNode
                 path_r[(size_t)plen * HIST_TREES]  = (float)r;
                 path_na[(size_t)plen * HIST_TREES] = (node << 5) | a;
@@ -1068,39 +1120,63 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist2_kernel(Problem P, D
                 if (rdepth == 0 || term) { delayed = rret; finish = true; }
             }
         }
-        if (finish) {  // back-up, leaf to root (MCTSTreeNodes.cpp:8-12, 59-62): two stores per level, the loads were the descent's
+        PROF_MARK(3)
+        if (finish) {
+            // back-up, leaf to root (MCTSTreeNodes.cpp:8-12, 59-62).  The returns chain down the path (ret = r + gamma * delayed: two operations
+            // per level, every lane); the Q updates -- a division each -- do not depend on one another, so lane j of the quad takes level j
+            // (4 + j, ...) and the quad does four at a time.  Count and Q of the chosen action are the descent's (path_n, path_q: nothing else
+            // writes this tree), the root's included; level 0 is the root, lane 0 hands its new statistics to the quad's registers.
             double del = delayed;
             for (int k = plen - 1; k >= 0; --k) {
-                const int na     = path_na[(size_t)k * HIST_TREES];
                 const double ret = (double)path_r[(size_t)k * HIST_TREES] + P.gamma * del;
-                const int act    = na & 31;
-                if ((na >> 5) == ROOT) {
-                    int n = 0;
-                    double q = 0.0;
-#pragma unroll
-                    for (int a2 = 0; a2 < AMAX; ++a2)
-                        if (a2 == act) { n = r_cn[a2]; q = r_cq[a2]; }
-                    ++n;
-                    q += (ret - q) / (double)n;
-#pragma unroll
-                    for (int a2 = 0; a2 < AMAX; ++a2)
-                        if (a2 == act) { r_cn[a2] = n; r_cq[a2] = q; }
-                    ++r_vis;
-                } else {
-                    uint32_t* bw    = tabw + (size_t)(na >> 5) * 16;
-                    const int n     = path_n[(size_t)k * HIST_TREES] + 1;
-                    const double q0 = path_q[(size_t)k * HIST_TREES];
-                    reinterpret_cast<uint16_t*>(bw + 1)[act] = (uint16_t)n;
-                    reinterpret_cast<double*>(bw + 4)[act]   = q0 + (ret - q0) / (double)n;
-                }
+                stage[(size_t)(2 * k) * HIST_TREES]     = (uint32_t)__double2loint(ret);   // (the simulation is over: its staged particle is no longer read)
+                stage[(size_t)(2 * k + 1) * HIST_TREES] = (uint32_t)__double2hiint(ret);
                 del = ret;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            for (int k0 = 0; k0 < plen; k0 += HIST_QUAD) {
+                const int k      = min(k0 + g.q, plen - 1);
+                const int na     = path_na[(size_t)k * HIST_TREES];
+                const double ret = __hiloint2double((int)stage[(size_t)(2 * k + 1) * HIST_TREES], (int)stage[(size_t)(2 * k) * HIST_TREES]);
+                const int act    = na & 31;
+                const int n      = path_n[(size_t)k * HIST_TREES] + 1;
+                const double q0  = path_q[(size_t)k * HIST_TREES];
+                const double qn  = q0 + (ret - q0) / (double)n;
+                if (k0 + g.q < plen && (na >> 5) != ROOT) {
+                    uint32_t* bw = tabw + (size_t)(na >> 5) * 16;
+                    reinterpret_cast<uint16_t*>(bw + 1)[act] = (uint16_t)n;
+                    reinterpret_cast<double*>(bw + 4)[act]   = qn;
+                }
+                if (k0 == 0) {   // the root's level is lane 0's
+                    const int ract   = (int)quad_get<0>((uint32_t)act), rn = (int)quad_get<0>((uint32_t)n);
+                    const double rq  = quad_get_f64<0>((uint32_t)__double2loint(qn), (uint32_t)__double2hiint(qn));
+#pragma unroll
+                    for (int a2 = 0; a2 < AMAX; ++a2)
+                        if (a2 == ract) { r_cn[a2] = rn; r_cq[a2] = rq; }
+                    ++r_vis;
+                }
             }
             if (!broken) ++sim;
             mode = 0; pend = false;
-            if (sim < P.sims) { request_particle(); have_particle = true; }
         }
+        {
+            // The one place of the loop where Philox blocks are made: what the next iteration draws -- a step's seven (the action, six rows), or
+            // a new simulation's eight on its own stream (the root sample first).  ensure() only prepares blocks: the draws are the same ones.
+            const bool new_sim = finish && sim < P.sims;
+            if (new_sim) g.stream(FBA_PHASE_SEARCH, (uint32_t)sim);
+            g.ensure(new_sim ? 8 : 7);
+            if (new_sim) { request_particle(); have_particle = true; }
+        }
+        PROF_MARK(4)
         ++iter;
+#ifdef FBA_PROFILE_SEARCH
+        prof_[5] += 1;
+#endif
     }
+#ifdef FBA_PROFILE_SEARCH
+    if (lane == 0)
+        for (int r2 = 0; r2 < 8; ++r2) atomicAdd(&g_search_prof[r2], (unsigned long long)prof_[r2]);
+#endif
     if (sim < P.sims) {   // parked: the four lanes of the quad hold the same values and store them to the same places
         int32_t* rn = reinterpret_cast<int32_t*>(D.s_root + (size_t)e * 6);
         double* rq  = D.s_root + (size_t)e * 6 + 2;
@@ -1171,10 +1247,21 @@ void launch_search(const Problem& P, const DeviceState& D, hipStream_t st)
         lds = (size_t)depth_cap * HIST_TREES * (sizeof(double) + sizeof(int32_t) + sizeof(float) + sizeof(int32_t)) + (size_t)P.Cs * HIST_TREES * sizeof(float);
         const dim3 qgrid(ceil_div(P.E, HIST_TREES));
         if (D.bkt) {   // the tree as one table of buckets, trips to memory requested an iteration ahead
-            lds += (size_t)4 * HistLayout(P.gw_N, P.gw_G, 4).ostride * sizeof(float);   // the prior's observation tables
-            if (P.hist_row <= 8) hipLaunchKernelGGL((search_hist2_kernel<8>), qgrid, block, lds, st, P, D);
-            else if (P.hist_row <= 12) hipLaunchKernelGGL((search_hist2_kernel<12>), qgrid, block, lds, st, P, D);
-            else hipLaunchKernelGGL((search_hist2_kernel<16>), qgrid, block, lds, st, P, D);
+            static const bool no_lrows = std::getenv("FBA_HIST_ROWS") && !std::strcmp(std::getenv("FBA_HIST_ROWS"), "hbm");   // A/B: transition rows from the padded tables
+            const bool lrows = P.hist_lds != nullptr && !no_lrows;
+            int nw = H2_WAVES;   // waves per workgroup: as many as 64 KB of LDS hold beside the shared tables (deep horizons have long paths)
+            while (nw > 1 && h2_shared_bytes(P, lrows) + (size_t)nw * h2_wave_bytes(P) > 64 * 1024) nw >>= 1;
+            const size_t lds2 = h2_shared_bytes(P, lrows) + (size_t)nw * h2_wave_bytes(P);
+            const dim3 grid2(ceil_div(P.E, HIST_TREES * nw)), block2(64 * nw);
+#define FBA_LAUNCH_H2(KV)                                                                                              \
+    do {                                                                                                               \
+        if (lrows) hipLaunchKernelGGL((search_hist2_kernel<KV, true>), grid2, block2, lds2, st, P, D);                 \
+        else hipLaunchKernelGGL((search_hist2_kernel<KV, false>), grid2, block2, lds2, st, P, D);                      \
+    } while (0)
+            if (P.hist_row <= 8) FBA_LAUNCH_H2(8);
+            else if (P.hist_row <= 12) FBA_LAUNCH_H2(12);
+            else FBA_LAUNCH_H2(16);
+#undef FBA_LAUNCH_H2
             return;
         }
         if (P.hist_row <= 8) hipLaunchKernelGGL((search_hist_kernel<8>), qgrid, block, lds, st, P, D);
