@@ -216,7 +216,7 @@ BA_MEANS = {
     "c3_reduced": ("episodic-factored-tiger", dict(model=N.MODEL_BA_FACTORED, belief="rejection_sampling", size=3, structure_prior=2, sims=4096, particles=1024,
                                                     horizon=10, episodes=5), 200000, 50000),
     "c4_size5_1k": ("gridworld", dict(model=N.MODEL_BA_FACTORED, belief="importance_sampling", size=5, structure_prior=2, sims=1024, particles=256, horizon=20,
-                                      episodes=2), 100000, 25000),
+                                      episodes=2), 200000, 25000),
     "c4_size5": ("gridworld", dict(model=N.MODEL_BA_FACTORED, belief="importance_sampling", size=5, structure_prior=2, sims=2048, particles=512, horizon=20,
                                    episodes=2), 50000, 25000),
     "c4_size3": ("gridworld", dict(model=N.MODEL_BA_FACTORED, belief="importance_sampling", size=3, structure_prior=2, sims=1024, particles=256, horizon=12,
@@ -232,9 +232,9 @@ def test_ba_per_episode_means_within_one_sigma_of_the_reference_order_oracle(nam
     generator, no streams -- (oracle/gen_ba_means.py -> tests/golden/oracle_ba_means.json).  The engine (Philox streams, device-order sums)
     runs 0.5-2e5 runs of the same configuration.  For every episode index:
       * |engine mean - oracle mean| <= 3 combined standard errors (what the two sample sizes can resolve);
-      * where both means are known well enough for north_star's bound to mean something -- combined standard error <= 0.4 sigma, sigma
-        = the standard error of a 1e4-run mean: fixtures of 4-8e4 runs -- also |difference| <= 1 sigma.  (Two honest 1e4-run means
-        differ by more than 1 sigma a third of the time; the bound is applied to means that are known 2.5 x better than that.)
+      * where both means are known well enough for north_star's bound to mean something -- combined standard error <= 0.6 sigma, sigma
+        = the standard error of a 1e4-run mean: fixtures of 4-8e4 runs against 2e5 engine runs -- also |difference| <= 1 sigma.  (Two honest
+        1e4-run means differ by more than 1 sigma half of the time; the bound is applied to means that are known about twice as well.)
       * the variances agree within 10 % (the returns are a few discrete values: a shifted mixture shows here first).
     c2_full is BASELINE configs[1] at its own size with an 8e4-run fixture; c3_full (configs[2] at its own size) and c2_importance keep
     1e4-run fixtures (their oracle runs are the expensive ones) beside reduced-size twins with 8e4; c4_* is configs[3]'s shape (gridworld
@@ -259,7 +259,7 @@ def test_ba_per_episode_means_within_one_sigma_of_the_reference_order_oracle(nam
         d = abs(st.mean - fix["mean"][ep])
         comb = (st.stder ** 2 + fix["stder"][ep] ** 2) ** 0.5
         assert d <= 3 * comb, (name, report)
-        if comb <= 0.4 * fix["stder_at_1e4"][ep]:
+        if comb <= 0.6 * fix["stder_at_1e4"][ep]:
             sharp += 1
             assert d <= fix["stder_at_1e4"][ep], (name, report)
         if fix["var"][ep] > 0:
