@@ -1613,10 +1613,13 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     D.scratch_slots = D.single_rec ? std::min(E, 1024) : 0;
     if (D.single_rec)
         if (const char* ev = std::getenv("FBA_SCRATCH_SLOTS")) D.scratch_slots = std::max(1, std::min(E, std::atoi(ev)));   // (tests: several chunks with a few slots)
-    D.rec_scratch = nullptr; D.copy_pending = nullptr;
-    CHK(dev_alloc(c, &D.p_rec, (size_t)(D.single_rec ? 1 : 2) * E * P.N * P.Cs, false));
-    if (D.single_rec) {
-        CHK(dev_alloc(c, &D.rec_scratch, (size_t)D.scratch_slots * P.N * P.Cs, false));
+    D.rec_scratch = nullptr; D.copy_pending = nullptr; D.rec_buf = nullptr;
+    CHK(dev_alloc(c, &D.p_rec, (D.single_rec ? (size_t)E + D.scratch_slots : (size_t)2 * E) * P.N * P.Cs, false));
+    if (D.single_rec) {   // E + scratch_slots buffers; a slot's filter and a scratch place's buffer change places after a resample / reset (swap_buffers_kernel)
+        CHK(dev_alloc(c, &D.rec_buf, (size_t)E + D.scratch_slots));
+        std::vector<int32_t> ids((size_t)E + D.scratch_slots);
+        for (size_t i = 0; i < ids.size(); ++i) ids[i] = (int32_t)i;
+        HIPC(hipMemcpy(D.rec_buf, ids.data(), ids.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         CHK(dev_alloc(c, &D.copy_pending, E));
     }
     if (P.reinvig || P.cheat || P.incub) {
@@ -2094,7 +2097,12 @@ static int belief_get_range(fba_ctx* c, int32_t slot, int32_t first, int32_t n, 
     }
     if (state || (counts && (P.C || P.hist))) {
         std::vector<float> tmp((size_t)n * P.Cs);
-        const size_t rb = c->D.single_rec ? (size_t)slot * (size_t)P.N : pb;   // (history particles: one record buffer per slot)
+        size_t rb = pb;
+        if (c->D.single_rec) {   // (history particles: one record buffer per slot, whichever of the pool it currently is)
+            int32_t buf = 0;
+            HIPCHK(c, hipMemcpy(&buf, c->D.rec_buf + slot, 4, hipMemcpyDeviceToHost));
+            rb = (size_t)buf * (size_t)P.N;
+        }
         HIPCHK(c, hipMemcpy(tmp.data(), c->D.p_rec + (rb + first) * P.Cs, tmp.size() * 4, hipMemcpyDeviceToHost));
         uint32_t hist_cnt = 0;
         if (P.hist) HIPCHK(c, hipMemcpy(&hist_cnt, c->D.hist_cnt + slot, 4, hipMemcpyDeviceToHost));

@@ -236,11 +236,48 @@ __device__ __forceinline__ void gather_records_side(float* __restrict__ dst, con
 // bits kept -- with the source particle's pending entry (side row {new state, entry}) inserted as word `ins`, the
 // end of its action's group: the `len` entries behind it move up by one.  A power-of-two group of lanes moves
 // one record in 16-byte pieces.
-__device__ __forceinline__ void gather_hist_records(float* __restrict__ dst, const float* __restrict__ src, const int32_t* s_src,
+template <class IDX>
+__device__ __forceinline__ void gather_hist_records(float* __restrict__ dst, const float* __restrict__ src, const IDX* s_src,
                                                     const int32_t* __restrict__ side, int len, int ins, int m, int C4, int group, int nthreads)
 {
     const int gid = threadIdx.x / group, part0 = threadIdx.x % group, ngroups = nthreads / group;
     const int n4 = (len + 6) >> 2;  // pieces that hold words 0 .. 2 + len
+    if (n4 <= group && m >= 4 * ngroups) {
+        // a whole filter at once (every source already drawn): one piece per lane, four records in flight per lane group
+        constexpr int FLY = 4;
+        const int part = min(part0, n4 - 1);
+        for (int j0 = gid; j0 < m; j0 += ngroups * FLY) {
+            uint4 cur[FLY];
+            uint32_t before[FLY];
+            int2 sd[FLY];
+#pragma unroll
+            for (int q = 0; q < FLY; ++q) {
+                const int j     = min(j0 + q * ngroups, m - 1);
+                const int p     = (int)s_src[j];
+                const uint4* sp = reinterpret_cast<const uint4*>(src) + (size_t)p * C4;
+                cur[q]    = sp[part];
+                before[q] = part > 0 ? sp[part - 1].w : 0u;
+                sd[q]     = *reinterpret_cast<const int2*>(side + (size_t)p * 2);
+            }
+#pragma unroll
+            for (int q = 0; q < FLY; ++q) {
+                const int j = j0 + q * ngroups;
+                if (j >= m || part0 >= n4) continue;
+                const int w0 = part * 4;
+                uint4 v;
+                v.x = w0 + 0 < ins ? cur[q].x : (w0 + 0 == ins ? (uint32_t)sd[q].y : before[q]);
+                v.y = w0 + 1 < ins ? cur[q].y : (w0 + 1 == ins ? (uint32_t)sd[q].y : cur[q].x);
+                v.z = w0 + 2 < ins ? cur[q].z : (w0 + 2 == ins ? (uint32_t)sd[q].y : cur[q].y);
+                v.w = w0 + 3 < ins ? cur[q].w : (w0 + 3 == ins ? (uint32_t)sd[q].y : cur[q].z);
+                if (part == 0) {  // the new state, as an index and as hist_pack (= the step's s')
+                    v.x = (uint32_t)sd[q].x;
+                    v.y = (v.y & 0xffffu) | ((((uint32_t)sd[q].y >> 10) & 0x3ffu) << 16);
+                }
+                (reinterpret_cast<uint4*>(dst) + (size_t)j * C4)[part] = v;
+            }
+        }
+        return;
+    }
     for (int j = gid; j < m; j += ngroups) {
         const int p      = s_src[j];
         const uint4* sp  = reinterpret_cast<const uint4*>(src) + (size_t)p * C4;
@@ -1310,6 +1347,8 @@ __global__ void __launch_bounds__(256) nested_update_kernel(Problem P, DeviceSta
 // is one new entry per particle, appended by the gather.
 // WLDS: the slot's weights live in LDS from the update pass to the last draw (N <= IS_LDS_MAX_N: 8 bytes each): the
 // normalised weights and their prefix sums never go to HBM, the N searches read LDS.  Same sums, same order.
+// history particles: all N sources are drawn before the gather when their 16-bit indices fit the workgroup's LDS beside the weights
+__host__ __device__ __forceinline__ bool hist_all_draws_first(int N) { return N <= 16384; }
 template <bool REG, int TIGER_TABLE, bool HIST = false, bool WLDS = false>
 __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceState D)
 {
@@ -1429,6 +1468,17 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
                 reinterpret_cast<float4*>(dcn)[(size_t)j * 4 + part] = v[q];
             }
         }
+    } else if (HIST && hist_all_draws_first(N)) {
+        // every source first (16-bit indices in LDS), then ONE pass over the filter with four records in flight per lane group: the
+        // 2 N / IS_BLOCK barriers of the round-by-round form, each behind a trip to memory, were most of this kernel
+        uint16_t* s_all = reinterpret_cast<uint16_t*>(s_w + (WLDS ? N : 0));
+        for (int j = tid; j < N; j += IS_BLOCK) {
+            g.stream(FBA_PHASE_RESAMPLE, (uint32_t)j);
+            s_all[j] = (uint16_t)weighted_pick_guided(wscan, N, g.u01() * total_w, total_w);
+            dw[j]    = w1;
+        }
+        __syncthreads();
+        gather_hist_records(dcn, scn, s_all, side, hist_n, 2 + hist_offset(hist_cnt, a) + hist_count(hist_cnt, a), N, C4, group, IS_BLOCK);
     } else
     for (int j0 = 0; j0 < N; j0 += IS_BLOCK) {
         const int j = j0 + tid;
@@ -2055,23 +2105,18 @@ __global__ void selftest_ucb_kernel(const double* L, const int32_t* n, int count
     if (i < count) out[i] = u * sqrt(L[i] / (double)n[i]);
 }
 
-// DeviceState::single_rec: the filter a resample / reset has built in the scratch pool becomes the slot's filter
-__global__ void __launch_bounds__(256) copy_back_kernel(Problem P, DeviceState D)
+// DeviceState::single_rec: the filter a resample / reset has built in its scratch place's buffer becomes the slot's filter -- the two
+// buffer indices change places (one thread per slot of the chunk)
+__global__ void __launch_bounds__(256) swap_buffers_kernel(Problem P, DeviceState D, int count)
 {
-    const int e = chunk_slot(D, blockIdx.y);
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= count) return;
+    const int e = chunk_slot(D, b);
     if (!D.copy_pending[e]) return;
-    const size_t n4 = (size_t)P.N * (size_t)(P.Cs / 4);
-    const float4* src = reinterpret_cast<const float4*>(D.rec_scratch + (size_t)scratch_place(D, e) * (size_t)P.N * (size_t)P.Cs);
-    float4* dst       = reinterpret_cast<float4*>(D.p_rec + (size_t)e * (size_t)P.N * (size_t)P.Cs);
-    const size_t per  = (n4 + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = lo + per < n4 ? lo + per : n4;
-    for (size_t k = lo + threadIdx.x; k < hi; k += 4 * 256) {
-        float4 v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = src[k + (size_t)q * 256 < hi ? k + (size_t)q * 256 : hi - 1];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (k + (size_t)q * 256 < hi) dst[k + (size_t)q * 256] = v[q];
-    }
+    const int place = P.E + scratch_place(D, e);
+    const int32_t mine = D.rec_buf[e];
+    D.rec_buf[e]     = D.rec_buf[place];
+    D.rec_buf[place] = mine;
 }
 __global__ void copy_flags_kernel(const uint8_t* src, uint8_t* dst, int n)
 {
@@ -2103,7 +2148,8 @@ static void launch_importance_single(const Problem& P, const DeviceState& D, hip
                              (P.domain == FBA_DOM_TIGER_EPISODIC || P.domain == FBA_DOM_TIGER_CONTINUOUS);
     // weights and prefix sums of a slot in LDS while its workgroup works on them (8 bytes per particle)
     const bool wlds = P.N <= IS_LDS_MAX_N && !P.dirichlet_regular;
-    const size_t wl = wlds ? (size_t)P.N * (sizeof(double) + ((tiger_table && P.packed) ? 4 : 0)) : 0;  // (packed tiger: + pending updates and sources, 16 bits each)
+    const size_t wl = (wlds ? (size_t)P.N * (sizeof(double) + ((tiger_table && P.packed) ? 4 : 0)) : 0) +  // (packed tiger: + pending updates and sources, 16 bits each)
+                      ((P.hist && hist_all_draws_first(P.N)) ? (size_t)P.N * 2 : 0);                       // (history particles: the drawn sources)
     const int grid_e = D.use_list ? D.scratch_slots /* (set to the chunk's count by the caller) */
                                   : (D.single_rec ? std::min(D.scratch_slots, P.E - D.slot_base) : P.E);   // (single_rec: one chunk of slots per launch)
 #define FBA_LAUNCH_IS(...)                                                                                         \
@@ -2165,7 +2211,7 @@ static void for_each_chunk(const Problem& P, const DeviceState& D, hipStream_t s
             Dc.use_list    = 1;
             const int cnt  = std::min(D.scratch_slots, n - i0);
             launch(Dc, cnt);
-            hipLaunchKernelGGL(copy_back_kernel, dim3(16, cnt), dim3(256), 0, st, P, Dc);
+            hipLaunchKernelGGL(swap_buffers_kernel, dim3(ceil_div(cnt, 256)), dim3(256), 0, st, P, Dc, cnt);
         }
         if (n > 0) (void)hipMemsetAsync(D.copy_pending, 0, (size_t)P.E, st);
         return;
@@ -2175,7 +2221,7 @@ static void for_each_chunk(const Problem& P, const DeviceState& D, hipStream_t s
         Dc.slot_base   = e0;
         const int cnt  = std::min(D.scratch_slots, P.E - e0);
         launch(Dc, cnt);
-        hipLaunchKernelGGL(copy_back_kernel, dim3(16, cnt), dim3(256), 0, st, P, Dc);
+        hipLaunchKernelGGL(swap_buffers_kernel, dim3(ceil_div(cnt, 256)), dim3(256), 0, st, P, Dc, cnt);
         (void)hipMemsetAsync(D.copy_pending + e0, 0, (size_t)cnt, st);
     }
 }

@@ -23,13 +23,13 @@ __device__ __forceinline__ Rng slot_rng(const Problem& P, const DeviceState& D, 
 
 __device__ __forceinline__ size_t pbase(const Problem& P, int e, int buf) { return ((size_t)buf * P.E + e) * (size_t)P.N; }
 // first record of slot e's current filter / of the filter a resample or reset is building (DeviceState::single_rec)
-__device__ __forceinline__ size_t rec_base(const Problem& P, const DeviceState& D, int e, int buf) { return D.single_rec ? (size_t)e * (size_t)P.N : pbase(P, e, buf); }
+__device__ __forceinline__ size_t rec_base(const Problem& P, const DeviceState& D, int e, int buf) { return D.single_rec ? (size_t)D.rec_buf[e] * (size_t)P.N : pbase(P, e, buf); }
 // the slot block `b` of a chunked launch works on: the b-th of the chunk, or of the compacted list (DeviceState::use_list)
 __device__ __forceinline__ int chunk_slot(const DeviceState& D, int b) { return D.use_list ? D.slot_list[D.slot_base + b] : D.slot_base + b; }
 __device__ __forceinline__ int scratch_place(const DeviceState& D, int e) { return D.use_list ? D.scratch_idx[e] : e - D.slot_base; }
 __device__ __forceinline__ float* rec_dst(const Problem& P, const DeviceState& D, int e, int other)
 {
-    return D.single_rec ? D.rec_scratch + (size_t)scratch_place(D, e) * (size_t)P.N * (size_t)P.Cs : D.p_rec + pbase(P, e, other) * (size_t)P.Cs;
+    return D.single_rec ? D.p_rec + (size_t)D.rec_buf[P.E + scratch_place(D, e)] * (size_t)P.N * (size_t)P.Cs : D.p_rec + pbase(P, e, other) * (size_t)P.Cs;
 }
 
 // particle record accessors (layout: fba_state.h)

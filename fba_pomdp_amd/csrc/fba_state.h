@@ -62,9 +62,11 @@ struct DeviceState {
     int32_t* mh_n_ep;   // [E] episodes in the history, the open one included
     // history particles (C4): ONE record buffer per slot; a resample / reset gathers into a scratch pool shared by a chunk of
     // slots and is copied back (the second buffer was a quarter of a slot's memory, and slots are what C4 lacks)
-    float* rec_scratch;       // [scratch_slots][N][Cs]
-    uint8_t* copy_pending;    // [E] the slot's new filter is in the scratch pool
-    int32_t single_rec;       // 1: p_rec holds one buffer per slot (records only; weights stay double-buffered)
+    float* rec_scratch;       // (unused since the buffers are swapped, not copied)
+    uint8_t* copy_pending;    // [E] the slot's new filter is in its scratch place's buffer: swap_buffers_kernel makes it the slot's
+    int32_t single_rec;       // 1: p_rec holds E + scratch_slots buffers [N][Cs]; rec_buf says which is whose (records only; weights stay double-buffered)
+    int32_t* rec_buf;         // [E + scratch_slots]: buffer of slot e; buffer of scratch place b at [E + b].  A resample / reset gathers into the
+                              // place's buffer and the two indices are swapped -- no copy (the copy back was a quarter of C4's belief update)
     int32_t slot_base;        // first slot of the chunk a chunked launch works on
     int32_t scratch_slots;
     // budgeted searches: only a few slots need a belief update or a reset per launch, scattered over all of them -- the chunked launches
