@@ -46,7 +46,8 @@ WORKLOADS = {
                domain="gridworld", model=2, belief="importance_sampling", size=7, structure_prior=2, sims=65536, particles=16384,
                horizon=20, episodes=2, slots=32768, search_budget=16384, tree_buckets=65536, cpu=dict(runs=8, episodes=1, sims=2048, particles=1024)),
     "c5": dict(name="configs[4]: collision avoidance 7x7, 2 obstacles (largest factored domain), 10^6 particles per belief, "
-                    "importance-weighted update + resample",
+                    "importance-weighted update + resample (4 beliefs in flight: the search is 4 lanes of one wave and measures nothing -- "
+                    "this workload times the filter)",
                domain="random-collision-avoidance", model=2, belief="importance_sampling", size=2, width=7, height=7, sims=16,
                particles=1_000_000, horizon=20, episodes=4, slots=4, cpu=dict(runs=2, episodes=1, sims=16, particles=20000)),
 }
@@ -122,7 +123,7 @@ def cpu_baseline(args):
 
 def committed_profile(name):
     """A counter summary committed under profiles/ (newest round first), or None."""
-    for tag in ("r03", "r02", "r01"):
+    for tag in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{tag}_{name}")
         if os.path.exists(path):
             with open(path) as f:
@@ -131,10 +132,14 @@ def committed_profile(name):
 
 
 def measured_traffic(args, w, kname, slots):
-    """HBM bytes of a FULL launch (every slot updates) of the roofline kernel from the committed rocprofv3 PMC
-    passes (FETCH_SIZE and WRITE_SIZE in separate runs of this same command; profiles/*.json says how they were
-    collected; FETCH_SIZE is corrected by the factor scripts/micro/pmc_calibrate measured for this kernel's access
-    shapes).  None when the workload differs from the profiled one."""
+    """Fabric bytes of a FULL launch (every slot updates) of the roofline kernel from the committed rocprofv3 PMC passes of this same command
+    (FETCH_SIZE and WRITE_SIZE in separate runs; profiles/*.json says how they were collected).  FETCH_SIZE tallies a read request at 64 B
+    while the memory side moves 128-byte lines (profiles/r04_randline_counters.json), so fetched bytes are the counter x 2, except where a
+    micro-kernel of known traffic measured another factor for the access shape (the sequential parking sweep of reject_tiger_lds_kernel).
+    None when the workload differs from a profiled one."""
+    if args.workload == "c3" and kname == "reject_kernel" and slots == 163840 and w["sims"] == 16384 and w["particles"] == 4096:
+        d, path = committed_profile("pmc_c3.json")
+        return (d["full_launch"]["traffic_bytes"], path) if d else (None, None)
     if args.workload != "c2" or slots != 262144 or w["sims"] != 4096 or w["particles"] != 4096:
         return None, None
     d, path = committed_profile("pmc_fetch_write.json" if kname == "reject_kernel" else "pmc_importance.json")
@@ -395,7 +400,7 @@ def main():
         if sp:
             # the search is a gather over node and particle records that are NOT cache resident at 262 144 slots (trees + filters: 34 GB): SURVEY
             # 8(d)'s "KB-scale, cache-resident" does not hold here.  What bounds it is the rate at which the memory system serves random 64-byte
-            # sectors (scripts/micro/randline: 48.7 G/s with every lane of 4 096 waves asking for its own), DESIGN.md section 5c.
+            # lines (scripts/micro/randline: 48.7 G/s with every lane of 4 096 waves asking for its own -- 128-byte lines, 6.2 TB/s), DESIGN.md section 5c.
             bps = sp["fetch_bytes_per_step"] + sp["write_bytes_per_step"]
             sectors = sp["fetch_sectors_64B_per_step"] * s_line["steps_per_s"]
             s_line.update({
@@ -406,9 +411,11 @@ def main():
                 "frac_algorithmic": sp["algorithmic_bytes_per_step"] * s_line["steps_per_launch"] / 1e9 / (s_avg_ms / 1e3) / HBM_PEAK_GBS if s_avg_ms > 0 else None,
                 "random_sectors_per_s": sectors, "random_sector_ceiling_per_s": sp["random_sector_ceiling_G_per_s"] * 1e9,
                 "frac_sector_ceiling": sectors / (sp["random_sector_ceiling_G_per_s"] * 1e9),
-                "traffic_note": "memory-side bytes per simulated step from the committed PMC passes of this command (FETCH_SIZE, exact for random 16-byte "
-                                "loads per lane, + WRITE_SIZE) x the steps of a timed launch; algorithmic = record bytes a step needs (DESIGN.md section 5c); "
-                                "random_sectors_per_s = fetched 64-byte sectors per step x this run's search steps/s, against the micro-benchmark's ceiling",
+                "traffic_note": "fabric bytes per simulated step from the committed PMC passes of this command (FETCH_SIZE x 2: a read request is one "
+                                "128-byte line tallied at 64 B, profiles/r04_randline_counters.json; + WRITE_SIZE) x the steps of a timed launch; "
+                                "algorithmic = a MODEL estimate of the record bytes a step needs (DESIGN.md section 5c), not a measurement; "
+                                "random_sectors_per_s = read requests (lines) per step x this run's search steps/s, against the micro-benchmark's "
+                                "ceiling of random lines per second",
             })
         out = {
             "metric": "simulated env steps/sec (belief+rollout)",

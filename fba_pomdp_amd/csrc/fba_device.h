@@ -1571,7 +1571,7 @@ __device__ __forceinline__ double fact_obs_prob(const Problem& P, Rng& g, const 
 // nodes, then the observation nodes; per node every Dirichlet row in CPT order, one running double sum.  `cnt` and
 // `prior` are particle blobs of the same structure.
 template <class View>
-__device__ double log_bd_score(const Problem& P, const View& cnt, const View& prior)
+__device__ __forceinline__ double log_bd_score(const Problem& P, const View& cnt, const View& prior)
 {
     const FDesc* fd = P.fd;
     double bd = 0;

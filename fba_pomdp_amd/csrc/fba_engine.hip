@@ -109,6 +109,37 @@ int dev_alloc(fba_ctx* c, T** p, size_t n, bool zero = true)
     return FBA_OK;
 }
 
+// gives a dev_alloc'ed buffer back before the ctx goes (buffers that are re-grown: the trace)
+template <typename T>
+void dev_free(fba_ctx* c, T*& p)
+{
+    if (!p) return;
+    auto it = std::find(c->allocs.begin(), c->allocs.end(), static_cast<void*>(p));
+    if (it != c->allocs.end()) c->allocs.erase(it);
+    (void)hipFree(p);
+    p = nullptr;
+}
+
+// room for `want` trace records (and, with trace = 2, their histograms: FBA_TRACE_HIST_BINS words each, so the cap is lower there --
+// 2^18 records = 64 MB of histograms instead of 1 GiB; later records are counted, not kept)
+int ensure_trace(fba_ctx* c, size_t want)
+{
+    const bool hist = c->cfg.trace >= 2 && c->P.S <= FBA_TRACE_HIST_BINS && !c->P.nested;
+    const size_t cap = std::min<size_t>(want, hist ? (size_t)1 << 18 : (size_t)1 << 22);
+    if ((size_t)c->D.trace_cap < cap) {
+        int rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));   // (nothing in flight reads the old buffers)
+        dev_free(c, c->D.trace);
+        dev_free(c, c->D.trace_hist);
+        if ((rc = dev_alloc(c, &c->D.trace, cap))) return rc;
+        if (hist)
+            if ((rc = dev_alloc(c, &c->D.trace_hist, cap * FBA_TRACE_HIST_BINS))) return rc;
+        c->D.trace_cap = (int32_t)cap;
+    }
+    HIPCHK(c, hipMemsetAsync(c->D.trace_count, 0, sizeof(int32_t), c->stream));
+    return FBA_OK;
+}
+
 // a device buffer that is freed on every way out of the function (the selftests return early through HIPCHK)
 template <typename T>
 struct ScratchBuf {
@@ -1009,17 +1040,7 @@ int ensure_outputs(fba_ctx* c, int runs)
         HIPCHK(c, hipMemsetAsync(c->D.returns, 0, need * sizeof(double), c->stream));
         HIPCHK(c, hipMemsetAsync(c->D.lengths, 0, need * sizeof(int32_t), c->stream));
     }
-    if (c->cfg.trace) {
-        const size_t cap = std::min<size_t>((size_t)std::max(runs, 1) * c->P.episodes * c->P.horizon, (size_t)1 << 22);
-        if ((size_t)c->D.trace_cap < cap) {
-            int rc;
-            if ((rc = dev_alloc(c, &c->D.trace, cap))) return rc;
-            if (c->cfg.trace >= 2 && c->P.S <= FBA_TRACE_HIST_BINS && !c->P.nested)
-                if ((rc = dev_alloc(c, &c->D.trace_hist, cap * FBA_TRACE_HIST_BINS))) return rc;
-            c->D.trace_cap = (int32_t)cap;
-        }
-        HIPCHK(c, hipMemsetAsync(c->D.trace_count, 0, sizeof(int32_t), c->stream));
-    }
+    if (c->cfg.trace) return ensure_trace(c, (size_t)std::max(runs, 1) * c->P.episodes * c->P.horizon);
     return FBA_OK;
 }
 
@@ -2276,16 +2297,8 @@ int fba_run_ticks(fba_ctx* c, int32_t ticks)
     if (!c || ticks < 0) return FBA_EINVAL;
     int rc;
     if (!c->started) {
-        if (c->cfg.trace) {  // room for one run's worth of records per slot (later ones are counted, not kept)
-            const size_t cap = std::min<size_t>((size_t)c->P.E * c->P.episodes * c->P.horizon, (size_t)1 << 22);
-            if ((size_t)c->D.trace_cap < cap) {
-                if ((rc = dev_alloc(c, &c->D.trace, cap))) return rc;
-                if (c->cfg.trace >= 2 && c->P.S <= FBA_TRACE_HIST_BINS && !c->P.nested)
-                    if ((rc = dev_alloc(c, &c->D.trace_hist, cap * FBA_TRACE_HIST_BINS))) return rc;
-                c->D.trace_cap = (int32_t)cap;
-            }
-            HIPCHK(c, hipMemsetAsync(c->D.trace_count, 0, sizeof(int32_t), c->stream));
-        }
+        if (c->cfg.trace)   // room for one run's worth of records per slot (later ones are counted, not kept)
+            if ((rc = ensure_trace(c, (size_t)c->P.E * c->P.episodes * c->P.horizon))) return rc;
         if ((rc = start_experiment(c, -1))) return rc;
         c->started = true;
     }
@@ -2368,7 +2381,7 @@ int fba_get_kernel_times(fba_ctx* c, fba_kernel_time* out)
     if (rc) return rc;
     // algorithmic bytes, SURVEY.md section 8(d): Pb = particle payload, Rt / Ro = bytes of the
     // transition / observation rows one step consults
-    // (always SURVEY's dense figure, 4 bytes per count, also when the particles are stored packed: DESIGN.md section 5)
+    // (SURVEY's dense figure, 4 bytes per count, unless one of the packed / history formulas below applies: DESIGN.md section 5)
     const uint64_t cell = 4;
     const uint64_t Pb = 4 + cell * (uint64_t)c->dense_C;
     uint64_t Rt = 0, Ro = 0;
@@ -2391,6 +2404,12 @@ int fba_get_kernel_times(fba_ctx* c, fba_kernel_time* out)
         // stated when the build does not move dense particles -- the attempts run from LDS, so an update reads the
         // filter once to park it, reads the N accepted sources and writes N records, 64 bytes each
         if (P.packed && P.N <= TIGER_LDS_MAX_N) out[FBA_K_BELIEF_RS].bytes = particles * 3 * (uint64_t)(P.Cs * 4);
+        // packed factored-tiger records (reject_kernel on 144-byte records at --size 3): SURVEY's formula on the bytes a packed particle has --
+        // an attempt reads its source record and one 4-byte word per two-cell Dirichlet row it samples, an accepted one writes a record
+        if (P.ft_packed) {
+            const uint64_t rec = (uint64_t)P.Cs * 4, rows = 4 * (uint64_t)(c->fdesc.FS + c->fdesc.FO);
+            out[FBA_K_BELIEF_RS].bytes = attempts * (rec + rows) + particles * rec;
+        }
     } else {
         out[FBA_K_BELIEF_IS].units = particles;
         out[FBA_K_BELIEF_IS].bytes = particles * (32 + Rt + Ro) + particles * (8 + 2 * Pb);

@@ -772,7 +772,7 @@ __device__ __forceinline__ void mh_increment(const Problem& P, float* cnt, int s
 // FBAPOMDPPrior::computePriorModel(structure): factored tiger (FactoredTigerPriors.cpp:293-321) = the prior with the listen
 // observation node set for its parent set; collision avoidance (CollisionAvoidancePriors.cpp:490-526) = the prior with every
 // obstacle's transition node, per action, set for its parent set.  A lane per node.
-__device__ void mh_compute_prior(const Problem& P, const DeviceState& D, const uint32_t* masks, float* out, int lane)
+__device__ __forceinline__ void mh_compute_prior(const Problem& P, const DeviceState& D, const uint32_t* masks, float* out, int lane)
 {
     MH_SYNC();
     mh_copy(out, D.prior, P.C, lane);
@@ -794,7 +794,7 @@ __device__ void mh_compute_prior(const Problem& P, const DeviceState& D, const u
 // FBAPOMDP::mutate: FactoredTigerFactoredPrior::mutate (FactoredTigerPriors.cpp:351-381) flips a random edge
 // (BABNModel.cpp:16-31) of O[listen][0]; CollisionAvoidanceFactoredPrior::mutate (CollisionAvoidancePriors.cpp:455-488)
 // draws an action and an obstacle, then flips a random edge of that transition node
-__device__ void mh_mutate(const Problem& P, Rng& g, uint32_t* masks, int lane)
+__device__ __forceinline__ void mh_mutate(const Problem& P, Rng& g, uint32_t* masks, int lane)
 {
     int word;
     uint32_t bit;
@@ -822,7 +822,7 @@ __device__ void mh_mutate(const Problem& P, Rng& g, uint32_t* masks, int lane)
     MH_SYNC();
 }
 // computePosteriorCounts (MHwithinGibbs.cpp:397-436): the prior plus one count per node and step of the history, a lane per node
-__device__ void mh_posterior(const Problem& P, const DeviceState& D, int e, const float* prior, const int32_t* seq, float* out, int lane)
+__device__ __forceinline__ void mh_posterior(const Problem& P, const DeviceState& D, int e, const float* prior, const int32_t* seq, float* out, int lane)
 {
     const FDesc* fd = P.fd;
     MH_SYNC();
@@ -849,35 +849,61 @@ __device__ __forceinline__ void mh_expected(const float* row, int n, float* out)
     for (int i = 1; i < n; ++i) sum += row[i];
     for (int i = 0; i < n; ++i) out[i] = ((double)sum <= 1e-300) ? 0.f : row[i] / sum;
 }
-// BABNModel::flattenT / flattenO (BABNModel.cpp:89-181), a lane per (action, state)
-__device__ void mh_flatten(const Problem& P, const float* model, float* T, float* O, int lane)
+// BABNModel::flattenT / flattenO (BABNModel.cpp:89-181), a lane per (action, state).  The expected rows of the state's nodes (FS or FO rows of
+// at most MAXROW values) are indexed by feature values, i.e. at run time: they sit in the LDS area of the score terms (MhScratch::terms,
+// idle while a model is flattened), `need` floats per lane -- a private array would live in scratch memory, 512 bytes per lane.
+__device__ __forceinline__ void mh_flatten(const Problem& P, const float* model, float* T, float* O, const MhScratch& m, int lane)
 {
     const FDesc* fd = P.fd;
     const GlobalView v{model};
     const int S = P.S, A = P.A, NO = P.O;
+    int need = 1;   // the longest total row length over the nodes of one (action, kind)
+    for (int a = 0; a < A; ++a) {
+        int ts = 0, os = 0;
+        for (int f = 0; f < fd->FS; ++f) ts += fd->nodes[a * fd->FS + f].out;
+        for (int f = 0; f < fd->FO; ++f) os += fd->nodes[A * fd->FS + a * fd->FO + f].out;
+        need = max(need, max(ts, os));
+    }
+    const int lanes = min(64, (MH_TERMS * 2) / need);   // (need <= MAXF * MAXROW = 128: at least 16 lanes)
+    float* ex = reinterpret_cast<float*>(m.terms) + (size_t)min(lane, lanes - 1) * need;
     MH_SYNC();
-    for (int i = lane; i < A * S; i += 64) {
+    for (int i = lane; i < A * S && lane < lanes; i += lanes) {
         const int a = i / S, s = i % S;
-        float ex[MAXF][MAXROW];
+        int off[MAXF + 1];
         const uint64_t fv = pack_features(s, fd->Sstep, fd->FS);
-        for (int f = 0; f < fd->FS; ++f) {
-            const FNode& nd = fd->nodes[a * fd->FS + f];
-            mh_expected(model + node_row(fd, nd, node_mask(fd, nd, v), fv), nd.out, ex[f]);
+        off[0] = 0;
+#pragma unroll
+        for (int f = 0; f < MAXF; ++f) {
+            off[f + 1] = off[f];
+            if (f < fd->FS) {
+                const FNode& nd = fd->nodes[a * fd->FS + f];
+                mh_expected(model + node_row(fd, nd, node_mask(fd, nd, v), fv), nd.out, ex + off[f]);
+                off[f + 1] = off[f] + nd.out;
+            }
         }
         for (int ns = 0; ns < S; ++ns) {
             const uint64_t nf = pack_features(ns, fd->Sstep, fd->FS);
             float p = 1;
-            for (int f = 0; f < fd->FS; ++f) p *= ex[f][feat(nf, f)];
+#pragma unroll
+            for (int f = 0; f < MAXF; ++f)
+                if (f < fd->FS) p *= ex[off[f] + feat(nf, f)];
             T[((size_t)s * A + a) * S + ns] = p;
         }
-        for (int f = 0; f < fd->FO; ++f) {  // (s plays the new state here)
-            const FNode& nd = fd->nodes[A * fd->FS + a * fd->FO + f];
-            mh_expected(model + node_row(fd, nd, node_mask(fd, nd, v), fv), nd.out, ex[f]);
+#pragma unroll
+        for (int f = 0; f < MAXF; ++f) {  // (s plays the new state here)
+            off[f + 1] = off[f];
+            if (f < fd->FO) {
+                const FNode& nd = fd->nodes[A * fd->FS + a * fd->FO + f];
+                mh_expected(model + node_row(fd, nd, node_mask(fd, nd, v), fv), nd.out, ex + off[f]);
+                off[f + 1] = off[f] + nd.out;
+            }
         }
         for (int o = 0; o < NO; ++o) {
             const uint64_t of = pack_features(o, fd->Ostep, fd->FO);
             float p = 1;
-            for (int f = 0; f < fd->FO; ++f) p *= ex[f][feat(of, f)];
+#pragma unroll
+            for (int f = 0; f < MAXF; ++f)
+                if (f < fd->FO) p *= ex[off[f] + feat(of, f)];
             O[((size_t)a * S + s) * NO + o] = p;
         }
     }
@@ -894,7 +920,7 @@ __device__ __forceinline__ int mh_sample_d(Rng& g, const double* m, int n, doubl
     }
     return n - 1;
 }
-__device__ bool mh_sample_history(const Problem& P, const DeviceState& D, int e, Rng& g, const MhScratch& m, const float* model, int lane)
+__device__ __forceinline__ bool mh_sample_history(const Problem& P, const DeviceState& D, int e, Rng& g, const MhScratch& m, const float* model, int lane)
 {
     const int S = P.S, A = P.A, NO = P.O;
     const int16_t *ha = D.mh_a + (size_t)e * P.episodes * P.horizon, *ho = D.mh_o + (size_t)e * P.episodes * P.horizon;
@@ -926,7 +952,7 @@ __device__ bool mh_sample_history(const Problem& P, const DeviceState& D, int e,
         return true;
     }
     // msgSampleStateHistory: a lane per state of a message; the normalising sums run over the states in order
-    mh_flatten(P, model, m.T, m.O, lane);
+    mh_flatten(P, model, m.T, m.O, m, lane);
     const float init = 1.0f / (float)S;
     const float prior_p = (float)((double)init / (double)(init * (float)S));  // categoricalDistr(size, init)::prob (distributions.cpp:12-35)
     for (int ep = 0; ep < n_ep; ++ep) {
@@ -971,7 +997,7 @@ __device__ bool mh_sample_history(const Problem& P, const DeviceState& D, int e,
 // BABNModel::LogBDScore (log_bd_score, fba_device.h): the lgamma terms of up to 64 Dirichlet rows at a time, a lane per row,
 // then ONE running sum over them in CPT order -- the order, and so the double, of the one-lane score
 template <class View>
-__device__ double mh_log_bd_score(const Problem& P, const View& cnt, const View& prior, const MhScratch& m, int lane)
+__device__ __forceinline__ double mh_log_bd_score(const Problem& P, const View& cnt, const View& prior, const MhScratch& m, int lane)
 {
     const FDesc* fd = P.fd;
     const int per = fd->FS + fd->FO, nn = P.A * per, W = min(64, MH_TERMS / m.stride);

@@ -1,5 +1,5 @@
 """Turn gpurun_out/refresh/ (scripts/refresh_profiles.sh) into the committed profiles/<tag>_* files.
-python scripts/collect_profiles.py [tag]      (default r03)"""
+python scripts/collect_profiles.py [tag]      (default r04)"""
 import csv
 import glob
 import json
@@ -10,7 +10,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "refresh")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 
 
 def dst(name):
@@ -69,16 +69,18 @@ if os.path.exists(os.path.join(SRC, "randline.jsonl")):
         for k, v in pk.items():
             # every shape runs a warm-up launch and a timed one: the timed one is the second
             cnt.setdefault(k, {})[name] = v[-1] * (KIB if name.endswith("_B") else 1.0) / accesses
+    best = lambda name: max(s["G_records_per_s"] for s in shapes if s["shape"] == name)
     rl = {"shapes": shapes, "per_access_counters_of_one_XCD_instance_sum": cnt,
-          "note": "rocprofv3 sums the TCC counters it collects; on this box the per-access figures come out at 1/8 of the bytes a shape moves "
-                  "(one XCD's share): load16 reports 8.0 B of FETCH_SIZE per access = 64 B x 1/8, TCC_EA0_RDREQ 0.125 per access, no 32-byte "
-                  "requests.  So a random 16-byte load per lane costs ONE 64-byte read request at the fabric, and FETCH_SIZE counts it in full "
-                  "(the guide's x2 is for wide coalesced streams whose 128-byte requests are tallied at 64 B); a store into a record that is not "
-                  "resident fetches nothing (FETCH_SIZE 0) and writes 32 B."}
+          "note": "rocprofv3 sums the TCC counters it collects; on this box the per-access figures come out at 1/8 of what a shape asks for "
+                  "(one XCD's share): load16 reports 8.0 B of FETCH_SIZE per access = 64 B x 1/8 and TCC_EA0_RDREQ 0.125 per access.  pair64 (two lanes, "
+                  "the two 64-byte halves of ONE random 128-byte line) makes HALF a request per lane access and runs at twice load16's rate; line128 (one "
+                  "lane, both halves) one request for 128 bytes.  So a read request is a 128-byte line, FETCH_SIZE tallies it at 64 B, and fetched "
+                  "bytes are FETCH_SIZE x 2 for every access shape (the guide's rule); a store into a line that is not resident fetches nothing.",
+          "G_records_per_s": {k: best(k) for k in ("load16", "load64", "pair64", "line128", "far2x64") if any(s["shape"] == k for s in shapes)}}
     json.dump(rl, open(dst("randline_counters.json"), "w"), indent=1)
     load16 = max(s["G_records_per_s"] for s in shapes if s["shape"] == "load16")
 else:
-    load16 = 48.7   # G random 64-byte sectors per second (profiles/r03_randline.jsonl)
+    raise SystemExit("gpurun_out/refresh/randline.jsonl is missing: the search kernel's ceiling (random lines per second) is measured, not assumed")
 
 # ---- the search kernel: memory-side bytes, L2 requests and misses per simulated step
 sk = find(fetch, "search_kernel")
@@ -95,8 +97,9 @@ if sk and line:
         "command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE | TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCC_HIT_sum TCC_MISS_sum | SQ_*> "
                    "--output-format csv -- python3 bench.py --steps 4 --warmup 0 --no-cpu-baseline   (one pass per counter group)",
         "kernel": sk, "launches": launches, "simulated_steps_of_those_launches": steps,
-        "fetch_bytes_per_step": f_b / steps, "write_bytes_per_step": w_b / steps,
-        "fetch_sectors_64B_per_step": f_b / 64.0 / steps,
+        "fetch_bytes_per_step_counter": f_b / steps,
+        "fetch_bytes_per_step": 2.0 * f_b / steps, "write_bytes_per_step": w_b / steps,    # (a read request is a 128-byte line tallied at 64 B)
+        "fetch_sectors_64B_per_step": f_b / 64.0 / steps,                                   # = read requests (128-byte lines) per step
         "l2_misses_per_step": sum(l2["TCC_MISS_sum"][find(l2["TCC_MISS_sum"], "search_kernel")]) / steps,
         "l2_hits_per_step": sum(l2["TCC_HIT_sum"][find(l2["TCC_HIT_sum"], "search_kernel")]) / steps,
         "l1_read_requests_per_step": sum(l2["TCP_TCC_READ_REQ_sum"][find(l2["TCP_TCC_READ_REQ_sum"], "search_kernel")]) / steps,
@@ -106,12 +109,12 @@ if sk and line:
         "lds_wave_instructions_per_64_steps": sum(sq["SQ_INSTS_LDS"][find(sq["SQ_INSTS_LDS"], "search_kernel")]) * 64.0 / steps,
         "sq_wait_any_over_wave_cycles": sum(sq["SQ_WAIT_ANY"][find(sq["SQ_WAIT_ANY"], "search_kernel")]) /
                                         max(sum(sq["SQ_WAVE_CYCLES"][find(sq["SQ_WAVE_CYCLES"], "search_kernel")]), 1.0),
-        # what a simulated step needs of its records: per simulation one 64-byte particle record, per tree level below the two LDS-resident ones
-        # a 64-byte node record read and 24 bytes of it written back; at 0.44 simulations and ~0.2 such levels per step
+        # MODEL estimate, not a measurement: per simulation one 64-byte particle record, per tree level below the two LDS-resident ones a
+        # 64-byte node record read and 24 bytes of it written back, at 0.44 simulations and ~0.2 such levels per step
         "algorithmic_bytes_per_step": 0.44 * 64.0 + 0.2 * (64.0 + 24.0),
-        "random_sector_ceiling_G_per_s": load16,
-        "fetch_calibration": "FETCH_SIZE is exact for this kernel's loads (random 16-byte loads per lane: one 64-byte request each, "
-                             "profiles/%s_randline_counters.json); no x2" % tag,
+        "algorithmic_bytes_per_step_is": "a model estimate (simulations per step and HBM tree levels per step of the round-3 analysis), kept for the bench line's frac_algorithmic",
+        "random_sector_ceiling_G_per_s": load16,   # random 128-byte LINES per second (scripts/micro/randline load16 of this refresh)
+        "fetch_calibration": "fetched bytes = FETCH_SIZE x 2: a read request is one 128-byte line tallied at 64 B (profiles/%s_randline_counters.json)" % tag,
         "per_launch_KiB": {"fetch": fetch[sk], "write": write[find(write, "search_kernel")]},
     }
     json.dump(doc, open(dst("pmc_search.json"), "w"), indent=1)
@@ -144,15 +147,14 @@ if rk:
         "config": "default bench workload, 262144 slots, packed particles (64 B records)",
         "kernel": "reject_kernel", "kernel_instantiation": rk,
         "fetch_bytes_per_launch_raw": f_full, "write_bytes_per_launch": w_full, "traffic_bytes_per_launch_raw": f_full + w_full,
-        "fetch_bytes_per_launch_calibrated": park_true + gather_raw, "traffic_bytes_per_launch_calibrated": park_true + gather_raw + w_full,
-        "traffic_bytes_per_launch_upper_bound_r02_formula": park_true + 2.0 * gather_raw + w_full,
+        "fetch_bytes_per_launch_calibrated": park_true + 2.0 * gather_raw, "traffic_bytes_per_launch_calibrated": park_true + 2.0 * gather_raw + w_full,
+        "traffic_bytes_per_launch_round3_undercount": park_true + gather_raw + w_full,
         "notes": [
             "counter unit KiB; per-launch figure = the largest launch (one in which every slot updates)",
             "WRITE_SIZE is exact on gfx950: slots x N x 64 B is the minimum this kernel can write",
             "FETCH_SIZE: the parking pass (4-byte words of every 64-byte record, records in order: a coalesced sweep) reports 1 / %.2f of its bytes "
-            "(profiles/r02_pmc_calibration.json); the gather's random 64-byte record reads are counted in full -- one 64-byte request per record, "
-            "profiles/%s_randline_counters.json -- which round 2 had doubled on the assumption that the memory side moves 128-byte lines "
-            "(kept as traffic_bytes_per_launch_upper_bound_r02_formula)" % (park_factor, tag),
+            "(profiles/r02_pmc_calibration.json); the gather's random 64-byte record reads are one 128-byte line request each, tallied at 64 B: x 2 "
+            "(profiles/%s_randline_counters.json: pair64 / line128).  Round 3 counted them once (kept as traffic_bytes_per_launch_round3_undercount)" % (park_factor, tag),
         ],
     }
     json.dump(doc, open(dst("pmc_fetch_write.json"), "w"), indent=1)
@@ -171,12 +173,10 @@ if os.path.exists(os.path.join(SRC, "is_fetch", "run_counter_collection.csv")):
             "fetch_bytes_per_launch_raw": f_full, "write_bytes_per_launch": w_full, "traffic_bytes_per_launch_raw": f_full + w_full,
             # the update pass sweeps the filter's records and weights in order (wide coalesced loads: tallied at half, the guide's x2); the
             # resample's gather reads random 64-byte records (counted in full).  The sweep is slots x N x (64 + 8) bytes.
-            "fetch_bytes_per_launch_calibrated": f_full + w_full / 2.0,
-            "traffic_bytes_per_launch_calibrated": f_full + w_full / 2.0 + w_full,
+            "fetch_bytes_per_launch_calibrated": 2.0 * f_full,
+            "traffic_bytes_per_launch_calibrated": 2.0 * f_full + w_full,
             "notes": ["per-launch figure = the largest launch (every slot updates)",
-                      "calibrated = FETCH_SIZE + half the bytes written: the update pass sweeps the filter's records and weights in order (as many bytes as "
-                      "the kernel writes, N x 72 B per slot), a wide coalesced stream that FETCH_SIZE tallies at half; the resample's random record reads "
-                      "are counted in full (profiles/%s_randline_counters.json)" % tag],
+                      "calibrated = FETCH_SIZE x 2 + WRITE_SIZE: every read request is a 128-byte line tallied at 64 B (profiles/%s_randline_counters.json)" % tag],
         }
         json.dump(doc, open(dst("pmc_importance.json"), "w"), indent=1)
         print("importance:", {k: v for k, v in doc.items() if k.startswith("traffic")})

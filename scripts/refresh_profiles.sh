@@ -36,9 +36,17 @@ if [ -x $R/scripts/micro/randline ]; then
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --output-format csv -d $OUT/rl_l2 -o run -- $R/scripts/micro/randline 32 1024 > $OUT/rl_l2.log 2>&1
 fi
 echo "[refresh] randline done"
-# the other BASELINE configs through the same bench.py
-for wl in c1 c3 c4 c5; do
+# the other BASELINE configs through the same bench.py (c4 apart: its steady state needs a warm-up past one whole first episode)
+for wl in c1 c3 c5; do
   timeout -k 10 400 $B --workload $wl --steps 4 --warmup 1 > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err || echo "[refresh] $wl failed"
 done
+( while sleep 60; do echo "[refresh] c4 running"; done ) &
+HB=$!
+timeout -k 10 900 $B --workload c4 --steps 10 --warmup 20 > $OUT/bench_c4.json 2> $OUT/bench_c4.err || echo "[refresh] c4 failed"
+kill $HB
+# C3's rejection kernel: traffic passes
+S3="--workload c3 --steps 4 --warmup 0 --no-cpu-baseline"
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/c3_fetch -o run -- $B $S3 > $OUT/c3_fetch.log 2>&1 || echo "[refresh] c3 fetch failed"
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/c3_write -o run -- $B $S3 > $OUT/c3_write.log 2>&1 || echo "[refresh] c3 write failed"
 cat $OUT/bench_default.json
 cat $OUT/c5.json
