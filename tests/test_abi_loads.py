@@ -84,3 +84,10 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("oracle/orc.c particle_hash", "").replace("oracle/orc.c dev_scan", ""), f
+
+
+def test_the_documented_build_command_names_every_translation_unit():
+    """INTEGRATION.md section 5 shows the hipcc command a maintainer can paste; it once fell a translation unit behind the build."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for src in N.SOURCES:
+        assert os.path.relpath(src, ROOT) in text, src
