@@ -1585,13 +1585,17 @@ __global__ void __launch_bounds__(256) chunk_totals_kernel(const double* w_base,
 // One workgroup per slot.  The chain carry_{c+1} = carry_c + total_c is sequential by definition
 // (device-order sums); the totals are staged through LDS in tiles so the one lane that chains them
 // never waits on HBM.
+// (block b works on slot slot_list[slot_base + b] when a list is given -- a chunk of the compacted list of a budgeted context -- else on slot_base + b)
 __global__ void __launch_bounds__(256) scan_carry_kernel(double* ctot_base, int ctot_stride, int nchunks, double* total_base,
-                                                         int total_stride, int which, const uint8_t* need, int count)
+                                                         int total_stride, int which, const uint8_t* need, int count,
+                                                         const int32_t* slot_list = nullptr, int slot_base = 0)
 {
     __shared__ double tile[CARRY_TILE];
     __shared__ double s_carry0;
-    const int e = blockIdx.x, tid = threadIdx.x;
-    if (e >= count || (need && !need[e])) return;
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= count) return;
+    const int e = slot_list ? slot_list[slot_base + blockIdx.x] : slot_base + (int)blockIdx.x;
+    if (need && !need[e]) return;
     double* ct = ctot_base + (size_t)e * ctot_stride;
     if (tid == 0) { s_carry0 = 0; ct[0] = 0; }
     for (int c0 = 0; c0 < nchunks; c0 += CARRY_TILE) {
@@ -1652,18 +1656,27 @@ __global__ void fill_kernel(double* p, int n, double v)
     if (i < n) p[i] = v;
 }
 
-template <bool REG>
+// a history-particle slot whose records are full (more real steps than episodes * horizon: only the per-step interface can get there) is
+// skipped by every launch of the update; is_multi_finish_kernel raises the fault
+__device__ __forceinline__ bool hist_update_refused(const Problem& P, const DeviceState& D, int e)
+{
+    return P.hist && hist_total(D.hist_cnt[e]) >= P.hist_cap;
+}
+// HIST: history particles (importance_kernel<HIST> cut at its block-wide synchronisation points, so that a slot's update spreads over
+// N / 1024 workgroups instead of walking its chain in one)
+template <bool REG, bool HIST = false>
 __global__ void __launch_bounds__(256) is_multi_step_kernel(Problem P, DeviceState D)
 {
-    __shared__ int32_t s_inc[MAXINC * 256];
-    const int e = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
-    if (!D.need_update[e]) return;
+    __shared__ int32_t s_inc[HIST ? 1 : MAXINC * 256];
+    const int e = chunk_slot(D, blockIdx.y), tid = threadIdx.x, lane = tid & 63;
+    if (!D.need_update[e] || hist_update_refused(P, D, e)) return;
     const int c = blockIdx.x * 4 + (tid >> 6), N = P.N;
     if (c * 256 >= N) return;
     const int a = D.action[e], o = D.obs[e], ninc = model_ninc(P);
     const size_t sb = pbase(P, e, D.bufsel[e]);
     double* sw = D.p_weight + sb;
-    float* scn = D.p_rec + sb * (size_t)P.Cs;
+    float* scn = D.p_rec + rec_base(P, D, e, D.bufsel[e]) * (size_t)P.Cs;
+    const uint32_t hist_cnt = HIST ? D.hist_cnt[e] : 0u;
     Rng g = slot_rng(P, D, e);
     const int i0 = c * 256 + lane * 4;
     double sum = 0;
@@ -1675,6 +1688,17 @@ __global__ void __launch_bounds__(256) is_multi_step_kernel(Problem P, DeviceSta
             float* cnt = scn + (size_t)i * P.Cs;
             int s = rec_state(cnt, P.C), so;
             double r;
+            if (HIST) {
+                const uint32_t* rec = reinterpret_cast<const uint32_t*>(cnt);
+                uint32_t sp = (rec[1] >> 16) & 0x3ffu, entry;
+                double prob;
+                gridworld_hist_step(P, g, rec + 2 + hist_offset(hist_cnt, a), hist_count(hist_cnt, a), rec[1], sp, a, so, r, entry, o, prob);
+                *reinterpret_cast<int2*>(D.p_side + ((size_t)e * N + i) * 2) = make_int2(gridworld_unpack_state(P, sp), (int)entry);
+                v     = sw[i] * prob;
+                sw[i] = v;
+                sum   = (k == 0) ? v : sum + v;
+                continue;
+            }
             sim_step<REG>(P, g, GlobalSearchView{cnt}, s, a, so, r, LdsInc<256>{s_inc + tid});
             if (defer_increments(P)) {  // see importance_kernel
                 int32_t* sd = D.p_side + ((size_t)e * N + i) * D.side_w;
@@ -1696,8 +1720,8 @@ __global__ void __launch_bounds__(256) is_multi_step_kernel(Problem P, DeviceSta
 
 __global__ void __launch_bounds__(256) is_multi_norm_kernel(Problem P, DeviceState D)
 {
-    const int e = blockIdx.y, lane = threadIdx.x & 63;
-    if (!D.need_update[e]) return;
+    const int e = chunk_slot(D, blockIdx.y), lane = threadIdx.x & 63;
+    if (!D.need_update[e] || hist_update_refused(P, D, e)) return;
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), N = P.N;
     if (c * 256 >= N) return;
     double* sw = D.p_weight + pbase(P, e, D.bufsel[e]);
@@ -1718,8 +1742,8 @@ __global__ void __launch_bounds__(256) is_multi_norm_kernel(Problem P, DeviceSta
 __global__ void __launch_bounds__(256) is_multi_resample_kernel(Problem P, DeviceState D)
 {
     __shared__ int32_t s_src[256];
-    const int e = blockIdx.y, tid = threadIdx.x;
-    if (!D.need_update[e]) return;
+    const int e = chunk_slot(D, blockIdx.y), tid = threadIdx.x;
+    if (!D.need_update[e] || hist_update_refused(P, D, e)) return;
     const int N = P.N, j0 = blockIdx.x * 256, j = j0 + tid;
     const int cur = D.bufsel[e];
     const size_t sb = pbase(P, e, cur), db = pbase(P, e, cur ^ 1);
@@ -1732,6 +1756,13 @@ __global__ void __launch_bounds__(256) is_multi_resample_kernel(Problem P, Devic
         D.p_weight[db + j] = 1.0 / (double)N;
     }
     __syncthreads();
+    if (P.hist) {   // the source record with its particle's pending entry inserted (gather_hist_records), into the slot's scratch place
+        const uint32_t hist_cnt = D.hist_cnt[e];
+        const int a = D.action[e];
+        gather_hist_records(rec_dst(P, D, e, cur ^ 1) + (size_t)j0 * P.Cs, D.p_rec + rec_base(P, D, e, cur) * (size_t)P.Cs, s_src, D.p_side + (size_t)e * N * 2,
+                            hist_total(hist_cnt), 2 + hist_offset(hist_cnt, a) + hist_count(hist_cnt, a), min(256, N - j0), C4, group, 256);
+        return;
+    }
     if (defer_increments(P))
         gather_records_side(D.p_rec + (db + j0) * (size_t)P.Cs, D.p_rec + sb * (size_t)P.Cs, s_src, D.p_side + (size_t)e * N * D.side_w, D.side_w,
                             min(256, N - j0), C4, P.C, group, 256);
@@ -1742,8 +1773,8 @@ __global__ void __launch_bounds__(256) is_multi_resample_kernel(Problem P, Devic
 
 __global__ void __launch_bounds__(256) is_multi_scan_kernel(Problem P, DeviceState D)
 {
-    const int e = blockIdx.y;
-    if (!D.need_update[e]) return;
+    const int e = chunk_slot(D, blockIdx.y);
+    if (!D.need_update[e] || hist_update_refused(P, D, e)) return;
     const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6), N = P.N;
     if (c * 256 >= N) return;
     const double* sw = D.p_weight + pbase(P, e, D.bufsel[e]);
@@ -1768,10 +1799,24 @@ __global__ void __launch_bounds__(256) is_multi_scan_kernel(Problem P, DeviceSta
         }
 }
 
-__global__ void is_multi_finish_kernel(Problem P, DeviceState D)
+__global__ void is_multi_finish_kernel(Problem P, DeviceState D, int count)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= P.E || !D.need_update[e]) return;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= count) return;
+    const int e = chunk_slot(D, b);
+    if (!D.need_update[e]) return;
+    if (P.hist) {
+        const uint32_t hist_cnt = D.hist_cnt[e];
+        if (hist_total(hist_cnt) >= P.hist_cap) {   // (as importance_kernel<HIST>)
+            atomicCAS(D.fault, 0, 0x40000000 + e);
+            D.need_update[e] = 0;
+            D.active[e]      = 0;
+            return;
+        }
+        D.hist_cnt[e] = hist_cnt + (1u << (8 * D.action[e]));
+        D.upd_entries[e] += (unsigned long long)P.N * (unsigned long long)hist_total(hist_cnt);
+        if (D.single_rec) D.copy_pending[e] = 1;
+    }
     D.bufsel[e] ^= 1;
     D.need_update[e] = 0;
     D.belief_steps[e] += (unsigned long long)P.N;
@@ -2251,6 +2296,30 @@ static void for_each_chunk(const Problem& P, const DeviceState& D, hipStream_t s
         (void)hipMemsetAsync(D.copy_pending + e0, 0, (size_t)cnt, st);
     }
 }
+// the importance update of `count` slots (all of them, a chunk, or a chunk of the compacted list: chunk_slot) as seven launches, so that a slot's
+// particles spread over many workgroups
+static void launch_importance_multi(const Problem& P, const DeviceState& D, int count, hipStream_t st)
+{
+    const int nchunks = (P.N + 255) / 256;
+    const dim3 cgrid(ceil_div(nchunks, 4), count), eg(ceil_div(count, 64));
+    const int32_t* list = D.use_list ? D.slot_list : nullptr;
+    if (P.hist) hipLaunchKernelGGL((is_multi_step_kernel<false, true>), cgrid, dim3(256), 0, st, P, D);
+    else if (P.dirichlet_regular) hipLaunchKernelGGL((is_multi_step_kernel<true, false>), cgrid, dim3(256), 0, st, P, D);
+    else hipLaunchKernelGGL((is_multi_step_kernel<false, false>), cgrid, dim3(256), 0, st, P, D);
+    hipLaunchKernelGGL(scan_carry_kernel, dim3(count), dim3(256), 0, st, D.ctot, D.ctot_stride, nchunks, D.is_tot, 2, 0, D.need_update, count, list, D.slot_base);
+    hipLaunchKernelGGL(is_multi_norm_kernel, cgrid, dim3(256), 0, st, P, D);
+    hipLaunchKernelGGL(scan_carry_kernel, dim3(count), dim3(256), 0, st, D.ctot, D.ctot_stride, nchunks, D.is_tot, 2, 1, D.need_update, count, list, D.slot_base);
+    hipLaunchKernelGGL(is_multi_scan_kernel, cgrid, dim3(256), 0, st, P, D);
+    hipLaunchKernelGGL(is_multi_resample_kernel, dim3(ceil_div(P.N, 256), count), dim3(256), 0, st, P, D);
+    hipLaunchKernelGGL(is_multi_finish_kernel, eg, dim3(64), 0, st, P, D, count);
+}
+// history particles: several workgroups per slot from this many particles up (FBA_HIST_MULTI=1 / 0 forces / forbids it: tests, A/B runs)
+static bool hist_update_multi(const Problem& P)
+{
+    static const char* ev = std::getenv("FBA_HIST_MULTI");
+    if (ev) return std::atoi(ev) != 0;
+    return P.N >= 4096;
+}
 void launch_belief_update(const Problem& P, const DeviceState& D, hipStream_t st)
 {
     if (P.nested) {
@@ -2301,6 +2370,7 @@ void launch_belief_update(const Problem& P, const DeviceState& D, hipStream_t st
     if (!D.is_multi) {
         if (D.single_rec)
             for_each_chunk(P, D, st, [&](const DeviceState& Dc, int cnt) {
+                if (P.hist && hist_update_multi(P)) { launch_importance_multi(P, Dc, cnt, st); return; }
                 if (!Dc.use_list) { launch_importance_single(P, Dc, st); return; }
                 DeviceState Dl   = Dc;           // (list mode: the launch's grid is the chunk's count; scratch places were fixed against
                 Dl.scratch_slots = cnt;          //  the pool's size when the list was built)
@@ -2314,16 +2384,7 @@ void launch_belief_update(const Problem& P, const DeviceState& D, hipStream_t st
         }
         return;
     }
-    const int nchunks = (P.N + 255) / 256;
-    const dim3 cgrid(ceil_div(nchunks, 4), P.E), eg(ceil_div(P.E, 64));
-    if (P.dirichlet_regular) hipLaunchKernelGGL(is_multi_step_kernel<true>, cgrid, dim3(256), 0, st, P, D);
-    else hipLaunchKernelGGL(is_multi_step_kernel<false>, cgrid, dim3(256), 0, st, P, D);
-    hipLaunchKernelGGL(scan_carry_kernel, dim3(P.E), dim3(256), 0, st, D.ctot, D.ctot_stride, nchunks, D.is_tot, 2, 0, D.need_update, P.E);
-    hipLaunchKernelGGL(is_multi_norm_kernel, cgrid, dim3(256), 0, st, P, D);
-    hipLaunchKernelGGL(scan_carry_kernel, dim3(P.E), dim3(256), 0, st, D.ctot, D.ctot_stride, nchunks, D.is_tot, 2, 1, D.need_update, P.E);
-    hipLaunchKernelGGL(is_multi_scan_kernel, cgrid, dim3(256), 0, st, P, D);
-    hipLaunchKernelGGL(is_multi_resample_kernel, dim3(ceil_div(P.N, 256), P.E), dim3(256), 0, st, P, D);
-    hipLaunchKernelGGL(is_multi_finish_kernel, eg, dim3(64), 0, st, P, D);
+    launch_importance_multi(P, D, P.E, st);
 }
 void launch_init(const Problem& P, const DeviceState& D, hipStream_t st)
 {
