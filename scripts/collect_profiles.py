@@ -199,3 +199,31 @@ if os.path.exists(os.path.join(SRC, "c5.json")) and os.path.getsize(os.path.join
     shutil.copy(os.path.join(SRC, "c5_stats", "run_kernel_stats.csv"), dst("c5_kernel_stats.csv"))
     print("c5:", c5["ms_per_update"], c5["frac_of_8TBs"], c5["frac_of_8TBs_on_pmc_traffic"])
 print(open(dst("bench_kernel_stats.csv")).read()[:700])
+
+# ---- C3's rejection kernel (packed factored-tiger records): fabric traffic of a full launch
+if os.path.exists(os.path.join(SRC, "c3_fetch", "run_counter_collection.csv")) and os.path.exists(os.path.join(SRC, "c3_write", "run_counter_collection.csv")):
+    f3 = per_kernel(os.path.join(SRC, "c3_fetch", "run_counter_collection.csv"), "FETCH_SIZE")
+    w3 = per_kernel(os.path.join(SRC, "c3_write", "run_counter_collection.csv"), "WRITE_SIZE")
+    rk3, sk3 = find(f3, "reject_kernel"), find(f3, "search_kernel")
+    ln = last_json(os.path.join(SRC, "c3_fetch.log"))
+    if rk3 and ln:
+        slots3, rec3 = ln["config"]["slots_per_gpu"], ln["roofline"]["particle_bytes_in_hbm"]
+        full = max(range(len(w3[rk3])), key=lambda i: w3[rk3][i])   # the launch in which every slot updates writes the most
+        doc = {
+            "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py --workload c3 --steps 4 --warmup 0 --no-cpu-baseline",
+            "config": ln["config"], "kernel": "reject_kernel", "kernel_instantiation": rk3,
+            "per_launch_GB": {"fetch_counter": [x * KIB / 1e9 for x in f3[rk3]], "write": [x * KIB / 1e9 for x in w3[rk3]]},
+            "full_launch": {"fetch_bytes_counter": f3[rk3][full] * KIB, "fetch_bytes_x2": 2 * f3[rk3][full] * KIB, "write_bytes": w3[rk3][full] * KIB,
+                            "traffic_bytes": 2 * f3[rk3][full] * KIB + w3[rk3][full] * KIB, "min_traffic_bytes": 2.0 * slots3 * 4096 * rec3,
+                            "note": "the launch in which every slot updates; FETCH_SIZE x 2: a read request is a 128-byte line tallied at 64 B "
+                                    "(profiles/%s_randline_counters.json)" % tag},
+            "search_kernel": {"kernel_instantiation": sk3, "per_launch_GB": {"fetch_counter": [x * KIB / 1e9 for x in f3[sk3]], "write": [x * KIB / 1e9 for x in w3[sk3]]}} if sk3 else None,
+            "bench_line_of_the_fetch_pass": ln,
+        }
+        json.dump(doc, open(dst("pmc_c3.json"), "w"), indent=1)
+        print("c3 reject:", doc["full_launch"])
+# ---- C4 steady state: appended to the round's file of C4 lines
+p4 = os.path.join(SRC, "bench_c4.json")
+if os.path.exists(p4) and os.path.getsize(p4):
+    with open(dst("c4_full_size.jsonl"), "a") as f:
+        f.write(open(p4).read().strip().splitlines()[-1] + "\n")
