@@ -1257,8 +1257,15 @@ struct GlobalEntries {
 
 // a Dirichlet row in registers: prior row (K / 4 aligned 16-byte loads; the words past n belong to the next row
 // or the table's padding and are not used) + this particle's increments
+// K = floats fetched (16-byte pieces); the loops over a row run to KL: a 12-float row holds at most 10 values (G <= 10 goals, N <= 8), and the
+// two padding places cost a sixth of every pass
 template <int K>
 struct HistRow {
+#ifdef FBA_ROW_FULL   /* A/B builds: walk the padding too */
+    static constexpr int KL = K;
+#else
+    static constexpr int KL = K == 12 ? 10 : K;
+#endif
     float r[K];
     __device__ __forceinline__ void fetch(const float* __restrict__ prior)
     {
@@ -1273,7 +1280,7 @@ struct HistRow {
     __device__ __forceinline__ void add(int n, const COUNTS& c)
     {
 #pragma unroll
-        for (int i = 0; i < K; ++i) r[i] = i < n ? r[i] + c.at(i) : 0.f;
+        for (int i = 0; i < KL; ++i) r[i] = i < n ? r[i] + c.at(i) : 0.f;
     }
     // sampleFromExpectedMult (random.cpp:244-255) for the uniform draw u: double total, float CDF against a double
     // threshold.  Counts are never negative, so the CDF does not decrease and "the first i with p < cdf(i), else
@@ -1282,7 +1289,7 @@ struct HistRow {
     {
         double total = (double)r[0];
 #pragma unroll
-        for (int i = 1; i < K; ++i)
+        for (int i = 1; i < KL; ++i)
             if (i < n) total += (double)r[i];
         const double p = u * total;
         // "p < (double)sum" for a float sum is "sum > pf" with pf the largest float <= p (p >= 0): the comparisons stay in fp32
@@ -1291,7 +1298,7 @@ struct HistRow {
         float sum = r[0];
         int pick  = 0;
 #pragma unroll
-        for (int i = 1; i < K; ++i) {
+        for (int i = 1; i < KL; ++i) {
             pick += (i < n && !(sum > pf)) ? 1 : 0;
             sum += r[i];
         }
@@ -1302,7 +1309,7 @@ struct HistRow {
     {
         float sum = r[0], mine = r[0];
 #pragma unroll
-        for (int i = 1; i < K; ++i)
+        for (int i = 1; i < KL; ++i)
             if (i < n) { sum += r[i]; mine = (i == o) ? r[i] : mine; }
         return ((double)sum <= 1e-300) ? 0.0f : mine / sum;
     }

@@ -879,7 +879,7 @@ int upload_prior(fba_ctx* c)
         {
             // the same rows deduplicated (Problem::hist_lds): a row slot -> one byte, the distinct rows K floats each
             const HistRowIds I(N, G, A);
-            const int K = c->P.hist_row <= 8 ? 8 : (c->P.hist_row <= 12 ? 12 : 16);
+            const int K = c->P.hist_row <= 8 ? 8 : (c->P.hist_row <= 10 ? 12 : 16);   // (a 12-float row is walked to 10: HistRow::KL)
             const int rid_bytes = (I.total + 15) & ~15;
             std::vector<uint8_t> blob((size_t)rid_bytes, 0);
             std::vector<float> rows;

@@ -800,6 +800,7 @@ __device__ __forceinline__ double quad_get_f64(uint32_t lo, uint32_t hi)
     return __hiloint2double((int)quad_get<LANE>(hi), (int)quad_get<LANE>(lo));
 }
 __device__ __forceinline__ uint32_t h2_home_line(uint32_t code, uint32_t nlines) { return __umulhi(child_hash((uint64_t)code), nlines); }
+// (24-bit multiplies for the row numbers and a cheaper 32-bit mix here were each about 1 % SLOWER on C4, same box: profiles/r04_search_experiments.txt 11)
 
 #ifndef FBA_HIST2_WAVES
 #define FBA_HIST2_WAVES 2   // waves per SIMD the register allocation aims at (3: at most 168 VGPRs)
@@ -810,7 +811,7 @@ constexpr int H2_WAVES = 4;                                   // waves per workg
 constexpr int H2_BLOCK = H2_WAVES * 64;
 __host__ __device__ __forceinline__ size_t h2_shared_bytes(const Problem& P, bool lrows)
 {
-    const int K = P.hist_row <= 8 ? 8 : (P.hist_row <= 12 ? 12 : 16);
+    const int K = P.hist_row <= 8 ? 8 : (P.hist_row <= 10 ? 12 : 16);
     return lrows ? (size_t)P.hist_rid_bytes + (size_t)P.hist_distinct * K * sizeof(float) : (size_t)4 * HistLayout(P.gw_N, P.gw_G, 4).ostride * sizeof(float);
 }
 __host__ __device__ __forceinline__ size_t h2_wave_bytes(const Problem& P)
@@ -1259,13 +1260,13 @@ void launch_search(const Problem& P, const DeviceState& D, hipStream_t st)
         else hipLaunchKernelGGL((search_hist2_kernel<KV, false>), grid2, block2, lds2, st, P, D);                      \
     } while (0)
             if (P.hist_row <= 8) FBA_LAUNCH_H2(8);
-            else if (P.hist_row <= 12) FBA_LAUNCH_H2(12);
+            else if (P.hist_row <= 10) FBA_LAUNCH_H2(12);
             else FBA_LAUNCH_H2(16);
 #undef FBA_LAUNCH_H2
             return;
         }
         if (P.hist_row <= 8) hipLaunchKernelGGL((search_hist_kernel<8>), qgrid, block, lds, st, P, D);
-        else if (P.hist_row <= 12) hipLaunchKernelGGL((search_hist_kernel<12>), qgrid, block, lds, st, P, D);
+        else if (P.hist_row <= 10) hipLaunchKernelGGL((search_hist_kernel<12>), qgrid, block, lds, st, P, D);
         else hipLaunchKernelGGL((search_hist_kernel<16>), qgrid, block, lds, st, P, D);
         return;
     }
