@@ -1472,6 +1472,8 @@ struct QuadRng {
     __device__ __forceinline__ uint64_t next64() { return at(draw++); }   // a draw all four lanes consume together
     __device__ __forceinline__ double u01() { return u01_of(next64()); }
     __device__ __forceinline__ int slow_int(int lo, int hi) { return lo + (int)floor(u01() * (double)(hi - lo)); }
+    // slow_int(0, 4): floor(u * 4) with u = (w >> 11) * 2^-53 is the top two bits of the draw -- the scaling is exact, so this is the same integer
+    __device__ __forceinline__ int slow_int4() { return (int)(next64() >> 62); }
 };
 __device__ __forceinline__ int quad_bcast(int addr0, int from, int v) { return __builtin_amdgcn_ds_bpermute(addr0 + 4 * from, v); }
 

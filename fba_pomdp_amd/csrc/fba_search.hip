@@ -1081,7 +1081,7 @@ __global__ void __launch_bounds__(H2_BLOCK) __attribute__((amdgpu_waves_per_eu(F
                 path_n[(size_t)plen * HIST_TREES] = a == 0 ? cn[0] : (a == 1 ? cn[1] : (a == 2 ? cn[2] : cn[3]));   // (unused at the root: its back-up works on the registers)
                 path_q[(size_t)plen * HIST_TREES] = a == 0 ? cq[0] : (a == 1 ? cq[1] : (a == 2 ? cq[2] : cq[3]));
             } else {
-                a = g.slow_int(0, 4);  // GridWorld::generateRandomAction :220-226
+                a = g.slow_int4();  // GridWorld::generateRandomAction :220-226 (slowRandomInt(0, 4))
             }
 #ifdef FBA_PROFILE_SEARCH
         }

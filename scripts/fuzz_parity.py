@@ -87,6 +87,8 @@ def draw(rng):
         kw["planner"] = rng.choice(["random", "ts"])
     if domain == "gridworld" and model == N.MODEL_BA_FACTORED and belief == "importance_sampling" and rng.random() < 0.6:
         kw["search_budget"] = rng.choice([1, 9, 60, 400])   # engine only: budgeted launches must give the results of whole searches
+    if domain == "gridworld" and model == N.MODEL_BA_FACTORED and belief == "importance_sampling" and rng.random() < 0.5:
+        kw["tree_buckets"] = max(8, kw["sims"] + rng.choice([0, 2, 40]))   # engine only: a bucket table that a dense little tree fills to the brim (lookups walk past their home line)
     return domain, model, belief, slots, kw
 
 
@@ -96,6 +98,7 @@ def one(domain, model, belief, slots, kw, seed):
     eng = fba.Engine(domain, model=model, belief=belief, planner=planner, seed=seed, slots=slots, trace=1, **kw)
     okw = dict(kw)
     okw.pop("search_budget", None)     # (a schedule of the engine, not a parameter of the algorithm)
+    okw.pop("tree_buckets", None)      # (the size of the engine's tree table, likewise)
     if domain == "centered-collision-avoidance":
         okw["ca_centered"] = 1
     o = orc.Oracle(domain=DOM[domain], model=model, belief=N.BELIEF_NAMES[belief], planner=N.PLANNER_NAMES[planner],
