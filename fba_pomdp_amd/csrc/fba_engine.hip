@@ -1156,6 +1156,7 @@ void fba_destroy(fba_ctx* c)
     for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto& p : c->free_events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (void* p : c->allocs) (void)hipFree(p);
+    if (c->D.list_count_host) (void)hipHostFree(c->D.list_count_host);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1763,6 +1764,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
             CHK(dev_alloc(c, &D.slot_list, E));
             CHK(dev_alloc(c, &D.scratch_idx, E));
             CHK(dev_alloc(c, &D.list_count, 1));
+            HIPC(hipHostMalloc(reinterpret_cast<void**>(&D.list_count_host), sizeof(int32_t), hipHostMallocDefault));
         }
     }
     CHK(dev_alloc(c, &c->d_prior, P.Cs));

@@ -2270,8 +2270,10 @@ static void for_each_chunk(const Problem& P, const DeviceState& D, hipStream_t s
         hipError_t he = hipMemsetAsync(D.list_count, 0, sizeof(int32_t), st);
         hipLaunchKernelGGL(build_slot_list_kernel, dim3(ceil_div(P.E, 256)), dim3(256), 0, st, P, D, flag);
         int32_t n = 0;
-        if (he == hipSuccess) he = hipMemcpyAsync(&n, D.list_count, sizeof n, hipMemcpyDeviceToHost, st);
+        int32_t* dst = D.list_count_host ? D.list_count_host : &n;
+        if (he == hipSuccess) he = hipMemcpyAsync(dst, D.list_count, sizeof n, hipMemcpyDeviceToHost, st);
         if (he == hipSuccess) he = hipStreamSynchronize(st);
+        if (he == hipSuccess) n = *dst;
         if (he != hipSuccess) {   // the count is unknown: nothing was launched, the request flags stay set -- the engine must hear of it (timed())
             g_launch_err = he;
             return;

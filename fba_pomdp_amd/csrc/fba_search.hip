@@ -1256,6 +1256,10 @@ void launch_search(const Problem& P, const DeviceState& D, hipStream_t st)
             const dim3 grid2(ceil_div(P.E, HIST_TREES * nw)), block2(64 * nw);
 #define FBA_LAUNCH_H2(KV)                                                                                              \
     do {                                                                                                               \
+        if (lds2 > 64 * 1024) {   /* (one wave of a very deep horizon: past the default limit of a workgroup's dynamic LDS) */ \
+            if (lrows) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&search_hist2_kernel<KV, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
+            else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&search_hist2_kernel<KV, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
+        }                                                                                                              \
         if (lrows) hipLaunchKernelGGL((search_hist2_kernel<KV, true>), grid2, block2, lds2, st, P, D);                 \
         else hipLaunchKernelGGL((search_hist2_kernel<KV, false>), grid2, block2, lds2, st, P, D);                      \
     } while (0)

@@ -73,6 +73,7 @@ struct DeviceState {
     // then run over a compacted list of those slots (block b of a launch works on slot slot_list[slot_base + b], scratch place b)
     int32_t* slot_list;       // [E] or null
     int32_t* list_count;      // [1]
+    int32_t* list_count_host; // [1] pinned host memory: where the launcher reads the count (a pageable destination is staged by the runtime)
     int32_t* scratch_idx;     // [E] the scratch place of a listed slot
     int32_t use_list;         // 1 in the DeviceState of a launch over the list
     // incubator belief (StructureIncubatorSampling.cpp): the weighted shadow filter, laid out like p_rec / p_weight / bufsel

@@ -871,6 +871,37 @@ def test_the_bucket_tree_gives_the_results_of_node_records(size, sims, buckets, 
     assert np.array_equal(r0[0], r1[0]) and np.array_equal(r0[1], r1[1])
 
 
+@pytest.mark.parametrize("horizon,episodes", [(35, 2), (60, 2)])
+def test_long_histories_and_deep_horizons_on_the_bucket_tree(horizon, episodes, monkeypatch):
+    """Records of more than 63 entries (episodes * horizon > 63): the quad's lanes cannot count in 6-bit fields, so every lane walks every entry for its
+    own feature as search_hist_kernel does; a horizon of 60 also makes a wave's paths long enough that a workgroup holds one or two waves instead of
+    four.  Same results as node records + hash table, and as the oracle."""
+    kw = dict(model=N.MODEL_BA_FACTORED, belief="importance_sampling", size=3, sims=48, particles=64, structure_prior=2, horizon=horizon,
+              episodes=episodes, runs=4, slots=4, seed=77 + horizon, trace=1)
+    out = []
+    for records in (True, False):
+        if records:
+            monkeypatch.setenv("FBA_HIST_TREE", "records")
+        else:
+            monkeypatch.delenv("FBA_HIST_TREE")
+        eng = fba.Engine("gridworld", **kw)
+        assert eng.particle_bytes < 4096
+        stats = eng.run_bapomdp()
+        out.append((eng.trace(), [(s.count, s.mean, s.m2) for s in stats]))
+        eng.close()
+    (t0, s0), (t1, s1) = out
+    assert len(t0) == len(t1) and s0 == s1
+    for name in t0.dtype.names:
+        assert np.array_equal(t0[name], t1[name]), name
+    okw = {k: v for k, v in kw.items() if k not in ("slots", "seed", "belief")}
+    o = orc.Oracle(domain=orc.DOM_GRIDWORLD, belief=orc.BELIEF_IMPORTANCE, rng_mode=orc.RNG_PHILOX, arith=orc.ARITH_DEV, philox_seed=kw["seed"], **okw)
+    ostats, res = o.run_bapomdp()
+    otr = o.trace(res.n_trace)
+    assert len(otr) == len(t1)
+    for name in t1.dtype.names:
+        assert np.array_equal(t1[name], otr[name]), name
+
+
 def test_a_bucket_tree_that_is_too_small_stops_the_experiment_loudly():
     """fba_config.tree_buckets below what a search needs: FBA_ESTATE with the knob's name, never a wrong action."""
     eng = fba.Engine("gridworld", model=N.MODEL_BA_FACTORED, belief="importance_sampling", size=3, sims=512, particles=64, structure_prior=2,
