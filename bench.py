@@ -44,7 +44,8 @@ WORKLOADS = {
                horizon=10, episodes=64, slots=163840, cpu=dict(runs=4, episodes=60, sims=2048, particles=1024)),   # (ten search waves per CU: what LDS holds)
     "c4": dict(name="configs[3]: gridworld (--size 7) FBA-POMDP, 65536 sims/step, 16384 particles, importance sampling, episode-sharded",
                domain="gridworld", model=2, belief="importance_sampling", size=7, structure_prior=2, sims=65536, particles=16384,
-               horizon=20, episodes=2, slots=32768, search_budget=16384, tree_buckets=65536, cpu=dict(runs=8, episodes=1, sims=2048, particles=1024)),
+               horizon=20, episodes=2, slots=49152, search_budget=16384, tree_buckets=32768, cpu=dict(runs=8, episodes=1, sims=2048, particles=1024)),
+               # (49 152 slots = three search waves of 16 trees on each of the 1 024 SIMDs; 32 768 buckets per tree: 17 800 in use; 5.5 MB per slot, 270 GB)
     "c5": dict(name="configs[4]: collision avoidance 7x7, 2 obstacles (largest factored domain), 10^6 particles per belief, "
                     "importance-weighted update + resample (4 beliefs in flight: the search is 4 lanes of one wave and measures nothing -- "
                     "this workload times the filter)",
@@ -320,7 +321,8 @@ def main():
         except fba.FbaError as e:
             if "out of memory" not in str(e) or slots <= 1:
                 raise
-            nxt = next((v for v in (245760, 196608, 163840, 131072) if v < slots), (slots * 7) // 8 if slots > 8 else slots // 2)
+            ladder = (32768, 16384) if args.workload == "c4" else (245760, 196608, 163840, 131072)   # (whole waves per SIMD: a partial round of waves costs more than it adds)
+            nxt = next((v for v in ladder if v < slots), (slots * 7) // 8 if slots > 8 else slots // 2)
             print(f"[bench] rank {rank}: {slots} slots do not fit ({e}); retrying with {nxt}", file=sys.stderr)
             slots = nxt
     if world > 1:   # weak scaling = the same work on every GPU: all ranks run the smallest count any of them could allocate

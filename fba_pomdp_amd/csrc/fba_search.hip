@@ -803,7 +803,8 @@ __device__ __forceinline__ uint32_t h2_home_line(uint32_t code, uint32_t nlines)
 // (24-bit multiplies for the row numbers and a cheaper 32-bit mix here were each about 1 % SLOWER on C4, same box: profiles/r04_search_experiments.txt 11)
 
 #ifndef FBA_HIST2_WAVES
-#define FBA_HIST2_WAVES 2   // waves per SIMD the register allocation aims at (3: at most 168 VGPRs)
+#define FBA_HIST2_WAVES 3   // waves per SIMD the register allocation aims at: 3 = at most 168 VGPRs, which the kernel meets with two spilled registers since
+                            // the root's statistics moved to LDS (with them in registers the cap spilled 14-17 and cost 24 %); 2 = 175, for A/B builds
 #endif
 // LROWS: every Dirichlet row of the prior comes from LDS (Problem::hist_lds: row ids + the distinct rows, shared by the H2_WAVES waves of a
 // workgroup); otherwise the transition rows come from the padded tables in HBM and only the observation tables sit in LDS.
@@ -818,7 +819,7 @@ __host__ __device__ __forceinline__ size_t h2_wave_bytes(const Problem& P)
 {
     const int depth_cap = P.max_depth > 0 ? P.max_depth : 1;
     return (size_t)depth_cap * HIST_TREES * (sizeof(double) + sizeof(int32_t) + sizeof(float) + sizeof(int32_t)) +
-           (size_t)(P.Cs > 2 * depth_cap ? P.Cs : 2 * depth_cap) * HIST_TREES * sizeof(float);
+           (size_t)(P.Cs > 2 * depth_cap ? P.Cs : 2 * depth_cap) * HIST_TREES * sizeof(float) + (size_t)12 * HIST_TREES * sizeof(float);   // (+ the root's statistics)
 }
 template <int K, bool LROWS>
 __global__ void __launch_bounds__(H2_BLOCK) __attribute__((amdgpu_waves_per_eu(FBA_HIST2_WAVES, FBA_HIST2_WAVES))) search_hist2_kernel(Problem P, DeviceState D)
@@ -836,6 +837,10 @@ __global__ void __launch_bounds__(H2_BLOCK) __attribute__((amdgpu_waves_per_eu(F
     int32_t* path_na = reinterpret_cast<int32_t*>(path_r - tl + (size_t)depth_cap * HIST_TREES) + tl;            // bucket << 5 | action
     uint32_t* stage  = reinterpret_cast<uint32_t*>(path_na - tl + (size_t)depth_cap * HIST_TREES) + tl;           // [Cs][trees]
                                                                                                                   // (stage also holds the back-up's returns: two words per level)
+    // the root's statistics, [4 counts, 4 Q's][trees]: read where the root is selected at and where it is backed up, i.e. twice per simulation -- in
+    // registers they were thirteen of the kernel's live values for the whole search
+    double* root_q  = reinterpret_cast<double*>(stage - tl + (size_t)max(P.Cs, 2 * depth_cap) * HIST_TREES) + tl;      // [4][trees]
+    int32_t* root_n = reinterpret_cast<int32_t*>(root_q - tl + (size_t)4 * HIST_TREES) + tl;                           // [4][trees]
     const HistLayout HL(P.gw_N, P.gw_G, 4);
     {   // the workgroup's shared tables: every thread, before any quad leaves
         const uint4* src = LROWS ? reinterpret_cast<const uint4*>(P.hist_lds) : reinterpret_cast<const uint4*>(P.hist_base + HL.obase0);
@@ -854,9 +859,7 @@ __global__ void __launch_bounds__(H2_BLOCK) __attribute__((amdgpu_waves_per_eu(F
     const int max_tree_depth = min(P.horizon - hist_len, P.max_depth);
     const float* prec   = D.p_rec + rec_base(P, D, e, D.bufsel[e]) * (size_t)P.Cs;
     const uint32_t hist_cnt = D.hist_cnt[e];
-    const int hist_n        = hist_total(hist_cnt);
-    const int n4            = (hist_n + 5) >> 2;  // 16-byte pieces of a record: state, structure bits, entries
-    const uint32_t hist_off = (uint32_t)hist_offset(hist_cnt, 1) << 8 | (uint32_t)hist_offset(hist_cnt, 2) << 16 | (uint32_t)hist_offset(hist_cnt, 3) << 24;
+    const int n4            = (hist_total(hist_cnt) + 5) >> 2;  // 16-byte pieces of a record: state, structure bits, entries
     const bool uni_exact    = (P.N & (P.N - 1)) == 0 && D.uni_total == 1.0;   // N = 2^k: the prefix sums of the weights 1/N are the exact values (i + 1) / N
 
     if (P.planner == FBA_PLANNER_RANDOM) {  // RandomPlanner::selectAction RandomPlanner.cpp:14-24
@@ -875,11 +878,9 @@ __global__ void __launch_bounds__(H2_BLOCK) __attribute__((amdgpu_waves_per_eu(F
     int sim               = budget > 0 ? D.s_sim[e] : 0;
     const bool resume     = sim > 0;
     int n_nodes = 1, tree_depth = 0;
-    unsigned long long steps = 0;
-    int r_vis = 0, r_cn[AMAX];
-    double r_cq[AMAX];
+    uint32_t steps = 0;   // (of this launch: at most sims x horizon)
 #pragma unroll
-    for (int a = 0; a < AMAX; ++a) { r_cn[a] = 0; r_cq[a] = 0.0; }
+    for (int a = 0; a < AMAX; ++a) { root_n[a * HIST_TREES] = 0; root_q[a * HIST_TREES] = 0.0; }
     uint32_t epoch;
     if (!resume) {
         epoch = D.epoch[e] + 1;
@@ -895,7 +896,7 @@ __global__ void __launch_bounds__(H2_BLOCK) __attribute__((amdgpu_waves_per_eu(F
         const int32_t* rn = reinterpret_cast<const int32_t*>(D.s_root + (size_t)e * 6);
         const double* rq  = D.s_root + (size_t)e * 6 + 2;
 #pragma unroll
-        for (int a = 0; a < AMAX; ++a) { r_cn[a] = rn[a]; r_cq[a] = rq[a]; r_vis += r_cn[a]; }
+        for (int a = 0; a < AMAX; ++a) { root_n[a * HIST_TREES] = rn[a]; root_q[a * HIST_TREES] = rq[a]; }
     }
     const uint32_t ekey = epoch << 28;
     int ts_src = -1;
@@ -1073,11 +1074,13 @@ __global__ void __launch_bounds__(H2_BLOCK) __attribute__((amdgpu_waves_per_eu(F
                 int vis = 0;
 #pragma unroll
                 for (int a2 = 0; a2 < AMAX; ++a2) {
-                    cn[a2] = at_root ? r_cn[a2] : cn[a2];
-                    cq[a2] = at_root ? r_cq[a2] : cq[a2];
+                    const int rn2 = root_n[a2 * HIST_TREES];
+                    const double rq2 = root_q[a2 * HIST_TREES];
+                    cn[a2] = at_root ? rn2 : cn[a2];
+                    cq[a2] = at_root ? rq2 : cq[a2];
                     vis += cn[a2];    // (ActionNode::_visit_count is the sum of its chance nodes' counts: every back-up through the node adds one to exactly one of them)
                 }
-                a = ucb_pick<AMAX>(P, g, D.log1p_tab, at_root ? r_vis : vis, cn, cq, true);
+                a = ucb_pick<AMAX>(P, g, D.log1p_tab, vis, cn, cq, true);   // (the root's visits are the sum of its counts too: MCTSTreeNodes.cpp:59-62)
                 path_n[(size_t)plen * HIST_TREES] = a == 0 ? cn[0] : (a == 1 ? cn[1] : (a == 2 ? cn[2] : cn[3]));   // (unused at the root: its back-up works on the registers)
                 path_q[(size_t)plen * HIST_TREES] = a == 0 ? cq[0] : (a == 1 ? cq[1] : (a == 2 ? cq[2] : cq[3]));
             } else {
@@ -1089,10 +1092,10 @@ __global__ void __launch_bounds__(H2_BLOCK) __attribute__((amdgpu_waves_per_eu(F
         if (do_step) {
 #endif
             if (LROWS)
-                term = gridworld_hist_step_quad<K, HIST_TREES, true>(P, g, stage + (size_t)(2 + ((hist_off >> (8 * a)) & 0xffu)) * HIST_TREES, hist_count(hist_cnt, a),
+                term = gridworld_hist_step_quad<K, HIST_TREES, true>(P, g, stage + (size_t)(2 + hist_offset(hist_cnt, a)) * HIST_TREES, hist_count(hist_cnt, a),
                                                                      hist_mask, sp, a, o, r, HistRowsLds<K>{s_rid, s_rows, HistRowIds(P.gw_N, P.gw_G, 4)});
             else
-                term = gridworld_hist_step_quad<K, HIST_TREES, true>(P, g, stage + (size_t)(2 + ((hist_off >> (8 * a)) & 0xffu)) * HIST_TREES, hist_count(hist_cnt, a),
+                term = gridworld_hist_step_quad<K, HIST_TREES, true>(P, g, stage + (size_t)(2 + hist_offset(hist_cnt, a)) * HIST_TREES, hist_count(hist_cnt, a),
                                                                      hist_mask, sp, a, o, r, HistRowsGlobal{P.hist_base, P.hist_alt, s_rows, HL});
             ++steps;
 #ifdef FBA_PROFILE_SEARCH
@@ -1151,10 +1154,8 @@ __global__ void __launch_bounds__(H2_BLOCK) __attribute__((amdgpu_waves_per_eu(F
                 if (k0 == 0) {   // the root's level is lane 0's
                     const int ract   = (int)quad_get<0>((uint32_t)act), rn = (int)quad_get<0>((uint32_t)n);
                     const double rq  = quad_get_f64<0>((uint32_t)__double2loint(qn), (uint32_t)__double2hiint(qn));
-#pragma unroll
-                    for (int a2 = 0; a2 < AMAX; ++a2)
-                        if (a2 == ract) { r_cn[a2] = rn; r_cq[a2] = rq; }
-                    ++r_vis;
+                    root_n[ract * HIST_TREES] = rn;   // (the quad's four lanes store the same values)
+                    root_q[ract * HIST_TREES] = rq;
                 }
             }
             if (!broken) ++sim;
@@ -1182,7 +1183,7 @@ __global__ void __launch_bounds__(H2_BLOCK) __attribute__((amdgpu_waves_per_eu(F
         int32_t* rn = reinterpret_cast<int32_t*>(D.s_root + (size_t)e * 6);
         double* rq  = D.s_root + (size_t)e * 6 + 2;
 #pragma unroll
-        for (int a = 0; a < AMAX; ++a) { rn[a] = r_cn[a]; rq[a] = r_cq[a]; }
+        for (int a = 0; a < AMAX; ++a) { rn[a] = root_n[a * HIST_TREES]; rq[a] = root_q[a * HIST_TREES]; }
         D.s_sim[e]   = sim;
         D.s_nodes[e] = n_nodes;
         D.s_depth[e] = tree_depth;
@@ -1193,6 +1194,10 @@ __global__ void __launch_bounds__(H2_BLOCK) __attribute__((amdgpu_waves_per_eu(F
     if (budget > 0) D.search_done[e] = 1;
     g.stream(FBA_PHASE_SEARCH, (uint32_t)P.sims + 1u);
     g.ensure(1);
+    int r_cn[AMAX];
+    double r_cq[AMAX];
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) { r_cn[a] = root_n[a * HIST_TREES]; r_cq[a] = root_q[a * HIST_TREES]; }
     const int best = ucb_pick<AMAX>(P, g, D.log1p_tab, 0, r_cn, r_cq, false);
     D.action[e]    = best;
     if (g.q == 0) D.sim_steps[e] += steps;
