@@ -1289,8 +1289,7 @@ struct HistRow {
     {
         double total = (double)r[0];
 #pragma unroll
-        for (int i = 1; i < KL; ++i)
-            if (i < n) total += (double)r[i];
+        for (int i = 1; i < KL; ++i) total += (double)r[i];   // (add() left 0.f in the places past n: adding them changes nothing)
         const double p = u * total;
         // "p < (double)sum" for a float sum is "sum > pf" with pf the largest float <= p (p >= 0): the comparisons stay in fp32
         float pf = (float)p;
