@@ -56,5 +56,6 @@ def test_tiger_kernels_use_no_scratch(tmp_path):
     assert len(mh) == 1 and all(v[0] == 0 and v[2] == 0 for v in mh.values()), mh
     regular = re.compile(r"search_kernelILb[01]ELi\d+ELb1E|(reject|importance)_kernelILb1E|is_multi_step_kernelILb1E")
     for name, (scratch, vgprs, spills) in seen.items():
-        if not regular.search(name):              # (the `regular` Dirichlet instantiations carry the gamma sampler)
-            assert spills == 0, (name, spills)    # no expected-mode kernel spills vector registers
+        if not regular.search(name) and "search_hist2_kernel" not in name:   # (the `regular` Dirichlet instantiations carry the gamma sampler;
+            assert spills == 0, (name, spills)                                #  search_hist2_kernel is capped at 168 registers, above)
+                                                                              # no other expected-mode kernel spills vector registers
