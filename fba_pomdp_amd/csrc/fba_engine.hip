@@ -1654,16 +1654,22 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
         CHK(dev_alloc(c, &D.p_weight_sh, (size_t)2 * E * P.N));
         CHK(dev_alloc(c, &D.bufsel_sh, E));
         CHK(dev_alloc(c, &D.need_update_sh, E));
-        // WeightedFilter::leastLikely (WeightedFilter.cpp:193-238) of N equal weights, with the container the reference uses
-        using queue_elements = std::pair<double, int>;
-        struct Less { bool operator()(queue_elements l, queue_elements r) const { return l.first < r.first; } };
-        std::priority_queue<queue_elements, std::vector<queue_elements>, Less> q;
-        const double w = 1.0 / (double)P.N;
-        for (int i = 0; i < P.incub; ++i) q.push({w, i});
-        for (int i = 0; i < P.N; ++i)
-            if (w < q.top().first) { q.pop(); q.push({w, i}); }
-        std::vector<int32_t> order;
-        for (int i = 0; i < P.incub; ++i) { order.push_back(q.top().second); q.pop(); }
+        // Which shadow particles are bred anew: the reference asks its weighted filter for the `incub` least likely particles
+        // (WeightedFilter.cpp:193-238) at a moment when all N weights are equal, so no particle ever displaces one of the first `incub`
+        // and the answer is those indices in the order a binary max-heap of equal keys releases them.  That order is libstdc++'s
+        // (std::push_heap / std::pop_heap, which its priority_queue is made of); it is computed here once, with a comparison that
+        // finds no key smaller than another.
+        std::vector<int32_t> heap, order;
+        const auto equal_keys = [](int32_t, int32_t) { return false; };
+        for (int i = 0; i < P.incub; ++i) {
+            heap.push_back(i);
+            std::push_heap(heap.begin(), heap.end(), equal_keys);
+        }
+        while (!heap.empty()) {
+            std::pop_heap(heap.begin(), heap.end(), equal_keys);
+            order.push_back(heap.back());
+            heap.pop_back();
+        }
         int32_t* d_order = nullptr;
         CHK(dev_alloc(c, &d_order, order.size()));
         HIPC(hipMemcpy(d_order, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice));
