@@ -1551,6 +1551,44 @@ __device__ __forceinline__ bool gridworld_hist_step_quad(const Problem& P, QuadR
     return found;
 }
 
+// One pass of a simulated step over ONE Dirichlet row per lane (lane f < 3 of the quad owns feature f), in the form search_hist2_kernel runs twice per
+// loop iteration: fetch the row, add the increments this particle's entries made to it, draw.  An entry counts where ((entry ^ pattern) & k) == 0,
+// at the value its field at `cshift` (+ 3 per feature) holds:
+//   transition pass  -- entries whose OLD state matches the current one (pattern = the state; kx / ky = 0x3f or 0x3ff: whether the x / y node has
+//                       the goal as a parent; kg = 0x3ff), counted at their NEW state's values (cshift 10);
+//   observation pass -- entries whose old state's feature equals the new state's (pattern = the new state; one field per mask: 7, 7 << 3, 15 << 6),
+//                       counted at their OBSERVATION's values (cshift 20; BABNModel::incrementCountsOf files them under the old state, App. A #6).
+// Records of at most 63 entries: lane q walks entries q, q + 4, ... for all three features (6-bit counters) and a DPP sum hands every lane the totals;
+// longer records: every lane walks every entry for its own feature.  Same counts either way, so the same row and the same draw as gridworld_hist_step_quad.
+template <int K, int STRIDE>
+__device__ __forceinline__ int hist_row_pass(const Problem& P, const QuadRng& g, const uint32_t* list, int n_list, uint32_t pattern, uint32_t kx, uint32_t ky,
+                                             uint32_t kg, int cshift, const float* rowp, int n, int f, double u)
+{
+    HistRow<K> row;
+    row.fetch(rowp);
+    if (P.hist_cap <= 63) {
+        RowCount6 cx{0}, cy{0}, cg{0};
+        for (int j = g.q; j < n_list; j += HIST_QUAD) {
+            const uint32_t e = list[j * STRIDE], d = e ^ pattern, c = e >> cshift;
+            cx.add((d & kx) == 0, (int)(c & 7u));
+            cy.add((d & ky) == 0, (int)((c >> 3) & 7u));
+            cg.add((d & kg) == 0, (int)((c >> 6) & 15u));
+        }
+        const uint64_t sx = quad_sum_u64(cx.v), sy = quad_sum_u64(cy.v), sg = quad_sum_u64(cg.v);   // (every lane executes every DPP sum)
+        row.add(n, RowCount6{f == 0 ? sx : (f == 1 ? sy : sg)});
+    } else {
+        const uint32_t k = f == 0 ? kx : (f == 1 ? ky : kg), fmask = f == 2 ? 15u : 7u;
+        const int shift = cshift + 3 * f;
+        RowCount cnt{0, 0};
+        for (int j = 0; j < n_list; ++j) {
+            const uint32_t e = list[j * STRIDE];
+            cnt.add(((e ^ pattern) & k) == 0, (int)((e >> shift) & fmask));
+        }
+        row.add(n, cnt);
+    }
+    return row.sample(u, n);
+}
+
 // BABNModel::computeObservationProbability (BABNModel.cpp:328-352)
 template <bool REG, class View>
 __device__ __forceinline__ double fact_obs_prob(const Problem& P, Rng& g, const View& cnt, int new_s, int a, int o)

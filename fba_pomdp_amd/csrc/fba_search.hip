@@ -1091,19 +1091,73 @@ __global__ void __launch_bounds__(H2_BLOCK) __attribute__((amdgpu_waves_per_eu(F
         PROF_MARK(1)
         if (do_step) {
 #endif
-            if (LROWS)
-                term = gridworld_hist_step_quad<K, HIST_TREES, true>(P, g, stage + (size_t)(2 + hist_offset(hist_cnt, a)) * HIST_TREES, hist_count(hist_cnt, a),
-                                                                     hist_mask, sp, a, o, r, HistRowsLds<K>{s_rid, s_rows, HistRowIds(P.gw_N, P.gw_G, 4)});
-            else
-                term = gridworld_hist_step_quad<K, HIST_TREES, true>(P, g, stage + (size_t)(2 + hist_offset(hist_cnt, a)) * HIST_TREES, hist_count(hist_cnt, a),
-                                                                     hist_mask, sp, a, o, r, HistRowsGlobal{P.hist_base, P.hist_alt, s_rows, HL});
-            ++steps;
-#ifdef FBA_PROFILE_SEARCH
-        }
-        PROF_MARK(2)
-        if (do_step) {
-#endif
+            // BAPOMDP::step over BABNModel (BAPOMDP.cpp:111-143, BABNModel.cpp:292-325) as two passes of hist_row_pass.  Pass A: the transition rows
+            // of (state, a) for every lane.  Pass B: the observation rows of (a, s') for the trees that are in their tree -- and, for the trees that are
+            // in a rollout, the transition rows of the NEXT step: a rollout never looks at an observation (POUCT.cpp:273-303 uses reward and terminal
+            // only), so its three observation draws are skipped and the pass the wave executes anyway carries a second simulated step.
+            const int f = min(g.q, 2), NW = P.gw_N, GW = P.gw_G, nrow = f == 2 ? GW : NW;
+            const HistRowsLds<K> rl{s_rid, s_rows, HistRowIds(P.gw_N, P.gw_G, 4)};
+            const HistRowsGlobal rg{P.hist_base, P.hist_alt, s_rows, HL};
+            int x = hist_x(sp), y = hist_y(sp), gl = hist_g(sp), cell = x * NW + y;
+            const uint32_t* listA = stage + (size_t)(2 + hist_offset(hist_cnt, a)) * HIST_TREES;
+            const int nA = hist_count(hist_cnt, a);
+            int nv;
+            {
+                const bool mx = (hist_mask >> (2 * a)) & 1u, my = (hist_mask >> (2 * a + 1)) & 1u;
+                const bool with_goal = f == 2 || ((hist_mask >> (2 * a + f)) & 1u);
+                const float* rowp = LROWS ? rl.t(a, f, with_goal, cell, gl) : rg.t(a, f, with_goal, cell, gl);
+                nv = hist_row_pass<K, HIST_TREES>(P, g, listA, nA, sp, mx ? 0x3ffu : 0x3fu, my ? 0x3ffu : 0x3fu, 0x3ffu, 10, rowp, nrow, f,
+                                                  u01_of(g.at(g.draw + (uint32_t)f)));
+            }
+            const int nx = quad_bcast(g.addr0, 0, nv), ny = quad_bcast(g.addr0, 1, nv), ng = quad_bcast(g.addr0, 2, nv);
+            const bool found = gridworld_on_goal(P, cell, gl);  // GridWorldBAExtension.cpp:74-99: terminal and reward from the OLD state
+            const uint32_t spN = hist_pack(nx, ny, ng);
+            // what pass B is for this tree
+            bool second = false;
+            uint32_t patB = spN, kxB = 7u, kyB = 7u << 3, kgB = 15u << 6;
+            int cshB = 20, nB = nA;
+            const uint32_t* listB = listA;
+            const float* rowB;
+            double uB;
+            if (mode == 1) {
+                const int nvf = f == 0 ? nx : (f == 1 ? ny : ng);
+                rowB = LROWS ? rl.o(a, f, nvf) : rg.o(a, f, nvf);
+                uB   = u01_of(g.at(g.draw + 3u + (uint32_t)f));
+            } else {
+                // the rollout's step ends here (its observation would be sampled from draws 3..5 of the step: skipped, never used)
+                rret += (found ? 1.0 : 0.0) * rdisc;
+                rdisc *= P.gamma;
+                --rdepth;
+                ++steps;
+                g.draw += 6;
+                sp = spN;
+                rowB = LROWS ? rl.o(a, f, 0) : rg.o(a, f, 0);   // (any row: nothing is counted into it and its draw is dropped)
+                uB   = 0.0;
+                nB   = 0;
+                if (rdepth == 0 || found) { delayed = rret; finish = true; }
+                else {   // the next step of the rollout, in this iteration's second pass
+                    second = true;
+                    g.ensure(4);   // its action and its three transition rows
+                    const int a2 = g.slow_int4();
+                    x = nx; y = ny; gl = ng; cell = x * NW + y;
+                    const bool mx = (hist_mask >> (2 * a2)) & 1u, my = (hist_mask >> (2 * a2 + 1)) & 1u;
+                    const bool with_goal = f == 2 || ((hist_mask >> (2 * a2 + f)) & 1u);
+                    listB = stage + (size_t)(2 + hist_offset(hist_cnt, a2)) * HIST_TREES;
+                    nB    = hist_count(hist_cnt, a2);
+                    patB = sp; kxB = mx ? 0x3ffu : 0x3fu; kyB = my ? 0x3ffu : 0x3fu; kgB = 0x3ffu; cshB = 10;
+                    rowB = LROWS ? rl.t(a2, f, with_goal, cell, gl) : rg.t(a2, f, with_goal, cell, gl);
+                    uB   = u01_of(g.at(g.draw + (uint32_t)f));
+                }
+            }
+            const int nvB = hist_row_pass<K, HIST_TREES>(P, g, listB, nB, patB, kxB, kyB, kgB, cshB, rowB, nrow, f, uB);
+            const int v0 = quad_bcast(g.addr0, 0, nvB), v1 = quad_bcast(g.addr0, 1, nvB), v2 = quad_bcast(g.addr0, 2, nvB);
             if (mode == 1) {  // traverseChanceNode
+                o = (v0 * NW + v1) * GW + v2;
+                r = found ? 1 : 0;
+                term = found;
+                g.draw += 6;
+                ++steps;
+                sp = spN;
                 path_r[(size_t)plen * HIST_TREES]  = (float)r;
                 path_na[(size_t)plen * HIST_TREES] = (node << 5) | a;
                 ++plen;
@@ -1117,13 +1171,18 @@ __global__ void __launch_bounds__(H2_BLOCK) __attribute__((amdgpu_waves_per_eu(F
                     pf[1] = lp[4 + g.q];
                     pend  = true;
                 }
-            } else {
-                rret += r * rdisc;
+            } else if (second) {
+                const bool found2 = gridworld_on_goal(P, cell, gl);
+                rret += (found2 ? 1.0 : 0.0) * rdisc;
                 rdisc *= P.gamma;
                 --rdepth;
-                if (rdepth == 0 || term) { delayed = rret; finish = true; }
+                ++steps;
+                g.draw += 6;
+                sp = hist_pack(v0, v1, v2);
+                if (rdepth == 0 || found2) { delayed = rret; finish = true; }
             }
         }
+        PROF_MARK(2)
         PROF_MARK(3)
         if (finish) {
             // back-up, leaf to root (MCTSTreeNodes.cpp:8-12, 59-62).  The returns chain down the path (ret = r + gamma * delayed: two operations
