@@ -1560,10 +1560,13 @@ __device__ __forceinline__ bool gridworld_hist_step_quad(const Problem& P, QuadR
 //                       counted at their OBSERVATION's values (cshift 20; BABNModel::incrementCountsOf files them under the old state, App. A #6).
 // Records of at most 63 entries: lane q walks entries q, q + 4, ... for all three features (6-bit counters) and a DPP sum hands every lane the totals;
 // longer records: every lane walks every entry for its own feature.  Same counts either way, so the same row and the same draw as gridworld_hist_step_quad.
+// (`obs` selects the pass; mx / my = the x / y transition node of the step's action has the goal as a parent)
 template <int K, int STRIDE>
-__device__ __forceinline__ int hist_row_pass(const Problem& P, const QuadRng& g, const uint32_t* list, int n_list, uint32_t pattern, uint32_t kx, uint32_t ky,
-                                             uint32_t kg, int cshift, const float* rowp, int n, int f, double u)
+__device__ __forceinline__ int hist_row_pass(const Problem& P, const QuadRng& g, const uint32_t* list, int n_list, uint32_t pattern, bool obs, bool mx, bool my,
+                                             const float* rowp, int n, int f, double u)
 {
+    const uint32_t kx = obs ? 7u : (mx ? 0x3ffu : 0x3fu), ky = obs ? (7u << 3) : (my ? 0x3ffu : 0x3fu), kg = obs ? (15u << 6) : 0x3ffu;
+    const int cshift = obs ? 20 : 10;
     HistRow<K> row;
     row.fetch(rowp);
     if (P.hist_cap <= 63) {

@@ -1106,16 +1106,14 @@ __global__ void __launch_bounds__(H2_BLOCK) __attribute__((amdgpu_waves_per_eu(F
                 const bool mx = (hist_mask >> (2 * a)) & 1u, my = (hist_mask >> (2 * a + 1)) & 1u;
                 const bool with_goal = f == 2 || ((hist_mask >> (2 * a + f)) & 1u);
                 const float* rowp = LROWS ? rl.t(a, f, with_goal, cell, gl) : rg.t(a, f, with_goal, cell, gl);
-                nv = hist_row_pass<K, HIST_TREES>(P, g, listA, nA, sp, mx ? 0x3ffu : 0x3fu, my ? 0x3ffu : 0x3fu, 0x3ffu, 10, rowp, nrow, f,
-                                                  u01_of(g.at(g.draw + (uint32_t)f)));
+                nv = hist_row_pass<K, HIST_TREES>(P, g, listA, nA, sp, false, mx, my, rowp, nrow, f, u01_of(g.at(g.draw + (uint32_t)f)));
             }
             const int nx = quad_bcast(g.addr0, 0, nv), ny = quad_bcast(g.addr0, 1, nv), ng = quad_bcast(g.addr0, 2, nv);
             const bool found = gridworld_on_goal(P, cell, gl);  // GridWorldBAExtension.cpp:74-99: terminal and reward from the OLD state
             const uint32_t spN = hist_pack(nx, ny, ng);
             // what pass B is for this tree
             bool second = false;
-            uint32_t patB = spN, kxB = 7u, kyB = 7u << 3, kgB = 15u << 6;
-            int cshB = 20, nB = nA;
+            int aB = a, nB = nA;   // (pass B walks the entries of this action: the step's own, or the rollout's next)
             const uint32_t* listB = listA;
             const float* rowB;
             double uB;
@@ -1138,18 +1136,16 @@ __global__ void __launch_bounds__(H2_BLOCK) __attribute__((amdgpu_waves_per_eu(F
                 else {   // the next step of the rollout, in this iteration's second pass
                     second = true;
                     g.ensure(4);   // its action and its three transition rows
-                    const int a2 = g.slow_int4();
+                    aB = g.slow_int4();
                     x = nx; y = ny; gl = ng; cell = x * NW + y;
-                    const bool mx = (hist_mask >> (2 * a2)) & 1u, my = (hist_mask >> (2 * a2 + 1)) & 1u;
-                    const bool with_goal = f == 2 || ((hist_mask >> (2 * a2 + f)) & 1u);
-                    listB = stage + (size_t)(2 + hist_offset(hist_cnt, a2)) * HIST_TREES;
-                    nB    = hist_count(hist_cnt, a2);
-                    patB = sp; kxB = mx ? 0x3ffu : 0x3fu; kyB = my ? 0x3ffu : 0x3fu; kgB = 0x3ffu; cshB = 10;
-                    rowB = LROWS ? rl.t(a2, f, with_goal, cell, gl) : rg.t(a2, f, with_goal, cell, gl);
+                    const bool with_goal = f == 2 || ((hist_mask >> (2 * aB + f)) & 1u);
+                    listB = stage + (size_t)(2 + hist_offset(hist_cnt, aB)) * HIST_TREES;
+                    nB    = hist_count(hist_cnt, aB);
+                    rowB = LROWS ? rl.t(aB, f, with_goal, cell, gl) : rg.t(aB, f, with_goal, cell, gl);
                     uB   = u01_of(g.at(g.draw + (uint32_t)f));
                 }
             }
-            const int nvB = hist_row_pass<K, HIST_TREES>(P, g, listB, nB, patB, kxB, kyB, kgB, cshB, rowB, nrow, f, uB);
+            const int nvB = hist_row_pass<K, HIST_TREES>(P, g, listB, nB, spN, mode == 1, (hist_mask >> (2 * aB)) & 1u, (hist_mask >> (2 * aB + 1)) & 1u, rowB, nrow, f, uB);
             const int v0 = quad_bcast(g.addr0, 0, nvB), v1 = quad_bcast(g.addr0, 1, nvB), v2 = quad_bcast(g.addr0, 2, nvB);
             if (mode == 1) {  // traverseChanceNode
                 o = (v0 * NW + v1) * GW + v2;
