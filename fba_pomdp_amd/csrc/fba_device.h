@@ -1282,6 +1282,14 @@ struct HistRow {
 #pragma unroll
         for (int i = 0; i < KL; ++i) r[i] = i < n ? r[i] + c.at(i) : 0.f;
     }
+    // the same for a row whose places past n already hold 0.f (the deduplicated rows of Problem::hist_lds are padded with zeros by the host) and counts
+    // that are zero there (no entry's feature value reaches past n): nothing to select
+    template <class COUNTS>
+    __device__ __forceinline__ void add_zero_padded(const COUNTS& c)
+    {
+#pragma unroll
+        for (int i = 0; i < KL; ++i) r[i] = r[i] + c.at(i);
+    }
     // sampleFromExpectedMult (random.cpp:244-255) for the uniform draw u: double total, float CDF against a double
     // threshold.  Counts are never negative, so the CDF does not decrease and "the first i with p < cdf(i), else
     // n - 1" is the number of i <= n - 2 with p >= cdf(i): no branches.
@@ -1561,7 +1569,8 @@ __device__ __forceinline__ bool gridworld_hist_step_quad(const Problem& P, QuadR
 // Records of at most 63 entries: lane q walks entries q, q + 4, ... for all three features (6-bit counters) and a DPP sum hands every lane the totals;
 // longer records: every lane walks every entry for its own feature.  Same counts either way, so the same row and the same draw as gridworld_hist_step_quad.
 // (`obs` selects the pass; mx / my = the x / y transition node of the step's action has the goal as a parent)
-template <int K, int STRIDE>
+// ZPAD: the row's places past n hold 0.f (rows from Problem::hist_lds).
+template <int K, int STRIDE, bool ZPAD = false>
 __device__ __forceinline__ int hist_row_pass(const Problem& P, const QuadRng& g, const uint32_t* list, int n_list, uint32_t pattern, bool obs, bool mx, bool my,
                                              const float* rowp, int n, int f, double u)
 {
@@ -1578,7 +1587,8 @@ __device__ __forceinline__ int hist_row_pass(const Problem& P, const QuadRng& g,
             cg.add((d & kg) == 0, (int)((c >> 6) & 15u));
         }
         const uint64_t sx = quad_sum_u64(cx.v), sy = quad_sum_u64(cy.v), sg = quad_sum_u64(cg.v);   // (every lane executes every DPP sum)
-        row.add(n, RowCount6{f == 0 ? sx : (f == 1 ? sy : sg)});
+        if (ZPAD) row.add_zero_padded(RowCount6{f == 0 ? sx : (f == 1 ? sy : sg)});
+        else row.add(n, RowCount6{f == 0 ? sx : (f == 1 ? sy : sg)});
     } else {
         const uint32_t k = f == 0 ? kx : (f == 1 ? ky : kg), fmask = f == 2 ? 15u : 7u;
         const int shift = cshift + 3 * f;

@@ -1106,7 +1106,7 @@ __global__ void __launch_bounds__(H2_BLOCK) __attribute__((amdgpu_waves_per_eu(F
                 const bool mx = (hist_mask >> (2 * a)) & 1u, my = (hist_mask >> (2 * a + 1)) & 1u;
                 const bool with_goal = f == 2 || ((hist_mask >> (2 * a + f)) & 1u);
                 const float* rowp = LROWS ? rl.t(a, f, with_goal, cell, gl) : rg.t(a, f, with_goal, cell, gl);
-                nv = hist_row_pass<K, HIST_TREES>(P, g, listA, nA, sp, false, mx, my, rowp, nrow, f, u01_of(g.at(g.draw + (uint32_t)f)));
+                nv = hist_row_pass<K, HIST_TREES, LROWS>(P, g, listA, nA, sp, false, mx, my, rowp, nrow, f, u01_of(g.at(g.draw + (uint32_t)f)));
             }
             const int nx = quad_bcast(g.addr0, 0, nv), ny = quad_bcast(g.addr0, 1, nv), ng = quad_bcast(g.addr0, 2, nv);
             const bool found = gridworld_on_goal(P, cell, gl);  // GridWorldBAExtension.cpp:74-99: terminal and reward from the OLD state
@@ -1145,7 +1145,7 @@ __global__ void __launch_bounds__(H2_BLOCK) __attribute__((amdgpu_waves_per_eu(F
                     uB   = u01_of(g.at(g.draw + (uint32_t)f));
                 }
             }
-            const int nvB = hist_row_pass<K, HIST_TREES>(P, g, listB, nB, spN, mode == 1, (hist_mask >> (2 * aB)) & 1u, (hist_mask >> (2 * aB + 1)) & 1u, rowB, nrow, f, uB);
+            const int nvB = hist_row_pass<K, HIST_TREES, LROWS>(P, g, listB, nB, spN, mode == 1, (hist_mask >> (2 * aB)) & 1u, (hist_mask >> (2 * aB + 1)) & 1u, rowB, nrow, f, uB);
             const int v0 = quad_bcast(g.addr0, 0, nvB), v1 = quad_bcast(g.addr0, 1, nvB), v2 = quad_bcast(g.addr0, 2, nvB);
             if (mode == 1) {  // traverseChanceNode
                 o = (v0 * NW + v1) * GW + v2;
