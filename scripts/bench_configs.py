@@ -26,7 +26,7 @@ CONFIGS = {
                    particles=4096, structure_prior=2, horizon=10, slots=16384, ticks=2),
     # (two episodes per run: a history particle holds episodes * (horizon + 1) entries, fba_device.h)
     "c4": dict(domain="gridworld", model=N.MODEL_BA_FACTORED, belief="importance_sampling", size=7, sims=65536,
-               particles=16384, structure_prior=2, horizon=20, episodes=2, slots=32768, ticks=2),   # (7.6 MB per slot: 35 000 fit in 288 GB)
+               particles=16384, structure_prior=2, horizon=20, episodes=2, slots=49152, tree_buckets=32768, ticks=2),   # (5.5 MB per slot; lock-step ticks: bench.py --workload c4 is the budgeted form)
     # the parity-sized variant of c4 (--size 5), fewer simulations so that a tick is short
     "c4small": dict(domain="gridworld", model=N.MODEL_BA_FACTORED, belief="importance_sampling", size=5, sims=8192,
                     particles=4096, structure_prior=2, horizon=20, slots=512, ticks=2),
