@@ -329,6 +329,7 @@ struct Problem {
     int32_t hist;       // history particles (gridworld FBA-POMDP, importance filter): a record holds the particle's increments as one
                         // 4-byte entry per real step over the shared prior tables (HistView below); C = 0 then, hist_cap entries per record
     int32_t hist_cap;
+    int32_t hist_compact;   // records of short histories stand closer than Cs words (hist_stride below)
     int32_t gw_N, gw_G;          // gridworld: N, number of goals (copies of GridDesc's, as kernel arguments)
     uint32_t gw_goalcell0, gw_goalcell1, gw_goalcell2, gw_goalcell3;  // gridworld: x*N + y of goal g, 8 bits each, four goals per word (scalars, not an
                                                                       // array: an indexed member pins the whole by-value struct to scratch memory)
@@ -1162,6 +1163,23 @@ __host__ __device__ __forceinline__ int hist_offset(uint32_t cnt, int a)
     return off;
 }
 __host__ __device__ __forceinline__ int hist_total(uint32_t cnt) { return hist_count(cnt, 0) + hist_count(cnt, 1) + hist_count(cnt, 2) + hist_count(cnt, 3); }
+
+// Words between the records of a slot whose histories hold `total` entries: 64 bytes up to 14 entries, 128 up to 30, the whole record (Cs)
+// beyond.  A belief update reads every record of a slot and its resampling gather reads N of them at random and writes N: at a fixed 176-byte
+// stride those three passes move 176-byte records of which 8 + 4 * total bytes are alive, and a random record straddles two 128-byte lines.
+// Every update rebuilds the slot's records in another buffer anyway, so it writes them at the stride of total + 1.
+__host__ __device__ __forceinline__ int hist_stride(const Problem& P, int total)
+{
+    if (!P.hist_compact) return P.Cs;
+    const int w = 2 + total;
+    return (w <= 16 && P.Cs > 16) ? 16 : ((w <= 32 && P.Cs > 32) ? 32 : P.Cs);
+}
+// the same from the 16-byte pieces that hold a record of `total` entries, n4 = (total + 5) >> 2 (total <= 14 <=> n4 <= 4, total <= 30 <=> n4 <= 8)
+__host__ __device__ __forceinline__ int hist_stride_of_pieces(const Problem& P, int n4)
+{
+    if (!P.hist_compact) return P.Cs;
+    return (n4 <= 4 && P.Cs > 16) ? 16 : ((n4 <= 8 && P.Cs > 32) ? 32 : P.Cs);
+}
 
 // where the rows of the padded tables start (host and device)
 struct HistLayout {

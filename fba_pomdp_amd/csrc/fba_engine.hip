@@ -1500,6 +1500,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
             P.C        = 0;  // word 0 = state, word 1 = structure bits, words 2.. = entries
         }
     }
+    P.hist_compact = P.hist && !(std::getenv("FBA_HIST_STRIDE") && !std::strcmp(std::getenv("FBA_HIST_STRIDE"), "full")) ? 1 : 0;   // (A/B switch: every record at the full stride)
     if (P.hist) P.Cs = (2 + P.hist_cap + 3) & ~3;
     else if (P.ft_packed) P.Cs = (P.C + 1 + 3) & ~3;   // 36 words at --size 3: the point is the bytes, not a power of two
     else {
@@ -2132,11 +2133,12 @@ static int belief_get_range(fba_ctx* c, int32_t slot, int32_t first, int32_t n, 
             HIPCHK(c, hipMemcpy(&buf, c->D.rec_buf + slot, 4, hipMemcpyDeviceToHost));
             rb = (size_t)buf * (size_t)P.N;
         }
-        HIPCHK(c, hipMemcpy(tmp.data(), c->D.p_rec + (rb + first) * P.Cs, tmp.size() * 4, hipMemcpyDeviceToHost));
         uint32_t hist_cnt = 0;
         if (P.hist) HIPCHK(c, hipMemcpy(&hist_cnt, c->D.hist_cnt + slot, 4, hipMemcpyDeviceToHost));
+        const size_t rs = P.hist ? (size_t)hist_stride(P, hist_total(hist_cnt)) : (size_t)P.Cs;   // words between this slot's records
+        HIPCHK(c, hipMemcpy(tmp.data(), c->D.p_rec + rb * P.Cs + (size_t)first * rs, (size_t)n * rs * 4, hipMemcpyDeviceToHost));
         for (int i = 0; i < n; ++i) {
-            const float* rec = tmp.data() + (size_t)i * P.Cs;
+            const float* rec = tmp.data() + (size_t)i * rs;
             if (state) std::memcpy(&state[i], &rec[P.C], 4);
             if (counts && P.ft_packed) {  // count = prior(cell, structure) + increments, then the structure word (PackedFtigerView)
                 const uint32_t* w = reinterpret_cast<const uint32_t*>(rec);

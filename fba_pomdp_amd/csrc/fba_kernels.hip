@@ -238,8 +238,10 @@ __device__ __forceinline__ void gather_records_side(float* __restrict__ dst, con
 // one record in 16-byte pieces.
 template <class IDX>
 __device__ __forceinline__ void gather_hist_records(float* __restrict__ dst, const float* __restrict__ src, const IDX* s_src,
-                                                    const int32_t* __restrict__ side, int len, int ins, int m, int C4, int group, int nthreads)
+                                                    const int32_t* __restrict__ side, int len, int ins, int m, int C4, int group, int nthreads,
+                                                    int C4d = 0)   // C4 / C4d: 16-byte pieces between source / destination records (hist_stride)
 {
+    if (C4d == 0) C4d = C4;
     const int gid = threadIdx.x / group, part0 = threadIdx.x % group, ngroups = nthreads / group;
     const int n4 = (len + 6) >> 2;  // pieces that hold words 0 .. 2 + len
     if (n4 <= group && m >= 4 * ngroups) {
@@ -273,7 +275,7 @@ __device__ __forceinline__ void gather_hist_records(float* __restrict__ dst, con
                     v.x = (uint32_t)sd[q].x;
                     v.y = (v.y & 0xffffu) | ((((uint32_t)sd[q].y >> 10) & 0x3ffu) << 16);
                 }
-                (reinterpret_cast<uint4*>(dst) + (size_t)j * C4)[part] = v;
+                (reinterpret_cast<uint4*>(dst) + (size_t)j * C4d)[part] = v;
             }
         }
         return;
@@ -281,7 +283,7 @@ __device__ __forceinline__ void gather_hist_records(float* __restrict__ dst, con
     for (int j = gid; j < m; j += ngroups) {
         const int p      = s_src[j];
         const uint4* sp  = reinterpret_cast<const uint4*>(src) + (size_t)p * C4;
-        uint4* dp        = reinterpret_cast<uint4*>(dst) + (size_t)j * C4;
+        uint4* dp        = reinterpret_cast<uint4*>(dst) + (size_t)j * C4d;
         const int2 sd    = *reinterpret_cast<const int2*>(side + (size_t)p * 2);
         for (int part = part0; part < n4; part += group) {
             const uint4 cur = sp[part];
@@ -1415,13 +1417,14 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
     double* wcur    = WLDS ? s_w : sw;   // where the update pass leaves the new weights
     int32_t* side   = D.p_side + (size_t)e * N * D.side_w;
     const bool defer = defer_increments(P);
-    const int C4 = P.Cs / 4, group = record_group(C4);
+    const int rs = HIST ? hist_stride(P, hist_n) : P.Cs, rd = HIST ? hist_stride(P, hist_n + 1) : P.Cs;   // words between the records read / written
+    const int C4 = rs / 4, group = record_group(HIST ? rd / 4 : C4);
     const int ninc = model_ninc(P);
     Rng g = slot_rng(P, D, e);
 
     for (int i = tid; i < N; i += IS_BLOCK) {
         g.stream(FBA_PHASE_IS_UPDATE, (uint32_t)i);
-        float* cnt = scn + (size_t)i * P.Cs;
+        float* cnt = scn + (size_t)i * rs;
         int s = rec_state(cnt, P.C), so;
         double r;
         if (HIST) {
@@ -1504,7 +1507,7 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
             dw[j]    = w1;
         }
         __syncthreads();
-        gather_hist_records(dcn, scn, s_all, side, hist_n, 2 + hist_offset(hist_cnt, a) + hist_count(hist_cnt, a), N, C4, group, IS_BLOCK);
+        gather_hist_records(dcn, scn, s_all, side, hist_n, 2 + hist_offset(hist_cnt, a) + hist_count(hist_cnt, a), N, C4, group, IS_BLOCK, rd / 4);
     } else
     for (int j0 = 0; j0 < N; j0 += IS_BLOCK) {
         const int j = j0 + tid;
@@ -1516,7 +1519,7 @@ __global__ void __launch_bounds__(IS_BLOCK) importance_kernel(Problem P, DeviceS
         }
         __syncthreads();
         const int m = min(IS_BLOCK, N - j0);
-        if (HIST) gather_hist_records(dcn + (size_t)j0 * P.Cs, scn, s_src, side, hist_n, 2 + hist_offset(hist_cnt, a) + hist_count(hist_cnt, a), m, C4, group, IS_BLOCK);
+        if (HIST) gather_hist_records(dcn + (size_t)j0 * rd, scn, s_src, side, hist_n, 2 + hist_offset(hist_cnt, a) + hist_count(hist_cnt, a), m, C4, group, IS_BLOCK, rd / 4);
         else if (defer) gather_records_side(dcn + (size_t)j0 * P.Cs, scn, s_src, side, D.side_w, m, C4, P.C, group, IS_BLOCK, TIGER_TABLE == 2);
         else gather_records(dcn + (size_t)j0 * P.Cs, scn, nullptr, s_src, nullptr, 0, 0, nullptr, m, C4, P.C, group, IS_BLOCK);
         __syncthreads();
@@ -1685,7 +1688,7 @@ __global__ void __launch_bounds__(256) is_multi_step_kernel(Problem P, DeviceSta
         double v = 0.0;
         if (i < N) {
             g.stream(FBA_PHASE_IS_UPDATE, (uint32_t)i);
-            float* cnt = scn + (size_t)i * P.Cs;
+            float* cnt = scn + (size_t)i * (HIST ? hist_stride(P, hist_total(hist_cnt)) : P.Cs);
             int s = rec_state(cnt, P.C), so;
             double r;
             if (HIST) {
@@ -1758,9 +1761,9 @@ __global__ void __launch_bounds__(256) is_multi_resample_kernel(Problem P, Devic
     __syncthreads();
     if (P.hist) {   // the source record with its particle's pending entry inserted (gather_hist_records), into the slot's scratch place
         const uint32_t hist_cnt = D.hist_cnt[e];
-        const int a = D.action[e];
-        gather_hist_records(rec_dst(P, D, e, cur ^ 1) + (size_t)j0 * P.Cs, D.p_rec + rec_base(P, D, e, cur) * (size_t)P.Cs, s_src, D.p_side + (size_t)e * N * 2,
-                            hist_total(hist_cnt), 2 + hist_offset(hist_cnt, a) + hist_count(hist_cnt, a), min(256, N - j0), C4, group, 256);
+        const int a = D.action[e], hist_n = hist_total(hist_cnt), rs4 = hist_stride(P, hist_n) / 4, rd = hist_stride(P, hist_n + 1);
+        gather_hist_records(rec_dst(P, D, e, cur ^ 1) + (size_t)j0 * rd, D.p_rec + rec_base(P, D, e, cur) * (size_t)P.Cs, s_src, D.p_side + (size_t)e * N * 2,
+                            hist_n, 2 + hist_offset(hist_cnt, a) + hist_count(hist_cnt, a), min(256, N - j0), rs4, record_group(rd / 4), 256, rd / 4);
         return;
     }
     if (defer_increments(P))
@@ -1850,7 +1853,7 @@ __global__ void __launch_bounds__(256) init_kernel(Problem P, DeviceState D, int
         const double w1h = 1.0 / (double)P.N;
         for (int i = i_lo + tid; i < i_hi; i += 256) {
             g.stream(FBA_PHASE_INIT, (uint32_t)i);
-            uint32_t* rec = reinterpret_cast<uint32_t*>(recs + (size_t)i * P.Cs);
+            uint32_t* rec = reinterpret_cast<uint32_t*>(recs + (size_t)i * hist_stride(P, 0));
             const int s0 = domain_start(P, g);
             rec[0] = (uint32_t)s0;
             uint32_t mask = 0;
@@ -1939,9 +1942,10 @@ __global__ void __launch_bounds__(256) reset_kernel(Problem P, DeviceState D, in
         }
         return;
     }
-    const int C4 = P.Cs / 4, group = record_group(C4);
-    const double w1 = 1.0 / (double)P.N;
     const int hist_n = P.hist ? hist_total(D.hist_cnt[e]) : 0;
+    const int rs = P.hist ? hist_stride(P, hist_n) : P.Cs;
+    const int C4 = rs / 4, group = record_group(C4);
+    const double w1 = 1.0 / (double)P.N;
     for (int j0 = i_lo; j0 < i_hi; j0 += 256) {
         const int j = j0 + tid;
         if (j < i_hi) {
@@ -1957,7 +1961,7 @@ __global__ void __launch_bounds__(256) reset_kernel(Problem P, DeviceState D, in
             const int gid = tid / group, part0 = tid % group, ngroups = 256 / group, n4 = (hist_n + 5) >> 2;
             for (int q = gid; q < m; q += ngroups) {
                 const float4* sp4 = reinterpret_cast<const float4*>(D.p_rec + rec_base(P, D, e, cur) * (size_t)P.Cs) + (size_t)s_src[q] * C4;
-                float4* dp4       = reinterpret_cast<float4*>(rec_dst(P, D, e, cur ^ 1) + (size_t)j0 * P.Cs) + (size_t)q * C4;
+                float4* dp4       = reinterpret_cast<float4*>(rec_dst(P, D, e, cur ^ 1) + (size_t)j0 * rs) + (size_t)q * C4;
                 const uint32_t nsp = gridworld_pack_state(P, s_ns[q]);
                 for (int part = part0; part < n4; part += group) {
                     float4 v = sp4[part];
@@ -2114,7 +2118,8 @@ __global__ void __launch_bounds__(256) flush_kernel(Problem P, DeviceState D)
     const bool lazy = slot_lazy(D, e);
     unsigned long long local = 0;
     for (int i = tid; i < P.N; i += 256) {
-        const float* cnt = D.p_rec + (rec_base(P, D, e, D.bufsel[e]) + i) * (size_t)P.Cs;
+        const float* cnt = P.hist ? D.p_rec + rec_base(P, D, e, D.bufsel[e]) * (size_t)P.Cs + (size_t)i * hist_stride(P, hist_total(D.hist_cnt[e]))
+                                  : D.p_rec + (rec_base(P, D, e, D.bufsel[e]) + i) * (size_t)P.Cs;
         const int st = lazy ? lazy_state(P, D, e, i) : rec_state(cnt, P.C);
         if (hist_on && (unsigned)st < (unsigned)FBA_TRACE_HIST_BINS) atomicAdd(&s_hist[st], 1u);
         uint64_t h = mix64((uint64_t)i * 0x9E3779B97F4A7C15ull + (uint64_t)(uint32_t)st);

@@ -559,7 +559,7 @@ __global__ void __launch_bounds__(SEARCH_BLOCK) search_hist_kernel(Problem P, De
             g.stream(FBA_PHASE_SEARCH, (uint32_t)sim);
             g.ensure(8);  // the root sample, the first action, six rows
             const int src = ts_src >= 0 ? ts_src : uniform_weight_pick(D.uni_scan, P.N, g.u01() * D.uni_total, D.uni_total);
-            const uint4* rp = reinterpret_cast<const uint4*>(prec + (size_t)src * P.Cs);
+            const uint4* rp = reinterpret_cast<const uint4*>(prec + (size_t)src * hist_stride(P, hist_n));
             const int n4 = (hist_n + 5) >> 2;  // state, structure bits, entries
             for (int k0 = g.q; k0 < n4; k0 += 4 * HIST_QUAD) {   // (four loads in flight per lane, as in search_kernel)
                 uint4 v[4];
@@ -819,7 +819,7 @@ __host__ __device__ __forceinline__ size_t h2_wave_bytes(const Problem& P)
 {
     const int depth_cap = P.max_depth > 0 ? P.max_depth : 1;
     return (size_t)depth_cap * HIST_TREES * (sizeof(double) + sizeof(int32_t) + sizeof(float) + sizeof(int32_t)) +
-           (size_t)(P.Cs > 2 * depth_cap ? P.Cs : 2 * depth_cap) * HIST_TREES * sizeof(float) + (size_t)12 * HIST_TREES * sizeof(float);   // (+ the root's statistics)
+           (size_t)(P.Cs > 2 * depth_cap ? P.Cs : 2 * depth_cap) * HIST_TREES * sizeof(float) + (size_t)14 * HIST_TREES * sizeof(float);   // (+ the root's statistics, the record geometry)
 }
 template <int K, bool LROWS>
 __global__ void __launch_bounds__(H2_BLOCK) __attribute__((amdgpu_waves_per_eu(FBA_HIST2_WAVES, FBA_HIST2_WAVES))) search_hist2_kernel(Problem P, DeviceState D)
@@ -841,6 +841,7 @@ __global__ void __launch_bounds__(H2_BLOCK) __attribute__((amdgpu_waves_per_eu(F
     // registers they were thirteen of the kernel's live values for the whole search
     double* root_q  = reinterpret_cast<double*>(stage - tl + (size_t)max(P.Cs, 2 * depth_cap) * HIST_TREES) + tl;      // [4][trees]
     int32_t* root_n = reinterpret_cast<int32_t*>(root_q - tl + (size_t)4 * HIST_TREES) + tl;                           // [4][trees]
+    int32_t* rec_geo = root_n - tl + (size_t)4 * HIST_TREES + tl;   // [trees]: pieces of a record | pieces between records << 8 (read twice per simulation)
     const HistLayout HL(P.gw_N, P.gw_G, 4);
     {   // the workgroup's shared tables: every thread, before any quad leaves
         const uint4* src = LROWS ? reinterpret_cast<const uint4*>(P.hist_lds) : reinterpret_cast<const uint4*>(P.hist_base + HL.obase0);
@@ -859,7 +860,8 @@ __global__ void __launch_bounds__(H2_BLOCK) __attribute__((amdgpu_waves_per_eu(F
     const int max_tree_depth = min(P.horizon - hist_len, P.max_depth);
     const float* prec   = D.p_rec + rec_base(P, D, e, D.bufsel[e]) * (size_t)P.Cs;
     const uint32_t hist_cnt = D.hist_cnt[e];
-    const int n4            = (hist_total(hist_cnt) + 5) >> 2;  // 16-byte pieces of a record: state, structure bits, entries
+    // 16-byte pieces of a record (state, structure bits, entries) and, above them, the 16-byte pieces between this slot's records (hist_stride)
+    *rec_geo = ((hist_total(hist_cnt) + 5) >> 2) | (hist_stride(P, hist_total(hist_cnt)) >> 2) << 8;
     const bool uni_exact    = (P.N & (P.N - 1)) == 0 && D.uni_total == 1.0;   // N = 2^k: the prefix sums of the weights 1/N are the exact values (i + 1) / N
 
     if (P.planner == FBA_PLANNER_RANDOM) {  // RandomPlanner::selectAction RandomPlanner.cpp:14-24
@@ -924,9 +926,10 @@ __global__ void __launch_bounds__(H2_BLOCK) __attribute__((amdgpu_waves_per_eu(F
             if (uni_exact) cur_src = max((int)ceil(u * (double)P.N) - 1, 0);   // the largest i with i / N < u (WeightedFilter.cpp:163-191 on exact prefix sums)
             else cur_src = uniform_weight_pick(D.uni_scan, P.N, u * D.uni_total, D.uni_total);
         }
-        const uint4* rp = reinterpret_cast<const uint4*>(prec + (size_t)cur_src * P.Cs);
+        const int n4s = *rec_geo;
+        const uint4* rp = reinterpret_cast<const uint4*>(prec) + __umul24((uint32_t)cur_src, (uint32_t)n4s >> 8);   // (N * Cs / 4 < 2^24)
 #pragma unroll
-        for (int j = 0; j < H2_PF; ++j) pf[j] = rp[min(g.q + HIST_QUAD * j, n4 - 1)];
+        for (int j = 0; j < H2_PF; ++j) pf[j] = rp[min(g.q + HIST_QUAD * j, (n4s & 0xff) - 1)];
     };
 
 #ifdef FBA_PROFILE_SEARCH
@@ -947,19 +950,20 @@ __global__ void __launch_bounds__(H2_BLOCK) __attribute__((amdgpu_waves_per_eu(F
                 request_particle();
             }
             have_particle = false;
+            const int n4s = *rec_geo;
 #pragma unroll
             for (int j = 0; j < H2_PF; ++j) {
                 const int k = g.q + HIST_QUAD * j;
-                if (k < n4) {
+                if (k < (n4s & 0xff)) {
                     stage[(4 * k + 0) * HIST_TREES] = pf[j].x;
                     stage[(4 * k + 1) * HIST_TREES] = pf[j].y;
                     stage[(4 * k + 2) * HIST_TREES] = pf[j].z;
                     stage[(4 * k + 3) * HIST_TREES] = pf[j].w;
                 }
             }
-            if (n4 > HIST_QUAD * H2_PF) {   // (records of more than 46 entries: the rest in place)
-                const uint4* rp = reinterpret_cast<const uint4*>(prec + (size_t)cur_src * P.Cs);
-                for (int k = g.q + HIST_QUAD * H2_PF; k < n4; k += HIST_QUAD) {
+            if ((n4s & 0xff) > HIST_QUAD * H2_PF) {   // (records of more than 46 entries: the rest in place)
+                const uint4* rp = reinterpret_cast<const uint4*>(prec) + __umul24((uint32_t)cur_src, (uint32_t)n4s >> 8);   // (N * Cs / 4 < 2^24)
+                for (int k = g.q + HIST_QUAD * H2_PF; k < (n4s & 0xff); k += HIST_QUAD) {
                     const uint4 v = rp[k];
                     stage[(4 * k + 0) * HIST_TREES] = v.x;
                     stage[(4 * k + 1) * HIST_TREES] = v.y;
