@@ -260,9 +260,29 @@ __device__ __forceinline__ int ucb_pick(const Problem& P, RNG& g, const double* 
             if (__popc(near) == 1 && scale < 1.0e30f) {
                 mask    = near;
                 decided = true;
+            } else if (AMAX <= 5 && scale < 1.0e30f) {   // (the instantiations of many actions would pay for the selects below with spilled registers)
+                //  * several actions within the margin that carry the SAME count and the SAME Q (young nodes of a domain whose rewards are mostly
+                //    zero: n = 1, Q = 0 each): their fp64 values are one and the same number, so they tie exactly, and every other action is below
+                //    them by more than the error bound -- the candidate set is `near`, again without the divisions and square roots.
+                const int f0 = __ffs(near) - 1;
+                int n0 = cn[0];
+                double q0 = cq[0];
+#pragma unroll
+                for (int a = 1; a < AMAX; ++a) { n0 = f0 == a ? cn[a] : n0; q0 = f0 == a ? cq[a] : q0; }
+                bool same = true;
+#pragma unroll
+                for (int a = 0; a < AMAX; ++a)
+                    if ((near >> a) & 1u) same = same && cn[a] == n0 && cq[a] == q0;
+                if (same) {
+                    mask    = near;
+                    decided = true;
+                }
             }
         }
     }
+#ifdef FBA_TIMING_NO_FP64_UCB   // timing-only builds (scripts/): what the fp64 fall-through costs -- WRONG results
+    if (!decided && explore) { mask = 1u; decided = true; }
+#endif
     if (!decided) {
         const double L = explore ? log1p_tab[visits] : 0.0;
 #pragma unroll

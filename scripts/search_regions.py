@@ -26,7 +26,8 @@ cfg = os.environ.get("FBA_CFG", "c2")
 slots = int(sys.argv[1]) if len(sys.argv) > 1 else (81920 if cfg == "c3" else 262144)
 if cfg == "c4":      # BASELINE configs[3]: gridworld N = 7, history particles, four lanes per tree (search_hist_kernel)
     slots = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-    kw = dict(size=7, sims=int(os.environ.get("FBA_SIMS", "65536")), particles=16384, structure_prior=2, horizon=20, episodes=2)
+    kw = dict(size=7, sims=int(os.environ.get("FBA_SIMS", "65536")), particles=16384, structure_prior=2, horizon=20, episodes=2,
+              search_budget=int(os.environ.get("FBA_BUDGET", "16384")), tree_buckets=int(os.environ.get("FBA_BUCKETS", "32768")))   # (bench.py's c4 shape)
     eng = fba.Engine("gridworld", model=fba.MODEL_BA_FACTORED, belief="importance_sampling", runs=1 << 30, slots=slots, seed=20261003, **kw)
 elif cfg == "c3":      # BASELINE configs[2]: factored tiger, 16384 simulations, packed records
     kw = dict(size=3, sims=16384, particles=4096, structure_prior=2, horizon=10, episodes=64)
