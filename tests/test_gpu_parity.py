@@ -902,6 +902,46 @@ def test_long_histories_and_deep_horizons_on_the_bucket_tree(horizon, episodes, 
         assert np.array_equal(t1[name], otr[name]), name
 
 
+@pytest.mark.parametrize("particles", [64, 4096])
+def test_records_at_the_stride_of_their_length_hold_the_beliefs_of_full_stride_records(particles, monkeypatch):
+    """History-particle records stand 64 bytes apart up to 14 entries, 128 up to 30, the whole record beyond (hist_stride): the per-step interface walks
+    a slot through 36 updates -- across both thresholds, by one workgroup per slot (64 particles) and by several (4 096) -- and after every one the filter
+    read back through fba_belief_get (states, weights, the materialised count tables) and single particles through fba_belief_get_particle are those of
+    a context whose records are always the full stride apart (FBA_HIST_STRIDE=full); the episode boundary's reset in between included."""
+    kw = dict(model=N.MODEL_BA_FACTORED, belief="importance_sampling", size=3, sims=16, particles=particles, structure_prior=2, horizon=18,
+              episodes=2, slots=2, seed=91)
+    monkeypatch.setenv("FBA_HIST_STRIDE", "full")
+    full = fba.Engine("gridworld", **kw)
+    monkeypatch.delenv("FBA_HIST_STRIDE")
+    comp = fba.Engine("gridworld", **kw)
+    assert comp.particle_bytes == full.particle_bytes
+    rng = np.random.default_rng(5)
+    for eng in (full, comp):
+        eng.belief_init()
+    for ep in range(2):
+        for eng in (full, comp):
+            eng.set_position(run=0, episode=ep, t=0)
+            eng.belief_reset_domain_state()
+        for t in range(18):
+            a = int(rng.integers(0, 4))
+            for eng in (full, comp):
+                eng.set_position(run=0, episode=ep, t=t)
+            # an observation the filter gives weight to: the first particle's state seen exactly (observations are indexed like states)
+            sf, _, _ = full.belief_get(0, counts=False)
+            ob = int(sf[0])
+            for eng in (full, comp):
+                eng.belief_update(a, ob)
+            s0, w0, c0 = full.belief_get(0, weights=True)
+            s1, w1, c1 = comp.belief_get(0, weights=True)
+            assert np.array_equal(s0, s1) and np.array_equal(w0, w1), (ep, t)
+            assert np.array_equal(c0.view(np.uint32), c1.view(np.uint32)), (ep, t)
+            i = int(rng.integers(0, particles))
+            p0, p1 = full.belief_get_particle(i, 0), comp.belief_get_particle(i, 0)
+            assert p0[0] == p1[0] and np.array_equal(p0[2].view(np.uint32), p1[2].view(np.uint32)), (ep, t, i)
+    full.close()
+    comp.close()
+
+
 def test_a_bucket_tree_that_is_too_small_stops_the_experiment_loudly():
     """fba_config.tree_buckets below what a search needs: FBA_ESTATE with the knob's name, never a wrong action."""
     eng = fba.Engine("gridworld", model=N.MODEL_BA_FACTORED, belief="importance_sampling", size=3, sims=512, particles=64, structure_prior=2,
