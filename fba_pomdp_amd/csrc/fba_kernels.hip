@@ -164,14 +164,50 @@ __device__ __forceinline__ void gather_records(float* __restrict__ dst, const fl
                                                bool packed = false)
 {
     const int gid = threadIdx.x / group, part0 = threadIdx.x % group, ngroups = nthreads / group;
+    if (C4 > group && C4 <= 4 * group) {
+        // a record of several pieces per lane (the 3.5 KB collision-avoidance particles): a lane group moves TWO records at a time, the
+        // pieces of both -- up to eight loads per lane -- in flight before the first is waited for.  One record at a time left a wave
+        // with four loads in flight and every record's loads behind the previous record's stores (vmcnt counts both).
+        for (int j0 = gid; j0 < m; j0 += 2 * ngroups) {
+            float4 v[2][4];
+            int t[2];
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int j = min(j0 + rr * ngroups, m - 1);
+                t[rr] = s_owner ? s_owner[j] : j;
+                const float4* sp = reinterpret_cast<const float4*>(src) + (size_t)s_src[t[rr]] * C4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[rr][q] = sp[min(part0 + q * group, C4 - 1)];
+            }
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int j = j0 + rr * ngroups;
+                if (j >= m) continue;
+                float4* dp = reinterpret_cast<float4*>(dst) + (size_t)j * C4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int pq = part0 + q * group;
+                    if (pq >= C4) continue;
+                    const int lo = pq * 4;
+                    for (int k = 0; k < ninc; ++k) bump_cell(v[rr][q], s_inc[k * inc_stride + t[rr]], lo, packed);
+                    if (s_state) {  // new domain state in word C
+                        const int d = C - lo;
+                        const float f = __int_as_float(s_state[t[rr]]);
+                        if (d == 0) v[rr][q].x = f; else if (d == 1) v[rr][q].y = f; else if (d == 2) v[rr][q].z = f; else if (d == 3) v[rr][q].w = f;
+                    }
+                    dp[pq] = v[rr][q];
+                }
+            }
+        }
+        return;
+    }
     for (int j = gid; j < m; j += ngroups) {
         const int t      = s_owner ? s_owner[j] : j;
         const float4* sp = reinterpret_cast<const float4*>(src) + (size_t)s_src[t] * C4;
         float4* dp       = reinterpret_cast<float4*>(dst) + (size_t)j * C4;
         if (C4 > group) {
-            // a record of several pieces per lane (the 3.5 KB collision-avoidance particles, dense gridworld ones): four loads
-            // in flight per lane before the first is waited for -- piece by piece, every load also waits for the store
-            // before it (vmcnt counts both)
+            // (records of more than four pieces per lane: the dense gridworld particles) four loads in flight per lane before the first
+            // is waited for -- piece by piece, every load also waits for the store before it (vmcnt counts both)
             for (int part = part0; part < C4; part += 4 * group) {
                 float4 v[4];
 #pragma unroll
