@@ -1361,20 +1361,19 @@ __device__ __forceinline__ int gridworld_unpack_state(const Problem& P, uint32_t
 // hist_pack(x, y, goal); returns the step's entry (what incrementCountsOf would add, :354-382, App. A #6:
 // observation rows at the OLD state's values) and P(real_o | a, s') from the counts after the step's own
 // increments (BABNModel.cpp:328-352).
-template <int KN, int KG>
-__device__ __forceinline__ bool gridworld_hist_step_k(const Problem& P, Rng& g, const uint32_t* __restrict__ ent, int n, uint32_t mask, uint32_t& sp,
-                                                      int a, int& o, double& r, uint32_t& entry, int real_o, double& prob)
+template <int KN, int KG, class ROWS>
+__device__ __forceinline__ bool gridworld_hist_step_k(const Problem& P, Rng& g, const ROWS& R, const uint32_t* __restrict__ ent, int n, uint32_t mask,
+                                                      uint32_t& sp, int a, int& o, double& r, uint32_t& entry, int real_o, double& prob)
 {
-    const HistLayout L(P.gw_N, P.gw_G, P.A);
-    const int N = L.N, G = L.G;
+    const int N = P.gw_N, G = P.gw_G;
     const int x = hist_x(sp), y = hist_y(sp), gl = hist_g(sp);
     const int cell = x * N + y;
     const bool mx = (mask >> (2 * a)) & 1u, my = (mask >> (2 * a + 1)) & 1u;
     HistRow<KN> rx, ry;
     HistRow<KG> rg;
-    rx.fetch(mx ? P.hist_alt + L.alt_row(a, 0, cell, gl) : P.hist_base + L.t_row(a, 0, false, cell, gl));
-    ry.fetch(my ? P.hist_alt + L.alt_row(a, 1, cell, gl) : P.hist_base + L.t_row(a, 1, false, cell, gl));
-    rg.fetch(P.hist_base + L.t_row(a, 2, true, cell, gl));
+    rx.fetch(R.t(a, 0, mx, cell, gl));
+    ry.fetch(R.t(a, 1, my, cell, gl));
+    rg.fetch(R.t(a, 2, true, cell, gl));
     // pass 1: the increments this particle has made to the rows T(a, .)(x, y [, goal])
     RowCount cx{0, 0}, cy{0, 0}, cg{0, 0};
     for (int j = 0; j < n; ++j) {
@@ -1390,9 +1389,9 @@ __device__ __forceinline__ bool gridworld_hist_step_k(const Problem& P, Rng& g, 
     const int ny = ry.sample(g.u01(), N);
     rg.add(G, cg);
     const int ng = rg.sample(g.u01(), G);
-    rx.fetch(P.hist_base + L.o_row(a, 0, nx));
-    ry.fetch(P.hist_base + L.o_row(a, 1, ny));
-    rg.fetch(P.hist_base + L.o_row(a, 2, ng));
+    rx.fetch(R.o(a, 0, nx));
+    ry.fetch(R.o(a, 1, ny));
+    rg.fetch(R.o(a, 2, ng));
     // pass 2: the increments to the rows O(a, .)(value of the new state's feature); a step increments them at
     // the row of the state it STARTED from
     RowCount ox{0, 0}, oy{0, 0}, og{0, 0};
@@ -1433,11 +1432,19 @@ __device__ __forceinline__ bool gridworld_hist_step_k(const Problem& P, Rng& g, 
     sp    = hist_pack(nx, ny, ng);
     return found;
 }
+// (R: where the rows come from -- HistRowsGlobal, or HistRowsLds<K> with K >= 8 for G <= 8 and K >= 12 beyond)
+template <class ROWS>
+__device__ __forceinline__ bool gridworld_hist_step(const Problem& P, Rng& g, const ROWS& R, const uint32_t* ent, int n, uint32_t mask, uint32_t& sp, int a,
+                                                    int& o, double& r, uint32_t& entry, int real_o, double& prob)
+{
+    if (P.gw_G <= 8) return gridworld_hist_step_k<8, 8>(P, g, R, ent, n, mask, sp, a, o, r, entry, real_o, prob);
+    return gridworld_hist_step_k<8, 12>(P, g, R, ent, n, mask, sp, a, o, r, entry, real_o, prob);   // (G <= 10)
+}
 __device__ __forceinline__ bool gridworld_hist_step(const Problem& P, Rng& g, const uint32_t* ent, int n, uint32_t mask, uint32_t& sp, int a, int& o,
                                                     double& r, uint32_t& entry, int real_o, double& prob)
 {
-    if (P.gw_G <= 8) return gridworld_hist_step_k<8, 8>(P, g, ent, n, mask, sp, a, o, r, entry, real_o, prob);
-    return gridworld_hist_step_k<8, 12>(P, g, ent, n, mask, sp, a, o, r, entry, real_o, prob);   // (G <= 10)
+    const HistLayout L(P.gw_N, P.gw_G, P.A);
+    return gridworld_hist_step(P, g, HistRowsGlobal{P.hist_base, P.hist_alt, P.hist_base + L.obase0, L}, ent, n, mask, sp, a, o, r, entry, real_o, prob);
 }
 
 // ---- the same step shared by the four lanes of a quad (search_hist_kernel) ---------------------------------------

@@ -13,6 +13,7 @@
 // HBM-streaming (one workgroup per slot, wave ballot / prefix-sum compaction, whole-record gathers).
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include "fba_kernels_common.h"
 
 
@@ -1703,12 +1704,21 @@ __device__ __forceinline__ bool hist_update_refused(const Problem& P, const Devi
 }
 // HIST: history particles (importance_kernel<HIST> cut at its block-wide synchronisation points, so that a slot's update spreads over
 // N / 1024 workgroups instead of walking its chain in one)
-template <bool REG, bool HIST = false>
+// K > 0 (history particles): the prior's Dirichlet rows, deduplicated, in LDS as the search has them (Problem::hist_lds, rows of K floats) -- six rows
+// per particle step otherwise come from L2, where the records streaming through evict them (the sweep fetched three times its records' bytes)
+template <bool REG, bool HIST = false, int K = 0>
 __global__ void __launch_bounds__(256) is_multi_step_kernel(Problem P, DeviceState D)
 {
     __shared__ int32_t s_inc[HIST ? 1 : MAXINC * 256];
+    extern __shared__ uint4 s_prior_rows[];   // K > 0: one byte per row slot (HistRowIds numbering), then the distinct rows
     const int e = chunk_slot(D, blockIdx.y), tid = threadIdx.x, lane = tid & 63;
     if (!D.need_update[e] || hist_update_refused(P, D, e)) return;
+    if (K > 0) {   // every thread, before any wave leaves
+        const uint4* src = reinterpret_cast<const uint4*>(P.hist_lds);
+        const int n16 = (P.hist_rid_bytes + P.hist_distinct * K * (int)sizeof(float)) / 16;
+        for (int i = tid; i < n16; i += 256) s_prior_rows[i] = src[i];
+        __syncthreads();
+    }
     const int c = blockIdx.x * 4 + (tid >> 6), N = P.N;
     if (c * 256 >= N) return;
     const int a = D.action[e], o = D.obs[e], ninc = model_ninc(P);
@@ -1731,7 +1741,13 @@ __global__ void __launch_bounds__(256) is_multi_step_kernel(Problem P, DeviceSta
                 const uint32_t* rec = reinterpret_cast<const uint32_t*>(cnt);
                 uint32_t sp = (rec[1] >> 16) & 0x3ffu, entry;
                 double prob;
-                gridworld_hist_step(P, g, rec + 2 + hist_offset(hist_cnt, a), hist_count(hist_cnt, a), rec[1], sp, a, so, r, entry, o, prob);
+                if (K > 0) {
+                    const HistRowsLds<(K > 0 ? K : 8)> rl{reinterpret_cast<const uint8_t*>(s_prior_rows),
+                                                           reinterpret_cast<const float*>(reinterpret_cast<const char*>(s_prior_rows) + P.hist_rid_bytes),
+                                                           HistRowIds(P.gw_N, P.gw_G, 4)};
+                    gridworld_hist_step(P, g, rl, rec + 2 + hist_offset(hist_cnt, a), hist_count(hist_cnt, a), rec[1], sp, a, so, r, entry, o, prob);
+                } else
+                    gridworld_hist_step(P, g, rec + 2 + hist_offset(hist_cnt, a), hist_count(hist_cnt, a), rec[1], sp, a, so, r, entry, o, prob);
                 *reinterpret_cast<int2*>(D.p_side + ((size_t)e * N + i) * 2) = make_int2(gridworld_unpack_state(P, sp), (int)entry);
                 v     = sw[i] * prob;
                 sw[i] = v;
@@ -2346,7 +2362,15 @@ static void launch_importance_multi(const Problem& P, const DeviceState& D, int 
     const int nchunks = (P.N + 255) / 256;
     const dim3 cgrid(ceil_div(nchunks, 4), count), eg(ceil_div(count, 64));
     const int32_t* list = D.use_list ? D.slot_list : nullptr;
-    if (P.hist) hipLaunchKernelGGL((is_multi_step_kernel<false, true>), cgrid, dim3(256), 0, st, P, D);
+    if (P.hist) {
+        // the prior's rows from LDS where the deduplicated blob exists (rows of K floats, K as upload_prior chose it) -- FBA_HIST_ROWS=hbm: from L2
+        static const bool rows_hbm = std::getenv("FBA_HIST_ROWS") && !std::strcmp(std::getenv("FBA_HIST_ROWS"), "hbm");
+        const int K = P.hist_row <= 8 ? 8 : (P.hist_row <= 10 ? 12 : 0);
+        const size_t lds = (size_t)P.hist_rid_bytes + (size_t)P.hist_distinct * K * sizeof(float);
+        if (P.hist_lds && K == 8 && !rows_hbm) hipLaunchKernelGGL((is_multi_step_kernel<false, true, 8>), cgrid, dim3(256), lds, st, P, D);
+        else if (P.hist_lds && K == 12 && !rows_hbm) hipLaunchKernelGGL((is_multi_step_kernel<false, true, 12>), cgrid, dim3(256), lds, st, P, D);
+        else hipLaunchKernelGGL((is_multi_step_kernel<false, true>), cgrid, dim3(256), 0, st, P, D);
+    }
     else if (P.dirichlet_regular) hipLaunchKernelGGL((is_multi_step_kernel<true, false>), cgrid, dim3(256), 0, st, P, D);
     else hipLaunchKernelGGL((is_multi_step_kernel<false, false>), cgrid, dim3(256), 0, st, P, D);
     hipLaunchKernelGGL(scan_carry_kernel, dim3(count), dim3(256), 0, st, D.ctot, D.ctot_stride, nchunks, D.is_tot, 2, 0, D.need_update, count, list, D.slot_base);
