@@ -1632,6 +1632,9 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     // history particles keep ONE record buffer per slot; a resample / reset builds the new filter in a scratch pool shared by a
     // chunk of slots (launch_belief_update / launch_reset: for_each_chunk) -- the second buffer was a quarter of a slot's memory
     D.single_rec = P.hist && !std::getenv("FBA_DOUBLE_BUFFER") ? 1 : 0;
+    D.ab_rows_hbm   = std::getenv("FBA_HIST_ROWS") && !std::strcmp(std::getenv("FBA_HIST_ROWS"), "hbm") ? 1 : 0;
+    D.ab_hist_multi = std::getenv("FBA_HIST_MULTI") ? (std::atoi(std::getenv("FBA_HIST_MULTI")) != 0 ? 2 : 1) : 0;
+    D.ab_no_etiger  = std::getenv("FBA_NO_ETIGER") && std::atoi(std::getenv("FBA_NO_ETIGER")) != 0 ? 1 : 0;
     D.slot_base = 0;
     D.scratch_slots = D.single_rec ? std::min(E, 1024) : 0;
     if (D.single_rec)

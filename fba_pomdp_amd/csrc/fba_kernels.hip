@@ -2364,7 +2364,7 @@ static void launch_importance_multi(const Problem& P, const DeviceState& D, int 
     const int32_t* list = D.use_list ? D.slot_list : nullptr;
     if (P.hist) {
         // the prior's rows from LDS where the deduplicated blob exists (rows of K floats, K as upload_prior chose it) -- FBA_HIST_ROWS=hbm: from L2
-        static const bool rows_hbm = std::getenv("FBA_HIST_ROWS") && !std::strcmp(std::getenv("FBA_HIST_ROWS"), "hbm");
+        const bool rows_hbm = D.ab_rows_hbm != 0;
         const int K = P.hist_row <= 8 ? 8 : (P.hist_row <= 10 ? 12 : 0);
         const size_t lds = (size_t)P.hist_rid_bytes + (size_t)P.hist_distinct * K * sizeof(float);
         if (P.hist_lds && K == 8 && !rows_hbm) hipLaunchKernelGGL((is_multi_step_kernel<false, true, 8>), cgrid, dim3(256), lds, st, P, D);
@@ -2381,10 +2381,9 @@ static void launch_importance_multi(const Problem& P, const DeviceState& D, int 
     hipLaunchKernelGGL(is_multi_finish_kernel, eg, dim3(64), 0, st, P, D, count);
 }
 // history particles: several workgroups per slot from this many particles up (FBA_HIST_MULTI=1 / 0 forces / forbids it: tests, A/B runs)
-static bool hist_update_multi(const Problem& P)
+static bool hist_update_multi(const Problem& P, const DeviceState& D)
 {
-    static const char* ev = std::getenv("FBA_HIST_MULTI");
-    if (ev) return std::atoi(ev) != 0;
+    if (D.ab_hist_multi) return D.ab_hist_multi == 2;
     return P.N >= 4096;
 }
 void launch_belief_update(const Problem& P, const DeviceState& D, hipStream_t st)
@@ -2437,7 +2436,7 @@ void launch_belief_update(const Problem& P, const DeviceState& D, hipStream_t st
     if (!D.is_multi) {
         if (D.single_rec)
             for_each_chunk(P, D, st, [&](const DeviceState& Dc, int cnt) {
-                if (P.hist && hist_update_multi(P)) { launch_importance_multi(P, Dc, cnt, st); return; }
+                if (P.hist && hist_update_multi(P, D)) { launch_importance_multi(P, Dc, cnt, st); return; }
                 if (!Dc.use_list) { launch_importance_single(P, Dc, st); return; }
                 DeviceState Dl   = Dc;           // (list mode: the launch's grid is the chunk's count; scratch places were fixed against
                 Dl.scratch_slots = cnt;          //  the pool's size when the list was built)

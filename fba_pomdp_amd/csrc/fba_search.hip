@@ -1277,7 +1277,7 @@ void launch_search(const Problem& P, const DeviceState& D, hipStream_t st)
 {
     const bool stage = P.model != FBA_MODEL_POMDP && P.Cs <= SEARCH_STAGE_WORDS;
     // the episodic tiger family on its own tree layout (ETIGER); FBA_NO_ETIGER=1 keeps the general layout, for A/B runs
-    static const bool no_etiger = std::getenv("FBA_NO_ETIGER") && std::atoi(std::getenv("FBA_NO_ETIGER")) != 0;
+    const bool no_etiger = D.ab_no_etiger != 0;
     // (the instantiations that exist on that layout: the tabular tiger BA-POMDP, planning on tiger itself, packed factored tiger)
     const bool tiger_table = P.model == FBA_MODEL_BA_TABLE && P.planner == FBA_PLANNER_POUCT && !P.dirichlet_regular && stage &&
                              (P.domain == FBA_DOM_TIGER_EPISODIC || P.domain == FBA_DOM_TIGER_CONTINUOUS) && !D.hash;
@@ -1312,7 +1312,7 @@ void launch_search(const Problem& P, const DeviceState& D, hipStream_t st)
         lds = (size_t)depth_cap * HIST_TREES * (sizeof(double) + sizeof(int32_t) + sizeof(float) + sizeof(int32_t)) + (size_t)P.Cs * HIST_TREES * sizeof(float);
         const dim3 qgrid(ceil_div(P.E, HIST_TREES));
         if (D.bkt) {   // the tree as one table of buckets, trips to memory requested an iteration ahead
-            static const bool no_lrows = std::getenv("FBA_HIST_ROWS") && !std::strcmp(std::getenv("FBA_HIST_ROWS"), "hbm");   // A/B: transition rows from the padded tables
+            const bool no_lrows = D.ab_rows_hbm != 0;   // A/B: transition rows from the padded tables
             const bool lrows = P.hist_lds != nullptr && !no_lrows;
             int nw = H2_WAVES;   // waves per workgroup: as many as 64 KB of LDS hold beside the shared tables (deep horizons have long paths)
             while (nw > 1 && h2_shared_bytes(P, lrows) + (size_t)nw * h2_wave_bytes(P) > 64 * 1024) nw >>= 1;

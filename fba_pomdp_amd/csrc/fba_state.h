@@ -74,6 +74,10 @@ struct DeviceState {
     int32_t* slot_list;       // [E] or null
     int32_t* list_count;      // [1]
     int32_t* list_count_host; // [1] pinned host memory: where the launcher reads the count (a pageable destination is staged by the runtime)
+    // A/B switches of the launchers, read from the environment when the context is created (tests and same-box comparisons flip them per context):
+    int8_t ab_rows_hbm;       // FBA_HIST_ROWS=hbm: history particles read the prior's rows from the padded tables (L2) instead of the deduplicated rows in LDS
+    int8_t ab_hist_multi;     // FBA_HIST_MULTI=0 / 1: 1 = never, 2 = always update a history-particle slot by several workgroups (0: from 4 096 particles)
+    int8_t ab_no_etiger;      // FBA_NO_ETIGER=1: the episodic tiger family on the general tree layout
     int32_t* scratch_idx;     // [E] the scratch place of a listed slot
     int32_t use_list;         // 1 in the DeviceState of a launch over the list
     // incubator belief (StructureIncubatorSampling.cpp): the weighted shadow filter, laid out like p_rec / p_weight / bufsel

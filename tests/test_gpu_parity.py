@@ -942,6 +942,35 @@ def test_records_at_the_stride_of_their_length_hold_the_beliefs_of_full_stride_r
     comp.close()
 
 
+@pytest.mark.parametrize("particles", [96, 4096])
+def test_every_switch_of_the_history_particle_path_gives_the_default_results(particles, monkeypatch):
+    """The A/B switches the profiles quote (read when a context is created): the prior's rows from L2 instead of LDS, in the search and in the update
+    pass (FBA_HIST_ROWS=hbm); the update by one workgroup per slot or by several, forced either way (FBA_HIST_MULTI=0 / 1); records always the full
+    stride apart (FBA_HIST_STRIDE=full); node records + hash table instead of the bucket table (FBA_HIST_TREE=records); double-buffered records
+    (FBA_DOUBLE_BUFFER=1).  Every trace field -- the per-step checksum over every particle's state, weight and counts among them -- and every
+    statistic equal the default build's."""
+    kw = dict(model=N.MODEL_BA_FACTORED, belief="importance_sampling", size=3, sims=24, particles=particles, structure_prior=2, horizon=9,
+              episodes=2, runs=3, slots=3, seed=4242, trace=1)
+
+    def run():
+        eng = fba.Engine("gridworld", **kw)
+        stats = eng.run_bapomdp()
+        out = (eng.trace(), [(s.count, s.mean, s.m2) for s in stats])
+        eng.close()
+        return out
+
+    t0, s0 = run()
+    assert len(t0) > 0
+    for name, value in (("FBA_HIST_ROWS", "hbm"), ("FBA_HIST_MULTI", "0"), ("FBA_HIST_MULTI", "1"), ("FBA_HIST_STRIDE", "full"),
+                        ("FBA_HIST_TREE", "records"), ("FBA_DOUBLE_BUFFER", "1")):
+        monkeypatch.setenv(name, value)
+        t1, s1 = run()
+        monkeypatch.delenv(name)
+        assert len(t1) == len(t0) and s1 == s0, (name, value)
+        for field in t0.dtype.names:
+            assert np.array_equal(t0[field], t1[field]), (name, value, field)
+
+
 def test_a_bucket_tree_that_is_too_small_stops_the_experiment_loudly():
     """fba_config.tree_buckets below what a search needs: FBA_ESTATE with the knob's name, never a wrong action."""
     eng = fba.Engine("gridworld", model=N.MODEL_BA_FACTORED, belief="importance_sampling", size=3, sims=512, particles=64, structure_prior=2,
