@@ -55,6 +55,11 @@ def test_tiger_kernels_use_no_scratch(tmp_path):
     # and a private array once cost it 1.6 KB of scratch per lane
     mh = {n: v for n, v in seen.items() if "mh_kernel" in n}
     assert len(mh) == 1 and all(v[0] == 0 and v[2] == 0 for v in mh.values()), mh
+    # the history particles' update pass (several workgroups per slot): the prior's rows in LDS (K = 8 / 12) or in L2 (K = 0); four waves per SIMD
+    upd = {n: v for n, v in seen.items() if "is_multi_step_kernelILb0ELb1E" in n}
+    assert len(upd) == 3, sorted(seen)
+    for name, (scratch, vgprs, spills) in upd.items():
+        assert scratch == 0 and spills == 0 and vgprs <= 128, (name, scratch, vgprs, spills)
     regular = re.compile(r"search_kernelILb[01]ELi\d+ELb1E|(reject|importance)_kernelILb1E|is_multi_step_kernelILb1E")
     for name, (scratch, vgprs, spills) in seen.items():
         if not regular.search(name) and "search_hist2_kernel" not in name:   # (the `regular` Dirichlet instantiations carry the gamma sampler;
