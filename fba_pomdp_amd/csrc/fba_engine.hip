@@ -1577,7 +1577,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     // History-particle searches keep their tree in one table of 64-byte buckets (search_hist2_kernel, fba_state.h) where its keys fit:
     // (parent bucket, action, observation) in 28 bits, counts below the root in 16.  FBA_HIST_TREE=records keeps node records + hash table
     // (search_hist_kernel), for A/B runs and for what does not fit.
-    D.bkt = nullptr; D.bkt_lines = 0; D.s_root = nullptr;
+    D.bkt = nullptr; D.bkt_lines = 0; D.s_root = nullptr; D.search_order = nullptr;
     size_t bkt_lines = 0;
     const bool force_records = std::getenv("FBA_HIST_TREE") && !std::strcmp(std::getenv("FBA_HIST_TREE"), "records");
     if (P.hist && P.sims <= 65536 && !force_records) {
@@ -1635,6 +1635,7 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
     D.ab_rows_hbm   = std::getenv("FBA_HIST_ROWS") && !std::strcmp(std::getenv("FBA_HIST_ROWS"), "hbm") ? 1 : 0;
     D.ab_hist_multi = std::getenv("FBA_HIST_MULTI") ? (std::atoi(std::getenv("FBA_HIST_MULTI")) != 0 ? 2 : 1) : 0;
     D.ab_no_etiger  = std::getenv("FBA_NO_ETIGER") && std::atoi(std::getenv("FBA_NO_ETIGER")) != 0 ? 1 : 0;
+    D.ab_lockstep   = std::getenv("FBA_HIST_LOCKSTEP") ? (std::atoi(std::getenv("FBA_HIST_LOCKSTEP")) != 0 ? 1 : 0) : 1;   // (on; only the bucket tree has it, below)
     D.slot_base = 0;
     D.scratch_slots = D.single_rec ? std::min(E, 1024) : 0;
     if (D.single_rec)
@@ -1777,6 +1778,8 @@ int fba_create(const fba_config* cfg, fba_ctx** out)
             HIPC(hipHostMalloc(reinterpret_cast<void**>(&D.list_count_host), sizeof(int32_t), hipHostMallocDefault));
         }
     }
+    if (D.bkt && D.ab_lockstep) CHK(dev_alloc(c, &D.search_order, (size_t)E));
+    if (!D.search_order) D.ab_lockstep = 0;   // (lock-step waves exist on the bucket tree only: search_hist2_kernel)
     CHK(dev_alloc(c, &c->d_prior, P.Cs));
     CHK(dev_alloc(c, &c->d_prior_dense, std::max(c->dense_C, 1)));
     if (P.hist) {

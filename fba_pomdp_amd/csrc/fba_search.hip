@@ -821,6 +821,23 @@ __host__ __device__ __forceinline__ size_t h2_wave_bytes(const Problem& P)
     return (size_t)depth_cap * HIST_TREES * (sizeof(double) + sizeof(int32_t) + sizeof(float) + sizeof(int32_t)) +
            (size_t)(P.Cs > 2 * depth_cap ? P.Cs : 2 * depth_cap) * HIST_TREES * sizeof(float) + (size_t)14 * HIST_TREES * sizeof(float);   // (+ the root's statistics, the record geometry)
 }
+// search_order (fba_state.h): a counting sort of the slots by the depth their searches have left (inactive slots first).  One workgroup; which of two
+// slots of equal depth comes first is left to the atomics -- every tree is independent, so no result can depend on it.
+__global__ void __launch_bounds__(1024) search_order_kernel(Problem P, DeviceState D)
+{
+    __shared__ int32_t s_cnt[258];
+    const int tid = threadIdx.x;
+    for (int k = tid; k < 258; k += 1024) s_cnt[k] = 0;
+    __syncthreads();
+    auto key_of = [&](int e) { return D.active[e] ? 1 + min(max(min(P.horizon - D.t[e], P.max_depth), 0), 255) : 0; };
+    for (int e = tid; e < P.E; e += 1024) atomicAdd(&s_cnt[key_of(e) + 1], 1);
+    __syncthreads();
+    if (tid == 0)
+        for (int k = 1; k < 258; ++k) s_cnt[k] += s_cnt[k - 1];   // s_cnt[key] = first place of the key
+    __syncthreads();
+    for (int e = tid; e < P.E; e += 1024) D.search_order[atomicAdd(&s_cnt[key_of(e)], 1)] = e;
+}
+
 template <int K, bool LROWS>
 __global__ void __launch_bounds__(H2_BLOCK) __attribute__((amdgpu_waves_per_eu(FBA_HIST2_WAVES, FBA_HIST2_WAVES))) search_hist2_kernel(Problem P, DeviceState D)
 {
@@ -851,8 +868,10 @@ __global__ void __launch_bounds__(H2_BLOCK) __attribute__((amdgpu_waves_per_eu(F
     }
     const uint8_t* s_rid = reinterpret_cast<const uint8_t*>(lds_all);
     const float* s_rows  = reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds_all) + (LROWS ? P.hist_rid_bytes : 0));
-    const int e = (blockIdx.x * (int)(blockDim.x >> 6) + wave) * HIST_TREES + tl;   // (the launcher picks 4, 2 or 1 waves per workgroup: what 64 KB of LDS hold)
-    if (e >= P.E || !D.active[e]) return;  // (a quad leaves together)
+    const int tree_k = (blockIdx.x * (int)(blockDim.x >> 6) + wave) * HIST_TREES + tl;   // (the launcher picks 4, 2 or 1 waves per workgroup: what 64 KB of LDS hold)
+    if (tree_k >= P.E) return;
+    const int e = D.ab_lockstep ? D.search_order[tree_k] : tree_k;   // (lock-step waves: slots dealt to waves by the depth their searches have left)
+    if (!D.active[e]) return;  // (a quad leaves together)
 
     QuadRng g;
     g.init(P.seed_lo, P.seed_hi, (uint32_t)D.run[e], (uint32_t)D.episode[e], (uint32_t)D.t[e], lane);
@@ -941,6 +960,17 @@ __global__ void __launch_bounds__(H2_BLOCK) __attribute__((amdgpu_waves_per_eu(F
         double cq[AMAX] = {0.0, 0.0, 0.0, 0.0};
         bool finish = false, do_step = true;
         double delayed = 0;
+        if (D.ab_lockstep) {
+            // Lock-step waves (FBA_HIST_LOCKSTEP=0 turns them off): the wave's trees start their simulations together -- a tree whose simulation is over
+            // waits in mode 3 until every tree of the wave that is still searching is there too.  Sixteen trees in sixteen phases made the wave
+            // execute the selection, the particle's consumption and the back-up in nearly every iteration for one or two trees each; in step, the
+            // selection runs in the iterations of the descent only, the other two once per simulation.  What the waiting costs is small because the
+            // wave's slots have the same depth left (search_order: a rollout runs to the horizon), so their simulations have nearly the same length.
+            // Every tree still runs the same simulations in the same order: no result changes.
+            const bool waiting = mode == 3;
+            if (__builtin_amdgcn_ballot_w64(waiting) == __builtin_amdgcn_ballot_w64(true)) mode = 0;
+            else if (waiting) do_step = false;
+        }
         if (mode == 0) {
             if (sim >= P.sims) break;
             if (budget > 0 && iter >= budget) break;   // out of iterations at a simulation boundary: park the search (below)
@@ -1218,7 +1248,7 @@ __global__ void __launch_bounds__(H2_BLOCK) __attribute__((amdgpu_waves_per_eu(F
                 }
             }
             if (!broken) ++sim;
-            mode = 0; pend = false;
+            mode = D.ab_lockstep ? 3 : 0; pend = false;
         }
         {
             // The one place of the loop where Philox blocks are made: what the next iteration draws -- a step's seven (the action, six rows), or
@@ -1318,6 +1348,7 @@ void launch_search(const Problem& P, const DeviceState& D, hipStream_t st)
             while (nw > 1 && h2_shared_bytes(P, lrows) + (size_t)nw * h2_wave_bytes(P) > 64 * 1024) nw >>= 1;
             const size_t lds2 = h2_shared_bytes(P, lrows) + (size_t)nw * h2_wave_bytes(P);
             const dim3 grid2(ceil_div(P.E, HIST_TREES * nw)), block2(64 * nw);
+            if (D.ab_lockstep) hipLaunchKernelGGL(search_order_kernel, dim3(1), dim3(1024), 0, st, P, D);
 #define FBA_LAUNCH_H2(KV)                                                                                              \
     do {                                                                                                               \
         if (lds2 > 64 * 1024) {   /* (one wave of a very deep horizon: past the default limit of a workgroup's dynamic LDS) */ \

@@ -78,6 +78,9 @@ struct DeviceState {
     int8_t ab_rows_hbm;       // FBA_HIST_ROWS=hbm: history particles read the prior's rows from the padded tables (L2) instead of the deduplicated rows in LDS
     int8_t ab_hist_multi;     // FBA_HIST_MULTI=0 / 1: 1 = never, 2 = always update a history-particle slot by several workgroups (0: from 4 096 particles)
     int8_t ab_no_etiger;      // FBA_NO_ETIGER=1: the episodic tiger family on the general tree layout
+    int8_t ab_lockstep;       // the trees of a search_hist2_kernel wave start their simulations together (FBA_HIST_LOCKSTEP=0: each on its own)
+    int32_t* search_order;    // [E] (bucket-tree contexts): the slots sorted by the depth their searches have left, rewritten in front of every
+                              // search launch -- tree k of the launch works on slot search_order[k], so a wave's trees run simulations of one length
     int32_t* scratch_idx;     // [E] the scratch place of a listed slot
     int32_t use_list;         // 1 in the DeviceState of a launch over the list
     // incubator belief (StructureIncubatorSampling.cpp): the weighted shadow filter, laid out like p_rec / p_weight / bufsel

@@ -947,7 +947,7 @@ def test_every_switch_of_the_history_particle_path_gives_the_default_results(par
     """The A/B switches the profiles quote (read when a context is created): the prior's rows from L2 instead of LDS, in the search and in the update
     pass (FBA_HIST_ROWS=hbm); the update by one workgroup per slot or by several, forced either way (FBA_HIST_MULTI=0 / 1); records always the full
     stride apart (FBA_HIST_STRIDE=full); node records + hash table instead of the bucket table (FBA_HIST_TREE=records); double-buffered records
-    (FBA_DOUBLE_BUFFER=1).  Every trace field -- the per-step checksum over every particle's state, weight and counts among them -- and every
+    (FBA_DOUBLE_BUFFER=1); every tree of a wave on its own instead of in lock-step (FBA_HIST_LOCKSTEP=0).  Every trace field -- the per-step checksum over every particle's state, weight and counts among them -- and every
     statistic equal the default build's."""
     kw = dict(model=N.MODEL_BA_FACTORED, belief="importance_sampling", size=3, sims=24, particles=particles, structure_prior=2, horizon=9,
               episodes=2, runs=3, slots=3, seed=4242, trace=1)
@@ -962,7 +962,7 @@ def test_every_switch_of_the_history_particle_path_gives_the_default_results(par
     t0, s0 = run()
     assert len(t0) > 0
     for name, value in (("FBA_HIST_ROWS", "hbm"), ("FBA_HIST_MULTI", "0"), ("FBA_HIST_MULTI", "1"), ("FBA_HIST_STRIDE", "full"),
-                        ("FBA_HIST_TREE", "records"), ("FBA_DOUBLE_BUFFER", "1")):
+                        ("FBA_HIST_TREE", "records"), ("FBA_DOUBLE_BUFFER", "1"), ("FBA_HIST_LOCKSTEP", "0")):
         monkeypatch.setenv(name, value)
         t1, s1 = run()
         monkeypatch.delenv(name)
