@@ -65,7 +65,7 @@ for k in ("is_multi_step_kernel", "is_multi_resample_kernel"):
 json.dump({
     "command": "scripts/c4_profiles.sh: rocprofv3 --kernel-trace --pmc <SQ_* | SQ_INSTS_VMEM_RD ... | FETCH_SIZE | WRITE_SIZE> --output-format csv -- python3 bench.py "
                "--workload c4 --steps 2 --warmup 8 --no-cpu-baseline  (one pass per counter group; sums over all launches of the run, warm-up included; SQ cycle "
-               "counters in quad-cycles summed over waves; 49 152 slots, three waves per SIMD, two rollout steps per iteration; collected by scripts/c4_collect.py)",
+               "counters in quad-cycles summed over waves; 49 152 slots, three waves per SIMD, two rollout steps per iteration, lock-step waves; collected by scripts/c4_collect.py)",
     "kernels": kern, "search_hist2_kernel_derived": derived, "belief_update_kernels_derived": upd, "bench_line_of_the_sq_pass": line,
 }, open(dst("c4_counters.json"), "w"), indent=1)
 stats = glob.glob(os.path.join(SRC, "c4_stats", "**", "*kernel_stats.csv"), recursive=True)
